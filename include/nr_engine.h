@@ -1,0 +1,96 @@
+/*
+ * nr_engine.h -- C-ABI of the MI355X-native NRMS scoring engine (libnr_engine.so).
+ *
+ * The reference (yusanshi/news-recommendation) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md section 2.2); this ABI is the drop-in boundary designed in SURVEY.md section 8 row b10: every
+ * entry point takes raw DEVICE pointers + sizes + a hipStream_t (passed as void*), transfers no
+ * ownership (the caller -- PyTorch in the Python host -- allocates every buffer incl. workspaces),
+ * returns 0 on success and a negative code on error (nr_last_error() gives the text; never aborts).
+ * Each function cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Dimensions supported by the hand-tuned kernels: word_embedding_dim D=300, num_attention_heads=15
+ * (d_k=20), query_vector_dim<=208; sequence lengths 20 (titles) and 50 (click history) are
+ * instantiated, see nr_supported_seq_len().  Other values return NR_ERR_UNSUPPORTED.
+ */
+#ifndef NR_ENGINE_H
+#define NR_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NR_OK 0
+#define NR_ERR_UNSUPPORTED (-1)
+#define NR_ERR_BADARG (-2)
+#define NR_ERR_LAUNCH (-3)
+
+/* Padded layout constants shared with the host (bf16 operand layouts). */
+#define NR_D 300        /* word_embedding_dim, src/config.py:34 */
+#define NR_KP 320       /* D padded to a multiple of the MFMA K step (32) */
+#define NR_HEADS 15     /* num_attention_heads, src/config.py:45 */
+#define NR_DK 20
+#define NR_NP 304       /* D padded to a multiple of 16 (rows of each packed W_Q/W_K/W_V block) */
+#define NR_QP 208       /* query_vector_dim (200, src/config.py:39) padded to a multiple of 16 */
+
+int nr_version(void);
+const char* nr_last_error(void);
+/* 1 if the MHSA kernels are instantiated for sequence length S (20, 50). */
+int nr_supported_seq_len(int S);
+
+/* K1 -- nn.Embedding forward (src/model/NRMS/news_encoder.py:38): out[i,:] = table[ids[i],:].
+ * Stand-alone gather used for parity and for the HBM-roofline measurement of the embedding gather.
+ * ids: int64[n_tokens]; table: f32[num_rows, d]; out: f32[n_tokens, d]. d % 4 == 0. */
+int nr_gather_rows_f32(const int64_t* ids, const float* table, float* out, int64_t n_tokens, int d,
+                       int64_t num_rows, void* stream);
+
+/* Pack the three nn.Linear(D,D) of MultiHeadSelfAttention (src/model/general/attention/multihead_self.py:36-38)
+ * into the bf16 operand layout of the kernels: Wp bf16[3*NR_NP][NR_KP] (Q rows, then K, then V; zero padded),
+ * bp f32[3*NR_NP].  Must be re-run whenever the fp32 parameters change (optimizer step). */
+int nr_pack_qkv(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                const float* bv, uint16_t* Wp, float* bp, void* stream);
+/* Same for AdditiveAttention.linear (src/model/general/attention/additive.py:17): Wa f32[qdim][D] ->
+ * Wap bf16[NR_QP][NR_KP], bap f32[NR_QP], qvp f32[NR_QP] (zero padded). */
+int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim, uint16_t* Wap,
+                     float* bap, float* qvp, void* stream);
+
+/* Multi-head self-attention forward, src/model/general/attention/multihead_self.py:46-75 with
+ * ScaledDotProductAttention :15-23 (exp / (sum + 1e-8), no W_O), fused with its input stage:
+ *   ids != NULL : news-encoder form, x[t,s,:] = table[ids[t,s],:] (src/model/NRMS/news_encoder.py:38)
+ *                 followed by F.dropout (:38-40) when p_drop > 0;
+ *   ids == NULL : user-encoder form, x = x_dense f32[n_seq, S, D] (src/model/NRMS/user_encoder.py:23).
+ * Output ctx bf16[n_seq*S][NR_KP] (cols >= D are zero); when p_drop > 0 the second F.dropout of the
+ * news encoder (:43-45) is applied to ctx.  Dropout uses a counter-based RNG keyed by (seed, site, element),
+ * reproducible by nr_dropout_mask().  */
+int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense,
+                const uint16_t* Wp, const float* bp, uint16_t* ctx, int64_t n_seq, int S,
+                float p_drop, uint64_t seed, void* stream);
+
+/* AdditiveAttention forward, src/model/general/attention/additive.py:27-53:
+ * out[t,:] = sum_s softmax_s(tanh(ctx[t,s,:] Wa^T + ba) . qv) * ctx[t,s,:].
+ * ctx bf16[n_seq*S][NR_KP]; out f32[n_seq][D]; attn_w f32[n_seq][S] (saved for backward, may be NULL). */
+int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp,
+                    float* out, float* attn_w, int64_t n_seq, int S, void* stream);
+
+/* DotProductClickPredictor.forward, src/model/general/click_predictor/dot_product.py:8-19:
+ * out[b,c] = cand[b,c,:] . user[b,:].  cand f32[B,C,D], user f32[B,D], out f32[B,C]. */
+int nr_score_dot(const float* cand, const float* user, float* out, int64_t B, int C, int d, void* stream);
+
+/* Evaluation-time scorer for ragged impressions (replaces the per-impression loop of
+ * src/evaluate.py:245-260 around NRMS.get_prediction, src/model/NRMS/__init__.py:73-84):
+ * nnz = cand_ptr[n_impr] (host value).  For impression i, for j in [cand_ptr[i], cand_ptr[i+1]): out[j] = news[cand_idx[j],:] . users[user_idx[i],:].
+ * A negative cand_idx selects the all-zero PADDED_NEWS vector (src/evaluate.py:203-204). */
+int nr_score_csr(const float* news, const float* users, const int32_t* cand_idx, const int64_t* cand_ptr,
+                 const int32_t* user_idx, float* out, int64_t n_impr, int64_t nnz, int d, void* stream);
+
+/* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
+ * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */
+int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream);
+
+/* Hardware probe: runs one v_mfma_f32_16x16x32_bf16 on A[16][32], B[32][16] (bf16 bits, row-major)
+ * and writes D f32[16][16]; used by the GPU tests to pin the fragment-layout assumptions. */
+int nr_probe_mfma(const uint16_t* A, const uint16_t* B, float* D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

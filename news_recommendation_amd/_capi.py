@@ -1,0 +1,71 @@
+"""ctypes binding of the C-ABI declared in include/nr_engine.h (libnr_engine.so).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``news_recommendation_amd/csrc/build.sh`` (hipcc, gfx950).  There is NO CPU
+fallback: if the shared object is missing or fails to load, importing callers
+get a RuntimeError.
+"""
+import ctypes
+import os
+from ctypes import c_void_p, c_int, c_int64, c_uint64, c_float, c_char_p
+
+_P = c_void_p
+SIGNATURES = {
+    'nr_version': ([], c_int),
+    'nr_last_error': ([], c_char_p),
+    'nr_supported_seq_len': ([c_int], c_int),
+    'nr_gather_rows_f32': ([_P, _P, _P, c_int64, c_int, c_int64, _P], c_int),
+    'nr_pack_qkv': ([_P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    'nr_pack_additive': ([_P, _P, _P, c_int, _P, _P, _P, _P], c_int),
+    'nr_mhsa_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_additive_fwd': ([_P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    'nr_score_dot': ([_P, _P, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_score_csr': ([_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P], c_int),
+    'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
+    'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
+}
+
+# layout constants mirrored from include/nr_engine.h
+NR_D, NR_KP, NR_HEADS, NR_DK, NR_NP, NR_QP = 300, 320, 15, 20, 304, 208
+
+LIB_NAME = 'libnr_engine.so'
+_lib = None
+
+
+def bind(lib):
+    """Attach argtypes/restype for every exported symbol (raises AttributeError if one is missing)."""
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load():
+    """Load (once) the in-tree HIP library; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            _lib = bind(ctypes.CDLL(path))
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"cannot load {path}: {e}. There is no CPU fallback.") from e
+    return _lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def check(lib, rc):
+    if rc != 0:
+        msg = lib.nr_last_error()
+        raise EngineError(f"nr_engine error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,123 @@
+// Additive-attention pooling forward for gfx950 (src/model/general/attention/additive.py:27-53):
+//   out[t,:] = sum_s softmax_s( tanh(x[t,s,:] Wa^T + ba) . qv ) * x[t,s,:]
+// x arrives as the bf16 ctx tile written by the MHSA kernel ([tokens][KP], K-padded with zeros).
+// Workgroup = 4 waves, NSEQ sequences of S tokens staged in LDS (same 656-B row stride as the MHSA kernel).
+// The [tokens,300]x[300,200] projection runs on MFMA as the TRANSPOSED product (A = Wa rows from L2 held in
+// registers, B = x^T fragments from LDS): a lane then holds 4 query-dim rows of one token, so tanh * qv is
+// reduced in-lane, across the 4 lane groups with two xor-shuffles, and per wave into an LDS partial-score
+// row (no atomics -> deterministic).  Softmax over the S tokens is one wave per sequence; the weighted sum
+// reads the LDS tile once.
+#pragma once
+#include "nr_common.h"
+#include "k_mhsa_fwd.h"
+
+namespace nr {
+
+template <int S, int NSEQ>
+struct AddGeom {
+  static constexpr int TOK = S * NSEQ;
+  static constexpr int MT = (TOK + 15) / 16;
+  static constexpr int ROWS = MT * 16;
+  static constexpr int X_BYTES = ROWS * XS * 2;
+  static constexpr int SC_BYTES = 4 * ROWS * 4;     // per-wave partial scores
+  static constexpr int W_BYTES = ROWS * 4;          // softmax weights
+  static constexpr int SMEM = X_BYTES + SC_BYTES + W_BYTES;
+  static constexpr int NTQ = QP / 16;               // 13 n-tiles of the query dim
+};
+
+struct AdditiveParams {
+  const u16* ctx;      // [n_seq*S][KP]
+  const u16* Wap;      // [QP][KP]
+  const float* bap;    // [QP]
+  const float* qvp;    // [QP]
+  float* out;          // [n_seq][D]
+  float* attn_w;       // [n_seq][S] or null
+  int64_t n_seq;
+};
+
+template <int S, int NSEQ>
+__global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
+  using Gm = AddGeom<S, NSEQ>;
+  NR_SMEM_DECL(smem);
+  u16* Xs = (u16*)smem;
+  float* sc = (float*)(smem + Gm::X_BYTES);            // [4][ROWS]
+  float* wl = (float*)(smem + Gm::X_BYTES + Gm::SC_BYTES);
+  const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
+  const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
+
+  // ---- stage the ctx tile (16-B pieces, 41 per LDS row incl. the stride padding) ------------------------
+  constexpr int PCS = XS / 8;   // 41 16-B pieces per LDS row
+  for (int i = tid; i < Gm::ROWS * PCS; i += WG) {
+    int r = i / PCS, c = i - r * PCS;
+    u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < KP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.ctx + (tok0 + r) * KP + c * 8);
+    *(u16x8*)(Xs + r * XS + c * 8) = v;
+  }
+  for (int i = tid; i < 4 * Gm::ROWS; i += WG) sc[i] = 0.0f;
+  __syncthreads();
+
+  // ---- scores: sum_n tanh(x.Wa[n] + ba[n]) * qv[n] ---------------------------------------------------------
+  const int w_eff = (w + (int)blockIdx.x) & 3;
+  float* myrow = sc + w * Gm::ROWS;
+  for (int cg = 0; cg < (Gm::NTQ + 1) / 2; ++cg) {
+    int G, mb, me;
+    unit_range(Gm::NTQ, Gm::MT, w_eff, cg, G, mb, me);
+    if (mb >= me) continue;
+    auto epi = [&](int wr, int m, f32x4 acc) {
+      f32x4 b4 = *(const f32x4*)(p.bap + wr + 4 * g);
+      f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
+      float s = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += fast_tanh(acc[r] + b4[r]) * q4[r];
+      s += shfl_xor(s, 16);
+      s += shfl_xor(s, 32);
+      if (g == 0) myrow[m * 16 + li] += s;     // lanes 0..15 -> 16 distinct tokens; same wave only
+    };
+    if (G == 2) {
+      int wrow[2] = {(2 * cg) * 16, (2 * cg + 1) * 16};
+      proj_block<2, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[j], m, acc); });
+    } else {
+      int wrow[1] = {(2 * cg) * 16};
+      proj_block<1, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[0], m, acc); });
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax over the S tokens of each sequence (one wave per sequence) ---------------------------------
+  for (int seq = w; seq < NSEQ; seq += 4) {
+    const int r = seq * S + l;
+    const bool live = l < S;
+    float v = live ? (sc[r] + sc[Gm::ROWS + r] + sc[2 * Gm::ROWS + r] + sc[3 * Gm::ROWS + r]) : -3.0e38f;
+    float mx = v;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, shfl_xor(mx, m));
+    float e = live ? fast_exp(v - mx) : 0.0f;
+    float sum = e;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += shfl_xor(sum, m);
+    float wt = e / sum;
+    if (live) {
+      wl[r] = wt;
+      if (p.attn_w != nullptr && seq0 + seq < p.n_seq) p.attn_w[(seq0 + seq) * S + l] = wt;
+    }
+  }
+  __syncthreads();
+
+  // ---- weighted sum: out[seq][c] = sum_s w[s] x[s][c] ------------------------------------------------------
+  for (int i = tid; i < NSEQ * D4; i += WG) {
+    const int seq = i / D4, c = i - seq * D4;
+    if (seq0 + seq >= p.n_seq) continue;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u16* xp = Xs + (seq * S) * XS + c * 4;
+#pragma unroll 5
+    for (int s = 0; s < S; ++s) {
+      u16x4 x = *(const u16x4*)(xp + s * XS);
+      float wt = wl[seq * S + s];
+      acc[0] += wt * bf2f(x[0]); acc[1] += wt * bf2f(x[1]); acc[2] += wt * bf2f(x[2]); acc[3] += wt * bf2f(x[3]);
+    }
+    *(f32x4*)(p.out + ((seq0 + seq) * D4 + c) * 4) = acc;
+  }
+}
+
+}  // namespace nr

@@ -1,0 +1,337 @@
+// Fused multi-head self-attention forward for gfx950:
+//   [embedding gather | dense load] -> (dropout) -> QKV projections (bf16 MFMA) -> per-head
+//   exp/(sum+1e-8) attention (MFMA, probabilities stay in registers) -> ctx (bf16) in HBM.
+// Replaces src/model/general/attention/multihead_self.py:15-23,46-75 and the embedding/dropout front of
+// src/model/NRMS/news_encoder.py:38-45.
+//
+// Workgroup = 4 waves, NSEQ sequences of S tokens (80 tokens for titles, 50 for a click history).
+// LDS (<= 80 KiB so two workgroups share a CU and overlap each other's gather / MFMA / VALU phases):
+//   Xs   [ROWS][XS]  bf16  token tile, K padded 300->320 (zeros), row stride 656 B (conflict-free fragments)
+//   Qs,Ks[ROWS][QS]  bf16  Q and K of the current 4-head group        } same region:
+//   Vt   [NSEQ][4][20][VS] bf16  V of the group, transposed (dv-major) } V is produced after Q,K are consumed
+// Heads are processed in groups of 4 (80 columns = exactly 5 MFMA n-tiles).  Per group:
+//   1. Q,K = W_{q,k} X^T + b  computed TRANSPOSED (A = W rows straight from L2 into registers, B = X^T from
+//      LDS) so every lane ends up with 4 consecutive q/k columns of one token -> one 8-B LDS store.
+//   2. S^T = K Q^T per (sequence, head): lane holds, for query column l&15, keys 4*(l>>4)+r of each key tile;
+//      exp / row-sum via two xor-shuffles; P packed to bf16 stays in registers in exactly the layout the next
+//      MFMA wants as its B operand (k-slot order (l>>4, j) is shared by A and B, so no transposition needed).
+//   3. V = X W_v^T + b computed NON-transposed (A = X) so a lane holds 4 consecutive tokens of one v column
+//      -> one 8-B store into the dv-major Vt tile (over the now dead Q/K tiles).
+//   4. ctx^T = V^T P^T: lane holds 4 consecutive dv of one query token -> one 8-B global store.
+#pragma once
+#include "nr_common.h"
+
+namespace nr {
+
+template <int S, int NSEQ>
+struct MhsaGeom {
+  static constexpr int TOK = S * NSEQ;
+  static constexpr int MT = (TOK + 15) / 16;
+  static constexpr int ROWS = MT * 16;
+  static constexpr int QT = (S + 15) / 16;            // query / key tiles per sequence
+  static constexpr int SP4 = (S + 3) / 4 * 4;
+  static constexpr int VS = SP4;                      // Vt row stride (elements)
+  static constexpr int TOKP = NSEQ == 1 ? SP4 : TOK;  // tokens whose V is stored
+  static constexpr int NPW = (NSEQ * HG + 3) / 4;     // (sequence, head) pairs per wave and group
+  static constexpr int DT = (DK + 15) / 16;           // dv tiles
+  static constexpr int X_BYTES = ROWS * XS * 2;
+  static constexpr int QK_BYTES = 2 * ROWS * QS * 2;
+  static constexpr int VT_BYTES = NSEQ * HG * DK * VS * 2 + 16;
+  static constexpr int R_BYTES = QK_BYTES > VT_BYTES ? QK_BYTES : VT_BYTES;
+  static constexpr int SMEM = X_BYTES + R_BYTES;
+  static_assert(NSEQ == 1 || S % 4 == 0, "packed sequences need S % 4 == 0");
+  static_assert(S <= 64, "one wave row per sequence");
+  static_assert(ROWS * 4 <= R_BYTES, "id staging fits");
+};
+
+struct MhsaParams {
+  const int64_t* ids;      // [n_seq*S] or null
+  const float* table;      // [num_rows][D]
+  int64_t num_rows;
+  const float* x_dense;    // [n_seq*S][D] when ids == null
+  const u16* Wp;           // [3*NP][KP]
+  const float* bp;         // [3*NP]
+  u16* ctx;                // [n_seq*S][KP]
+  int64_t n_seq;
+  DropCfg dc;
+};
+
+// One (column-group, token-tile range) block of the projection GEMM.  G n-tiles of W are held in registers
+// for the full K (G*40 VGPRs) and reused over the token tiles; the X fragment read from LDS feeds G MFMAs.
+template <int G, bool W_IS_A, typename Epi>
+__device__ __forceinline__ void proj_block(const u16* __restrict__ Wp, const int (&wrow)[G], const u16* Xs, int m_begin,
+                                           int m_end, Epi&& epi) {
+  const int l = lane_id(), g = l >> 4, li = l & 15;
+  u16x8 wf[G][KSTEPS];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const u16* wp = Wp + (size_t)(wrow[j] + li) * KP + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wf[j][ks] = *(const u16x8*)(wp + ks * 32);
+  }
+  for (int m = m_begin; m < m_end; ++m) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u16* xp = Xs + (m * 16 + li) * XS + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      u16x8 xf = *(const u16x8*)(xp + ks * 32);
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        acc[j] = W_IS_A ? mfma_16x16x32_bf16(wf[j][ks], xf, acc[j]) : mfma_16x16x32_bf16(xf, wf[j][ks], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) epi(j, m, acc[j]);
+  }
+}
+
+// Stage the workgroup's token tile into LDS as bf16 (gather from the fp32 table, or dense fp32 rows).
+template <int S, int NSEQ>
+__device__ __forceinline__ void stage_tokens(const MhsaParams& p, u16* Xs, int* ids_s, int64_t seq0) {
+  using Gm = MhsaGeom<S, NSEQ>;
+  const int tid = threadIdx.x;
+  const bool gather = p.ids != nullptr;
+  const int64_t tok0 = seq0 * S;
+  const int64_t tok_total = p.n_seq * S;
+  // ids (or validity flags) -> LDS
+  for (int r = tid; r < Gm::ROWS; r += WG) {
+    int v = -1;
+    if (r < Gm::TOK && tok0 + r < tok_total) {
+      if (gather) {
+        int64_t id = p.ids[tok0 + r];
+        id = id < 0 ? 0 : (id >= p.num_rows ? p.num_rows - 1 : id);
+        v = (int)id;
+      } else {
+        v = 0;
+      }
+    }
+    ids_s[r] = v;
+  }
+  // zero the K padding (cols D..XS) of every row
+  constexpr int PADQ = (XS - D) / 4;
+  for (int i = tid; i < Gm::ROWS * PADQ; i += WG) {
+    int r = i / PADQ, c = i - r * PADQ;
+    *(u16x4*)(Xs + r * XS + D + c * 4) = u16x4{0, 0, 0, 0};
+  }
+  __syncthreads();
+  constexpr int TOTAL = Gm::ROWS * D4;
+  constexpr int U = 8;   // independent 16-B loads in flight per lane
+  for (int base = 0; base < TOTAL; base += WG * U) {
+    f32x4 v[U];
+    int rr[U], cc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int i = base + u * WG + tid;
+      int r = i / D4, c = i - r * D4;
+      rr[u] = r; cc[u] = c;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < TOTAL) {
+        int id = ids_s[r];
+        if (id >= 0) {
+          const float* src = gather ? p.table + ((size_t)id * D4 + c) * 4 : p.x_dense + ((size_t)(tok0 + r) * D4 + c) * 4;
+          v[u] = *(const f32x4*)src;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int i = base + u * WG + tid;
+      if (i < TOTAL) {
+        f32x4 x = v[u];
+        if (p.dc.enabled) {
+          uint32_t keep = drop_keep4(p.dc, 1u, (uint64_t)(tok0 + rr[u]) * D4 + cc[u]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * p.dc.scale : 0.0f;
+        }
+        *(u16x4*)(Xs + rr[u] * XS + cc[u] * 4) = pack4(x);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int S, int NSEQ>
+__global__ __launch_bounds__(WG, 2) void mhsa_fwd_kernel(MhsaParams p) {
+  using Gm = MhsaGeom<S, NSEQ>;
+  NR_SMEM_DECL(smem);
+  u16* Xs = (u16*)smem;
+  u16* Qs = (u16*)(smem + Gm::X_BYTES);
+  u16* Ks = Qs + Gm::ROWS * QS;
+  u16* Vt = Qs;
+  const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
+
+  stage_tokens<S, NSEQ>(p, Xs, (int*)Qs, seq0);
+
+  const float inv_sqrt_dk = 1.0f / sqrtf((float)DK);
+
+  for (int hg = 0; hg < NGROUPS; ++hg) {
+    const int nh = (H - hg * HG) < HG ? (H - hg * HG) : HG;
+    const int NT = (nh * DK + 15) / 16;
+    const int w_eff = (w + hg + (int)blockIdx.x) & 3;     // rotate the wave that gets the odd unit
+
+    // ---- 1. Q, K projections (transposed product) -> Qs, Ks ------------------------------------------
+    for (int cg = 0; cg < NT; ++cg) {
+      int G, mb, me;
+      unit_range(2 * NT, Gm::MT, w_eff, cg, G, mb, me);
+      if (mb >= me) continue;
+      int wrow[2], ncol[2];
+      u16* dst[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int t = 2 * cg + j;
+        bool isq = t < NT;
+        int tt = isq ? t : t - NT;
+        wrow[j] = (isq ? 0 : NP) + hg * (HG * DK) + tt * 16;
+        ncol[j] = tt * 16;
+        dst[j] = isq ? Qs : Ks;
+      }
+      proj_block<2, true>(p.Wp, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) {
+        f32x4 b4 = *(const f32x4*)(p.bp + wrow[j] + 4 * g);
+        acc += b4;
+        *(u16x4*)(dst[j] + (m * 16 + li) * QS + ncol[j] + 4 * g) = pack4(acc);
+      });
+    }
+    __syncthreads();
+
+    // ---- 2. scores S^T = K Q^T, exp / (sum + 1e-8), P -> registers ---------------------------------------
+    u16x4 pk[Gm::NPW][Gm::QT][Gm::QT];
+#pragma unroll
+    for (int i = 0; i < Gm::NPW; ++i) {
+      const int pidx = w + 4 * i;
+      if (pidx < NSEQ * nh) {
+        const int seq = pidx / nh, hd = pidx - seq * nh;
+        u16x8 kf[Gm::QT], qf[Gm::QT];
+#pragma unroll
+        for (int t = 0; t < Gm::QT; ++t) {
+          int row = seq * S + t * 16 + li;
+          row = row < Gm::ROWS ? row : Gm::ROWS - 1;
+          const u16* kp_ = Ks + row * QS + hd * DK + 8 * g;
+          const u16* qp_ = Qs + row * QS + hd * DK + 8 * g;
+          u16x4 z = u16x4{0, 0, 0, 0};
+          u16x4 klo = (8 * g < DK) ? *(const u16x4*)kp_ : z;
+          u16x4 khi = (8 * g + 4 < DK) ? *(const u16x4*)(kp_ + 4) : z;
+          u16x4 qlo = (8 * g < DK) ? *(const u16x4*)qp_ : z;
+          u16x4 qhi = (8 * g + 4 < DK) ? *(const u16x4*)(qp_ + 4) : z;
+          kf[t] = cat8(klo, khi);
+          qf[t] = cat8(qlo, qhi);
+        }
+#pragma unroll
+        for (int qt = 0; qt < Gm::QT; ++qt) {
+          f32x4 sacc[Gm::QT];
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int kt = 0; kt < Gm::QT; ++kt) {
+            sacc[kt] = mfma_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              sacc[kt][r] *= inv_sqrt_dk;
+              if (kt * 16 + 4 * g + r < S) mx = fmaxf(mx, sacc[kt][r]);
+            }
+          }
+          mx = fmaxf(mx, shfl_xor(mx, 16));
+          mx = fmaxf(mx, shfl_xor(mx, 32));
+          float sum = 0.0f;
+#pragma unroll
+          for (int kt = 0; kt < Gm::QT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float e = (kt * 16 + 4 * g + r < S) ? fast_exp(sacc[kt][r] - mx) : 0.0f;
+              sacc[kt][r] = e;
+              sum += e;
+            }
+          sum += shfl_xor(sum, 16);
+          sum += shfl_xor(sum, 32);
+          // exp(s)/(sum exp(s) + 1e-8)  ==  exp(s-mx)/(sum exp(s-mx) + 1e-8*exp(-mx))   (multihead_self.py:16-20)
+          float rden = fast_rcp(sum + 1e-8f * fast_exp(-mx));
+#pragma unroll
+          for (int kt = 0; kt < Gm::QT; ++kt) pk[i][kt][qt] = pack4(sacc[kt] * rden);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 3. V projection (A = X) -> Vt (dv-major), overwriting Q/K ---------------------------------------
+    for (int cg = 0; cg < (NT + 1) / 2; ++cg) {
+      int G, mb, me;
+      unit_range(NT, Gm::MT, w_eff, cg, G, mb, me);
+      if (mb >= me) continue;
+      auto epi = [&](int wr, int t, int m, f32x4 acc) {
+        const int vcol = t * 16 + li;
+        const int t0 = m * 16 + 4 * g;
+        if (vcol < nh * DK && t0 < Gm::TOKP) {
+          const float b = p.bp[wr + li];
+          acc += f32x4{b, b, b, b};
+          const int seq = t0 / S, tis = t0 - seq * S;
+          const int hd = vcol / DK, dv = vcol - hd * DK;
+          *(u16x4*)(Vt + ((seq * HG + hd) * DK + dv) * Gm::VS + tis) = pack4(acc);
+        }
+      };
+      if (G == 2) {
+        int wrow[2] = {2 * NP + hg * (HG * DK) + (2 * cg) * 16, 2 * NP + hg * (HG * DK) + (2 * cg + 1) * 16};
+        proj_block<2, false>(p.Wp, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[j], 2 * cg + j, m, acc); });
+      } else {
+        int wrow[1] = {2 * NP + hg * (HG * DK) + (2 * cg) * 16};
+        proj_block<1, false>(p.Wp, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[0], 2 * cg, m, acc); });
+      }
+    }
+    __syncthreads();
+
+    // ---- 4. ctx^T = V^T P^T -> global ctx (bf16), second dropout fused ------------------------------------
+#pragma unroll
+    for (int i = 0; i < Gm::NPW; ++i) {
+      const int pidx = w + 4 * i;
+      if (pidx < NSEQ * nh) {
+        const int seq = pidx / nh, hd = pidx - seq * nh;
+        const int64_t seqg = seq0 + seq;
+#pragma unroll
+        for (int dt = 0; dt < Gm::DT; ++dt) {
+          int dvrow = dt * 16 + li;
+          dvrow = dvrow < DK ? dvrow : DK - 1;
+          const u16* vb = Vt + ((seq * HG + hd) * DK + dvrow) * Gm::VS;
+          u16x8 af[(Gm::QT + 1) / 2];
+#pragma unroll
+          for (int kp = 0; kp < (Gm::QT + 1) / 2; ++kp) {
+            const int key0 = (2 * kp) * 16 + 4 * g, key1 = (2 * kp + 1) * 16 + 4 * g;
+            u16x4 z = u16x4{0, 0, 0, 0};
+            u16x4 lo = key0 < Gm::SP4 ? *(const u16x4*)(vb + key0) : z;
+            u16x4 hi = (2 * kp + 1 < Gm::QT && key1 < Gm::SP4) ? *(const u16x4*)(vb + key1) : z;
+            af[kp] = cat8(lo, hi);
+          }
+#pragma unroll
+          for (int qt = 0; qt < Gm::QT; ++qt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < (Gm::QT + 1) / 2; ++kp) {
+              u16x4 hi = (2 * kp + 1 < Gm::QT) ? pk[i][(2 * kp + 1 < Gm::QT) ? 2 * kp + 1 : 0][qt] : u16x4{0, 0, 0, 0};
+              acc = mfma_16x16x32_bf16(af[kp], cat8(pk[i][2 * kp][qt], hi), acc);
+            }
+            const int dv0 = dt * 16 + 4 * g, q = qt * 16 + li;
+            if (dv0 < DK && q < S && seqg < p.n_seq) {
+              const int64_t tok = seqg * S + q;
+              const int col = (hg * HG + hd) * DK + dv0;
+              if (p.dc.enabled) {
+                uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)tok * D4 + (col >> 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = ((keep >> j) & 1u) ? acc[j] * p.dc.scale : 0.0f;
+              }
+              *(u16x4*)(p.ctx + tok * KP + col) = pack4(acc);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // zero the K padding of the ctx rows this workgroup owns (cols D..KP)
+  constexpr int PADQ = (KP - D) / 4;
+  for (int i = tid; i < Gm::TOK * PADQ; i += WG) {
+    int r = i / PADQ, c = i - r * PADQ;
+    int64_t tok = seq0 * S + r;
+    if (tok < p.n_seq * S) *(u16x4*)(p.ctx + tok * KP + D + c * 4) = u16x4{0, 0, 0, 0};
+  }
+}
+
+}  // namespace nr

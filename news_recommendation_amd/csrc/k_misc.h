@@ -1,0 +1,139 @@
+// Small kernels: stand-alone embedding gather, weight packing, dot-product scorers, dropout-mask export, MFMA probe.
+#pragma once
+#include "nr_common.h"
+
+namespace nr {
+
+// ---- K1: stand-alone embedding row gather (nn.Embedding forward) -------------------------------------------
+// One float4 per lane; a d=300 row is 75 float4, so consecutive lanes read consecutive 16-B pieces of a row
+// (coalesced 1200-B row reads).  Grid-stride over float4 pieces.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                          float* __restrict__ out, int64_t n_tokens, int d4, int64_t num_rows) {
+  int64_t total = n_tokens * d4;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t tok = i / d4;
+    int c = (int)(i - tok * d4);
+    int64_t id = ids[tok];
+    id = id < 0 ? 0 : (id >= num_rows ? num_rows - 1 : id);
+    f32x4 v = *(const f32x4*)(table + (id * d4 + c) * 4);
+    *(f32x4*)(out + i * 4) = v;
+  }
+}
+
+// ---- weight packing: fp32 nn.Linear parameters -> zero-padded bf16 MFMA operand layout -----------------------
+__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                       const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                       u16* __restrict__ Wp, float* __restrict__ bp) {
+  int total = 3 * NP * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int row = i / KP, k = i - row * KP;
+    int which = row / NP, n = row - which * NP;
+    const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
+    float v = (n < D && k < D) ? W[n * D + k] : 0.0f;
+    Wp[i] = f2bf(v);
+    if (k == 0) {
+      const float* b = which == 0 ? bq : (which == 1 ? bk : bv);
+      bp[row] = n < D ? b[n] : 0.0f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                            const float* __restrict__ qv, int qdim, u16* __restrict__ Wap,
+                                                            float* __restrict__ bap, float* __restrict__ qvp) {
+  int total = QP * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n = i / KP, k = i - n * KP;
+    float v = (n < qdim && k < D) ? Wa[n * D + k] : 0.0f;
+    Wap[i] = f2bf(v);
+    if (k == 0) {
+      bap[n] = n < qdim ? ba[n] : 0.0f;
+      qvp[n] = n < qdim ? qv[n] : 0.0f;
+    }
+  }
+}
+
+// ---- K7: dot-product scorers -------------------------------------------------------------------------------
+// one wave per (b, c) pair; lanes stride the feature dim with float4 loads, shuffle-reduce.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void score_dot_kernel(const float* __restrict__ cand, const float* __restrict__ user,
+                                                        float* __restrict__ out, int64_t B, int C, int d4) {
+  int64_t pair = (int64_t)blockIdx.x * 4 + wave_id();
+  int64_t npairs = B * C;
+  int l = lane_id();
+  float acc = 0.0f;
+  if (pair < npairs) {
+    int64_t b = pair / C;
+    const f32x4* cv = (const f32x4*)(cand + pair * d4 * 4);
+    const f32x4* uv = (const f32x4*)(user + b * d4 * 4);
+    for (int c = l; c < d4; c += 64) {
+      f32x4 x = cv[c], y = uv[c];
+      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+  }
+  acc = wave_sum(acc);
+  if (pair < npairs && l == 0) out[pair] = acc;
+}
+
+// ragged (CSR) evaluation scorer: one wave per candidate slot; impression found by the block's binary search.
+__global__ __launch_bounds__(256) void score_csr_kernel(const float* __restrict__ news, const float* __restrict__ users,
+                                                        const int32_t* __restrict__ cand_idx, const int64_t* __restrict__ cand_ptr,
+                                                        const int32_t* __restrict__ user_idx, float* __restrict__ out,
+                                                        int64_t n_impr, int64_t nnz, int d4) {
+  int64_t j = (int64_t)blockIdx.x * 4 + wave_id();
+  int l = lane_id();
+  float acc = 0.0f;
+  bool live = j < nnz;
+  if (live) {
+    // largest i with cand_ptr[i] <= j
+    int64_t lo = 0, hi = n_impr;
+    while (hi - lo > 1) {
+      int64_t mid = (lo + hi) >> 1;
+      if (cand_ptr[mid] <= j) lo = mid; else hi = mid;
+    }
+    int32_t ni = cand_idx[j];
+    if (ni >= 0) {
+      const f32x4* cv = (const f32x4*)(news + (int64_t)ni * d4 * 4);
+      const f32x4* uv = (const f32x4*)(users + (int64_t)user_idx[lo] * d4 * 4);
+      for (int c = l; c < d4; c += 64) {
+        f32x4 x = cv[c], y = uv[c];
+        acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (live && l == 0) out[j] = acc;
+}
+
+// ---- dropout mask export (verification of the fused kernels' RNG) -------------------------------------------
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, int64_t n_elem, DropCfg dc, int site) {
+  int64_t nquad = (n_elem + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t m = drop_keep4(dc, (uint32_t)site, (uint64_t)q);
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n_elem) mask[q * 4 + j] = ((m >> j) & 1u) ? 1.0f : 0.0f;
+  }
+}
+
+// ---- MFMA layout probe ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void probe_mfma_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ Dm) {
+  int l = lane_id();
+  int g = l >> 4, i = l & 15;
+  u16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = A[i * 32 + g * 8 + j];          // A[i][k]
+    b[j] = B[(g * 8 + j) * 16 + i];        // B[k][n=i]
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = mfma_16x16x32_bf16(a, b, c);
+  for (int r = 0; r < 4; ++r) Dm[(g * 4 + r) * 16 + i] = c[r];
+}
+
+}  // namespace nr

@@ -1,0 +1,161 @@
+// libnr_engine.so -- C-ABI entry points (include/nr_engine.h) and kernel launches.
+#include "nr_common.h"
+#include "k_misc.h"
+#include "k_mhsa_fwd.h"
+#include "k_additive_fwd.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return NR_ERR_LAUNCH;
+  }
+  return NR_OK;
+}
+
+nr::DropCfg make_drop(float p, uint64_t seed) {
+  nr::DropCfg dc;
+  dc.enabled = p > 0.0f ? 1 : 0;
+  dc.k0 = (uint32_t)seed;
+  dc.k1 = (uint32_t)(seed >> 32);
+  double t = (double)p * 4294967296.0;
+  dc.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  dc.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+  return dc;
+}
+
+int grid_for(int64_t work, int per_block, int cap) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+template <typename K>
+int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
+
+}  // namespace
+
+extern "C" {
+
+int nr_version(void) { return 1; }
+const char* nr_last_error(void) { return g_err; }
+int nr_supported_seq_len(int S) { return (S == 20 || S == 50) ? 1 : 0; }
+
+int nr_gather_rows_f32(const int64_t* ids, const float* table, float* out, int64_t n_tokens, int d, int64_t num_rows,
+                       void* stream) {
+  if (!ids || !table || !out || d <= 0 || (d & 3) || num_rows <= 0 || n_tokens < 0) return fail(NR_ERR_BADARG, "nr_gather_rows_f32: bad argument");
+  if (n_tokens == 0) return NR_OK;
+  int grid = grid_for(n_tokens * (d / 4), 256, 256 * 8);
+  NR_LAUNCH(nr::gather_rows_kernel, grid, 256, 0, (hipStream_t)stream, ids, table, out, n_tokens, d / 4, num_rows);
+  return check_launch("nr_gather_rows_f32");
+}
+
+int nr_pack_qkv(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                uint16_t* Wp, float* bp, void* stream) {
+  if (!Wq || !bq || !Wk || !bk || !Wv || !bv || !Wp || !bp) return fail(NR_ERR_BADARG, "nr_pack_qkv: null pointer");
+  NR_LAUNCH(nr::pack_qkv_kernel, 256, 256, 0, (hipStream_t)stream, Wq, bq, Wk, bk, Wv, bv, Wp, bp);
+  return check_launch("nr_pack_qkv");
+}
+
+int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim, uint16_t* Wap, float* bap, float* qvp,
+                     void* stream) {
+  if (!Wa || !ba || !qv || !Wap || !bap || !qvp) return fail(NR_ERR_BADARG, "nr_pack_additive: null pointer");
+  if (qdim <= 0 || qdim > NR_QP) return fail(NR_ERR_UNSUPPORTED, "nr_pack_additive: query_vector_dim must be in [1,208]");
+  NR_LAUNCH(nr::pack_additive_kernel, 64, 256, 0, (hipStream_t)stream, Wa, ba, qv, qdim, Wap, bap, qvp);
+  return check_launch("nr_pack_additive");
+}
+
+int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                const float* bp, uint16_t* ctx, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+  if (!Wp || !bp || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: bad argument");
+  if ((ids == nullptr) == (x_dense == nullptr)) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: exactly one of ids / x_dense");
+  if (ids && (!table || num_rows <= 0)) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: ids without table");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: dropout probability out of range");
+  if (n_seq == 0) return NR_OK;
+  nr::MhsaParams p;
+  p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_dense = x_dense;
+  p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  if (S == 20) {
+    constexpr int NSEQ = 4;
+    using G = nr::MhsaGeom<20, NSEQ>;
+    if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 50) {
+    constexpr int NSEQ = 1;
+    using G = nr::MhsaGeom<50, NSEQ>;
+    if (allow_smem(nr::mhsa_fwd_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::mhsa_fwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    return fail(NR_ERR_UNSUPPORTED, "nr_mhsa_fwd: sequence length not instantiated (20, 50)");
+  }
+  return check_launch("nr_mhsa_fwd");
+}
+
+int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out,
+                    float* attn_w, int64_t n_seq, int S, void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || !out || n_seq < 0) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
+  if (n_seq == 0) return NR_OK;
+  nr::AdditiveParams p;
+  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.attn_w = attn_w; p.n_seq = n_seq;
+  if (S == 20) {
+    constexpr int NSEQ = 4;
+    using G = nr::AddGeom<20, NSEQ>;
+    if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 50) {
+    constexpr int NSEQ = 1;
+    using G = nr::AddGeom<50, NSEQ>;
+    if (allow_smem(nr::additive_fwd_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_fwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd: sequence length not instantiated (20, 50)");
+  }
+  return check_launch("nr_additive_fwd");
+}
+
+int nr_score_dot(const float* cand, const float* user, float* out, int64_t B, int C, int d, void* stream) {
+  if (!cand || !user || !out || B < 0 || C <= 0 || d <= 0 || (d & 3)) return fail(NR_ERR_BADARG, "nr_score_dot: bad argument");
+  if (B == 0) return NR_OK;
+  int64_t pairs = B * C;
+  NR_LAUNCH(nr::score_dot_kernel, (pairs + 3) / 4, 256, 0, (hipStream_t)stream, cand, user, out, B, C, d / 4);
+  return check_launch("nr_score_dot");
+}
+
+int nr_score_csr(const float* news, const float* users, const int32_t* cand_idx, const int64_t* cand_ptr,
+                 const int32_t* user_idx, float* out, int64_t n_impr, int64_t nnz, int d, void* stream) {
+  if (!news || !users || !cand_idx || !cand_ptr || !user_idx || !out || n_impr < 0 || nnz < 0 || d <= 0 || (d & 3))
+    return fail(NR_ERR_BADARG, "nr_score_csr: bad argument");
+  if (nnz == 0 || n_impr == 0) return NR_OK;
+  NR_LAUNCH(nr::score_csr_kernel, (nnz + 3) / 4, 256, 0, (hipStream_t)stream, news, users, cand_idx, cand_ptr, user_idx, out,
+            n_impr, nnz, d / 4);
+  return check_launch("nr_score_csr");
+}
+
+int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream) {
+  if (!mask || n_elem < 0 || p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_dropout_mask: bad argument");
+  if (n_elem == 0) return NR_OK;
+  nr::DropCfg dc = make_drop(p_drop, seed);
+  dc.enabled = 1;
+  NR_LAUNCH(nr::dropout_mask_kernel, grid_for((n_elem + 3) / 4, 256, 2048), 256, 0, (hipStream_t)stream, mask, n_elem, dc, site);
+  return check_launch("nr_dropout_mask");
+}
+
+int nr_probe_mfma(const uint16_t* A, const uint16_t* B, float* D, void* stream) {
+  if (!A || !B || !D) return fail(NR_ERR_BADARG, "nr_probe_mfma: null pointer");
+  NR_LAUNCH(nr::probe_mfma_kernel, 1, 64, 0, (hipStream_t)stream, A, B, D);
+  return check_launch("nr_probe_mfma");
+}
+
+}  // extern "C"

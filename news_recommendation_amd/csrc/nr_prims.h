@@ -1,0 +1,55 @@
+// Device primitives for the gfx950 (CDNA4 / MI355X) kernels of the NRMS scoring engine.
+// Wave = 64 lanes.  MFMA fragment layout (v_mfma_f32_16x16x32_bf16):
+//   A: lane l holds A[i = l&15][k = (l>>4)*8 + j], j = 0..7   (8 bf16 = 4 VGPRs)
+//   B: lane l holds B[k = (l>>4)*8 + j][n = l&15]
+//   C/D: lane l, reg r  ->  row = (l>>4)*4 + r, col = l&15      (4 fp32)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NR_SMEM_DECL(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+#define NR_LAUNCH(kern, gx, bx, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
+
+namespace nr {
+
+typedef unsigned short u16;
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+__device__ __forceinline__ float bf2f(u16 h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7 in fp32
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
+
+inline int set_max_dynamic_lds(const void* kernel, int bytes) {
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+__device__ __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+}  // namespace nr

@@ -1,0 +1,190 @@
+// Wave-level CPU emulator of the device primitives used by the engine's HIP
+// kernels.  TEST INFRASTRUCTURE ONLY: it exists so that kernel *logic* (tiling,
+// fragment indexing, barriers, reductions) can be debugged bit-for-bit in the
+// GPU-less build container.  It shadows news_recommendation_amd/csrc/nr_prims.h
+// on the include path of the emulation build (tests/emu/build_emu.sh) and is
+// never compiled into, or loaded by, the product library.
+//
+// Execution model: one OS thread; every GPU thread of a workgroup is a fiber
+// (hand-rolled x86-64 context switch).  Fibers run until they reach a
+// collective (workgroup barrier, wave shuffle, MFMA) and then yield, so a
+// missing barrier shows up as stale data just as (more aggressively than) on
+// hardware.  Workgroups run one after another.
+//
+// MFMA semantics follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//   v_mfma_f32_16x16x32_bf16: lane l holds A[i=l&15][k=(l>>4)*8+j], B[k=(l>>4)*8+j][n=l&15],
+//   C/D: col = l&15, row = (l>>4)*4 + reg.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <functional>
+
+#define NR_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace nr_emu {
+
+struct Dim3 { unsigned x, y, z; };
+
+struct Fiber {
+  void* sp = nullptr;
+  unsigned char* stack = nullptr;
+  bool done = false;
+  Dim3 tid{0, 0, 0};
+};
+
+struct WaveState {
+  int arrived = 0;
+  unsigned gen = 0;
+  uint32_t stage[64][12];   // a(4 dwords) b(4 dwords) c(4 dwords) or shuffle payload
+};
+
+struct BlockState {
+  std::vector<Fiber> fibers;
+  std::vector<WaveState> waves;
+  int nthreads = 0;
+  int alive = 0;
+  int arrived = 0;
+  unsigned gen = 0;
+  int cur = 0;
+  void* sched_sp = nullptr;
+  Dim3 bid{0, 0, 0}, bdim{1, 1, 1}, gdim{1, 1, 1};
+  unsigned char* smem = nullptr;
+  size_t smem_bytes = 0;
+  std::function<void()> body;
+};
+
+extern BlockState* g_blk;
+
+extern "C" void nr_emu_switch(void** save_sp, void* load_sp);
+
+inline Fiber& cur_fiber() { return g_blk->fibers[g_blk->cur]; }
+inline void yield() { Fiber& f = cur_fiber(); nr_emu_switch(&f.sp, g_blk->sched_sp); }
+
+inline void block_sync() {
+  BlockState* b = g_blk;
+  unsigned my = b->gen;
+  if (++b->arrived == b->alive) { b->arrived = 0; b->gen++; return; }
+  while (b->gen == my) yield();
+}
+inline void wave_sync() {
+  BlockState* b = g_blk;
+  int w = b->cur / 64;
+  WaveState& ws = b->waves[w];
+  int lanes = std::min(64, b->nthreads - w * 64);
+  unsigned my = ws.gen;
+  if (++ws.arrived == lanes) { ws.arrived = 0; ws.gen++; return; }
+  while (ws.gen == my) yield();
+}
+
+void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body);
+
+}  // namespace nr_emu
+
+#define threadIdx (nr_emu::cur_fiber().tid)
+#define blockIdx (nr_emu::g_blk->bid)
+#define blockDim (nr_emu::g_blk->bdim)
+#define gridDim (nr_emu::g_blk->gdim)
+#define __syncthreads() nr_emu::block_sync()
+
+// dynamic LDS
+#define NR_SMEM_DECL(name) unsigned char* name = nr_emu::g_blk->smem
+
+// launch: NR_LAUNCH(kernel, grid_x, block_x, smem_bytes, stream, args...)
+#define NR_LAUNCH(kern, gx, bx, smem, stream, ...)                                           \
+  nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), 1, 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
+                 (size_t)(smem), [&]() { kern(__VA_ARGS__); })
+
+namespace nr {
+
+typedef unsigned short u16;
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+__forceinline__ float bf2f(u16 h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+__forceinline__ u16 f2bf(float f) {   // round-to-nearest-even, as v_cvt_pk_bf16_f32
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+__forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  memcpy(&ws.stage[l][0], &a, 16);
+  memcpy(&ws.stage[l][4], &b, 16);
+  nr_emu::wave_sync();
+  // D[row][col], col = l&15, row = (l>>4)*4 + r ; A[i][k], lane (i, g) holds k = g*8+j
+  f32x4 d = c;
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      u16 av[8], bv[8];
+      memcpy(av, &ws.stage[g * 16 + row][0], 16);
+      memcpy(bv, &ws.stage[g * 16 + col][4], 16);
+      for (int j = 0; j < 8; ++j) acc += bf2f(av[j]) * bf2f(bv[j]);
+    }
+    d[r] = acc;
+  }
+  nr_emu::wave_sync();
+  return d;
+}
+
+__forceinline__ float shfl_xor(float v, int mask) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  memcpy(&ws.stage[l][0], &v, 4);
+  nr_emu::wave_sync();
+  float r; memcpy(&r, &ws.stage[(l ^ mask) & 63][0], 4);
+  nr_emu::wave_sync();
+  return r;
+}
+__forceinline__ float shfl(float v, int src) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  memcpy(&ws.stage[l][0], &v, 4);
+  nr_emu::wave_sync();
+  float r; memcpy(&r, &ws.stage[src & 63][0], 4);
+  nr_emu::wave_sync();
+  return r;
+}
+
+__forceinline__ float fast_exp(float x) { return expf(x); }
+__forceinline__ float fast_tanh(float x) { return tanhf(x); }
+__forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+
+__forceinline__ void atomic_add(float* p, float v) { *p += v; }
+
+template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }
+
+inline int set_max_dynamic_lds(const void*, int) { return 0; }
+
+__forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+}  // namespace nr

@@ -1,0 +1,248 @@
+"""Backend-agnostic parity checks of the HIP kernels against the oracle.
+Called with the CPU wave-emulation backend (not gpu) and with the real library on cuda:0 (gpu)."""
+import numpy as np
+
+from news_recommendation_amd import _capi
+from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_QP, NR_HEADS
+from oracle import nrms_numpy as onp
+from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
+
+H = NR_HEADS
+
+
+def ck(be, rc):
+    _capi.check(be.lib, rc)
+
+
+def make_params(seed=0, V=300, qdim=200, emb_std=0.5):
+    rng = np.random.default_rng(seed)
+    return onp.random_nrms_params(rng, V, NR_D, qdim, np.float32, emb_std=emb_std)
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_probe_mfma(be):
+    rng = np.random.default_rng(1)
+    A = bf16_round(rng.normal(size=(16, 32)).astype(np.float32))
+    B = bf16_round(rng.normal(size=(32, 16)).astype(np.float32))
+    B[3, 5] = 7.0     # asymmetric marker
+    d = be.poison((16, 16), np.float32)
+    ck(be, be.lib.nr_probe_mfma(be.ptr(be.dev(f32_to_bf16(A))), be.ptr(be.dev(f32_to_bf16(B))), be.ptr(d), be.stream))
+    be.sync()
+    np.testing.assert_allclose(be.np(d), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+def check_gather(be, n_tokens=1000, V=777):
+    rng = np.random.default_rng(2)
+    table = rng.normal(size=(V, NR_D)).astype(np.float32)
+    ids = rng.integers(0, V, size=n_tokens).astype(np.int64)
+    ids[:3] = [0, V - 1, 0]
+    out = be.poison((n_tokens, NR_D), np.float32)
+    ck(be, be.lib.nr_gather_rows_f32(be.ptr(be.dev(ids)), be.ptr(be.dev(table)), be.ptr(out), n_tokens, NR_D, V, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(out), table[ids])          # bit exact
+
+
+def pack_qkv(be, params, prefix):
+    m = prefix + 'multihead_self_attention.'
+    Wp = be.poison((3 * NR_NP, NR_KP), np.uint16)
+    bp = be.poison((3 * NR_NP,), np.float32)
+    hs = [be.dev(params[m + n]) for n in ('W_Q.weight', 'W_Q.bias', 'W_K.weight', 'W_K.bias', 'W_V.weight', 'W_V.bias')]
+    ck(be, be.lib.nr_pack_qkv(*[be.ptr(h) for h in hs], be.ptr(Wp), be.ptr(bp), be.stream))
+    return Wp, bp
+
+
+def pack_additive(be, params, prefix):
+    a = prefix + 'additive_attention.'
+    W, b, q = params[a + 'linear.weight'], params[a + 'linear.bias'], params[a + 'attention_query_vector']
+    Wap = be.poison((NR_QP, NR_KP), np.uint16)
+    bap = be.poison((NR_QP,), np.float32)
+    qvp = be.poison((NR_QP,), np.float32)
+    ck(be, be.lib.nr_pack_additive(be.ptr(be.dev(W)), be.ptr(be.dev(b)), be.ptr(be.dev(q)), W.shape[0],
+                                   be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.stream))
+    return Wap, bap, qvp
+
+
+def check_pack(be):
+    params = make_params(3)
+    Wp, bp = pack_qkv(be, params, 'news_encoder.')
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    be.sync()
+    m = 'news_encoder.multihead_self_attention.'
+    Wp, bp = be.np(Wp), be.np(bp)
+    for i, n in enumerate(('W_Q', 'W_K', 'W_V')):
+        blk = Wp[i * NR_NP:(i + 1) * NR_NP]
+        assert np.array_equal(blk[:NR_D, :NR_D], f32_to_bf16(params[m + n + '.weight']))
+        assert not blk[NR_D:].any() and not blk[:, NR_D:].any()
+        assert np.array_equal(bp[i * NR_NP:i * NR_NP + NR_D], params[m + n + '.bias'])
+        assert not bp[i * NR_NP + NR_D:(i + 1) * NR_NP].any()
+    a = 'news_encoder.additive_attention.'
+    Wap = be.np(Wap)
+    assert np.array_equal(Wap[:200, :NR_D], f32_to_bf16(params[a + 'linear.weight']))
+    assert not Wap[200:].any() and not Wap[:, NR_D:].any()
+    assert np.array_equal(be.np(bap)[:200], params[a + 'linear.bias']) and not be.np(bap)[200:].any()
+    assert np.array_equal(be.np(qvp)[:200], params[a + 'attention_query_vector']) and not be.np(qvp)[200:].any()
+
+
+# ---------------------------------------------------------------------------------------------------
+def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0):
+    """MHSA with the engine's rounding points (bf16 X, W, QKV, P; fp32 accumulate), float64 arithmetic between."""
+    m = prefix + 'multihead_self_attention.'
+    xq = bf16_round(x.astype(np.float32)).astype(np.float64)
+    W = {n: bf16_round(params[m + n + '.weight']).astype(np.float64) for n in ('W_Q', 'W_K', 'W_V')}
+    b = {n: params[m + n + '.bias'].astype(np.float64) for n in ('W_Q', 'W_K', 'W_V')}
+    B, S, D = x.shape
+    dk = D // H
+
+    def proj(n):
+        y = bf16_round((xq @ W[n].T + b[n]).astype(np.float32)).astype(np.float64)
+        return y.reshape(B, S, H, dk).transpose(0, 2, 1, 3)
+    q, k, v = proj('W_Q'), proj('W_K'), proj('W_V')
+    s = (q @ np.swapaxes(k, -1, -2)) / np.sqrt(np.float32(dk)).astype(np.float64)
+    e = np.exp(s)
+    pr = e / (e.sum(-1, keepdims=True) + 1e-8)
+    pr = bf16_round(pr.astype(np.float32)).astype(np.float64)
+    ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, S, D)
+    if mask2 is not None:
+        ctx = ctx * mask2 * scale
+    return ctx
+
+
+def run_mhsa(be, params, prefix, S, n_seq, ids=None, table=None, x=None, p_drop=0.0, seed=0):
+    Wp, bp = pack_qkv(be, params, prefix)
+    ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    if ids is not None:
+        hi, ht = be.dev(ids.astype(np.int64)), be.dev(table)
+        ck(be, be.lib.nr_mhsa_fwd(be.ptr(hi), be.ptr(ht), table.shape[0], None, be.ptr(Wp), be.ptr(bp), be.ptr(ctx),
+                                  n_seq, S, p_drop, seed, be.stream))
+    else:
+        hx = be.dev(x.astype(np.float32))
+        ck(be, be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(hx), be.ptr(Wp), be.ptr(bp), be.ptr(ctx),
+                                  n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    return be.np(ctx), ctx
+
+
+def export_mask(be, n_elem, p, seed, site):
+    m = be.poison((n_elem,), np.float32)
+    ck(be, be.lib.nr_dropout_mask(be.ptr(m), n_elem, p, seed, site, be.stream))
+    be.sync()
+    return be.np(m)
+
+
+def assert_ctx_close(ctx_u16, ref, what):
+    got = bf16_to_f32(ctx_u16[:, :NR_D]).astype(np.float64)
+    assert not ctx_u16[:, NR_D:].any(), f'{what}: ctx K-padding not zero'
+    ref = ref.reshape(got.shape)
+    err = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    # 2 bf16 ulps relative + a small absolute floor (bf16 rounding of P/QKV can flip the last bit)
+    bad = err > (2.0 ** -7) * np.abs(ref) + 4e-3 * scale
+    assert not bad.any(), f'{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.4g} (scale {scale:.3g})'
+    return err.max() / scale
+
+
+def check_mhsa_gather(be, n_seq=6, V=300, p_drop=0.0, seed=1234):
+    S = 20
+    params = make_params(4, V)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(1, V, size=(n_seq, S))
+    ids[:, 13:] = 0                       # right padding, row 0 is an ordinary row
+    ids[1] = 0
+    table = params['news_encoder.word_embedding.weight']
+    ctx_np, _ = run_mhsa(be, params, 'news_encoder.', S, n_seq, ids=ids, table=table, p_drop=p_drop, seed=seed)
+    x = table[ids].astype(np.float64)
+    mask2, scale = None, 1.0
+    if p_drop > 0:
+        scale = np.float32(1.0 / (1.0 - p_drop))
+        m1 = export_mask(be, n_seq * S * NR_D, p_drop, seed, 1).reshape(n_seq, S, NR_D)
+        mask2 = export_mask(be, n_seq * S * NR_D, p_drop, seed, 2).reshape(n_seq, S, NR_D)
+        keep = m1.mean()
+        assert abs(keep - (1 - p_drop)) < 0.02, keep
+        assert abs(mask2.mean() - (1 - p_drop)) < 0.02
+        assert not np.array_equal(m1, mask2)
+        x = x * m1 * scale
+    ref = mhsa_quantized_oracle(x, params, 'news_encoder.', mask2, scale)
+    rel = assert_ctx_close(ctx_np, ref, f'mhsa gather S=20 p={p_drop}')
+    # and against the un-quantized fp64 oracle at bf16-level tolerance
+    m = 'news_encoder.multihead_self_attention.'
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    full, _ = onp.mhsa(x, p64[m + 'W_Q.weight'], p64[m + 'W_Q.bias'], p64[m + 'W_K.weight'], p64[m + 'W_K.bias'],
+                       p64[m + 'W_V.weight'], p64[m + 'W_V.bias'], H)
+    if mask2 is not None:
+        full = full * mask2 * scale
+    got = bf16_to_f32(ctx_np[:, :NR_D]).reshape(full.shape)
+    assert np.abs(got - full).max() < 0.03 * np.abs(full).max()
+    return rel
+
+
+def check_mhsa_dense(be, n_seq=3):
+    S = 50
+    params = make_params(6)
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 0.7, size=(n_seq, S, NR_D)).astype(np.float32)
+    x[0, :20] = 0.0                       # left-padded history slots (zero vectors at eval time)
+    ctx_np, _ = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x)
+    ref = mhsa_quantized_oracle(x, params, 'user_encoder.')
+    return assert_ctx_close(ctx_np, ref, 'mhsa dense S=50')
+
+
+def check_additive(be, S=20, n_seq=6):
+    params = make_params(8)
+    rng = np.random.default_rng(9)
+    ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
+    ctx[:, :NR_D] = rng.normal(0, 0.6, size=(n_seq * S, NR_D))
+    ctx_u = f32_to_bf16(ctx)
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    out = be.poison((n_seq, NR_D), np.float32)
+    aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw),
+                                  n_seq, S, be.stream))
+    be.sync()
+    a = 'news_encoder.additive_attention.'
+    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)
+    ref, w, _ = onp.additive(x, bf16_round(params[a + 'linear.weight']).astype(np.float64),
+                             params[a + 'linear.bias'].astype(np.float64),
+                             params[a + 'attention_query_vector'].astype(np.float64))
+    np.testing.assert_allclose(be.np(aw), w, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(be.np(out), ref, rtol=2e-4, atol=2e-5)
+
+
+def check_score_dot(be, B=37, C=3):
+    rng = np.random.default_rng(10)
+    cand = rng.normal(size=(B, C, NR_D)).astype(np.float32)
+    user = rng.normal(size=(B, NR_D)).astype(np.float32)
+    out = be.poison((B, C), np.float32)
+    ck(be, be.lib.nr_score_dot(be.ptr(be.dev(cand)), be.ptr(be.dev(user)), be.ptr(out), B, C, NR_D, be.stream))
+    be.sync()
+    np.testing.assert_allclose(be.np(out), onp.dot_score(cand.astype(np.float64), user.astype(np.float64)), rtol=1e-5, atol=1e-4)
+
+
+def check_score_csr(be, n_news=50, n_users=7, n_impr=11):
+    rng = np.random.default_rng(11)
+    news = rng.normal(size=(n_news, NR_D)).astype(np.float32)
+    users = rng.normal(size=(n_users, NR_D)).astype(np.float32)
+    lens = rng.integers(0, 9, size=n_impr)
+    lens[2] = 0                                       # empty impression
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(ptr[-1])
+    cidx = rng.integers(0, n_news, size=nnz).astype(np.int32)
+    cidx[::5] = -1                                    # PADDED_NEWS
+    uidx = rng.integers(0, n_users, size=n_impr).astype(np.int32)
+    out = be.poison((nnz,), np.float32)
+    ck(be, be.lib.nr_score_csr(be.ptr(be.dev(news)), be.ptr(be.dev(users)), be.ptr(be.dev(cidx)), be.ptr(be.dev(ptr)),
+                               be.ptr(be.dev(uidx)), be.ptr(out), n_impr, nnz, NR_D, be.stream))
+    be.sync()
+    ref = np.zeros(nnz)
+    for i in range(n_impr):
+        for j in range(ptr[i], ptr[i + 1]):
+            ref[j] = 0.0 if cidx[j] < 0 else news[cidx[j]].astype(np.float64) @ users[uidx[i]].astype(np.float64)
+    np.testing.assert_allclose(be.np(out), ref, rtol=1e-5, atol=1e-4)
+
+
+def check_bad_args(be):
+    assert be.lib.nr_mhsa_fwd(None, None, 0, None, None, None, None, 1, 20, 0.0, 0, be.stream) != 0
+    assert b'nr_mhsa_fwd' in be.lib.nr_last_error()
+    Wp = be.empty((3 * NR_NP, NR_KP), np.uint16); bp = be.empty((3 * NR_NP,), np.float32)
+    ctx = be.empty((4 * 33, NR_KP), np.uint16); x = be.empty((4, 33, NR_D), np.float32)
+    rc = be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(x), be.ptr(Wp), be.ptr(bp), be.ptr(ctx), 4, 33, 0.0, 0, be.stream)
+    assert rc == -1 and be.lib.nr_supported_seq_len(33) == 0 and be.lib.nr_supported_seq_len(20) == 1

@@ -1,0 +1,24 @@
+"""Kernel-logic parity on CPU: the HIP kernel sources compiled against the wave emulator (tests/emu) and
+checked against the oracle.  Confirms tiling / fragment indexing / barriers before a GPU is spent on them;
+the -m gpu twin (tests/test_kernels_gpu.py) runs the same checks on the product library."""
+import pytest
+from tests import kernel_checks as kc
+from tests.backends import EmuBackend
+
+
+@pytest.fixture(scope='module')
+def be():
+    return EmuBackend()
+
+
+def test_probe_mfma(be): kc.check_probe_mfma(be)
+def test_gather(be): kc.check_gather(be, n_tokens=300)
+def test_pack(be): kc.check_pack(be)
+def test_mhsa_gather(be): kc.check_mhsa_gather(be, n_seq=6)
+def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=5, p_drop=0.2)
+def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=2)
+def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=6)
+def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=2)
+def test_score_dot(be): kc.check_score_dot(be)
+def test_score_csr(be): kc.check_score_csr(be)
+def test_bad_args(be): kc.check_bad_args(be)

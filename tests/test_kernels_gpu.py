@@ -1,0 +1,26 @@
+"""GPU parity tests proper: the product library (libnr_engine.so, hand-written HIP for gfx950) through the
+C-ABI on cuda:0, checked against the oracle.  Same checks as tests/test_kernels_emu.py at larger sizes."""
+import pytest
+from tests import kernel_checks as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from tests.backends import GpuBackend
+    return GpuBackend()
+
+
+def test_probe_mfma(be): kc.check_probe_mfma(be)
+def test_gather(be): kc.check_gather(be, n_tokens=100003, V=70976)
+def test_pack(be): kc.check_pack(be)
+def test_mhsa_gather(be): kc.check_mhsa_gather(be, n_seq=1027, V=5000)
+def test_mhsa_gather_small(be): kc.check_mhsa_gather(be, n_seq=3, V=300)
+def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=515, V=5000, p_drop=0.2)
+def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=131)
+def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=1027)
+def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=131)
+def test_score_dot(be): kc.check_score_dot(be, B=513, C=3)
+def test_score_csr(be): kc.check_score_csr(be, n_news=5000, n_users=300, n_impr=1000)
+def test_bad_args(be): kc.check_bad_args(be)
