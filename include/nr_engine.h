@@ -58,12 +58,15 @@ int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim
  *   ids != NULL : news-encoder form, x[t,s,:] = table[ids[t,s],:] (src/model/NRMS/news_encoder.py:38)
  *                 followed by F.dropout (:38-40) when p_drop > 0;
  *   ids == NULL : user-encoder form, x = x_dense f32[n_seq, S, D] (src/model/NRMS/user_encoder.py:23).
- * Output ctx bf16[n_seq*S][NR_KP] (cols >= D are zero); when p_drop > 0 the second F.dropout of the
+ * Output ctx bf16[n_seq*S][NR_KP]; column D holds 1.0 and columns D+1.. are zero (so that GEMMs against ctx
+ * also yield the bias gradient).  Training: q_save/k_save bf16[n_seq*S][NR_KP] and vt_save
+ * bf16[n_seq][15][20][S rounded up to 4] receive Q, K (row-major) and V (dv-major blocks) for nr_attn_bwd;
+ * pass NULL for inference.  When p_drop > 0 the second F.dropout of the
  * news encoder (:43-45) is applied to ctx.  Dropout uses a counter-based RNG keyed by (seed, site, element),
  * reproducible by nr_dropout_mask().  */
 int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense,
-                const uint16_t* Wp, const float* bp, uint16_t* ctx, int64_t n_seq, int S,
-                float p_drop, uint64_t seed, void* stream);
+                const uint16_t* Wp, const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save,
+                uint16_t* vt_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
 
 /* AdditiveAttention forward, src/model/general/attention/additive.py:27-53:
  * out[t,:] = sum_s softmax_s(tanh(ctx[t,s,:] Wa^T + ba) . qv) * ctx[t,s,:].
@@ -81,6 +84,41 @@ int nr_score_dot(const float* cand, const float* user, float* out, int64_t B, in
  * A negative cand_idx selects the all-zero PADDED_NEWS vector (src/evaluate.py:203-204). */
 int nr_score_csr(const float* news, const float* users, const int32_t* cand_idx, const int64_t* cand_ptr,
                  const int32_t* user_idx, float* out, int64_t n_impr, int64_t nnz, int d, void* stream);
+
+/* ---- backward (autograd of the forward entry points; the reference relies on torch.autograd,
+ * triggered at src/train.py:231) -------------------------------------------------------------------------- */
+#define NR_LDG (3 * NR_KP)   /* row length of the dQKV gradient matrix: [dQ | dK | dV], each NR_KP wide */
+
+/* Backward of ScaledDotProductAttention (multihead_self.py:15-23) per (sequence, head).  The upstream gradient of
+ * ctx is assembled on the fly as dC = (dctx_gemm + attn_w (x) g_out) * dropout2, i.e. the additive layer's
+ * dpre @ Wa (bf16 [n_seq*S][ldc], a plain GEMM done by the caller) plus its direct term.  Writes
+ * dqkv bf16[n_seq*S][NR_LDG] (padding columns untouched: zero-fill once). */
+int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm,
+                int ldc, const float* attn_w, const float* g_out, uint16_t* dqkv, int64_t n_seq, int S,
+                float p_drop, uint64_t seed, void* stream);
+
+/* Backward of AdditiveAttention (additive.py:35-52) up to the pre-activation: dpre bf16[n_seq*S][NR_QP] and
+ * per-workgroup partial sums of the query-vector gradient dq_part f32[nr_additive_bwd_grid()][NR_QP]
+ * (sum over rows = d attention_query_vector).  The caller finishes with two plain GEMMs:
+ * d linear.weight|bias = dpre^T @ ctx (bias = column D, where ctx holds 1.0) and dctx_gemm = dpre @ Wa. */
+int64_t nr_additive_bwd_grid(int64_t n_seq, int S);
+int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp,
+                    const float* attn_w, const float* g_out, uint16_t* dpre, float* dq_part, int64_t n_seq, int S,
+                    void* stream);
+
+/* Token matrix for the weight-gradient GEMM dW = dqkv^T @ Xb: Xb bf16[n_tokens][NR_KP] = dropout1(table[ids]) (or
+ * dense f32 rows), column D = 1.0 (bias gradient), rest 0. */
+int nr_gather_bf16(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, uint16_t* Xb,
+                   int64_t n_tokens, float p_drop, uint64_t seed, void* stream);
+
+/* Backward of nn.Embedding(padding_idx=0) (news_encoder.py:15-20): grad_table[ids[t]] += dropout1(dx[t]) for
+ * ids[t] != 0.  dx bf16[n_tokens][ldx]; grad_table f32[num_rows][D] (accumulated with fp32 atomics). */
+int nr_embed_scatter_add(const int64_t* ids, const uint16_t* dx, int ldx, float* grad_table, int64_t num_rows,
+                         int64_t n_tokens, float p_drop, uint64_t seed, void* stream);
+
+/* Backward of DotProductClickPredictor: d_cand[b,c,:] = dl[b,c]*user[b,:], d_user[b,:] = sum_c dl[b,c]*cand[b,c,:]. */
+int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user,
+                     int64_t B, int C, int d, void* stream);
 
 /* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
  * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */

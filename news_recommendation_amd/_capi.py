@@ -17,7 +17,13 @@ SIGNATURES = {
     'nr_gather_rows_f32': ([_P, _P, _P, c_int64, c_int, c_int64, _P], c_int),
     'nr_pack_qkv': ([_P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     'nr_pack_additive': ([_P, _P, _P, c_int, _P, _P, _P, _P], c_int),
-    'nr_mhsa_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_mhsa_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_additive_bwd_grid': ([c_int64, c_int], c_int64),
+    'nr_additive_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    'nr_gather_bf16': ([_P, _P, c_int64, _P, _P, c_int64, c_float, c_uint64, _P], c_int),
+    'nr_embed_scatter_add': ([_P, _P, c_int, _P, c_int64, c_int64, c_float, c_uint64, _P], c_int),
+    'nr_score_dot_bwd': ([_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_additive_fwd': ([_P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_score_dot': ([_P, _P, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_score_csr': ([_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P], c_int),
@@ -27,6 +33,7 @@ SIGNATURES = {
 
 # layout constants mirrored from include/nr_engine.h
 NR_D, NR_KP, NR_HEADS, NR_DK, NR_NP, NR_QP = 300, 320, 15, 20, 304, 208
+NR_LDG = 3 * NR_KP
 
 LIB_NAME = 'libnr_engine.so'
 _lib = None

@@ -23,6 +23,7 @@ struct AddGeom {
   static constexpr int W_BYTES = ROWS * 4;          // softmax weights
   static constexpr int SMEM = X_BYTES + SC_BYTES + W_BYTES;
   static constexpr int NTQ = QP / 16;               // 13 n-tiles of the query dim
+  static constexpr int BWD_SMEM = X_BYTES + 4 * QP * 4 + ROWS * 4;   // backward: tile + dq partials + ds
 };
 
 struct AdditiveParams {

@@ -51,7 +51,10 @@ struct MhsaParams {
   const float* x_dense;    // [n_seq*S][D] when ids == null
   const u16* Wp;           // [3*NP][KP]
   const float* bp;         // [3*NP]
-  u16* ctx;                // [n_seq*S][KP]
+  u16* ctx;                // [n_seq*S][KP]  (col D holds 1.0 so that ctx^T-GEMMs also produce bias gradients)
+  u16* q_save;             // training: [n_seq*S][KP] (cols >= D untouched) or null
+  u16* k_save;             // training: [n_seq*S][KP] or null
+  u16* vt_save;            // training: [n_seq][H][DK][SP4]  (dv-major V blocks) or null
   int64_t n_seq;
   DropCfg dc;
 };
@@ -190,7 +193,14 @@ __global__ __launch_bounds__(WG, 2) void mhsa_fwd_kernel(MhsaParams p) {
       proj_block<2, true>(p.Wp, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) {
         f32x4 b4 = *(const f32x4*)(p.bp + wrow[j] + 4 * g);
         acc += b4;
-        *(u16x4*)(dst[j] + (m * 16 + li) * QS + ncol[j] + 4 * g) = pack4(acc);
+        u16x4 v = pack4(acc);
+        *(u16x4*)(dst[j] + (m * 16 + li) * QS + ncol[j] + 4 * g) = v;
+        if (p.q_save != nullptr) {      // keep Q / K (bf16, row-major) for the attention backward
+          const int64_t tok = seq0 * S + m * 16 + li;
+          const int col = hg * (HG * DK) + ncol[j] + 4 * g;
+          if (m * 16 + li < Gm::TOK && tok < p.n_seq * S && col < D)
+            *(u16x4*)((dst[j] == Qs ? p.q_save : p.k_save) + tok * KP + col) = v;
+        }
       });
     }
     __syncthreads();
@@ -265,7 +275,10 @@ __global__ __launch_bounds__(WG, 2) void mhsa_fwd_kernel(MhsaParams p) {
           acc += f32x4{b, b, b, b};
           const int seq = t0 / S, tis = t0 - seq * S;
           const int hd = vcol / DK, dv = vcol - hd * DK;
-          *(u16x4*)(Vt + ((seq * HG + hd) * DK + dv) * Gm::VS + tis) = pack4(acc);
+          u16x4 v = pack4(acc);
+          *(u16x4*)(Vt + ((seq * HG + hd) * DK + dv) * Gm::VS + tis) = v;
+          if (p.vt_save != nullptr && seq0 + seq < p.n_seq)
+            *(u16x4*)(p.vt_save + (((seq0 + seq) * H + hg * HG + hd) * DK + dv) * Gm::SP4 + tis) = v;
         }
       };
       if (G == 2) {
@@ -325,12 +338,12 @@ __global__ __launch_bounds__(WG, 2) void mhsa_fwd_kernel(MhsaParams p) {
     __syncthreads();
   }
 
-  // zero the K padding of the ctx rows this workgroup owns (cols D..KP)
+  // K padding of the ctx rows this workgroup owns: col D = 1.0 (bias-gradient column), cols D+1..KP = 0
   constexpr int PADQ = (KP - D) / 4;
   for (int i = tid; i < Gm::TOK * PADQ; i += WG) {
     int r = i / PADQ, c = i - r * PADQ;
     int64_t tok = seq0 * S + r;
-    if (tok < p.n_seq * S) *(u16x4*)(p.ctx + tok * KP + D + c * 4) = u16x4{0, 0, 0, 0};
+    if (tok < p.n_seq * S) *(u16x4*)(p.ctx + tok * KP + D + c * 4) = u16x4{(u16)(c == 0 ? 0x3F80 : 0), 0, 0, 0};
   }
 }
 

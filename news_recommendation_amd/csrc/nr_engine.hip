@@ -3,6 +3,7 @@
 #include "k_misc.h"
 #include "k_mhsa_fwd.h"
 #include "k_additive_fwd.h"
+#include "k_bwd.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -78,8 +79,11 @@ int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim
 }
 
 int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
-                const float* bp, uint16_t* ctx, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+                const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, int64_t n_seq, int S,
+                float p_drop, uint64_t seed, void* stream) {
   if (!Wp || !bp || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: bad argument");
+  if ((q_save != nullptr) != (k_save != nullptr) || (q_save != nullptr) != (vt_save != nullptr))
+    return fail(NR_ERR_BADARG, "nr_mhsa_fwd: q_save / k_save / vt_save must be given together");
   if ((ids == nullptr) == (x_dense == nullptr)) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: exactly one of ids / x_dense");
   if (ids && (!table || num_rows <= 0)) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: ids without table");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: dropout probability out of range");
@@ -87,6 +91,7 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   nr::MhsaParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_dense = x_dense;
   p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save;
   if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::MhsaGeom<20, NSEQ>;
@@ -123,6 +128,95 @@ int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
     return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd: sequence length not instantiated (20, 50)");
   }
   return check_launch("nr_additive_fwd");
+}
+
+int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
+                const float* attn_w, const float* g_out, uint16_t* dqkv, int64_t n_seq, int S, float p_drop, uint64_t seed,
+                void* stream) {
+  if (!q_save || !k_save || !vt_save || !dctx_gemm || !attn_w || !g_out || !dqkv || n_seq < 0 || ldc < NR_D || (ldc & 3))
+    return fail(NR_ERR_BADARG, "nr_attn_bwd: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_bwd: dropout probability out of range");
+  if (n_seq == 0) return NR_OK;
+  nr::AttnBwdParams p;
+  p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
+  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  const int64_t pairs = n_seq * NR_HEADS;
+  if (S == 20) {
+    constexpr int WPB = 4;
+    using G = nr::AttnBwdGeom<20, WPB>;
+    if (allow_smem(nr::attn_bwd_kernel<20, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), (pairs + WPB - 1) / WPB, WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 50) {
+    constexpr int WPB = 2;
+    using G = nr::AttnBwdGeom<50, WPB>;
+    if (allow_smem(nr::attn_bwd_kernel<50, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::attn_bwd_kernel<50, WPB>), (pairs + WPB - 1) / WPB, WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd: sequence length not instantiated (20, 50)");
+  }
+  return check_launch("nr_attn_bwd");
+}
+
+int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
+  if (S == 20) return (n_seq + 3) / 4;
+  if (S == 50) return n_seq;
+  return -1;
+}
+
+int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w,
+                    const float* g_out, uint16_t* dpre, float* dq_part, int64_t n_seq, int S, void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || !attn_w || !g_out || !dpre || !dq_part || n_seq < 0)
+    return fail(NR_ERR_BADARG, "nr_additive_bwd: bad argument");
+  if (n_seq == 0) return NR_OK;
+  nr::AdditiveBwdParams p;
+  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
+  p.dq_part = dq_part; p.n_seq = n_seq;
+  if (S == 20) {
+    constexpr int NSEQ = 4;
+    using G = nr::AddGeom<20, NSEQ>;
+    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else if (S == 50) {
+    constexpr int NSEQ = 1;
+    using G = nr::AddGeom<50, NSEQ>;
+    if (allow_smem(nr::additive_bwd_kernel<50, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_bwd_kernel<50, NSEQ>), n_seq, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else {
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd: sequence length not instantiated (20, 50)");
+  }
+  return check_launch("nr_additive_bwd");
+}
+
+int nr_gather_bf16(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, uint16_t* Xb,
+                   int64_t n_tokens, float p_drop, uint64_t seed, void* stream) {
+  if (!Xb || n_tokens < 0 || (ids == nullptr) == (x_dense == nullptr) || (ids && (!table || num_rows <= 0)))
+    return fail(NR_ERR_BADARG, "nr_gather_bf16: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_gather_bf16: dropout probability out of range");
+  if (n_tokens == 0) return NR_OK;
+  NR_LAUNCH(nr::gather_bf16_kernel, grid_for(n_tokens * (NR_KP / 4), 256, 4096), 256, 0, (hipStream_t)stream, ids, table, num_rows,
+            x_dense, Xb, n_tokens, make_drop(p_drop, seed));
+  return check_launch("nr_gather_bf16");
+}
+
+int nr_embed_scatter_add(const int64_t* ids, const uint16_t* dx, int ldx, float* grad_table, int64_t num_rows, int64_t n_tokens,
+                         float p_drop, uint64_t seed, void* stream) {
+  if (!ids || !dx || !grad_table || num_rows <= 0 || n_tokens < 0 || ldx < NR_D || (ldx & 3))
+    return fail(NR_ERR_BADARG, "nr_embed_scatter_add: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_embed_scatter_add: dropout probability out of range");
+  if (n_tokens == 0) return NR_OK;
+  NR_LAUNCH(nr::embed_scatter_add_kernel, grid_for(n_tokens * (NR_D / 4), 256, 4096), 256, 0, (hipStream_t)stream, ids, dx, ldx,
+            grad_table, num_rows, n_tokens, make_drop(p_drop, seed));
+  return check_launch("nr_embed_scatter_add");
+}
+
+int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user, int64_t B, int C, int d,
+                     void* stream) {
+  if (!dl || !cand || !user || !d_cand || !d_user || B < 0 || C <= 0 || d <= 0 || (d & 3))
+    return fail(NR_ERR_BADARG, "nr_score_dot_bwd: bad argument");
+  if (B == 0) return NR_OK;
+  NR_LAUNCH(nr::score_dot_bwd_kernel, grid_for(B * (d / 4), 256, 2048), 256, 0, (hipStream_t)stream, dl, cand, user, d_cand,
+            d_user, B, C, d / 4);
+  return check_launch("nr_score_dot_bwd");
 }
 
 int nr_score_dot(const float* cand, const float* user, float* out, int64_t B, int C, int d, void* stream) {

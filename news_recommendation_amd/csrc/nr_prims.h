@@ -34,6 +34,14 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 
+// orders this wave's LDS traffic for cross-lane exchange through LDS (hardware keeps a wave's DS ops in order;
+// this only stops the compiler from moving accesses across the point)
+__device__ __forceinline__ void wave_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_tanh(float x) {

@@ -175,6 +175,8 @@ __forceinline__ float shfl(float v, int src) {
   return r;
 }
 
+__forceinline__ void wave_barrier() { nr_emu::wave_sync(); }
+
 __forceinline__ float fast_exp(float x) { return expf(x); }
 __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 __forceinline__ float fast_rcp(float x) { return 1.0f / x; }

@@ -107,18 +107,23 @@ def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0):
     return ctx
 
 
-def run_mhsa(be, params, prefix, S, n_seq, ids=None, table=None, x=None, p_drop=0.0, seed=0):
+def run_mhsa(be, params, prefix, S, n_seq, ids=None, table=None, x=None, p_drop=0.0, seed=0, save=False):
     Wp, bp = pack_qkv(be, params, prefix)
     ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    sp4 = (S + 3) // 4 * 4
+    sv = (be.empty((n_seq * S, NR_KP), np.uint16), be.empty((n_seq * S, NR_KP), np.uint16),
+          be.empty((n_seq, H, 20, sp4), np.uint16)) if save else (None, None, None)
     if ids is not None:
         hi, ht = be.dev(ids.astype(np.int64)), be.dev(table)
         ck(be, be.lib.nr_mhsa_fwd(be.ptr(hi), be.ptr(ht), table.shape[0], None, be.ptr(Wp), be.ptr(bp), be.ptr(ctx),
-                                  n_seq, S, p_drop, seed, be.stream))
+                                  be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), n_seq, S, p_drop, seed, be.stream))
     else:
         hx = be.dev(x.astype(np.float32))
         ck(be, be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(hx), be.ptr(Wp), be.ptr(bp), be.ptr(ctx),
-                                  n_seq, S, p_drop, seed, be.stream))
+                                  be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), n_seq, S, p_drop, seed, be.stream))
     be.sync()
+    if save:
+        return be.np(ctx), sv
     return be.np(ctx), ctx
 
 
@@ -131,7 +136,7 @@ def export_mask(be, n_elem, p, seed, site):
 
 def assert_ctx_close(ctx_u16, ref, what):
     got = bf16_to_f32(ctx_u16[:, :NR_D]).astype(np.float64)
-    assert not ctx_u16[:, NR_D:].any(), f'{what}: ctx K-padding not zero'
+    assert (ctx_u16[:, NR_D] == 0x3F80).all() and not ctx_u16[:, NR_D + 1:].any(), f'{what}: ctx K-padding wrong'
     ref = ref.reshape(got.shape)
     err = np.abs(got - ref)
     scale = np.abs(ref).max()
@@ -240,9 +245,161 @@ def check_score_csr(be, n_news=50, n_users=7, n_impr=11):
 
 
 def check_bad_args(be):
-    assert be.lib.nr_mhsa_fwd(None, None, 0, None, None, None, None, 1, 20, 0.0, 0, be.stream) != 0
+    assert be.lib.nr_mhsa_fwd(None, None, 0, None, None, None, None, None, None, None, 1, 20, 0.0, 0, be.stream) != 0
     assert b'nr_mhsa_fwd' in be.lib.nr_last_error()
     Wp = be.empty((3 * NR_NP, NR_KP), np.uint16); bp = be.empty((3 * NR_NP,), np.float32)
     ctx = be.empty((4 * 33, NR_KP), np.uint16); x = be.empty((4, 33, NR_D), np.float32)
-    rc = be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(x), be.ptr(Wp), be.ptr(bp), be.ptr(ctx), 4, 33, 0.0, 0, be.stream)
+    rc = be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(x), be.ptr(Wp), be.ptr(bp), be.ptr(ctx), None, None, None, 4, 33, 0.0, 0, be.stream)
     assert rc == -1 and be.lib.nr_supported_seq_len(33) == 0 and be.lib.nr_supported_seq_len(20) == 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward kernels
+# ---------------------------------------------------------------------------------------------------
+def close_bf16(got, ref, what, rel=2.0 ** -6, floor=6e-3):
+    got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    scale = np.abs(ref).max() + 1e-30
+    bad = err > rel * np.abs(ref) + floor * scale
+    assert not bad.any(), f'{what}: {bad.sum()}/{bad.size} off, max err {err.max():.4g}, scale {scale:.4g}'
+    return err.max() / scale
+
+
+def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77):
+    from news_recommendation_amd._capi import NR_LDG
+    params = make_params(12)
+    rng = np.random.default_rng(13)
+    x = rng.normal(0, 0.7, size=(n_seq, S, NR_D)).astype(np.float32)
+    ctx_np, sv = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x, p_drop=0.0, save=True)
+    qs, ks, vts = [be.np(h) for h in sv]
+    dk = 20
+    q = bf16_to_f32(qs[:, :NR_D]).astype(np.float64).reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
+    k = bf16_to_f32(ks[:, :NR_D]).astype(np.float64).reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
+    v = bf16_to_f32(vts).astype(np.float64)[:, :, :, :S].transpose(0, 1, 3, 2)            # [n,H,S,dk]
+    # the saved tensors are what the forward used: check them against the quantised oracle
+    m = 'user_encoder.multihead_self_attention.'
+    xq = bf16_round(x).astype(np.float64)
+    for name, t in (('W_Q', q), ('W_K', k), ('W_V', v)):
+        ref = xq @ bf16_round(params[m + name + '.weight']).astype(np.float64).T + params[m + name + '.bias']
+        ref = ref.reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
+        close_bf16(t, ref, 'saved ' + name, rel=2.0 ** -7, floor=1e-3)
+    dg = rng.normal(0, 0.05, size=(n_seq * S, NR_D)).astype(np.float32)
+    dg_u = f32_to_bf16(dg)
+    aw = rng.random(size=(n_seq, S)).astype(np.float32); aw /= aw.sum(1, keepdims=True)
+    go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
+    dqkv = be.empty((n_seq * S, NR_LDG), np.uint16)
+    ck(be, be.lib.nr_attn_bwd(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
+                              be.ptr(be.dev(go)), be.ptr(dqkv), n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    out = be.np(dqkv)
+    dC = bf16_to_f32(dg_u).astype(np.float64).reshape(n_seq, S, NR_D) + aw[:, :, None].astype(np.float64) * go[:, None, :]
+    if p_drop > 0:
+        mask2 = export_mask(be, n_seq * S * NR_D, p_drop, seed, 2).reshape(n_seq, S, NR_D)
+        dC = dC * mask2 * np.float32(1.0 / (1.0 - p_drop))
+    dC = bf16_round(dC.astype(np.float32)).astype(np.float64)
+    g = dC.reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
+    e = np.exp(q @ np.swapaxes(k, -1, -2) / np.sqrt(np.float32(dk)).astype(np.float64))
+    attn = e / (e.sum(-1, keepdims=True) + 1e-8)
+    dattn = g @ np.swapaxes(v, -1, -2)
+    dv = np.swapaxes(attn, -1, -2) @ g
+    dS = attn * (dattn - (attn * dattn).sum(-1, keepdims=True)) / np.sqrt(dk)
+    dq = dS @ k
+    dkk = np.swapaxes(dS, -1, -2) @ q
+    mg = lambda t: t.transpose(0, 2, 1, 3).reshape(n_seq * S, NR_D)
+    rels = []
+    for i, (name, ref) in enumerate((('dQ', dq), ('dK', dkk), ('dV', dv))):
+        got = bf16_to_f32(out[:, i * NR_KP:i * NR_KP + NR_D])
+        rels.append(close_bf16(got, mg(ref), f'attn_bwd {name} S={S}'))
+        assert not out[:, i * NR_KP + NR_D:(i + 1) * NR_KP].any()
+    return rels
+
+
+def check_additive_bwd(be, S=20, n_seq=6):
+    params = make_params(14)
+    rng = np.random.default_rng(15)
+    ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
+    ctx[:, :NR_D] = rng.normal(0, 0.6, size=(n_seq * S, NR_D))
+    ctx[:, NR_D] = 1.0
+    ctx_u = f32_to_bf16(ctx)
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    hctx = be.dev(ctx_u)
+    out = be.poison((n_seq, NR_D), np.float32)
+    aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw), n_seq, S, be.stream))
+    go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
+    nwg = be.lib.nr_additive_bwd_grid(n_seq, S)
+    dpre = be.empty((n_seq * S, NR_QP), np.uint16)
+    dqp = be.poison((nwg, NR_QP), np.float32)
+    ck(be, be.lib.nr_additive_bwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)),
+                                  be.ptr(dpre), be.ptr(dqp), n_seq, S, be.stream))
+    be.sync()
+    a = 'news_encoder.additive_attention.'
+    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)
+    W = bf16_round(params[a + 'linear.weight']).astype(np.float64)
+    b = params[a + 'linear.bias'].astype(np.float64); qv = params[a + 'attention_query_vector'].astype(np.float64)
+    _, w, temp = onp.additive(x, W, b, qv)
+    g = go.astype(np.float64)
+    dw = np.einsum('bd,bsd->bs', g, x)
+    ds = w * (dw - (w * dw).sum(1, keepdims=True))
+    dpre_ref = ds[:, :, None] * qv[None, None, :] * (1 - temp * temp)
+    dq_ref = np.einsum('bs,bsq->q', ds, temp)
+    got = bf16_to_f32(be.np(dpre))
+    close_bf16(got[:, :200], dpre_ref.reshape(-1, 200), 'additive_bwd dpre', rel=2.0 ** -7, floor=2e-3)
+    assert not got[:, 200:].any()
+    dq = be.np(dqp).astype(np.float64).sum(0)
+    np.testing.assert_allclose(dq[:200], dq_ref, rtol=2e-3, atol=2e-4 * np.abs(dq_ref).max())
+    # cross-check the full additive backward formula chain against the oracle's additive_bwd
+    dx_ref, dW_ref, db_ref, dqv_ref = onp.additive_bwd(g, x, w, temp, W, qv)
+    np.testing.assert_allclose(dq_ref, dqv_ref, rtol=1e-9)
+    np.testing.assert_allclose(dpre_ref.reshape(-1, 200).T @ x.reshape(-1, NR_D), dW_ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w[:, :, None] * g[:, None, :] + dpre_ref @ W, dx_ref, rtol=1e-9, atol=1e-12)
+
+
+def check_gather_bf16(be, n_tokens=257, V=400, p_drop=0.2, seed=5):
+    rng = np.random.default_rng(16)
+    table = rng.normal(size=(V, NR_D)).astype(np.float32)
+    ids = rng.integers(0, V, size=n_tokens).astype(np.int64)
+    Xb = be.poison((n_tokens, NR_KP), np.uint16)
+    ck(be, be.lib.nr_gather_bf16(be.ptr(be.dev(ids)), be.ptr(be.dev(table)), V, None, be.ptr(Xb), n_tokens, p_drop, seed, be.stream))
+    be.sync()
+    m1 = export_mask(be, n_tokens * NR_D, p_drop, seed, 1).reshape(n_tokens, NR_D)
+    ref = f32_to_bf16((table[ids] * m1 * np.float32(1.0 / (1.0 - p_drop))).astype(np.float32))
+    got = be.np(Xb)
+    assert np.array_equal(bf16_to_f32(got[:, :NR_D]), bf16_to_f32(ref))      # value compare: -0 == +0
+    assert (got[:, NR_D] == 0x3F80).all() and not got[:, NR_D + 1:].any()
+    # dense mode, no dropout
+    x = rng.normal(size=(n_tokens, NR_D)).astype(np.float32)
+    ck(be, be.lib.nr_gather_bf16(None, None, 0, be.ptr(be.dev(x)), be.ptr(Xb), n_tokens, 0.0, 0, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(Xb)[:, :NR_D], f32_to_bf16(x))
+
+
+def check_scatter_add(be, n_tokens=999, V=50, p_drop=0.2, seed=6):
+    rng = np.random.default_rng(17)
+    ids = rng.integers(0, V, size=n_tokens).astype(np.int64)
+    ids[::7] = 0
+    dx = rng.normal(size=(n_tokens, NR_D)).astype(np.float32)
+    dxu = f32_to_bf16(dx)
+    grad = be.dev(np.full((V, NR_D), 0.5, dtype=np.float32))
+    ck(be, be.lib.nr_embed_scatter_add(be.ptr(be.dev(ids)), be.ptr(be.dev(dxu)), NR_D, be.ptr(grad), V, n_tokens, p_drop, seed, be.stream))
+    be.sync()
+    m1 = export_mask(be, n_tokens * NR_D, p_drop, seed, 1).reshape(n_tokens, NR_D)
+    ref = np.full((V, NR_D), 0.5, dtype=np.float64)
+    contrib = bf16_to_f32(dxu).astype(np.float64) * m1 * np.float64(np.float32(1.0 / (1.0 - p_drop)))
+    nz = ids != 0
+    np.add.at(ref, ids[nz], contrib[nz])
+    got = be.np(grad)
+    assert np.all(got[0] == 0.5)                       # padding_idx row untouched
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-4)
+
+
+def check_score_bwd(be, B=33, C=3):
+    rng = np.random.default_rng(18)
+    cand = rng.normal(size=(B, C, NR_D)).astype(np.float32)
+    user = rng.normal(size=(B, NR_D)).astype(np.float32)
+    dl = rng.normal(size=(B, C)).astype(np.float32)
+    dc = be.poison((B, C, NR_D), np.float32); du = be.poison((B, NR_D), np.float32)
+    ck(be, be.lib.nr_score_dot_bwd(be.ptr(be.dev(dl)), be.ptr(be.dev(cand)), be.ptr(be.dev(user)), be.ptr(dc), be.ptr(du), B, C, NR_D, be.stream))
+    be.sync()
+    np.testing.assert_allclose(be.np(dc), dl[:, :, None] * user[:, None, :], rtol=1e-6)
+    np.testing.assert_allclose(be.np(du), np.einsum('bc,bcd->bd', dl, cand), rtol=1e-5, atol=1e-5)

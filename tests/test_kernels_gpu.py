@@ -24,3 +24,11 @@ def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=131)
 def test_score_dot(be): kc.check_score_dot(be, B=513, C=3)
 def test_score_csr(be): kc.check_score_csr(be, n_news=5000, n_users=300, n_impr=1000)
 def test_bad_args(be): kc.check_bad_args(be)
+def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=203)
+def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=0.2)
+def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
+def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)
+def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
+def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
+def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
+def test_score_bwd(be): kc.check_score_bwd(be, B=513)

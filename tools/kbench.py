@@ -40,10 +40,10 @@ kern = {
   'pack': pack,
   'gather_zipf': lambda: ck(lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), T * 20, NR_D, V, st())),
   'gather_uniform': lambda: ck(lib.nr_gather_rows_f32(ids_u.data_ptr(), table.data_ptr(), gout.data_ptr(), T * 20, NR_D, V, st())),
-  'mhsa_news': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), T, 20, 0.0, 0, st())),
-  'mhsa_news_drop': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), T, 20, 0.2, 1, st())),
+  'mhsa_news': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), None, None, None, T, 20, 0.0, 0, st())),
+  'mhsa_news_drop': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), None, None, None, T, 20, 0.2, 1, st())),
   'additive_news': lambda: ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), aw.data_ptr(), T, 20, st())),
-  'mhsa_user': lambda: ck(lib.nr_mhsa_fwd(None, None, 0, nv.data_ptr() + 3 * B * NR_D * 4, Wp.data_ptr(), bp.data_ptr(), ctxu.data_ptr(), B, 50, 0.0, 0, st())),
+  'mhsa_user': lambda: ck(lib.nr_mhsa_fwd(None, None, 0, nv.data_ptr() + 3 * B * NR_D * 4, Wp.data_ptr(), bp.data_ptr(), ctxu.data_ptr(), None, None, None, B, 50, 0.0, 0, st())),
   'additive_user': lambda: ck(lib.nr_additive_fwd(ctxu.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), uv.data_ptr(), awu.data_ptr(), B, 50, st())),
   'score': lambda: ck(lib.nr_score_dot(nv.data_ptr(), uv.data_ptr(), logits.data_ptr(), B, 3, NR_D, st())),
 }
