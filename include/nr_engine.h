@@ -29,7 +29,7 @@ extern "C" {
 #define NR_KP 320       /* D padded to a multiple of the MFMA K step (32) */
 #define NR_HEADS 15     /* num_attention_heads, src/config.py:45 */
 #define NR_DK 20
-#define NR_NP 304       /* D padded to a multiple of 16 (rows of each packed W_Q/W_K/W_V block) */
+#define NR_NP 320       /* rows of each packed W_Q/W_K/W_V block (= NR_KP, so the packed matrix doubles as the [960][320] dgrad operand) */
 #define NR_QP 208       /* query_vector_dim (200, src/config.py:39) padded to a multiple of 16 */
 
 int nr_version(void);

@@ -32,7 +32,7 @@ SIGNATURES = {
 }
 
 # layout constants mirrored from include/nr_engine.h
-NR_D, NR_KP, NR_HEADS, NR_DK, NR_NP, NR_QP = 300, 320, 15, 20, 304, 208
+NR_D, NR_KP, NR_HEADS, NR_DK, NR_NP, NR_QP = 300, 320, 15, 20, 320, 208
 NR_LDG = 3 * NR_KP
 
 LIB_NAME = 'libnr_engine.so'

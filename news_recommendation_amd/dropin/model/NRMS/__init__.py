@@ -1,0 +1,47 @@
+"""NRMS -- interface of src/model/NRMS/__init__.py:7-84."""
+import torch
+
+from .news_encoder import NewsEncoder
+from .user_encoder import UserEncoder
+from ..general.click_predictor.dot_product import DotProductClickPredictor
+
+
+class NRMS(torch.nn.Module):
+    """Input 1 + K candidate news and a list of user clicked news, produce the click logits."""
+
+    def __init__(self, config, pretrained_word_embedding=None):
+        super().__init__()
+        self.config = config
+        self.news_encoder = NewsEncoder(config, pretrained_word_embedding)
+        self.user_encoder = UserEncoder(config)
+        self.click_predictor = DotProductClickPredictor()
+
+    def forward(self, candidate_news, clicked_news):
+        """candidate_news: list[1+K] of {"title": int64 [B, L]}, clicked_news: list[N] of the same
+        (the DataLoader's default collation, train.py:202-203) -> [B, 1+K].
+
+        The reference encodes the 1+K+N positions one by one (__init__.py:38-42); here all B*(1+K+N) titles are
+        stacked into ONE id matrix and encoded by one kernel chain."""
+        dev = self.news_encoder.word_embedding.weight.device
+        cand = torch.stack([x["title"] for x in candidate_news], dim=1)       # [B, C, L]
+        click = torch.stack([x["title"] for x in clicked_news], dim=1)        # [B, N, L]
+        B, C, L = cand.shape
+        N = click.shape[1]
+        ids = torch.cat([cand.reshape(B * C, L), click.reshape(B * N, L)], dim=0).to(dev, non_blocking=True)
+        vec = self.news_encoder.encode_ids(ids)                               # [B*(C+N), D]
+        candidate_news_vector = vec[:B * C].view(B, C, -1)
+        clicked_news_vector = vec[B * C:].view(B, N, -1)
+        user_vector = self.user_encoder(clicked_news_vector)
+        return self.click_predictor(candidate_news_vector, user_vector)
+
+    def get_news_vector(self, news):
+        """{"title": [batch, L]} -> [batch, D]   (evaluate.py:198)."""
+        return self.news_encoder(news)
+
+    def get_user_vector(self, clicked_news_vector):
+        """[batch, N, D] -> [batch, D]   (evaluate.py:226-230)."""
+        return self.user_encoder(clicked_news_vector)
+
+    def get_prediction(self, news_vector, user_vector):
+        """[C, D], [D] -> [C]   (evaluate.py:257)."""
+        return self.click_predictor(news_vector.unsqueeze(dim=0), user_vector.unsqueeze(dim=0)).squeeze(dim=0)

@@ -1,0 +1,30 @@
+"""NRMS NewsEncoder -- interface of src/model/NRMS/news_encoder.py:10-48."""
+import torch
+import torch.nn as nn
+
+from news_recommendation_amd import ops
+from ..general.attention.multihead_self import MultiHeadSelfAttention
+from ..general.attention.additive import AdditiveAttention
+
+
+class NewsEncoder(torch.nn.Module):
+    def __init__(self, config, pretrained_word_embedding):
+        super().__init__()
+        self.config = config
+        if pretrained_word_embedding is None:
+            self.word_embedding = nn.Embedding(config.num_words, config.word_embedding_dim, padding_idx=0)
+        else:
+            self.word_embedding = nn.Embedding.from_pretrained(pretrained_word_embedding, freeze=False, padding_idx=0)
+        self.multihead_self_attention = MultiHeadSelfAttention(config.word_embedding_dim, config.num_attention_heads)
+        self.additive_attention = AdditiveAttention(config.query_vector_dim, config.word_embedding_dim)
+
+    def encode_ids(self, ids):
+        """ids: int64 [n_titles, num_words_title] on the model's device -> [n_titles, D].  One fused launch chain
+        (gather -> dropout -> MHSA -> dropout -> additive) for any number of titles."""
+        return ops.encode_titles(ids, self.word_embedding.weight, self.multihead_self_attention,
+                                 self.additive_attention, self.config.dropout_probability, self.training)
+
+    def forward(self, news):
+        """news: {"title": int64 [batch, num_words_title]} (CPU or GPU) -> [batch, word_embedding_dim]."""
+        ids = news["title"].to(self.word_embedding.weight.device, non_blocking=True)
+        return self.encode_ids(ids)

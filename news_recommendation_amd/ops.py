@@ -1,0 +1,365 @@
+"""Autograd-capable host wrappers around the C-ABI kernels (libnr_engine.so).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and
+autograd bookkeeping.  All encoder math runs in the hand-written HIP kernels;
+the only library calls are the plain bf16 GEMMs of the backward pass
+(``torch.mm`` -> hipBLASLt): dpre@Wa, dpre^T@ctx, dqkv@W, dqkv^T@X.
+
+There is no CPU path: tensors must live on a ROCm device and the HIP library
+must be built, otherwise a RuntimeError is raised.
+"""
+import torch
+
+from . import _capi
+from ._capi import NR_D, NR_KP, NR_NP, NR_QP, NR_HEADS, NR_DK, NR_LDG
+
+_BF16_AS_I16 = torch.int16   # bf16 buffers crossing the C-ABI are raw 16-bit words
+
+
+def _lib():
+    return _capi.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be on the GPU: the NRMS engine has no CPU fallback "
+                           f"(got device {t.device}); move the model with .to('cuda:0')")
+
+
+def _ck(rc):
+    _capi.check(_lib(), rc)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def check_dims(d_model, heads, qdim=None):
+    if d_model != NR_D or heads != NR_HEADS:
+        raise NotImplementedError(
+            f"the HIP kernels are instantiated for word_embedding_dim={NR_D}, num_attention_heads={NR_HEADS} "
+            f"(got {d_model}, {heads})")
+    if qdim is not None and not (0 < qdim <= NR_QP):
+        raise NotImplementedError(f"query_vector_dim must be in [1, {NR_QP}] (got {qdim})")
+
+
+def new_seed():
+    """Seed for the kernels' counter-based dropout RNG, drawn from torch's CPU generator (torch.manual_seed-able)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# weight packing (fp32 parameters -> zero-padded bf16 MFMA operands); re-done every call so the kernels
+# always see the live parameter storage the optimizer updates in place
+# ----------------------------------------------------------------------------------------------------------
+def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
+    dev = Wq.device
+    Wp = torch.empty(3 * NR_NP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+    bp = torch.empty(3 * NR_NP, dtype=torch.float32, device=dev)
+    args = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
+    _ck(_lib().nr_pack_qkv(*[_ptr(a) for a in args], _ptr(Wp), _ptr(bp), _stream()))
+    return Wp, bp
+
+
+def pack_additive(Wa, ba, qv):
+    dev = Wa.device
+    qdim = Wa.shape[0]
+    Wap = torch.empty(NR_QP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+    bap = torch.empty(NR_QP, dtype=torch.float32, device=dev)
+    qvp = torch.empty(NR_QP, dtype=torch.float32, device=dev)
+    a = [_f32c(Wa), _f32c(ba), _f32c(qv)]
+    _ck(_lib().nr_pack_additive(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), qdim, _ptr(Wap), _ptr(bap), _ptr(qvp), _stream()))
+    return Wap, bap, qvp
+
+
+def _bf16(t_i16):
+    return t_i16.view(torch.bfloat16)
+
+
+def _mm_f32(a, b):
+    """bf16 x bf16 GEMM with fp32 result (hipBLASLt accumulates in fp32)."""
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except TypeError:            # older torch: round to bf16 at the end
+        return torch.mm(a, b).float()
+
+
+_ws = {}
+
+
+def _workspace(key, shape, dtype, device, zero=False):
+    """Reusable scratch buffers that live only inside one backward call."""
+    k = (key, tuple(shape), dtype, str(device))
+    t = _ws.get(k)
+    if t is None:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        _ws[k] = t
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fused encoder: [gather | dense] -> MHSA -> additive pooling
+# ----------------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    """out[n_seq, D] = AdditiveAttention(dropout2(MHSA(dropout1(x)))),  x = table[ids] or a dense [n_seq,S,D] tensor.
+
+    Mirrors src/model/NRMS/news_encoder.py:27-48 (ids form, dropout) and src/model/NRMS/user_encoder.py:15-26
+    (dense form, no dropout)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, x_dense, Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, S, p_drop, seed):
+        lib = _lib()
+        gather = ids is not None
+        dev = Wq.device
+        n_seq = ids.shape[0] if gather else x_dense.shape[0]
+        if not lib.nr_supported_seq_len(S):
+            raise NotImplementedError(f"sequence length {S} is not instantiated in the HIP kernels (20, 50)")
+        need_grad = any(ctx.needs_input_grad)
+        Wp, bp = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
+        Wap, bap, qvp = pack_additive(Wa, ba, qv)
+        cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        sp4 = (S + 3) // 4 * 4
+        if need_grad:
+            qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+            ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+            vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
+        else:
+            qs = ks = vts = None
+        if gather:
+            ids_c = ids.contiguous()
+            tab = table.detach()
+            assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
+            _ck(lib.nr_mhsa_fwd(_ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream()))
+            xd = None
+        else:
+            ids_c = None
+            xd = _f32c(x_dense)
+            _ck(lib.nr_mhsa_fwd(None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream()))
+        out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+        aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+        _ck(lib.nr_additive_fwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream()))
+        if need_grad:
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp)
+            ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib()
+        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp = ctx.saved_tensors
+        S, p_drop, seed, n_seq, qdim, gather = ctx.meta
+        dev = cbuf.device
+        ntok = n_seq * S
+        g_out = g_out.to(torch.float32).contiguous()
+        # ---- additive attention backward: dpre (kernel), then two plain GEMMs ---------------------------------
+        nwg = lib.nr_additive_bwd_grid(n_seq, S)
+        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+        _ck(lib.nr_additive_bwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
+                                _ptr(dq_part), n_seq, S, _stream()))
+        d_qv = dq_part.sum(dim=0)[:qdim]
+        dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
+        dWa_ext = _mm_f32(dpre_b.t(), ctx_b)                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
+        dctx_gemm = torch.mm(dpre_b, Wap_b[:, :NR_D])             # [ntok, D] bf16
+        # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
+        dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
+        _ck(lib.nr_attn_bwd(_ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(dqkv),
+                            n_seq, S, p_drop, seed, _stream()))
+        dqkv_b = _bf16(dqkv)
+        # ---- weight gradients: dW_ext = dqkv^T @ [X | 1] --------------------------------------------------------------
+        Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
+        if gather:
+            _ck(lib.nr_gather_bf16(_ptr(ids), _ptr(table.detach()), table.shape[0], None, _ptr(Xb), ntok, p_drop, seed, _stream()))
+        else:
+            _ck(lib.nr_gather_bf16(None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream()))
+        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))                   # [960, KP]
+        gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
+        gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
+        # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
+        dX = torch.mm(dqkv_b, _bf16(Wp)[:, :NR_D])                # [ntok, D] bf16
+        d_table = d_x = None
+        if gather:
+            if ctx.needs_input_grad[1]:
+                d_table = torch.zeros_like(table, dtype=torch.float32)
+                dXi = dX.view(_BF16_AS_I16)
+                _ck(lib.nr_embed_scatter_add(_ptr(ids), _ptr(dXi), NR_D, _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream()))
+        elif ctx.needs_input_grad[2]:
+            d_x = dX.float().view(n_seq, S, NR_D)
+        return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)
+
+
+def encode_titles(ids, table, mhsa, additive, p_drop, training):
+    """NRMS news encoder on a [n_titles, L] int64 id tensor (already on the GPU)."""
+    _require_cuda(table, "word_embedding.weight")
+    check_dims(table.shape[1], mhsa.num_attention_heads, additive.linear.weight.shape[0])
+    p = float(p_drop) if training else 0.0
+    seed = new_seed() if p > 0 else 0
+    return _EncoderFn.apply(ids, table, None, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias,
+                            mhsa.W_V.weight, mhsa.W_V.bias, additive.linear.weight, additive.linear.bias,
+                            additive.attention_query_vector, ids.shape[1], p, seed)
+
+
+def encode_dense(x, mhsa, additive):
+    """NRMS user encoder on a dense [n_seq, S, D] float tensor."""
+    _require_cuda(x, "clicked_news_vector")
+    check_dims(x.shape[2], mhsa.num_attention_heads, additive.linear.weight.shape[0])
+    return _EncoderFn.apply(None, None, x, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias,
+                            mhsa.W_V.weight, mhsa.W_V.bias, additive.linear.weight, additive.linear.bias,
+                            additive.attention_query_vector, x.shape[1], 0.0, 0)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# dot-product scorer
+# ----------------------------------------------------------------------------------------------------------
+class _DotScoreFn(torch.autograd.Function):
+    """src/model/general/click_predictor/dot_product.py:8-19."""
+
+    @staticmethod
+    def forward(ctx, cand, user):
+        B, C, D = cand.shape
+        c, u = _f32c(cand), _f32c(user)
+        out = torch.empty(B, C, dtype=torch.float32, device=cand.device)
+        _ck(_lib().nr_score_dot(_ptr(c), _ptr(u), _ptr(out), B, C, D, _stream()))
+        ctx.save_for_backward(c, u)
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        c, u = ctx.saved_tensors
+        B, C, D = c.shape
+        dl = dl.to(torch.float32).contiguous()
+        dc, du = torch.empty_like(c), torch.empty_like(u)
+        _ck(_lib().nr_score_dot_bwd(_ptr(dl), _ptr(c), _ptr(u), _ptr(dc), _ptr(du), B, C, D, _stream()))
+        return dc, du
+
+
+def dot_score(cand, user):
+    _require_cuda(cand, "candidate_news_vector")
+    if cand.shape[-1] % 4:
+        raise NotImplementedError("feature dim must be a multiple of 4")
+    return _DotScoreFn.apply(cand, user)
+
+
+def score_csr(news_mat, user_mat, cand_idx, cand_ptr, user_idx):
+    """Batched replacement of the per-impression loop of src/evaluate.py:245-260 (see nr_score_csr)."""
+    _require_cuda(news_mat, "news matrix")
+    nnz = int(cand_idx.numel())
+    out = torch.empty(nnz, dtype=torch.float32, device=news_mat.device)
+    n, u = _f32c(news_mat), _f32c(user_mat)
+    _ck(_lib().nr_score_csr(_ptr(n), _ptr(u), _ptr(cand_idx), _ptr(cand_ptr), _ptr(user_idx), _ptr(out),
+                            int(user_idx.numel()), nnz, n.shape[1], _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# stand-alone L0 modules (same math, un-fused entry points for callers that use the primitives directly)
+# ----------------------------------------------------------------------------------------------------------
+class _MhsaFn(torch.autograd.Function):
+    """MultiHeadSelfAttention.forward(Q) with K=V=Q, length=None (multihead_self.py:46-75) on a dense input."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv):
+        lib = _lib()
+        n_seq, S, _ = x.shape
+        if not lib.nr_supported_seq_len(S):
+            raise NotImplementedError(f"sequence length {S} is not instantiated in the HIP kernels (20, 50)")
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad)
+        Wp, bp = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
+        xd = _f32c(x)
+        cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        sp4 = (S + 3) // 4 * 4
+        qs = ks = vts = None
+        if need_grad:
+            qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+            ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+            vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
+        _ck(lib.nr_mhsa_fwd(None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf), _ptr(qs), _ptr(ks), _ptr(vts),
+                            n_seq, S, 0.0, 0, _stream()))
+        if need_grad:
+            ctx.save_for_backward(xd, qs, ks, vts, Wp)
+        return _bf16(cbuf)[:, :NR_D].float().view(n_seq, S, NR_D)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        xd, qs, ks, vts, Wp = ctx.saved_tensors
+        n_seq, S, _ = xd.shape
+        dev = xd.device
+        ntok = n_seq * S
+        dctx = g.reshape(ntok, NR_D).to(torch.bfloat16).contiguous()
+        zw = torch.zeros(n_seq, S, dtype=torch.float32, device=dev)
+        zg = torch.zeros(n_seq, NR_D, dtype=torch.float32, device=dev)
+        dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)
+        _ck(lib.nr_attn_bwd(_ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), n_seq, S, 0.0, 0, _stream()))
+        dqkv_b = _bf16(dqkv)
+        Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
+        _ck(lib.nr_gather_bf16(None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream()))
+        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
+        gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
+        gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
+        dX = torch.mm(dqkv_b, _bf16(Wp)[:, :NR_D]).float().view(n_seq, S, NR_D)
+        return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2]
+
+
+def mhsa_dense(x, mhsa):
+    _require_cuda(x, "MultiHeadSelfAttention input")
+    check_dims(x.shape[2], mhsa.num_attention_heads)
+    return _MhsaFn.apply(x, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias, mhsa.W_V.weight, mhsa.W_V.bias)
+
+
+class _AdditiveFn(torch.autograd.Function):
+    """AdditiveAttention.forward (additive.py:27-53) on a dense [n_seq, S, D] input."""
+
+    @staticmethod
+    def forward(ctx, x, Wa, ba, qv):
+        lib = _lib()
+        n_seq, S, _ = x.shape
+        if not lib.nr_supported_seq_len(S):
+            raise NotImplementedError(f"sequence length {S} is not instantiated in the HIP kernels (20, 50)")
+        dev = x.device
+        Wap, bap, qvp = pack_additive(Wa, ba, qv)
+        cb = torch.zeros(n_seq * S, NR_KP, dtype=torch.bfloat16, device=dev)
+        cb[:, :NR_D] = x.detach().reshape(n_seq * S, NR_D).to(torch.bfloat16)
+        cb[:, NR_D] = 1.0
+        cbuf = cb.view(_BF16_AS_I16)
+        out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+        aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+        _ck(lib.nr_additive_fwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream()))
+        ctx.save_for_backward(cbuf, aw, Wap, bap, qvp)
+        ctx.qdim = Wa.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib()
+        cbuf, aw, Wap, bap, qvp = ctx.saved_tensors
+        n_seq, S = aw.shape
+        dev = cbuf.device
+        ntok = n_seq * S
+        g_out = g_out.to(torch.float32).contiguous()
+        nwg = lib.nr_additive_bwd_grid(n_seq, S)
+        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+        _ck(lib.nr_additive_bwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream()))
+        qdim = ctx.qdim
+        dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
+        dx = torch.mm(_bf16(dpre), _bf16(Wap)[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
+        return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim]
+
+
+def additive_dense(x, additive):
+    _require_cuda(x, "AdditiveAttention input")
+    check_dims(x.shape[2], NR_HEADS, additive.linear.weight.shape[0])
+    return _AdditiveFn.apply(x, additive.linear.weight, additive.linear.bias, additive.attention_query_vector)

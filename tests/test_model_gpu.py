@@ -1,0 +1,206 @@
+"""GPU parity of the drop-in NRMS modules (news_recommendation_amd/dropin/model) against
+ (a) the golden vectors produced by the imported reference (tests/golden, oracle/make_golden.py) and
+ (b) the oracle (torch port on CPU, numpy with explicit dropout masks).
+Tolerances are bf16-operand / fp32-accumulate level and are stated next to each check."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import nrms_numpy as onp
+from oracle.make_golden import CASES, make_cfg
+from oracle.nrms_torch import OracleNRMS
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rel_err(got, ref, floor=0.0):
+    """max |got-ref| relative to max |ref| (+ an absolute floor for tensors that are analytically ~0, e.g. the
+    gradient of W_K.bias: a per-query constant shift of the scores cancels in exp/(sum+1e-8))."""
+    got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref).max() / (np.abs(ref).max() + floor + 1e-30)
+
+
+def grad_floor(ref_grads):
+    """2e-2 of the largest bias gradient in the model: with the 4-5e-2 bounds below this lets an analytically-zero
+    gradient (W_K.bias) carry rounding noise of at most ~1e-3 of a typical bias gradient (bf16 dK rows summed)."""
+    return 2e-2 * max(np.abs(np.asarray(v)).max() for k, v in ref_grads.items() if k.endswith('bias'))
+
+
+def build(V, d, H, Q, N, L, params, p=0.2):
+    from news_recommendation_amd.dropin.model.NRMS import NRMS
+    m = NRMS(make_cfg(V, d, H, Q, N, L, p))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})     # reference key names
+    return m.to(DEV)
+
+
+def as_lists(ids):
+    return [{'title': torch.from_numpy(ids[:, j])} for j in range(ids.shape[1])]
+
+
+def test_golden_base_forward_and_grads(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'nrms_base.npz'))
+    V, d, H, Q, B, C, N, L, seed = CASES['base']
+    params = onp.random_nrms_params(np.random.default_rng(seed), V, d, Q, np.float32, emb_std=0.5)
+    m = build(V, d, H, Q, N, L, params).eval()
+    logits = m(as_lists(g['cand_ids']), as_lists(g['click_ids']))
+    assert logits.shape == (B, C) and logits.is_cuda
+    # bf16 operands, fp32 accumulation: 1.5e-2 of the logit scale (SURVEY 8 c4 measured 4e-3 on |logit|~0.1)
+    assert rel_err(logits.detach().cpu().numpy(), g['f32_logits']) < 1.5e-2
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.zeros(B, dtype=torch.long, device=DEV))
+    assert abs(loss.item() - float(g['f32_loss'])) < 1e-2
+    loss.backward()
+    fl = grad_floor({k[len('f32_grad/'):]: g[k] for k in g.files if k.startswith('f32_grad/')})
+    for k, p in m.named_parameters():
+        gr = p.grad.detach().cpu().numpy()
+        if f'f32_grad/{k}' in g:
+            assert rel_err(gr, g[f'f32_grad/{k}'], fl) < 4e-2, k
+        else:
+            assert abs(np.linalg.norm(gr.astype(np.float64)) / g[f'f32_gradnorm/{k}'] - 1) < 4e-2, k
+            assert np.abs(gr[:8, :16] - g[f'f32_gradslice/{k}']).max() < 4e-2 * np.abs(gr).max(), k
+            if k.endswith('word_embedding.weight'):
+                assert np.all(gr[0] == 0)                                  # padding_idx row
+                rs = g[f'f32_gradrowsum/{k}']
+                assert np.abs(gr.sum(1) - rs).max() < 4e-2 * np.abs(rs).max() + 1e-4
+    # eval-time entry points (evaluate.py:198,226-230,257)
+    with torch.no_grad():
+        nv = m.get_news_vector({'title': torch.from_numpy(g['cand_ids'].reshape(-1, L))})
+        assert rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 1.5e-2
+        cv = torch.stack([m.get_news_vector(x) for x in as_lists(g['click_ids'])], dim=1)
+        uv = m.get_user_vector(cv)
+        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 1.5e-2
+        pr = m.get_prediction(nv[:C], uv[0])
+        assert pr.shape == (C,) and len(pr.tolist()) == C
+        assert np.abs(pr.cpu().numpy() - g['f32_pred0']).max() < 1.5e-2 * np.abs(g['f32_logits']).max()
+
+
+def mind_batch(rng, B, C=3, N=50, L=20, V=70976):
+    def titles(n):
+        ids = np.minimum(rng.zipf(1.3, size=(n, L)), V - 1)
+        lens = rng.integers(4, L + 1, size=n)
+        ids[np.arange(L)[None, :] >= lens[:, None]] = 0
+        return ids
+    cand = titles(B * C).reshape(B, C, L)
+    click = titles(B * N).reshape(B, N, L)
+    hist = rng.integers(0, N + 1, size=B)
+    for b in range(B):
+        click[b, :N - hist[b]] = 0
+    return cand.astype(np.int64), click.astype(np.int64)
+
+
+def test_mind_shape_vs_torch_oracle():
+    """MIND-small shapes (V=70,976, L=20, N=50, d=300) at B=24: logits and every gradient vs the CPU fp32 oracle."""
+    rng = np.random.default_rng(21)
+    V = 70976
+    params = onp.random_nrms_params(rng, V, 300, 200, np.float32, emb_std=0.4)
+    cand, click = mind_batch(rng, 24, V=V)
+    ref = OracleNRMS(V, 300, 15, 200, 0.2)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    ref.eval()
+    lr = ref(as_lists(cand), as_lists(click))
+    torch.nn.CrossEntropyLoss()(lr, torch.zeros(24, dtype=torch.long)).backward()
+    m = build(V, 300, 15, 200, 50, 20, params).eval()
+    lg = m(as_lists(cand), as_lists(click))
+    torch.nn.CrossEntropyLoss()(lg, torch.zeros(24, dtype=torch.long, device=DEV)).backward()
+    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1.5e-2
+    gref = dict(ref.named_parameters())
+    fl = grad_floor({k: v.grad.numpy() for k, v in gref.items()})
+    for k, p in m.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), gref[k].grad.numpy(), fl)
+        assert e < 5e-2, (k, e)
+    assert torch.all(m.news_encoder.word_embedding.weight.grad[0] == 0)
+
+
+def test_training_mode_dropout_matches_oracle_with_exported_masks():
+    """Train mode: the fused kernels' dropout (both sites) reproduced in the numpy oracle via nr_dropout_mask."""
+    from tests.backends import GpuBackend
+    from tests.kernel_checks import export_mask
+    rng = np.random.default_rng(22)
+    V, B, C, N, L = 3000, 6, 3, 50, 20
+    params = onp.random_nrms_params(rng, V, 300, 200, np.float32, emb_std=0.4)
+    cand, click = mind_batch(rng, B, V=V)
+    m = build(V, 300, 15, 200, N, L, params, p=0.2).train()
+    torch.manual_seed(1234)
+    l1 = m(as_lists(cand), as_lists(click))
+    torch.manual_seed(1234)
+    l2 = m(as_lists(cand), as_lists(click))
+    assert torch.equal(l1, l2)                                   # same seed -> same masks
+    l3 = m(as_lists(cand), as_lists(click))
+    assert not torch.equal(l1, l3)                               # next draw differs
+    m.eval()
+    assert not torch.equal(m(as_lists(cand), as_lists(click)), l1)
+    m.train()
+    torch.manual_seed(1234)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())           # what ops.new_seed() drew
+    T = B * (C + N)
+    be = GpuBackend()
+    m1 = export_mask(be, T * L * 300, 0.2, seed, 1).reshape(T, L, 300)
+    m2 = export_mask(be, T * L * 300, 0.2, seed, 2).reshape(T, L, 300)
+    masks = dict(cand1=m1[:B * C], cand2=m2[:B * C], click1=m1[B * C:], click2=m2[B * C:])
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref, cache = onp.nrms_forward(cand, click, p64, 15, p_drop=np.float32(0.2), masks={k: v.astype(np.float64) for k, v in masks.items()})
+    assert rel_err(l1.detach().cpu().numpy(), ref) < 1.5e-2
+    loss = torch.nn.CrossEntropyLoss()(l1, torch.zeros(B, dtype=torch.long, device=DEV))
+    m.zero_grad()
+    loss.backward()
+    _, dl = onp.cross_entropy_target0(ref)
+    grads = onp.nrms_backward(dl, cache, p64, 15)
+    fl = grad_floor(grads)
+    for k, p in m.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), grads[k], fl)
+        assert e < 5e-2, (k, e)
+
+
+def test_state_dict_roundtrip_and_optimizer_step():
+    """Parameters are ordinary nn.Parameters updated in place by torch.optim.Adam (train.py:127-128,227-233);
+    the kernels must see the new values on the next call (no stale packed copies)."""
+    rng = np.random.default_rng(23)
+    V = 2000
+    params = onp.random_nrms_params(rng, V, 300, 200, np.float32, emb_std=0.4)
+    m = build(V, 300, 15, 200, 50, 20, params).eval()
+    sd = m.state_dict()
+    assert set(sd) == set(params) and all(tuple(sd[k].shape) == params[k].shape for k in params)
+    cand, click = mind_batch(rng, 8, V=V)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)   # train.py learning_rate (config.py:19)
+    l0 = m(as_lists(cand), as_lists(click))
+    loss0 = torch.nn.CrossEntropyLoss()(l0, torch.zeros(8, dtype=torch.long, device=DEV))
+    opt.zero_grad(); loss0.backward(); opt.step()
+    l1 = m(as_lists(cand), as_lists(click))
+    loss1 = torch.nn.CrossEntropyLoss()(l1, torch.zeros(8, dtype=torch.long, device=DEV))
+    assert loss1.item() < loss0.item()                           # one Adam step on the same batch lowers the loss
+    ref = OracleNRMS(V, 300, 15, 200, 0.2)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    ref.eval()
+    lr = ref(as_lists(cand), as_lists(click))
+    assert rel_err(l1.detach().cpu().numpy(), lr.detach().numpy()) < 1.5e-2
+
+
+def test_standalone_primitives_match_oracle():
+    """MultiHeadSelfAttention / AdditiveAttention / DotProductClickPredictor used directly."""
+    from news_recommendation_amd.dropin.model.general.attention.multihead_self import MultiHeadSelfAttention
+    from news_recommendation_amd.dropin.model.general.attention.additive import AdditiveAttention
+    from news_recommendation_amd.dropin.model.general.click_predictor.dot_product import DotProductClickPredictor
+    from oracle.nrms_torch import OracleMHSA, OracleAdditive
+    torch.manual_seed(0)
+    mh, ad = MultiHeadSelfAttention(300, 15).to(DEV), AdditiveAttention(200, 300).to(DEV)
+    rm, ra = OracleMHSA(300, 15), OracleAdditive(200, 300)
+    rm.load_state_dict({k: v.cpu() for k, v in mh.state_dict().items()})
+    ra.load_state_dict({k: v.cpu() for k, v in ad.state_dict().items()})
+    x = torch.randn(9, 50, 300) * 0.5
+    xg = x.clone().to(DEV).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yg, yr = ad(mh(xg)), ra(rm(xr))
+    assert rel_err(yg.detach().cpu().numpy(), yr.detach().numpy()) < 1.5e-2
+    w = torch.randn(9, 300)
+    (yg * w.to(DEV)).sum().backward(); (yr * w).sum().backward()
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 5e-2
+    refp = list(rm.named_parameters()) + list(ra.named_parameters())
+    fl = grad_floor({k: q.grad.numpy() for k, q in refp})
+    for (k, p), (_, q) in zip(list(mh.named_parameters()) + list(ad.named_parameters()), refp):
+        assert rel_err(p.grad.cpu().numpy(), q.grad.numpy(), fl) < 5e-2, k
+    cp = DotProductClickPredictor()
+    c, u = torch.randn(5, 7, 300), torch.randn(5, 300)
+    np.testing.assert_allclose(cp(c.to(DEV), u.to(DEV)).cpu().numpy(), torch.bmm(c, u.unsqueeze(-1)).squeeze(-1).numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        mh(xg, length=torch.tensor([3] * 9))
