@@ -22,9 +22,14 @@ class NRMS(torch.nn.Module):
 
         The reference encodes the 1+K+N positions one by one (__init__.py:38-42); here all B*(1+K+N) titles are
         stacked into ONE id matrix and encoded by one kernel chain."""
-        dev = self.news_encoder.word_embedding.weight.device
         cand = torch.stack([x["title"] for x in candidate_news], dim=1)       # [B, C, L]
         click = torch.stack([x["title"] for x in clicked_news], dim=1)        # [B, N, L]
+        return self.forward_ids(cand, click)
+
+    def forward_ids(self, cand, click):
+        """Same as forward() on already-stacked id tensors: cand int64 [B, C, L], click int64 [B, N, L]
+        (host or device resident)."""
+        dev = self.news_encoder.word_embedding.weight.device
         B, C, L = cand.shape
         N = click.shape[1]
         ids = torch.cat([cand.reshape(B * C, L), click.reshape(B * N, L)], dim=0).to(dev, non_blocking=True)

@@ -34,6 +34,52 @@ def _ck(rc):
     _capi.check(_lib(), rc)
 
 
+# ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py) --------------------
+_prof = None
+
+
+class profile:
+    """``with ops.profile() as rec:`` records a (start, end) HIP-event pair around every kernel launch / GEMM issued
+    by this module on the current stream; ``rec.summary()`` -> {name: (n_launches, avg_us, total_us)}."""
+
+    def __init__(self, only=None):
+        self.events = {}
+        self.only = only
+
+    def __enter__(self):
+        global _prof
+        self._prev, _prof = _prof, self
+        return self
+
+    def __exit__(self, *a):
+        global _prof
+        _prof = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for k, ev in self.events.items():
+            us = [a.elapsed_time(b) * 1e3 for a, b in ev]
+            out[k] = (len(us), sum(us) / len(us), sum(us))
+        return out
+
+
+def _timed(name, fn):
+    rec = _prof
+    if rec is None or (rec.only is not None and name not in rec.only):
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    rec.events.setdefault(name, []).append((e0, e1))
+    return r
+
+
+def _call(name, fn, *args):
+    _timed(name, lambda: _ck(fn(*args)))
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -65,7 +111,7 @@ def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
     Wp = torch.empty(3 * NR_NP, NR_KP, dtype=_BF16_AS_I16, device=dev)
     bp = torch.empty(3 * NR_NP, dtype=torch.float32, device=dev)
     args = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
-    _ck(_lib().nr_pack_qkv(*[_ptr(a) for a in args], _ptr(Wp), _ptr(bp), _stream()))
+    _call('nr_pack_qkv', _lib().nr_pack_qkv, *[_ptr(a) for a in args], _ptr(Wp), _ptr(bp), _stream())
     return Wp, bp
 
 
@@ -76,7 +122,7 @@ def pack_additive(Wa, ba, qv):
     bap = torch.empty(NR_QP, dtype=torch.float32, device=dev)
     qvp = torch.empty(NR_QP, dtype=torch.float32, device=dev)
     a = [_f32c(Wa), _f32c(ba), _f32c(qv)]
-    _ck(_lib().nr_pack_additive(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), qdim, _ptr(Wap), _ptr(bap), _ptr(qvp), _stream()))
+    _call('nr_pack_additive', _lib().nr_pack_additive, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), qdim, _ptr(Wap), _ptr(bap), _ptr(qvp), _stream())
     return Wap, bap, qvp
 
 
@@ -84,12 +130,26 @@ def _bf16(t_i16):
     return t_i16.view(torch.bfloat16)
 
 
-def _mm_f32(a, b):
+_HAS_OUT_DTYPE = None
+
+
+def _mm_f32(a, b, name='gemm_f32'):
     """bf16 x bf16 GEMM with fp32 result (hipBLASLt accumulates in fp32)."""
-    try:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    except TypeError:            # older torch: round to bf16 at the end
-        return torch.mm(a, b).float()
+    global _HAS_OUT_DTYPE
+    if _HAS_OUT_DTYPE is None:
+        try:
+            t = torch.zeros(16, 16, dtype=torch.bfloat16, device=a.device)
+            torch.mm(t, t, out_dtype=torch.float32)
+            _HAS_OUT_DTYPE = True
+        except (TypeError, RuntimeError):
+            _HAS_OUT_DTYPE = False
+    if _HAS_OUT_DTYPE:
+        return _timed(name, lambda: torch.mm(a, b, out_dtype=torch.float32))
+    return _timed(name, lambda: torch.mm(a, b).float())     # older torch: round to bf16 at the end
+
+
+def _mm(a, b, name='gemm'):
+    return _timed(name, lambda: torch.mm(a, b))
 
 
 _ws = {}
@@ -137,17 +197,17 @@ class _EncoderFn(torch.autograd.Function):
             ids_c = ids.contiguous()
             tab = table.detach()
             assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
-            _ck(lib.nr_mhsa_fwd(_ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream()))
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd, _ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream())
             xd = None
         else:
             ids_c = None
             xd = _f32c(x_dense)
-            _ck(lib.nr_mhsa_fwd(None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream()))
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream())
         out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-        _ck(lib.nr_additive_fwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream()))
+        _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
         if need_grad:
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
@@ -165,35 +225,35 @@ class _EncoderFn(torch.autograd.Function):
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
         dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        _ck(lib.nr_additive_bwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
-                                _ptr(dq_part), n_seq, S, _stream()))
+        _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
+                                _ptr(dq_part), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
         dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
-        dWa_ext = _mm_f32(dpre_b.t(), ctx_b)                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        dWa_ext = _mm_f32(dpre_b.t(), ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
-        dctx_gemm = torch.mm(dpre_b, Wap_b[:, :NR_D])             # [ntok, D] bf16
+        dctx_gemm = _mm(dpre_b, Wap_b[:, :NR_D], f'gemm_dctx[S={S}]')             # [ntok, D] bf16
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
-        _ck(lib.nr_attn_bwd(_ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(dqkv),
-                            n_seq, S, p_drop, seed, _stream()))
+        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(dqkv),
+                            n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
         # ---- weight gradients: dW_ext = dqkv^T @ [X | 1] --------------------------------------------------------------
         Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
         if gather:
-            _ck(lib.nr_gather_bf16(_ptr(ids), _ptr(table.detach()), table.shape[0], None, _ptr(Xb), ntok, p_drop, seed, _stream()))
+            _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, _ptr(ids), _ptr(table.detach()), table.shape[0], None, _ptr(Xb), ntok, p_drop, seed, _stream())
         else:
-            _ck(lib.nr_gather_bf16(None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream()))
-        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))                   # [960, KP]
+            _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
+        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb), f'gemm_dWqkv[S={S}]')    # [960, KP]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
-        dX = torch.mm(dqkv_b, _bf16(Wp)[:, :NR_D])                # [ntok, D] bf16
+        dX = _mm(dqkv_b, _bf16(Wp)[:, :NR_D], f'gemm_dX[S={S}]')          # [ntok, D] bf16
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:
                 d_table = torch.zeros_like(table, dtype=torch.float32)
                 dXi = dX.view(_BF16_AS_I16)
-                _ck(lib.nr_embed_scatter_add(_ptr(ids), _ptr(dXi), NR_D, _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream()))
+                _call(f'nr_embed_scatter_add[S={S}]', lib.nr_embed_scatter_add, _ptr(ids), _ptr(dXi), NR_D, _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
         elif ctx.needs_input_grad[2]:
             d_x = dX.float().view(n_seq, S, NR_D)
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)
@@ -230,7 +290,7 @@ class _DotScoreFn(torch.autograd.Function):
         B, C, D = cand.shape
         c, u = _f32c(cand), _f32c(user)
         out = torch.empty(B, C, dtype=torch.float32, device=cand.device)
-        _ck(_lib().nr_score_dot(_ptr(c), _ptr(u), _ptr(out), B, C, D, _stream()))
+        _call('nr_score_dot', _lib().nr_score_dot, _ptr(c), _ptr(u), _ptr(out), B, C, D, _stream())
         ctx.save_for_backward(c, u)
         return out
 
@@ -240,7 +300,7 @@ class _DotScoreFn(torch.autograd.Function):
         B, C, D = c.shape
         dl = dl.to(torch.float32).contiguous()
         dc, du = torch.empty_like(c), torch.empty_like(u)
-        _ck(_lib().nr_score_dot_bwd(_ptr(dl), _ptr(c), _ptr(u), _ptr(dc), _ptr(du), B, C, D, _stream()))
+        _call('nr_score_dot_bwd', _lib().nr_score_dot_bwd, _ptr(dl), _ptr(c), _ptr(u), _ptr(dc), _ptr(du), B, C, D, _stream())
         return dc, du
 
 
@@ -257,8 +317,8 @@ def score_csr(news_mat, user_mat, cand_idx, cand_ptr, user_idx):
     nnz = int(cand_idx.numel())
     out = torch.empty(nnz, dtype=torch.float32, device=news_mat.device)
     n, u = _f32c(news_mat), _f32c(user_mat)
-    _ck(_lib().nr_score_csr(_ptr(n), _ptr(u), _ptr(cand_idx), _ptr(cand_ptr), _ptr(user_idx), _ptr(out),
-                            int(user_idx.numel()), nnz, n.shape[1], _stream()))
+    _call('nr_score_csr', _lib().nr_score_csr, _ptr(n), _ptr(u), _ptr(cand_idx), _ptr(cand_ptr), _ptr(user_idx), _ptr(out),
+                            int(user_idx.numel()), nnz, n.shape[1], _stream())
     return out
 
 
@@ -285,8 +345,8 @@ class _MhsaFn(torch.autograd.Function):
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
-        _ck(lib.nr_mhsa_fwd(None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf), _ptr(qs), _ptr(ks), _ptr(vts),
-                            n_seq, S, 0.0, 0, _stream()))
+        _call('nr_mhsa_fwd', lib.nr_mhsa_fwd, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf), _ptr(qs), _ptr(ks), _ptr(vts),
+                            n_seq, S, 0.0, 0, _stream())
         if need_grad:
             ctx.save_for_backward(xd, qs, ks, vts, Wp)
         return _bf16(cbuf)[:, :NR_D].float().view(n_seq, S, NR_D)
@@ -302,10 +362,10 @@ class _MhsaFn(torch.autograd.Function):
         zw = torch.zeros(n_seq, S, dtype=torch.float32, device=dev)
         zg = torch.zeros(n_seq, NR_D, dtype=torch.float32, device=dev)
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)
-        _ck(lib.nr_attn_bwd(_ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), n_seq, S, 0.0, 0, _stream()))
+        _call('nr_attn_bwd', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), n_seq, S, 0.0, 0, _stream())
         dqkv_b = _bf16(dqkv)
         Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
-        _ck(lib.nr_gather_bf16(None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream()))
+        _call('nr_gather_bf16', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
         dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
@@ -336,7 +396,7 @@ class _AdditiveFn(torch.autograd.Function):
         cbuf = cb.view(_BF16_AS_I16)
         out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-        _ck(lib.nr_additive_fwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream()))
+        _call('nr_additive_fwd', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp)
         ctx.qdim = Wa.shape[0]
         return out
@@ -352,7 +412,7 @@ class _AdditiveFn(torch.autograd.Function):
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
         dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        _ck(lib.nr_additive_bwd(_ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream()))
+        _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
         qdim = ctx.qdim
         dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
         dx = torch.mm(_bf16(dpre), _bf16(Wap)[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)

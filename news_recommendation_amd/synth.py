@@ -1,0 +1,82 @@
+"""Synthetic MIND-small-shaped inputs.  No dataset files are needed: the generator
+emits the id tensors the hot path consumes (and, for the drop-in launcher, can be written out in the
+reference's on-disk formats later)."""
+import numpy as np
+
+MIND_SMALL = dict(num_words=70976, num_news=65238, num_clicked=50, title_len=20, neg_k=2)
+
+
+def zipf_ids(rng, shape, num_words, s=1.05):
+    """Zipf(s)-distributed token ids over 1..num_words-1 (rank-frequency like natural text)."""
+    # inverse-CDF sampling on a truncated zeta via the continuous approximation
+    u = rng.random(size=shape)
+    n = num_words - 1
+    if abs(s - 1.0) < 1e-6:
+        r = np.exp(u * np.log(n))
+    else:
+        r = ((n ** (1 - s) - 1) * u + 1) ** (1 / (1 - s))
+    return np.clip(r.astype(np.int64), 1, n)
+
+
+def news_titles(rng, n_news, title_len=20, num_words=70976, dist='zipf'):
+    """[n_news, title_len] int64: 4..title_len real tokens (mean ~11), right-padded with 0."""
+    if dist == 'zipf':
+        ids = zipf_ids(rng, (n_news, title_len), num_words)
+    else:
+        ids = rng.integers(1, num_words, size=(n_news, title_len))
+    lens = np.clip(rng.normal(11, 4, size=n_news).round().astype(np.int64), 4, title_len)
+    ids[np.arange(title_len)[None, :] >= lens[:, None]] = 0
+    return ids.astype(np.int64)
+
+
+def history_lengths(rng, n, num_clicked=50):
+    """clipped lognormal history lengths in [0, num_clicked], mean ~32."""
+    return np.clip(rng.lognormal(3.6, 0.8, size=n).round().astype(np.int64), 0, num_clicked)
+
+
+def train_batch(rng, news, B, num_clicked=50, neg_k=2):
+    """One train-shaped batch: candidate news indices [B, 1+K] (positive first, data_preprocess.py:63-66) and
+    LEFT-padded history indices [B, N] with -1 for padding (dataset.py:79-83)."""
+    n_news = news.shape[0]
+    cand = rng.integers(0, n_news, size=(B, 1 + neg_k))
+    hl = history_lengths(rng, B, num_clicked)
+    hist = rng.integers(0, n_news, size=(B, num_clicked))
+    hist[np.arange(num_clicked)[None, :] < (num_clicked - hl)[:, None]] = -1
+    return cand, hist
+
+
+def batch_token_ids(news, cand, hist):
+    """news-index batches -> token id tensors [B, C, L], [B, N, L]; padded history slots are all-zero titles
+    (training-time semantics)."""
+    L = news.shape[1]
+    pad = np.zeros((1, L), dtype=np.int64)
+    tab = np.concatenate([news, pad], axis=0)
+    return tab[cand], tab[np.where(hist < 0, news.shape[0], hist)]
+
+
+def eval_impressions(rng, n_news, n_impr, num_clicked=50, mean_cands=37):
+    """Eval-shaped impressions: per impression a left-padded history (news indices, -1 = PADDED_NEWS) and a ragged
+    candidate list (lognormal length in [2, 300], mean ~37)."""
+    hl = history_lengths(rng, n_impr, num_clicked)
+    hist = rng.integers(0, n_news, size=(n_impr, num_clicked))
+    hist[np.arange(num_clicked)[None, :] < (num_clicked - hl)[:, None]] = -1
+    lens = np.clip(rng.lognormal(np.log(mean_cands) - 0.32, 0.8, size=n_impr).round().astype(np.int64), 2, 300)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cands = rng.integers(0, n_news, size=int(ptr[-1])).astype(np.int32)
+    return hist, cands, ptr
+
+
+def teacher_labels(rng, scores, ptr):
+    """y ~ Bernoulli(sigmoid(2 z - 1.5)) on per-impression z-scored teacher scores, forced >= 1 positive and
+    >= 1 negative."""
+    labels = np.zeros(len(scores), dtype=np.int64)
+    for i in range(len(ptr) - 1):
+        s = scores[ptr[i]:ptr[i + 1]]
+        z = (s - s.mean()) / (s.std() + 1e-9)
+        y = (rng.random(len(s)) < 1 / (1 + np.exp(-(2 * z - 1.5)))).astype(np.int64)
+        if y.sum() == 0:
+            y[np.argmax(z)] = 1
+        if y.sum() == len(y):
+            y[np.argmin(z)] = 0
+        labels[ptr[i]:ptr[i + 1]] = y
+    return labels
