@@ -116,6 +116,13 @@ int nr_gather_bf16(const int64_t* ids, const float* table, int64_t num_rows, con
 int nr_embed_scatter_add(const int64_t* ids, const uint16_t* dx, int ldx, float* grad_table, int64_t num_rows,
                          int64_t n_tokens, float p_drop, uint64_t seed, void* stream);
 
+/* Same result without contended atomics: the caller passes the token ids sorted ascending together with the
+ * permutation (ids_sorted[i] = ids[perm[i]]); each table row is reduced in registers and written once.
+ * grad_table must be zero on entry (rows are stored, not accumulated, unless a run spans two waves). */
+int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, const uint16_t* dx, int ldx,
+                            float* grad_table, int64_t num_rows, int64_t n_tokens, float p_drop, uint64_t seed,
+                            void* stream);
+
 /* Backward of DotProductClickPredictor: d_cand[b,c,:] = dl[b,c]*user[b,:], d_user[b,:] = sum_c dl[b,c]*cand[b,c,:]. */
 int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user,
                      int64_t B, int C, int d, void* stream);

@@ -23,6 +23,7 @@ SIGNATURES = {
     'nr_additive_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_gather_bf16': ([_P, _P, c_int64, _P, _P, c_int64, c_float, c_uint64, _P], c_int),
     'nr_embed_scatter_add': ([_P, _P, c_int, _P, c_int64, c_int64, c_float, c_uint64, _P], c_int),
+    'nr_embed_scatter_sorted': ([_P, _P, _P, c_int, _P, c_int64, c_int64, c_float, c_uint64, _P], c_int),
     'nr_score_dot_bwd': ([_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_additive_fwd': ([_P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_score_dot': ([_P, _P, _P, c_int64, c_int, c_int, _P], c_int),

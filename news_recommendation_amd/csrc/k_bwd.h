@@ -414,6 +414,75 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* _
   }
 }
 
+// Sorted variant: positions are sorted by id (ids_sorted ascending, perm = original token index), so all
+// contributions to one table row are adjacent.  One wave reduces CH consecutive positions in registers (lane =
+// one 4-column quad, lanes 0..10 a second quad) and writes each finished row once; only rows whose run touches
+// the chunk boundary (and may continue in a neighbour wave) use atomics.  grad_table must start zeroed.
+constexpr int SC_CH = 32;
+__global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t* __restrict__ ids_sorted,
+                                                                   const int64_t* __restrict__ perm, const u16* __restrict__ dx,
+                                                                   int ldx, float* __restrict__ grad_table, int64_t num_rows,
+                                                                   int64_t n_tokens, DropCfg dc) {
+  const int l = lane_id();
+  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave_id()) * SC_CH;
+  if (s0 >= n_tokens) return;
+  const int cnt = (int)((n_tokens - s0) < SC_CH ? (n_tokens - s0) : SC_CH);
+  // each lane keeps one (id, token) pair of the chunk; broadcast by shuffle while walking the chunk
+  int64_t my_id = -1, my_tok = 0;
+  if (l < cnt) { my_id = ids_sorted[s0 + l]; my_tok = perm[s0 + l]; }
+  int id_lo = (int)my_id, tok_lo = (int)my_tok;            // ids and token indices fit in 31 bits
+  const int id_last = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), cnt - 1));
+  if (id_last <= 0) return;                                // chunk is all padding (sorted: ids <= 0 come first)
+  const int id_before = s0 > 0 ? (int)ids_sorted[s0 - 1] : -1;
+  const int id_after = s0 + cnt < n_tokens ? (int)ids_sorted[s0 + cnt] : -1;
+  const bool two = l < (D4 - 64);
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cur = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), 0));
+  auto flush = [&](int id, bool shared) {
+    if (id <= 0 || id >= num_rows) return;
+    float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
+    if (shared) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomic_add(dst + j, a0[j]);
+      if (two) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomic_add(dst + 256 + j, a1[j]);
+      }
+    } else {
+      *(f32x4*)dst = a0;
+      if (two) *(f32x4*)(dst + 256) = a1;
+    }
+  };
+  bool first = true;
+  for (int i = 0; i < cnt; ++i) {
+    const int id = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), i));
+    const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
+    if (id != cur) {
+      flush(cur, first && cur == id_before);
+      first = false;
+      cur = id;
+      a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
+    }
+    if (id <= 0) continue;
+    const u16* row = dx + (int64_t)tok * ldx;
+    u16x4 v0 = *(const u16x4*)(row + l * 4);
+    u16x4 v1 = two ? *(const u16x4*)(row + 256 + l * 4) : u16x4{0, 0, 0, 0};
+    uint32_t k0 = 0xF, k1 = 0xF;
+    float sc = 1.0f;
+    if (dc.enabled) {
+      k0 = drop_keep4(dc, 1u, (uint64_t)tok * D4 + l);
+      k1 = two ? drop_keep4(dc, 1u, (uint64_t)tok * D4 + 64 + l) : 0u;
+      sc = dc.scale;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((k0 >> j) & 1u) a0[j] += bf2f(v0[j]) * sc;
+      if ((k1 >> j) & 1u) a1[j] += bf2f(v1[j]) * sc;
+    }
+  }
+  flush(cur, (first && cur == id_before) || cur == id_after);
+}
+
 // d_cand[b,c,:] = dl[b,c] * user[b,:];  d_user[b,:] = sum_c dl[b,c] * cand[b,c,:]
 __global__ __launch_bounds__(256) void score_dot_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ cand,
                                                             const float* __restrict__ user, float* __restrict__ d_cand,

@@ -209,6 +209,19 @@ int nr_embed_scatter_add(const int64_t* ids, const uint16_t* dx, int ldx, float*
   return check_launch("nr_embed_scatter_add");
 }
 
+int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, const uint16_t* dx, int ldx, float* grad_table,
+                            int64_t num_rows, int64_t n_tokens, float p_drop, uint64_t seed, void* stream) {
+  if (!ids_sorted || !perm || !dx || !grad_table || num_rows <= 0 || n_tokens < 0 || ldx < NR_D || (ldx & 3) ||
+      n_tokens >= (1LL << 31) || num_rows >= (1LL << 31))
+    return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: dropout probability out of range");
+  if (n_tokens == 0) return NR_OK;
+  const int64_t waves = (n_tokens + nr::SC_CH - 1) / nr::SC_CH;
+  NR_LAUNCH(nr::embed_scatter_sorted_kernel, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, ldx, grad_table,
+            num_rows, n_tokens, make_drop(p_drop, seed));
+  return check_launch("nr_embed_scatter_sorted");
+}
+
 int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user, int64_t B, int C, int d,
                      void* stream) {
   if (!dl || !cand || !user || !d_cand || !d_user || B < 0 || C <= 0 || d <= 0 || (d & 3))

@@ -1,0 +1,92 @@
+"""Run the reference's UNCHANGED entry scripts (src/train.py, src/evaluate.py) on the MI355X engine.
+
+    python -m news_recommendation_amd.launcher train    --reference /path/to/reference/src --workdir RUN_DIR
+    python -m news_recommendation_amd.launcher evaluate --reference /path/to/reference/src --workdir RUN_DIR
+
+How the drop-in works:
+  * sys.path = [<this package>/dropin, <repo root>, <reference>/src, ...]: ``import model.NRMS`` resolves to the
+    engine's ``dropin/model`` package (same class names / signatures / state_dict keys), while ``config``,
+    ``dataset``, ``evaluate`` and ``train`` resolve to the reference's read-only files;
+  * two shims for this container's package set: a no-op ``torch.utils.tensorboard.SummaryWriter``
+    when tensorboard is not installed, and ``numpy.Inf`` (removed in NumPy 2, used at train.py:31);
+  * cwd = RUN_DIR, which holds ./data (reference formats), ./checkpoint, ./runs -- every reference path is
+    cwd-relative;
+  * under torchrun (WORLD_SIZE > 1) each rank pins its own GPU (so the reference's hard-coded ``cuda:0`` is the local
+    device), replicas are synchronised and gradients are all-reduced over RCCL by post-accumulate hooks -- train.py
+    needs no DDP wrapper.
+"""
+import argparse
+import os
+import runpy
+import sys
+import types
+
+
+def install_shims():
+    import numpy
+    if not hasattr(numpy, 'Inf'):
+        numpy.Inf = numpy.inf
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        mod = types.ModuleType('torch.utils.tensorboard')
+
+        class SummaryWriter:               # the reference only calls add_scalar / add_scalars (train.py:238-255)
+            def __init__(self, *a, **k): pass
+            def add_scalar(self, *a, **k): pass
+            def add_scalars(self, *a, **k): pass
+            def close(self): pass
+        mod.SummaryWriter = SummaryWriter
+        sys.modules['torch.utils.tensorboard'] = mod
+
+
+def _patch_dp():
+    """Data parallelism without touching train.py: wrap the engine's NRMS constructor so every new model is
+    broadcast from rank 0 and gets the gradient all-reduce hooks."""
+    from news_recommendation_amd import dist as nrdist
+    rank, world, local = nrdist.init_from_env()
+    if world <= 1:
+        return
+    import model.NRMS as M
+    orig_to = M.NRMS.to
+
+    def to(self, *a, **k):
+        out = orig_to(self, *a, **k)
+        if not getattr(out, '_nr_dp', False) and next(out.parameters()).is_cuda:
+            nrdist.broadcast_parameters(out)
+            nrdist.attach_grad_allreduce(out)
+            out._nr_dp = True
+        return out
+    M.NRMS.to = to
+
+
+def run(script, reference_src, workdir, model_name='NRMS'):
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+    reference_src = os.path.abspath(reference_src)
+    if os.environ.get('WORLD_SIZE', '1') != '1' and 'LOCAL_RANK' in os.environ:
+        os.environ.setdefault('HIP_VISIBLE_DEVICES', os.environ['LOCAL_RANK'])   # cuda:0 == the local GPU
+    os.environ['MODEL_NAME'] = model_name
+    sys.dont_write_bytecode = True            # the reference tree is read-only
+    for p in (reference_src, repo, os.path.join(here, 'dropin')):
+        if p in sys.path:
+            sys.path.remove(p)
+        sys.path.insert(0, p)
+    install_shims()
+    os.chdir(workdir)
+    _patch_dp()
+    runpy.run_path(os.path.join(reference_src, script + '.py'), run_name='__main__')
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('script', choices=['train', 'evaluate'])
+    ap.add_argument('--reference', default=os.environ.get('NR_REFERENCE_SRC', '/root/reference/src'))
+    ap.add_argument('--workdir', default='.')
+    ap.add_argument('--model', default='NRMS')
+    a = ap.parse_args(argv)
+    run(a.script, a.reference, a.workdir, a.model)
+
+
+if __name__ == '__main__':
+    main()

@@ -152,6 +152,25 @@ def _mm(a, b, name='gemm'):
     return _timed(name, lambda: torch.mm(a, b))
 
 
+def _wgrad(a, b, name):
+    """a^T @ b for tall-skinny bf16 a [n, M], b [n, N] (n = tokens, up to ~5e5; M, N <= 960) with fp32 result.
+    hipBLASLt does not split K for this shape, so the token dim is cut into chunks that are reduced by a
+    batched GEMM (one [M, chunk] x [chunk, N] product per chunk) and summed in fp32."""
+    n = a.shape[0]
+    nc = 1
+    for c in (256, 128, 64, 32, 16, 8, 4, 2):
+        if n % c == 0 and n // c >= 512:
+            nc = c
+            break
+    if nc == 1:
+        return _mm_f32(a.t(), b, name)
+
+    def run():
+        part = torch.bmm(a.view(nc, n // nc, a.shape[1]).transpose(1, 2), b.view(nc, n // nc, b.shape[1]))
+        return part.float().sum(dim=0)
+    return _timed(name, run)
+
+
 _ws = {}
 
 
@@ -229,7 +248,7 @@ class _EncoderFn(torch.autograd.Function):
                                 _ptr(dq_part), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
         dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
-        dWa_ext = _mm_f32(dpre_b.t(), ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
         dctx_gemm = _mm(dpre_b, Wap_b[:, :NR_D], f'gemm_dctx[S={S}]')             # [ntok, D] bf16
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
@@ -243,7 +262,7 @@ class _EncoderFn(torch.autograd.Function):
             _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, _ptr(ids), _ptr(table.detach()), table.shape[0], None, _ptr(Xb), ntok, p_drop, seed, _stream())
         else:
             _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
-        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb), f'gemm_dWqkv[S={S}]')    # [960, KP]
+        dW_ext = _wgrad(dqkv_b, _bf16(Xb), f'gemm_dWqkv[S={S}]')       # [960, KP]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
@@ -253,7 +272,10 @@ class _EncoderFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 d_table = torch.zeros_like(table, dtype=torch.float32)
                 dXi = dX.view(_BF16_AS_I16)
-                _call(f'nr_embed_scatter_add[S={S}]', lib.nr_embed_scatter_add, _ptr(ids), _ptr(dXi), NR_D, _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
+                # sort token ids so that every table row is reduced by adjacent lanes instead of contended atomics
+                ids_sorted, perm = _timed('sort_ids', lambda: torch.sort(ids.view(-1)))
+                _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_D,
+                      _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
         elif ctx.needs_input_grad[2]:
             d_x = dX.float().view(n_seq, S, NR_D)
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)

@@ -80,3 +80,45 @@ def teacher_labels(rng, scores, ptr):
             y[np.argmin(z)] = 0
         labels[ptr[i]:ptr[i + 1]] = y
     return labels
+
+
+def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_impr=60, num_words=500, seed=0,
+                            title_len=20, num_clicked=50, neg_k=2):
+    """Write a tiny synthetic data tree in the reference's on-disk formats so that its UNCHANGED train.py /
+    evaluate.py can run from ``root`` as cwd (file schemas: src/dataset.py:27-37, src/evaluate.py:57-65,87-93,
+    135-143; writers: src/data_preprocess.py:45-49,77-81,205).  Returns the directory."""
+    import os
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    titles = news_titles(rng, n_news, title_len, num_words)
+    nid = [f'N{i + 1}' for i in range(n_news)]
+    news = pd.DataFrame({
+        'id': nid, 'category': rng.integers(1, 10, n_news), 'subcategory': rng.integers(1, 30, n_news),
+        'title': [str(list(map(int, t))) for t in titles],
+        'abstract': [str([0] * 50)] * n_news,
+        'title_entities': [str([0] * title_len)] * n_news, 'abstract_entities': [str([0] * 50)] * n_news})
+    users = [f'U{i + 1}' for i in range(n_users)]
+    for split in ('train', 'val', 'test'):
+        os.makedirs(os.path.join(root, 'data', split), exist_ok=True)
+        news.to_csv(os.path.join(root, 'data', split, 'news_parsed.tsv'), sep='\t', index=False)
+    pd.DataFrame({'user': users, 'int': np.arange(1, n_users + 1)}).to_csv(
+        os.path.join(root, 'data', 'train', 'user2int.tsv'), sep='\t', index=False)
+
+    def hist_str(k):
+        return ' '.join(rng.choice(nid, size=k)) if k > 0 else ' '
+    rows = []
+    for _ in range(n_train):
+        k = int(history_lengths(rng, 1, num_clicked)[0])
+        rows.append({'user': int(rng.integers(1, n_users + 1)), 'clicked_news': hist_str(k),
+                     'candidate_news': ' '.join(rng.choice(nid, size=1 + neg_k)), 'clicked': '1 ' + ' '.join(['0'] * neg_k)})
+    pd.DataFrame(rows).to_csv(os.path.join(root, 'data', 'train', 'behaviors_parsed.tsv'), sep='\t', index=False)
+    for split in ('val', 'test'):
+        with open(os.path.join(root, 'data', split, 'behaviors.tsv'), 'w') as f:
+            for i in range(n_val_impr):
+                k = int(history_lengths(rng, 1, num_clicked)[0])
+                c = int(rng.integers(2, 12))
+                lab = rng.integers(0, 2, c)
+                lab[0], lab[1] = 1, 0
+                imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c), lab))
+                f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist_str(k)}\t{imp}\n")
+    return root

@@ -393,6 +393,29 @@ def check_scatter_add(be, n_tokens=999, V=50, p_drop=0.2, seed=6):
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-4)
 
 
+def check_scatter_sorted(be, n_tokens=999, V=50, p_drop=0.2, seed=6):
+    rng = np.random.default_rng(19)
+    ids = np.minimum(rng.zipf(1.3, size=n_tokens), V - 1).astype(np.int64)      # heavy duplicates: long runs
+    ids[::3] = 0
+    dx = rng.normal(size=(n_tokens, NR_D)).astype(np.float32)
+    dxu = f32_to_bf16(dx)
+    perm = np.argsort(ids, kind='stable').astype(np.int64)
+    grad = be.dev(np.zeros((V, NR_D), dtype=np.float32))
+    ck(be, be.lib.nr_embed_scatter_sorted(be.ptr(be.dev(ids[perm])), be.ptr(be.dev(perm)), be.ptr(be.dev(dxu)), NR_D, be.ptr(grad),
+                                          V, n_tokens, p_drop, seed, be.stream))
+    be.sync()
+    ref = np.zeros((V, NR_D), dtype=np.float64)
+    contrib = bf16_to_f32(dxu).astype(np.float64)
+    if p_drop > 0:
+        m1 = export_mask(be, n_tokens * NR_D, p_drop, seed, 1).reshape(n_tokens, NR_D)
+        contrib = contrib * m1 * np.float64(np.float32(1.0 / (1.0 - p_drop)))
+    nz = ids != 0
+    np.add.at(ref, ids[nz], contrib[nz])
+    got = be.np(grad)
+    assert np.all(got[0] == 0)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)
+
+
 def check_score_bwd(be, B=33, C=3):
     rng = np.random.default_rng(18)
     cand = rng.normal(size=(B, C, NR_D)).astype(np.float32)

@@ -1,0 +1,83 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every declared symbol, the drop-in
+package mirrors the reference's module API / state_dict, the product fails LOUDLY without a GPU (no CPU fallback),
+and the launcher really runs the reference's unchanged train.py against the engine's model package."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/src'
+
+
+def test_library_exports_every_declared_symbol():
+    from news_recommendation_amd import _capi
+    hdr = open(os.path.join(ROOT, 'include', 'nr_engine.h')).read()
+    declared = set(re.findall(r'^\s*(?:int|int64_t|const char\*)\s+(nr_\w+)\s*\(', hdr, flags=re.M))
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load()                                   # built by __graft_entry__.build()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nr_version() >= 1 and lib.nr_supported_seq_len(20) == 1 and lib.nr_supported_seq_len(7) == 0
+    assert lib.nr_additive_bwd_grid(10, 20) == 3 and lib.nr_additive_bwd_grid(10, 50) == 10
+    # argument validation happens before any device work, so it can be exercised without a GPU
+    assert lib.nr_gather_rows_f32(None, None, None, 5, 300, 10, None) == -2
+    assert b'nr_gather_rows_f32' in lib.nr_last_error()
+
+
+def test_dropin_state_dict_matches_reference_keys():
+    from news_recommendation_amd.dropin.model.NRMS import NRMS
+    from oracle.make_golden import make_cfg
+    from oracle.nrms_numpy import nrms_param_shapes
+    m = NRMS(make_cfg(777, 300, 15, 200, 50, 20, 0.2))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == nrms_param_shapes(777)
+    assert [n for n, _ in m.named_children()] == ['news_encoder', 'user_encoder', 'click_predictor']
+    pre = torch.randn(777, 300)
+    m2 = NRMS(make_cfg(777, 300, 15, 200, 50, 20, 0.2), pre)
+    assert torch.equal(m2.news_encoder.word_embedding.weight.detach(), pre)      # row 0 NOT zeroed
+    assert m2.news_encoder.word_embedding.padding_idx == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    from news_recommendation_amd.dropin.model.NRMS import NRMS
+    from oracle.make_golden import make_cfg
+    m = NRMS(make_cfg(100, 300, 15, 200, 50, 20, 0.2))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.get_news_vector({'title': torch.zeros(2, 20, dtype=torch.long)})
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.get_user_vector(torch.zeros(2, 50, 300))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.get_prediction(torch.zeros(3, 300), torch.zeros(300))
+
+
+def test_product_does_not_import_oracle_or_emulator():
+    pkg = os.path.join(ROOT, 'news_recommendation_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.sh')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+                assert 'tests/emu' not in src.replace('tests/emu/ for the CPU emulation build', ''), f
+                assert 'libnr_engine_emu' not in src, f
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+@pytest.mark.skipif(torch.cuda.is_available(), reason="container-only check")
+def test_launcher_runs_unchanged_reference_train_against_engine(tmp_path):
+    """train.py (unchanged, read-only) is executed by the launcher; it builds the ENGINE's NRMS, loads the data with
+    the reference's own dataset.py and reaches the first forward, where the engine refuses to run without a GPU."""
+    from news_recommendation_amd import synth
+    synth.write_reference_dataset(str(tmp_path))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, '-m', 'news_recommendation_amd.launcher', 'train', '--reference', REF, '--workdir', str(tmp_path)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert 'Load training dataset with size 256' in out, out[-2000:]             # reference train.py:116
+    assert 'news_recommendation_amd/dropin/model/NRMS' in out, out[-2000:]       # traceback goes through OUR model
+    assert 'no CPU fallback' in out, out[-2000:]

@@ -30,3 +30,5 @@ def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=2)
 def test_gather_bf16(be): kc.check_gather_bf16(be)
 def test_scatter_add(be): kc.check_scatter_add(be)
 def test_score_bwd(be): kc.check_score_bwd(be)
+def test_scatter_sorted(be): kc.check_scatter_sorted(be)
+def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=130, V=9, p_drop=0.0)

@@ -32,3 +32,5 @@ def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
 def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
 def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
 def test_score_bwd(be): kc.check_score_bwd(be, B=513)
+def test_scatter_sorted(be): kc.check_scatter_sorted(be, n_tokens=200001, V=3000)
+def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=54321, V=70976, p_drop=0.0)
