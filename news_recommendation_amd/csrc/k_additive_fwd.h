@@ -63,24 +63,25 @@ __global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
   float* myrow = sc + w * Gm::ROWS;
   for (int cg = 0; cg < (Gm::NTQ + 1) / 2; ++cg) {
     int G, mb, me;
-    unit_range(Gm::NTQ, Gm::MT, w_eff, cg, G, mb, me);
+    unit_range(Gm::NTQ, Gm::MT, w_eff, 4, cg, G, mb, me);
     if (mb >= me) continue;
-    auto epi = [&](int wr, int m, f32x4 acc) {
-      f32x4 b4 = *(const f32x4*)(p.bap + wr + 4 * g);
+    auto epi = [&](int wr, int m, f32x4 acc) {          // acc already holds x.Wa[n] + ba[n] (bias = accumulator init)
       f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
       float s = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s += fast_tanh(acc[r] + b4[r]) * q4[r];
+      for (int r = 0; r < 4; ++r) s += fast_tanh(acc[r]) * q4[r];
       s += shfl_xor(s, 16);
       s += shfl_xor(s, 32);
       if (g == 0) myrow[m * 16 + li] += s;     // lanes 0..15 -> 16 distinct tokens; same wave only
     };
     if (G == 2) {
       int wrow[2] = {(2 * cg) * 16, (2 * cg + 1) * 16};
-      proj_block<2, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[j], m, acc); });
+      const f32x4 binit[2] = {*(const f32x4*)(p.bap + wrow[0] + 4 * g), *(const f32x4*)(p.bap + wrow[1] + 4 * g)};
+      proj_block<2, true>(p.Wap, wrow, Xs, mb, me, binit, [&](int j, int m, f32x4 acc) { epi(wrow[j], m, acc); });
     } else {
       int wrow[1] = {(2 * cg) * 16};
-      proj_block<1, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(wrow[0], m, acc); });
+      const f32x4 binit[1] = {*(const f32x4*)(p.bap + wrow[0] + 4 * g)};
+      proj_block<1, true>(p.Wap, wrow, Xs, mb, me, binit, [&](int j, int m, f32x4 acc) { epi(wrow[0], m, acc); });
     }
   }
   __syncthreads();

@@ -27,16 +27,21 @@ template <int S, int WPB>
 struct AttnBwdGeom {
   static constexpr int QT = (S + 15) / 16;
   static constexpr int R = QT * 16;                 // padded sequence length
-  static constexpr int RS = R + 8;                  // row stride of [x][token] matrices
+  static constexpr int RS = R + 8;                  // row stride of the dv-major V block in LDS
   static constexpr int DS = 24;                     // row stride of [token][d] matrices (DK=20 padded to 24)
   static constexpr int SP4 = (S + 3) / 4 * 4;
   static constexpr int KS = (R + 31) / 32;          // k-steps over tokens
-  static constexpr int TD_ELEMS = R * DS;           // Qm, Km, Vm, dCm
-  static constexpr int DT_ELEMS = DK * RS + 32;     // Qt, Kt, dCt (+slack for the 8-wide reads of the last row)
-  static constexpr int TT_ELEMS = R * RS + 32;      // PmT, dSt
-  static constexpr int WAVE_ELEMS = 4 * TD_ELEMS + 3 * DT_ELEMS + 2 * TT_ELEMS;
+  static constexpr int KP2 = (QT + 1) / 2;          // pairs of token tiles (one 32-wide MFMA k-step each)
+  static constexpr int DTL = (DK + 15) / 16;        // tiles over the head dim
+  static constexpr int TD_ELEMS = S * DS;           // Qm, Km, dCm : S rows (tile reads clamp the row index)
+  static constexpr int VT_ELEMS = DK * RS + 32;     // Vt [dv][token] (+slack for the 8-wide reads of the last row)
+  static constexpr int WAVE_ELEMS = 3 * TD_ELEMS + VT_ELEMS;
   static constexpr int WAVE_BYTES = (WAVE_ELEMS * 2 + 15) / 16 * 16;
   static constexpr int SMEM = WPB * WAVE_BYTES;
+  static constexpr int PCS = DK / 4;                // 8-B pieces per 20-wide row
+  static constexpr int IT = (S * PCS + 63) / 64;    // row-piece iterations per lane
+  static constexpr int VP = SP4 / 4;                // 8-B pieces per dv row of the saved V block
+  static constexpr int ITV = (DK * VP + 63) / 64;
 };
 
 struct AttnBwdParams {
@@ -54,6 +59,22 @@ struct AttnBwdParams {
 
 __device__ __forceinline__ u16x8 ld8(const u16* p) { return cat8(*(const u16x4*)p, *(const u16x4*)(p + 4)); }
 
+// Register image of one (sequence, head) pair's inputs: loaded one pair ahead so the global-memory latency of
+// pair i+1 hides behind the MFMA work of pair i.
+template <int IT, int ITV>
+struct AttnBwdRegs {
+  u16x4 q[IT], k[IT], dg[IT], v[ITV];
+  f32x4 go[IT];
+  float wt[IT];
+};
+
+// Layout algebra used below (16x16x32 MFMA, lane = (g, li)):
+//   AL(M) : fragment read from a row-major LDS matrix M[row][k]: lane holds M[li][k-slots]  -> A or B operand
+//   CL(X) : accumulator tile of X[a][b]: lane holds X[4g+r][li].  A CL tile packed to bf16 is, without moving any
+//           data, (1) a B operand "X with k = a" and (2) an A operand "X^T with k = a" (slot (g, r) <-> a = 4g+r,
+//           a second tile fills slots j >= 4).  So everything that contracts over the ROW index of a CL tile is free.
+//   Transposes LDS->CL are done by the matrix core itself: CL(M) = AL(M) x Identity.
+// No scattered LDS writes, one wave barrier per pair.
 template <int S, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
   using Gm = AttnBwdGeom<S, WPB>;
@@ -62,199 +83,250 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
   u16* base = (u16*)(smem + w * Gm::WAVE_BYTES);
   u16* Qm = base;
   u16* Km = Qm + Gm::TD_ELEMS;
-  u16* Vm = Km + Gm::TD_ELEMS;
-  u16* dCm = Vm + Gm::TD_ELEMS;
-  u16* Qt = dCm + Gm::TD_ELEMS;
-  u16* Kt = Qt + Gm::DT_ELEMS;
-  u16* dCt = Kt + Gm::DT_ELEMS;
-  u16* PmT = dCt + Gm::DT_ELEMS;
-  u16* dSt = PmT + Gm::TT_ELEMS;
+  u16* dCm = Km + Gm::TD_ELEMS;
+  u16* Vt = dCm + Gm::TD_ELEMS;
 
-  const int64_t pair = (int64_t)blockIdx.x * WPB + w;
-  const bool live = pair < p.n_seq * H;
-  const int64_t seq = live ? pair / H : 0;
-  const int hd = live ? (int)(pair - seq * H) : 0;
-  const int64_t tok0 = seq * S;
+  const int64_t n_pairs = p.n_seq * H;
+  const int64_t stride = (int64_t)gridDim.x * WPB;
+  int64_t pair = (int64_t)blockIdx.x * WPB + w;
 
-  // zero the whole wave-private scratch once: every padding row / column must be finite (zero)
+  AttnBwdRegs<Gm::IT, Gm::ITV> rg;
+  auto load_regs = [&](int64_t pr) {
+    const int64_t seq = pr / H;
+    const int hd = (int)(pr - seq * H);
+    const int64_t tok0 = seq * S;
+#pragma unroll
+    for (int it = 0; it < Gm::IT; ++it) {
+      const int i = it * 64 + l;
+      if (i < S * Gm::PCS) {
+        const int r = i / Gm::PCS, c = (i - r * Gm::PCS) * 4;
+        rg.q[it] = *(const u16x4*)(p.q_save + (tok0 + r) * KP + hd * DK + c);
+        rg.k[it] = *(const u16x4*)(p.k_save + (tok0 + r) * KP + hd * DK + c);
+        rg.dg[it] = *(const u16x4*)(p.dctx_gemm + (tok0 + r) * p.ldc + hd * DK + c);
+        rg.go[it] = *(const f32x4*)(p.g_out + seq * D + hd * DK + c);
+        rg.wt[it] = p.attn_w[tok0 + r];
+      }
+    }
+    const u16* vblk = p.vt_save + (seq * H + hd) * DK * Gm::SP4;
+#pragma unroll
+    for (int it = 0; it < Gm::ITV; ++it) {
+      const int i = it * 64 + l;
+      if (i < DK * Gm::VP) rg.v[it] = *(const u16x4*)(vblk + i * 4);     // block is dense: [dv][SP4]
+    }
+  };
+  // registers -> wave-private LDS, all 8-B row-major stores; dC assembled with its direct term and dropout
+  auto store_lds = [&](int64_t pr) {
+    const int64_t seq = pr / H;
+    const int hd = (int)(pr - seq * H);
+    const int64_t tok0 = seq * S;
+#pragma unroll
+    for (int it = 0; it < Gm::IT; ++it) {
+      const int i = it * 64 + l;
+      if (i < S * Gm::PCS) {
+        const int r = i / Gm::PCS, c = (i - r * Gm::PCS) * 4;
+        *(u16x4*)(Qm + r * Gm::DS + c) = rg.q[it];
+        *(u16x4*)(Km + r * Gm::DS + c) = rg.k[it];
+        f32x4 dc4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dc4[j] = bf2f(rg.dg[it][j]) + rg.wt[it] * rg.go[it][j];
+        if (p.dc.enabled) {
+          uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dc4[j] = ((keep >> j) & 1u) ? dc4[j] * p.dc.scale : 0.0f;
+        }
+        *(u16x4*)(dCm + r * Gm::DS + c) = pack4(dc4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < Gm::ITV; ++it) {
+      const int i = it * 64 + l;
+      if (i < DK * Gm::VP) {
+        const int dv = i / Gm::VP, t = (i - dv * Gm::VP) * 4;
+        u16x4 v = rg.v[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (t + j < S) ? v[j] : (u16)0;     // tokens >= S of the block hold bias junk
+        *(u16x4*)(Vt + dv * Gm::RS + t) = v;
+      }
+    }
+  };
+
+  if (pair < n_pairs) load_regs(pair);
+  // zero the wave-private scratch ONCE: padding columns must be finite (zero); real positions are rewritten per pair
   for (int i = l; i < Gm::WAVE_BYTES / 16; i += 64) *(u16x8*)(base + i * 8) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   wave_barrier();
 
-  if (live) {
-    // ---- load Q, K (row-major + transposed copies), V (from dv-major blocks), dC (with direct term + dropout) ----
-    constexpr int PCS = DK / 4;   // 8-B pieces per 20-wide row
-    for (int i = l; i < S * PCS; i += 64) {
-      const int r = i / PCS, c = (i - r * PCS) * 4;
-      u16x4 q = *(const u16x4*)(p.q_save + (tok0 + r) * KP + hd * DK + c);
-      u16x4 k = *(const u16x4*)(p.k_save + (tok0 + r) * KP + hd * DK + c);
-      *(u16x4*)(Qm + r * Gm::DS + c) = q;
-      *(u16x4*)(Km + r * Gm::DS + c) = k;
+  const float inv_sqrt_dk = 1.0f / sqrtf((float)DK);
+  const u16 ONE = 0x3F80;
+  const u16x4 Z4 = u16x4{0, 0, 0, 0};
+  // AL fragment over the head dim from a [token][DS] matrix: slots d = 8g + j (d >= DK are zero)
+  auto frag_d = [&](const u16* M, int row) -> u16x8 {
+    row = row < S ? row : S - 1;
+    const u16* q_ = M + row * Gm::DS + 8 * g;
+    u16x4 lo = (8 * g < DK) ? *(const u16x4*)q_ : Z4;
+    u16x4 hi = (8 * g + 4 < DK) ? *(const u16x4*)(q_ + 4) : Z4;
+    return cat8(lo, hi);
+  };
+  // AL fragment of dC with the CL-compatible slot order over dv: slots j<4 -> dv = 4g+j, j>=4 -> dv = 16+4g+(j-4)
+  auto frag_dc_perm = [&](int row) -> u16x8 {
+    row = row < S ? row : S - 1;
+    const u16* q_ = dCm + row * Gm::DS;
+    u16x4 lo = *(const u16x4*)(q_ + 4 * g);                                  // 4g+3 <= 15 < DK
+    u16x4 hi = (16 + 4 * g < DK) ? *(const u16x4*)(q_ + 16 + 4 * g) : Z4;
+    return cat8(lo, hi);
+  };
+  // identity B operands: ident[t][k][n] = (k == 16 t + n) with natural slots k = 8g + j
+  u16x8 ident[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        Qt[(c + j) * Gm::RS + r] = q[j];
-        Kt[(c + j) * Gm::RS + r] = k[j];
-      }
-      // dC[q][dv] = (dctx_gemm + w[q] * g_out[dv]) * dropout2
-      u16x4 dg = *(const u16x4*)(p.dctx_gemm + (tok0 + r) * p.ldc + hd * DK + c);
-      f32x4 go = *(const f32x4*)(p.g_out + seq * D + hd * DK + c);
-      const float wt = p.attn_w[tok0 + r];
-      f32x4 dc4;
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dc4[j] = bf2f(dg[j]) + wt * go[j];
-      if (p.dc.enabled) {
-        uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dc4[j] = ((keep >> j) & 1u) ? dc4[j] * p.dc.scale : 0.0f;
-      }
-      u16x4 dcb = pack4(dc4);
-      *(u16x4*)(dCm + r * Gm::DS + c) = dcb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dCt[(c + j) * Gm::RS + r] = dcb[j];
-    }
-    constexpr int VP = Gm::SP4 / 4;   // 8-B pieces per dv row of the saved block
-    const u16* vblk = p.vt_save + (seq * H + hd) * DK * Gm::SP4;
-    for (int i = l; i < DK * VP; i += 64) {
-      const int dv = i / VP, t = (i - dv * VP) * 4;
-      u16x4 v = *(const u16x4*)(vblk + dv * Gm::SP4 + t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (t + j < S) Vm[(t + j) * Gm::DS + dv] = v[j];
-    }
-  }
-  wave_barrier();
+    for (int j = 0; j < 8; ++j) ident[t][j] = (8 * g + j == 16 * t + li) ? ONE : (u16)0;
 
-  if (live) {
-    const float inv_sqrt_dk = 1.0f / sqrtf((float)DK);
-    // fragments over the head dim (k-slots: d = 8g + j; g == 3 and the upper half of g == 2 are padding)
-    auto frag_d = [&](const u16* M, int row) -> u16x8 {
-      const u16* q_ = M + row * Gm::DS + 8 * g;
-      u16x4 z = u16x4{0, 0, 0, 0};
-      u16x4 lo = (8 * g < DK) ? *(const u16x4*)q_ : z;
-      u16x4 hi = (8 * g + 4 < DK) ? *(const u16x4*)(q_ + 4) : z;
-      return cat8(lo, hi);
-    };
-    u16x8 kf[Gm::QT], qf[Gm::QT], vf[Gm::QT], cf[Gm::QT];
+  while (pair < n_pairs) {
+    const int64_t seq = pair / H;
+    const int hd = (int)(pair - seq * H);
+    const int64_t tok0 = seq * S;
+    store_lds(pair);
+    const int64_t next = pair + stride;
+    if (next < n_pairs) load_regs(next);          // prefetch the next pair while this one is computed
+    wave_barrier();
+
+    // ---- operand preparation ----------------------------------------------------------------------------------------
+    u16x8 kf[Gm::QT], qf[Gm::QT], cperm[Gm::QT];
+    u16x4 kcl[Gm::QT][Gm::DTL], qcl[Gm::QT][Gm::DTL], ccl[Gm::QT][Gm::DTL];   // CL(K), CL(Q), CL(dC) tiles [token tile][d tile]
 #pragma unroll
     for (int t = 0; t < Gm::QT; ++t) {
       kf[t] = frag_d(Km, t * 16 + li);
       qf[t] = frag_d(Qm, t * 16 + li);
-      vf[t] = frag_d(Vm, t * 16 + li);
-      cf[t] = frag_d(dCm, t * 16 + li);
+      u16x8 cf = frag_d(dCm, t * 16 + li);
+      cperm[t] = frag_dc_perm(t * 16 + li);
+#pragma unroll
+      for (int dt = 0; dt < Gm::DTL; ++dt) {
+        kcl[t][dt] = pack4(mfma_16x16x32_bf16(kf[t], ident[dt], f32x4{0.f, 0.f, 0.f, 0.f}));
+        qcl[t][dt] = pack4(mfma_16x16x32_bf16(qf[t], ident[dt], f32x4{0.f, 0.f, 0.f, 0.f}));
+        ccl[t][dt] = pack4(mfma_16x16x32_bf16(cf, ident[dt], f32x4{0.f, 0.f, 0.f, 0.f}));
+      }
     }
-    u16x4 dsb[Gm::QT][Gm::QT];     // dS^T packed bf16: [key tile][query tile]
+    // V as an A operand "V[key][k = dv]" per key tile: CL(Vt)[dv][key] tiles for dv tiles 0,1 -> slots j<4 / j>=4
+    u16x8 va[Gm::QT];
+#pragma unroll
+    for (int kt = 0; kt < Gm::QT; ++kt) {
+      u16x4 part[Gm::DTL];
+#pragma unroll
+      for (int dt = 0; dt < Gm::DTL; ++dt) {
+        int dvrow = dt * 16 + li;
+        dvrow = dvrow < DK ? dvrow : DK - 1;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < Gm::KS; ++ks) {
+          // B = identity selecting token kt*16 + n out of the 32 tokens of k-step ks
+          u16x8 idt = (kt / 2 == ks) ? ident[kt & 1] : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          acc = mfma_16x16x32_bf16(ld8(Vt + dvrow * Gm::RS + ks * 32 + 8 * g), idt, acc);
+        }
+        // rows dv >= DK of the second dv tile are clamped duplicates: zero them (they sit in k-slots of the dP products)
+        if (dt * 16 + 4 * g >= DK) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        part[dt] = pack4(acc);
+      }
+      va[kt] = cat8(part[0], Gm::DTL > 1 ? part[Gm::DTL - 1] : Z4);
+    }
+
+    u16x4 dsT[Gm::QT][Gm::QT];    // CL(dS^T)  [key tile][query tile]
+    u16x4 dsN[Gm::QT][Gm::QT];    // CL(dS)    [query tile][key tile]
+    u16x4 pN[Gm::QT][Gm::QT];     // CL(P)     [query tile][key tile]
 #pragma unroll
     for (int qt = 0; qt < Gm::QT; ++qt) {
-      // ---- recompute P^T (column = query li, rows = keys) --------------------------------------------------
+      // ---- transposed pass: P^T (col = query li, rows = keys), row sums, dP^T, row dots ---------------------------
       f32x4 pT[Gm::QT];
-      float mx = -3.0e38f;
+      float sum = 0.0f;
 #pragma unroll
       for (int kt = 0; kt < Gm::QT; ++kt) {
         pT[kt] = mfma_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pT[kt][r] *= inv_sqrt_dk;
-          if (kt * 16 + 4 * g + r < S) mx = fmaxf(mx, pT[kt][r]);
-        }
-      }
-      mx = fmaxf(mx, shfl_xor(mx, 16));
-      mx = fmaxf(mx, shfl_xor(mx, 32));
-      float sum = 0.0f;
-#pragma unroll
-      for (int kt = 0; kt < Gm::QT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = (kt * 16 + 4 * g + r < S) ? fast_exp(pT[kt][r] - mx) : 0.0f;
+          float e = fast_exp(fminf(pT[kt][r] * inv_sqrt_dk, EXP_CLAMP));     // same formula as the forward kernel
+          e = (kt * 16 + 4 * g + r < S) ? e : 0.0f;
           pT[kt][r] = e;
           sum += e;
         }
+      }
       sum += shfl_xor(sum, 16);
       sum += shfl_xor(sum, 32);
-      const float rden = fast_rcp(sum + 1e-8f * fast_exp(-mx));
-      // ---- dP^T = V dC^T, dS^T = P^T * (dP^T - sum_keys P^T dP^T) / sqrt(dk) ---------------------------------
-      f32x4 dP[Gm::QT];
+      const float rden = fast_rcp(sum + 1e-8f);
       float dot = 0.0f;
+      f32x4 dPT[Gm::QT];
 #pragma unroll
       for (int kt = 0; kt < Gm::QT; ++kt) {
         pT[kt] = pT[kt] * rden;
-        dP[kt] = mfma_16x16x32_bf16(vf[kt], cf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+        dPT[kt] = mfma_16x16x32_bf16(va[kt], cperm[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // dP^T[key][q] = sum_dv V dC
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dot += pT[kt][r] * dP[kt][r];
+        for (int r = 0; r < 4; ++r) dot += pT[kt][r] * dPT[kt][r];
       }
       dot += shfl_xor(dot, 16);
       dot += shfl_xor(dot, 32);
-      const int q = qt * 16 + li;
 #pragma unroll
       for (int kt = 0; kt < Gm::QT; ++kt) {
         f32x4 ds;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = pT[kt][r] * (dP[kt][r] - dot) * inv_sqrt_dk;
-        u16x4 pb = pack4(pT[kt]);
-        dsb[kt][qt] = pack4(ds);
-        // transposed copies [key][query] for the products that contract over queries
+        for (int r = 0; r < 4; ++r) ds[r] = pT[kt][r] * (dPT[kt][r] - dot) * inv_sqrt_dk;
+        dsT[kt][qt] = pack4(ds);
+      }
+      // ---- normal pass for the same query tile: P, dS with rows = queries 4g+r (row stats fetched from lane 4g+r) --
+      float rden_r[4], dot_r[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rden_r[r] = shfl(rden, 4 * g + r);
+        dot_r[r] = shfl(dot, 4 * g + r);
+      }
+#pragma unroll
+      for (int kt = 0; kt < Gm::QT; ++kt) {
+        f32x4 sN = mfma_16x16x32_bf16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // S[q][key]
+        // dP[q][key] = sum_dv dC[q][dv] V[key][dv]:  A = CL(dC)^T-style operand is not needed: contract over dv with
+        // A = dC AL in the permuted slot order, B = V operand of the key tile (same slot order)
+        f32x4 dPN = mfma_16x16x32_bf16(cperm[qt], va[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+        f32x4 pv, dv4;
+        const bool keyok = kt * 16 + li < S;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          if (key < S && q < S) {
-            PmT[key * Gm::RS + q] = pb[r];
-            dSt[key * Gm::RS + q] = dsb[kt][qt][r];
-          }
+          const bool ok = keyok && (qt * 16 + 4 * g + r < S);
+          float e = fast_exp(fminf(sN[r] * inv_sqrt_dk, EXP_CLAMP)) * rden_r[r];
+          e = ok ? e : 0.0f;
+          pv[r] = e;
+          dv4[r] = ok ? e * (dPN[r] - dot_r[r]) * inv_sqrt_dk : 0.0f;
+        }
+        pN[qt][kt] = pack4(pv);
+        dsN[qt][kt] = pack4(dv4);
+      }
+    }
+
+    // ---- output products: every A/B operand below is a packed CL tile already in registers --------------------------
+    // dQ^T[d][q]   = sum_key K^T[d][key] dS^T[key][q] : A = CL(K)  (k = key), B = CL(dS^T) (k = key)
+    // dK^T[d][key] = sum_q   Q^T[d][q]   dS[q][key]   : A = CL(Q)  (k = q),   B = CL(dS)   (k = q)
+    // dV^T[dv][key]= sum_q   dC^T[dv][q] P[q][key]    : A = CL(dC) (k = q),   B = CL(P)    (k = q)
+#pragma unroll
+    for (int dt = 0; dt < Gm::DTL; ++dt) {
+      const int d0 = dt * 16 + 4 * g;     // CL(K)[key][d]: as A operand its rows are d = li of tile dt
+#pragma unroll
+      for (int ot = 0; ot < Gm::QT; ++ot) {       // output token tile (queries for dQ, keys for dK / dV)
+        f32x4 aq = f32x4{0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
+#pragma unroll
+        for (int kp = 0; kp < Gm::KP2; ++kp) {
+          const int t0 = 2 * kp, t1 = (2 * kp + 1 < Gm::QT) ? 2 * kp + 1 : 0;
+          const bool has1 = 2 * kp + 1 < Gm::QT;
+          aq = mfma_16x16x32_bf16(cat8(kcl[t0][dt], has1 ? kcl[t1][dt] : Z4), cat8(dsT[t0][ot], has1 ? dsT[t1][ot] : Z4), aq);
+          ak = mfma_16x16x32_bf16(cat8(qcl[t0][dt], has1 ? qcl[t1][dt] : Z4), cat8(dsN[t0][ot], has1 ? dsN[t1][ot] : Z4), ak);
+          av = mfma_16x16x32_bf16(cat8(ccl[t0][dt], has1 ? ccl[t1][dt] : Z4), cat8(pN[t0][ot], has1 ? pN[t1][ot] : Z4), av);
+        }
+        // A operand rows: i = li -> d = dt*16 + li; output CL: rows d = dt*16 + 4g + r, col = token ot*16 + li
+        const int tok = ot * 16 + li;
+        if (d0 < DK && tok < S) {
+          u16* dst = p.dqkv + (tok0 + tok) * LDG + hd * DK + d0;
+          *(u16x4*)dst = pack4(aq);
+          *(u16x4*)(dst + KP) = pack4(ak);
+          *(u16x4*)(dst + 2 * KP) = pack4(av);
         }
       }
     }
-    // ---- dQ^T[d][q] = sum_key Kt[d][key] dS^T[key][q]  (B operand straight from registers) -------------------
-#pragma unroll
-    for (int dt = 0; dt < (DK + 15) / 16; ++dt) {
-      int drow = dt * 16 + li;
-      drow = drow < DK ? drow : DK - 1;
-      const int d0 = dt * 16 + 4 * g;
-      u16x8 af[(Gm::QT + 1) / 2];
-#pragma unroll
-      for (int kp = 0; kp < (Gm::QT + 1) / 2; ++kp) {
-        u16x4 z = u16x4{0, 0, 0, 0};
-        u16x4 lo = *(const u16x4*)(Kt + drow * Gm::RS + (2 * kp) * 16 + 4 * g);
-        u16x4 hi = (2 * kp + 1 < Gm::QT) ? *(const u16x4*)(Kt + drow * Gm::RS + (2 * kp + 1) * 16 + 4 * g) : z;
-        af[kp] = cat8(lo, hi);
-      }
-#pragma unroll
-      for (int qt = 0; qt < Gm::QT; ++qt) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kp = 0; kp < (Gm::QT + 1) / 2; ++kp) {
-          u16x4 hi = (2 * kp + 1 < Gm::QT) ? dsb[(2 * kp + 1 < Gm::QT) ? 2 * kp + 1 : 0][qt] : u16x4{0, 0, 0, 0};
-          acc = mfma_16x16x32_bf16(af[kp], cat8(dsb[2 * kp][qt], hi), acc);
-        }
-        const int q = qt * 16 + li;
-        if (d0 < DK && q < S) *(u16x4*)(p.dqkv + (tok0 + q) * LDG + hd * DK + d0) = pack4(acc);
-      }
-    }
-  }
-  wave_barrier();
-  if (live) {
-    // ---- dK^T[d][key] = sum_q Qt[d][q] dSt[key][q] ;  dV^T[dv][key] = sum_q dCt[dv][q] PmT[key][q] --------------
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const u16* At = which == 0 ? Qt : dCt;
-      const u16* Bt = which == 0 ? dSt : PmT;
-#pragma unroll
-      for (int dt = 0; dt < (DK + 15) / 16; ++dt) {
-        int drow = dt * 16 + li;
-        drow = drow < DK ? drow : DK - 1;
-        const int d0 = dt * 16 + 4 * g;
-        u16x8 af[Gm::KS];
-#pragma unroll
-        for (int ks = 0; ks < Gm::KS; ++ks) af[ks] = ld8(At + drow * Gm::RS + ks * 32 + 8 * g);
-#pragma unroll
-        for (int kt = 0; kt < Gm::QT; ++kt) {
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < Gm::KS; ++ks)
-            acc = mfma_16x16x32_bf16(af[ks], ld8(Bt + (kt * 16 + li) * Gm::RS + ks * 32 + 8 * g), acc);
-          const int key = kt * 16 + li;
-          if (d0 < DK && key < S)
-            *(u16x4*)(p.dqkv + (tok0 + key) * LDG + (which == 0 ? KP : 2 * KP) + hd * DK + d0) = pack4(acc);
-        }
-      }
-    }
+    wave_barrier();        // all LDS reads of this pair done before the next pair's stores
+    pair = next;
   }
 }
 
@@ -294,20 +366,36 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
   __syncthreads();
 
   // ---- dw[tok] = g_out . x[tok];  ds = w * (dw - sum_s w dw)  (softmax backward) -------------------------------
-  for (int seq = w; seq < NSEQ; seq += 4) {
-    if (seq0 + seq >= p.n_seq) continue;
-    const float* go = p.g_out + (seq0 + seq) * D;
-    float mydw = 0.0f;           // lane s keeps dw of token s
-    for (int s = 0; s < S; ++s) {
-      const u16* xr = Xs + (seq * S + s) * XS;
+  // three lanes per token, 25 quads (100 columns) each; partials combined through LDS (dqp is still free here)
+  {
+    float* dwp = dqp;                                   // [3][ROWS] scratch (4*QP floats >= 3*ROWS)
+    const int tok = tid / 3, part = tid - tok * 3;
+    if (tok < Gm::TOK) {
+      const int seq = tok / S;
       float a = 0.0f;
-      for (int c = l; c < D; c += 64) a += go[c] * bf2f(xr[c]);
-      a = wave_sum(a);
-      if (l == s) mydw = a;
+      if (seq0 + seq < p.n_seq) {
+        const float* go = p.g_out + (seq0 + seq) * D + part * 100;
+        const u16* xr = Xs + tok * XS + part * 100;
+#pragma unroll 5
+        for (int c = 0; c < 25; ++c) {
+          f32x4 g4 = *(const f32x4*)(go + c * 4);
+          u16x4 x4 = *(const u16x4*)(xr + c * 4);
+          a += g4[0] * bf2f(x4[0]) + g4[1] * bf2f(x4[1]) + g4[2] * bf2f(x4[2]) + g4[3] * bf2f(x4[3]);
+        }
+      }
+      dwp[part * Gm::ROWS + tok] = a;
     }
-    const float wt = l < S ? p.attn_w[(seq0 + seq) * S + l] : 0.0f;
-    const float tot = wave_sum(wt * mydw);
-    if (l < S) dsv[seq * S + l] = wt * (mydw - tot);
+    __syncthreads();
+    for (int seq = w; seq < NSEQ; seq += 4) {
+      const bool live = l < S && seq0 + seq < p.n_seq;
+      const int r = seq * S + l;
+      const float mydw = live ? dwp[r] + dwp[Gm::ROWS + r] + dwp[2 * Gm::ROWS + r] : 0.0f;
+      const float wt = live ? p.attn_w[(seq0 + seq) * S + l] : 0.0f;
+      const float tot = wave_sum(wt * mydw);
+      if (l < S) dsv[r] = wt * (mydw - tot);
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * QP; i += WG) dqp[i] = 0.0f;
   }
   __syncthreads();
 
@@ -315,18 +403,17 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
   const int w_eff = (w + (int)blockIdx.x) & 3;
   for (int cg = 0; cg < (Gm::NTQ + 1) / 2; ++cg) {
     int G, mb, me;
-    unit_range(Gm::NTQ, Gm::MT, w_eff, cg, G, mb, me);
+    unit_range(Gm::NTQ, Gm::MT, w_eff, 4, cg, G, mb, me);
     if (mb >= me) continue;
     f32x4 dqa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    auto epi = [&](int j, int wr, int m, f32x4 acc) {
-      f32x4 b4 = *(const f32x4*)(p.bap + wr + 4 * g);
+    auto epi = [&](int j, int wr, int m, f32x4 acc) {   // acc = x.Wa[n] + ba[n] (bias = accumulator init)
       f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
       const int r_ = m * 16 + li;
       const float ds = dsv[r_];
       f32x4 dp;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = fast_tanh(acc[r] + b4[r]);
+        float t = fast_tanh(acc[r]);
         dp[r] = ds * q4[r] * (1.0f - t * t);
         dqa[j][r] += ds * t;
       }
@@ -335,10 +422,12 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
     int wr0 = (2 * cg) * 16, wr1 = (2 * cg + 1) * 16;
     if (G == 2) {
       int wrow[2] = {wr0, wr1};
-      proj_block<2, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(j, wrow[j], m, acc); });
+      const f32x4 binit[2] = {*(const f32x4*)(p.bap + wr0 + 4 * g), *(const f32x4*)(p.bap + wr1 + 4 * g)};
+      proj_block<2, true>(p.Wap, wrow, Xs, mb, me, binit, [&](int j, int m, f32x4 acc) { epi(j, wrow[j], m, acc); });
     } else {
       int wrow[1] = {wr0};
-      proj_block<1, true>(p.Wap, wrow, Xs, mb, me, [&](int j, int m, f32x4 acc) { epi(0, wrow[0], m, acc); });
+      const f32x4 binit[1] = {*(const f32x4*)(p.bap + wr0 + 4 * g)};
+      proj_block<1, true>(p.Wap, wrow, Xs, mb, me, binit, [&](int j, int m, f32x4 acc) { epi(0, wrow[0], m, acc); });
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -16,7 +16,8 @@ constexpr int NGROUPS = (H + HG - 1) / HG;   // 4 groups: 4,4,4,3 heads
 constexpr int NP = NR_NP;          // 304 rows per packed W block
 constexpr int QP = NR_QP;          // 208
 constexpr int QS = HG * DK + 8;    // 88: LDS row stride (elements) of the per-group Q / K tiles (176 B)
-constexpr int WG = 256;            // threads per workgroup (4 waves)
+constexpr int WG = 256;            // threads per workgroup of the 4-wave kernels
+constexpr float EXP_CLAMP = 80.0f; // exp() argument clamp: keeps sum_j exp(s_j) finite in fp32 for S <= 64 (the reference overflows to inf/nan there)
 constexpr int D4 = D / 4;          // 75 float4 per embedding row
 
 static_assert(D % 4 == 0 && DK % 4 == 0 && (HG * DK) % 16 == 0, "geometry");
@@ -53,15 +54,17 @@ __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site,
   return m;
 }
 
-// ---- balanced split of (column-group, token-tile) GEMM units over the 4 waves -----------------------
-// Column groups are pairs of 16-row n-tiles (a trailing single when the tile count is odd).  Tile-units are
-// ordered (group, token-tile, tile-in-group); wave w owns tile-unit range [w*TU/4, (w+1)*TU/4) and a
+// ---- balanced split of (column-group, token-tile) GEMM units over the nw waves of a workgroup -----------------------
+// Column groups are gs (1 or 2) consecutive 16-row n-tiles (a trailing single when the tile count is odd).  Tile-units are
+// ordered (group, token-tile, tile-in-group); wave w owns tile-unit range [w*TU/nw, (w+1)*TU/nw) and a
 // (group, token-tile) unit belongs to the wave that owns its first tile-unit.
-__device__ __forceinline__ void unit_range(int ntiles, int MT, int w, int cg, int& G, int& m_begin, int& m_end) {
+__device__ __forceinline__ void unit_range(int ntiles, int MT, int w, int nw, int cg, int& G, int& m_begin, int& m_end,
+                                           int gs = 2) {
   int TU = ntiles * MT;
-  int lo = (w * TU) / 4, hi = ((w + 1) * TU) / 4;
-  G = (2 * cg + 1 < ntiles) ? 2 : 1;
-  int base = cg * 2 * MT;
+  int lo = (w * TU) / nw, hi = ((w + 1) * TU) / nw;
+  G = ntiles - cg * gs;
+  G = G > gs ? gs : G;
+  int base = cg * gs * MT;
   int a = lo - base, b = hi - base;
   m_begin = a <= 0 ? 0 : (a + G - 1) / G;
   m_end = b <= 0 ? 0 : (b + G - 1) / G;

@@ -6,6 +6,7 @@
 #include "k_bwd.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -94,14 +95,29 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save;
   if (S == 20) {
     constexpr int NSEQ = 4;
-    using G = nr::MhsaGeom<20, NSEQ>;
-    if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-    NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+    const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: "4x2" (4 waves, pair groups), "8x1", "8x2"
+    int v = var ? atoi(var) : 81;
+    if (v == 42) {
+      constexpr int NW = 4, GS = 2;
+      using G = nr::MhsaGeom<20, NSEQ, NW>;
+      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
+    } else if (v == 82) {
+      constexpr int NW = 8, GS = 2;
+      using G = nr::MhsaGeom<20, NSEQ, NW>;
+      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
+    } else {
+      constexpr int NW = 8, GS = 1;      // 8 waves: 4 waves per SIMD with two workgroups per CU -> latency hiding
+      using G = nr::MhsaGeom<20, NSEQ, NW>;
+      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
+    }
   } else if (S == 50) {
-    constexpr int NSEQ = 1;
-    using G = nr::MhsaGeom<50, NSEQ>;
-    if (allow_smem(nr::mhsa_fwd_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-    NR_LAUNCH((nr::mhsa_fwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+    constexpr int NSEQ = 1, NW = 4, GS = 2;
+    using G = nr::MhsaGeom<50, NSEQ, NW>;
+    if (allow_smem(nr::mhsa_fwd_kernel<50, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::mhsa_fwd_kernel<50, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
   } else {
     return fail(NR_ERR_UNSUPPORTED, "nr_mhsa_fwd: sequence length not instantiated (20, 50)");
   }
@@ -141,16 +157,20 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
   p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
   const int64_t pairs = n_seq * NR_HEADS;
+  // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
+  // grid (used by the tests to force many pairs per wave on small inputs).
+  const char* capenv = getenv("NR_ATTN_BWD_MAX_WGS");
+  const int capdiv = capenv ? atoi(capenv) : 0;
   if (S == 20) {
     constexpr int WPB = 4;
     using G = nr::AttnBwdGeom<20, WPB>;
     if (allow_smem(nr::attn_bwd_kernel<20, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), (pairs + WPB - 1) / WPB, WPB * 64, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 3 * 2), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 50) {
     constexpr int WPB = 2;
     using G = nr::AttnBwdGeom<50, WPB>;
     if (allow_smem(nr::attn_bwd_kernel<50, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::attn_bwd_kernel<50, WPB>), (pairs + WPB - 1) / WPB, WPB * 64, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::attn_bwd_kernel<50, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 2 * 2), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else {
     return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd: sequence length not instantiated (20, 50)");
   }

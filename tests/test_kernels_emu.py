@@ -32,3 +32,11 @@ def test_scatter_add(be): kc.check_scatter_add(be)
 def test_score_bwd(be): kc.check_score_bwd(be)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be)
 def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=130, V=9, p_drop=0.0)
+
+
+def test_attn_bwd_persistent_loop(be, monkeypatch):
+    """few workgroups, many (sequence, head) pairs per wave: exercises the pair loop and the register prefetch"""
+    monkeypatch.setenv('NR_ATTN_BWD_MAX_WGS', '2')
+    kc.check_attn_bwd(be, S=20, n_seq=4, p_drop=0.2)
+    monkeypatch.setenv('NR_ATTN_BWD_MAX_WGS', '1')
+    kc.check_attn_bwd(be, S=50, n_seq=1)

@@ -34,3 +34,11 @@ def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
 def test_score_bwd(be): kc.check_score_bwd(be, B=513)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be, n_tokens=200001, V=3000)
 def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=54321, V=70976, p_drop=0.0)
+
+
+def test_attn_bwd_persistent_loop(be, monkeypatch):
+    monkeypatch.setenv('NR_ATTN_BWD_MAX_WGS', '3')
+    kc.check_attn_bwd(be, S=20, n_seq=40, p_drop=0.2)
+    kc.check_attn_bwd(be, S=50, n_seq=9)
+    monkeypatch.delenv('NR_ATTN_BWD_MAX_WGS')
+    kc.check_attn_bwd(be, S=20, n_seq=2500)          # > 1536 workgroups of pairs: the production grid loops too

@@ -1,0 +1,47 @@
+"""Run one engine kernel a few times (for rocprofv3 --pmc passes).  Usage: python tools/prof_kernel.py NAME [B]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from news_recommendation_amd import _capi, synth
+from news_recommendation_amd._capi import *
+name = sys.argv[1]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+dev = torch.device('cuda:0'); lib = _capi.load(); st = lambda: torch.cuda.current_stream().cuda_stream
+V = 70976; T = B * 53
+g = torch.Generator().manual_seed(0)
+table = torch.randn(V, NR_D, generator=g).mul_(0.4).to(dev)
+news = synth.news_titles(np.random.default_rng(0), 65238, 20, V)
+cand, hist = synth.train_batch(np.random.default_rng(1), news, B)
+c, h = synth.batch_token_ids(news, cand, hist)
+ids = torch.from_numpy(np.concatenate([c.reshape(-1, 20), h.reshape(-1, 20)])).to(dev)
+W = [torch.randn(300, 300, generator=g).mul_(0.06).to(dev) for _ in range(3)]; bb = [torch.randn(300, generator=g).mul_(0.05).to(dev) for _ in range(3)]
+Wa = torch.randn(200, 300, generator=g).mul_(0.06).to(dev); ba = torch.zeros(200, device=dev); qv = torch.randn(200, generator=g).mul_(0.1).to(dev)
+Wp = torch.empty(3 * NR_NP, NR_KP, dtype=torch.int16, device=dev); bp = torch.empty(3 * NR_NP, device=dev)
+Wap = torch.empty(NR_QP, NR_KP, dtype=torch.int16, device=dev); bap = torch.empty(NR_QP, device=dev); qvp = torch.empty(NR_QP, device=dev)
+ctx = torch.empty(T * 20, NR_KP, dtype=torch.int16, device=dev)
+qs = torch.empty_like(ctx); ks = torch.empty_like(ctx); vts = torch.empty(T, 15, 20, 20, dtype=torch.int16, device=dev)
+nv = torch.empty(T, NR_D, device=dev); aw = torch.empty(T, 20, device=dev)
+ck = lambda rc: _capi.check(lib, rc)
+ck(lib.nr_pack_qkv(W[0].data_ptr(), bb[0].data_ptr(), W[1].data_ptr(), bb[1].data_ptr(), W[2].data_ptr(), bb[2].data_ptr(), Wp.data_ptr(), bp.data_ptr(), st()))
+ck(lib.nr_pack_additive(Wa.data_ptr(), ba.data_ptr(), qv.data_ptr(), 200, Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), st()))
+mh = lambda p, save: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(),
+                                        qs.data_ptr() if save else None, ks.data_ptr() if save else None, vts.data_ptr() if save else None, T, 20, p, 1, st()))
+mh(0.0, True)
+ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), aw.data_ptr(), T, 20, st()))
+gout = torch.randn(T, NR_D, generator=g).to(dev)
+dpre = torch.empty(T * 20, NR_QP, dtype=torch.int16, device=dev); dqp = torch.empty(lib.nr_additive_bwd_grid(T, 20), NR_QP, device=dev)
+dctx = torch.randn(T * 20, NR_D, generator=g).mul_(0.05).to(dev).to(torch.bfloat16)
+dqkv = torch.zeros(T * 20, NR_LDG, dtype=torch.int16, device=dev)
+fns = {
+  'mhsa_infer': lambda: mh(0.0, False), 'mhsa_train': lambda: mh(0.2, True),
+  'additive_fwd': lambda: ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), aw.data_ptr(), T, 20, st())),
+  'additive_bwd': lambda: ck(lib.nr_additive_bwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw.data_ptr(), gout.data_ptr(), dpre.data_ptr(), dqp.data_ptr(), T, 20, st())),
+  'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
+}
+fn = fns[name]
+for _ in range(2): fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): fn()
+e1.record(); torch.cuda.synchronize()
+print(name, 'avg_us', e0.elapsed_time(e1) / 5 * 1e3)
