@@ -239,6 +239,17 @@ def main():
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": dom[1], "launches": dom[0], "bytes_per_launch": nbytes}
 
+    # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes from
+    # the committed rocprofv3 --pmc passes of the same workload (profiles/traffic.json, made by tools/gpu_check.sh)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            tr = json.load(f).get(dominant)
+        if tr is not None and B == 512:
+            roofline["traffic"] = tr["bytes"]
+            roofline["traffic_source"] = tr["source"]
+    except (OSError, ValueError):
+        pass
+
     # the embedding gather on its own (north_star: fraction of HBM roofline for the gather)
     lib = _capi.load()
     cand, click = batches[0]
