@@ -127,6 +127,65 @@ int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, cons
 int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user,
                      int64_t B, int C, int d, void* stream);
 
+/* ---- NAML / LSTUR: convolutional text encoder, pooling variants, element encoders ------------------------------
+ * "seqpad" layout used below: bf16 [n_seq*(S+1)+1][NR_KP]; token s of sequence q sits in row q*(S+1)+1+s and the rows
+ * q*(S+1) are all-zero separators (never written by the kernels: zero-fill once), so a tap shift is a row offset. */
+
+/* 1 if the additive-attention kernels are instantiated for S (4 = NAML view stack, 20, 50); conv kernels: 20, 50. */
+int nr_supported_pool_len(int S);
+int nr_supported_conv_len(int S);
+
+/* Pack nn.Conv2d(1, F, (3, D), padding=(1,0)) parameters (src/model/NAML/news_encoder.py:15-17, src/model/LSTUR/news_encoder.py:24-28;
+ * weight f32 [F][1][3][D], bias f32 [F]) into the forward operand Wc bf16 [3][NR_KP][NR_KP] (tap, filter, d), the
+ * data-gradient operand Wd bf16 [3][NR_KP][NR_KP] (Wd[t][d][f] = W[f][2-t][d]; may be NULL) and bc f32 [NR_KP]. */
+int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uint16_t* Wd, float* bc, void* stream);
+
+/* TextEncoder front (NAML news_encoder.py:21-32; LSTUR news_encoder.py:58-67):
+ * act = dropout(relu(conv3(dropout(table[ids])) + bias)) as bf16 [n_seq*S][NR_KP] (col D = 1.0, cols > D zero) -- the
+ * input layout of nr_additive_fwd.  Training: x_save (seqpad, col D = 1.0 on token rows) receives the masked bf16 tokens
+ * for the weight-gradient GEMMs; NULL for inference.  tok_offset shifts the dropout counters (site 1 = tokens, site 2 =
+ * activations) so several texts can share one seed. */
+int nr_conv3_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
+                 uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
+/* Data gradient of the convolution: dx bf16 [n_seq*S][NR_KP] (cols < D) from dy_pad (seqpad) and Wd. */
+int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int64_t n_seq, int S, void* stream);
+/* Gradient through dropout+relu: dy_pad[row(q,s)] = (dact_gemm[t] + attn_w[t] * g_out[q]) * [act[t] != 0] / (1 - p_drop);
+ * dact_gemm bf16 [n_seq*S][ldc] = dpre @ Wa (plain GEMM by the caller), g_out f32 rows of stride g_stride. */
+int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, const float* attn_w, const float* g_out, int64_t g_stride,
+                    uint16_t* dy_pad, int64_t n_seq, int S, float p_drop, void* stream);
+
+/* nr_additive_fwd with strided outputs: out f32 rows of stride out_stride (may be NULL) and/or out_b, a bf16 copy in the
+ * ctx layout (row i at out_b + i*out_b_stride: cols 0..D-1, col D = 1.0, rest 0) that can feed another pooling level
+ * directly (NAML final_attention over the 4 views, news_encoder.py:108-114; NAML user encoder, user_encoder.py:18). */
+int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
+                       uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, void* stream);
+/* Input gradient of a pooling level: dx[t][:] = dgemm[t][:] + attn_w[t] * g_out[seq(t)][:], f32 [n_seq*S][D]; view_major != 0
+ * stores row t at (t % S) * n_seq + t / S (S contiguous [n_seq][D] blocks, one per view). */
+int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const float* g_out, float* dx, int64_t n_seq, int S,
+                   int view_major, void* stream);
+
+/* NAML ElementEncoder (news_encoder.py:40-47) for every category row at once: E f32 [2][ncat][D],
+ * E[w][c] = relu(W_w emb[c] + b_w), w = 0 category, 1 subcategory (shared embedding f32 [ncat][dcat], W_w f32 [D][dcat]). */
+int nr_element_table_fwd(const float* emb, int ncat, int dcat, const float* W0, const float* b0, const float* W1, const float* b1,
+                         float* E, void* stream);
+/* Its backward from dE f32 [2][ncat][D]: dW f32 [2][D][dcat], db f32 [2][D], demb f32 [ncat][dcat] (row 0 zero: padding_idx). */
+int nr_element_table_bwd(const float* emb, int ncat, int dcat, const float* W0, const float* W1, const float* E, const float* dE,
+                         float* dW, float* db, float* demb, void* stream);
+/* Rows 4t+2 / 4t+3 of the view stack bf16 [4T][NR_KP] from the element tables (rows 4t / 4t+1 come from nr_additive_fwd_ex). */
+int nr_views_fill(const int64_t* cat, const int64_t* sub, const float* E, int ncat, uint16_t* views, int64_t T, void* stream);
+
+/* Segmented row reduction dst[ids[i]] += src[perm-order rows] for D-wide f32 rows (ids sorted ascending with their permutation,
+ * as nr_embed_scatter_sorted; dst zero on entry); rows with id <= pad_row are skipped (-1: none). */
+int nr_scatter_sorted_f32(const int64_t* ids_sorted, const int64_t* perm, const float* src, int64_t ld, float* dst, int64_t num_rows,
+                          int64_t n, int pad_row, void* stream);
+/* Generic atomic row scatter-add, any width d: dst[ids[i]][0:d] += row_scale[i] * src[i][0:d] (row_scale may be NULL). */
+int nr_rows_scatter_add(const int64_t* ids, const float* src, int64_t ld, const float* row_scale, float* dst, int64_t num_rows, int d,
+                        int64_t n, int pad_row, void* stream);
+/* out[i][0:d] = row_scale[i] * table[ids[i]][0:d] into rows of stride ldo (LSTUR: category / subcategory columns of the 900-d
+ * news vector, src/model/LSTUR/news_encoder.py:52-55,69-75; user_embedding row with its dropout2d factor, LSTUR/__init__.py:74-77). */
+int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_rows, int d, const float* row_scale, float* out,
+                           int64_t ldo, int64_t n, void* stream);
+
 /* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
  * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream);

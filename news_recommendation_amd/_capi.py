@@ -28,6 +28,20 @@ SIGNATURES = {
     'nr_additive_fwd': ([_P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_score_dot': ([_P, _P, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_score_csr': ([_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P], c_int),
+    'nr_supported_pool_len': ([c_int], c_int),
+    'nr_supported_conv_len': ([c_int], c_int),
+    'nr_pack_conv': ([_P, _P, c_int, c_int, _P, _P, _P, _P], c_int),
+    'nr_conv3_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, c_int64, _P], c_int),
+    'nr_conv3_dgrad': ([_P, _P, _P, c_int64, c_int, _P], c_int),
+    'nr_conv_act_bwd': ([_P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, c_float, _P], c_int),
+    'nr_additive_fwd_ex': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P], c_int),
+    'nr_additive_dx': ([_P, c_int, _P, _P, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_element_table_fwd': ([_P, c_int, c_int, _P, _P, _P, _P, _P, _P], c_int),
+    'nr_element_table_bwd': ([_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    'nr_views_fill': ([_P, _P, _P, c_int, _P, c_int64, _P], c_int),
+    'nr_scatter_sorted_f32': ([_P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, _P], c_int),
+    'nr_rows_scatter_add': ([_P, _P, c_int64, _P, _P, c_int64, c_int, c_int64, c_int, _P], c_int),
+    'nr_gather_rows_strided': ([_P, _P, c_int64, c_int, _P, _P, c_int64, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
 }

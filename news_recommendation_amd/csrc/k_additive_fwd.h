@@ -31,7 +31,10 @@ struct AdditiveParams {
   const u16* Wap;      // [QP][KP]
   const float* bap;    // [QP]
   const float* qvp;    // [QP]
-  float* out;          // [n_seq][D]
+  float* out;          // [n_seq][out_stride] (first D columns of each row) or null
+  int64_t out_stride;  // row stride of out in floats (D when the pooled vectors are dense)
+  u16* out_b;          // optional bf16 copy in the ctx layout: row i at out_b + i*out_b_stride, cols 0..D-1, col D = 1.0, rest 0
+  int64_t out_b_stride;
   float* attn_w;       // [n_seq][S] or null
   int64_t n_seq;
 };
@@ -118,7 +121,16 @@ __global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
       float wt = wl[seq * S + s];
       acc[0] += wt * bf2f(x[0]); acc[1] += wt * bf2f(x[1]); acc[2] += wt * bf2f(x[2]); acc[3] += wt * bf2f(x[3]);
     }
-    *(f32x4*)(p.out + ((seq0 + seq) * D4 + c) * 4) = acc;
+    if (p.out != nullptr) *(f32x4*)(p.out + (seq0 + seq) * p.out_stride + c * 4) = acc;
+    if (p.out_b != nullptr) *(u16x4*)(p.out_b + (seq0 + seq) * p.out_b_stride + c * 4) = pack4(acc);
+  }
+  if (p.out_b != nullptr) {
+    constexpr int PADQ = (KP - D) / 4;
+    for (int i = tid; i < NSEQ * PADQ; i += WG) {
+      const int seq = i / PADQ, c = i - seq * PADQ;
+      if (seq0 + seq < p.n_seq)
+        *(u16x4*)(p.out_b + (seq0 + seq) * p.out_b_stride + D + c * 4) = u16x4{(u16)(c == 0 ? 0x3F80 : 0), 0, 0, 0};
+    }
   }
 }
 

@@ -508,10 +508,15 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* _
 // one 4-column quad, lanes 0..10 a second quad) and writes each finished row once; only rows whose run touches
 // the chunk boundary (and may continue in a neighbour wave) use atomics.  grad_table must start zeroed.
 constexpr int SC_CH = 32;
+__device__ __forceinline__ f32x4 ld_row4(const u16* p) { u16x4 v = *(const u16x4*)p; return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
+__device__ __forceinline__ f32x4 ld_row4(const float* p) { return *(const f32x4*)p; }
+
+// SRC = u16 (bf16 rows) or float.  Rows with id <= pad_row are skipped (pad_row = 0: nn.Embedding(padding_idx=0); -1: none).
+template <typename SRC>
 __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t* __restrict__ ids_sorted,
-                                                                   const int64_t* __restrict__ perm, const u16* __restrict__ dx,
-                                                                   int ldx, float* __restrict__ grad_table, int64_t num_rows,
-                                                                   int64_t n_tokens, DropCfg dc) {
+                                                                   const int64_t* __restrict__ perm, const SRC* __restrict__ dx,
+                                                                   int64_t ldx, float* __restrict__ grad_table, int64_t num_rows,
+                                                                   int64_t n_tokens, DropCfg dc, int pad_row) {
   const int l = lane_id();
   const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave_id()) * SC_CH;
   if (s0 >= n_tokens) return;
@@ -521,14 +526,14 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
   if (l < cnt) { my_id = ids_sorted[s0 + l]; my_tok = perm[s0 + l]; }
   int id_lo = (int)my_id, tok_lo = (int)my_tok;            // ids and token indices fit in 31 bits
   const int id_last = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), cnt - 1));
-  if (id_last <= 0) return;                                // chunk is all padding (sorted: ids <= 0 come first)
-  const int id_before = s0 > 0 ? (int)ids_sorted[s0 - 1] : -1;
-  const int id_after = s0 + cnt < n_tokens ? (int)ids_sorted[s0 + cnt] : -1;
+  if (id_last <= pad_row) return;                          // chunk is all padding (sorted: ids <= pad_row come first)
+  const int id_before = s0 > 0 ? (int)ids_sorted[s0 - 1] : -2;
+  const int id_after = s0 + cnt < n_tokens ? (int)ids_sorted[s0 + cnt] : -2;
   const bool two = l < (D4 - 64);
   f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), 0));
   auto flush = [&](int id, bool shared) {
-    if (id <= 0 || id >= num_rows) return;
+    if (id <= pad_row || id >= num_rows) return;
     float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
     if (shared) {
 #pragma unroll
@@ -552,10 +557,10 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
       cur = id;
       a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
     }
-    if (id <= 0) continue;
-    const u16* row = dx + (int64_t)tok * ldx;
-    u16x4 v0 = *(const u16x4*)(row + l * 4);
-    u16x4 v1 = two ? *(const u16x4*)(row + 256 + l * 4) : u16x4{0, 0, 0, 0};
+    if (id <= pad_row) continue;
+    const SRC* row = dx + (int64_t)tok * ldx;
+    f32x4 v0 = ld_row4(row + l * 4);
+    f32x4 v1 = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t k0 = 0xF, k1 = 0xF;
     float sc = 1.0f;
     if (dc.enabled) {
@@ -565,8 +570,8 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if ((k0 >> j) & 1u) a0[j] += bf2f(v0[j]) * sc;
-      if ((k1 >> j) & 1u) a1[j] += bf2f(v1[j]) * sc;
+      if ((k0 >> j) & 1u) a0[j] += v0[j] * sc;
+      if ((k1 >> j) & 1u) a1[j] += v1[j] * sc;
     }
   }
   flush(cur, (first && cur == id_before) || cur == id_after);

@@ -1,0 +1,273 @@
+// Three-tap token convolution for gfx950: the title / abstract CNN of NAML and LSTUR,
+//   y[s][f] = b[f] + sum_{w=0..2} sum_d x[s + w - 1][d] * W[f][w][d]     (zero rows outside the sequence)
+// = nn.Conv2d(1, F, (3, D), padding=(1, 0)) on [B,1,S,D], squeezed and transposed
+// (src/model/NAML/news_encoder.py:15-17,27-36; src/model/LSTUR/news_encoder.py:24-28,62-69),
+// fused with its input stage (embedding gather + F.dropout, NAML :23-25 / LSTUR :58-60) and its
+// output stage (F.relu + F.dropout, NAML :30-32 / LSTUR :64-67).
+//
+// The same kernel is the data gradient of the convolution: dX[s][d] = sum_w' sum_f dY[s + w' - 1][f] Wd[d][w'][f]
+// with Wd[d][w'][f] = W[f][2 - w'][d] (flipped taps, transposed filters) -- dense bf16 input, plain epilogue.
+//
+// "seqpad" layout (LDS tile and the HBM buffers x_pad / x_save): row(seq, s) = seq*(S+1) + 1 + s, rows seq*(S+1)
+// are all-zero separators shared by neighbouring sequences, so the tap shift is a plain row offset and needs no
+// boundary tests.  In HBM the buffer has n_seq*(S+1)+1 rows of KP bf16.
+//
+// Workgroup = 4 waves, NSEQ sequences.  GEMM per workgroup: [TOK] x [3*KP] x [304]; filters are the MFMA A operand
+// (rows straight from L2 into registers, one tap at a time), tokens the B operand (fragments from the LDS tile at
+// row + tap); a wave keeps the accumulators of its (column group, token tiles) block across the three taps.  The lane
+// ends up with 4 consecutive filters of one token -> one 8-B store.
+#pragma once
+#include "nr_common.h"
+
+namespace nr {
+
+constexpr int NPC = KP;          // rows per tap block of the packed conv weight [3][NPC][KP]
+constexpr int NTF = (D + 15) / 16;   // 19 filter tiles
+
+template <int S, int NSEQ>
+struct ConvGeom {
+  static constexpr int TOK = S * NSEQ;
+  static constexpr int MT = (TOK + 15) / 16;
+  static constexpr int PR = NSEQ * (S + 1) + 1;       // seqpad rows of the tile
+  static constexpr int X_BYTES = (PR * XS * 2 + 15) / 16 * 16;
+  static constexpr int IDS_BYTES = (TOK * 4 + 15) / 16 * 16;
+  static constexpr int SMEM = X_BYTES + IDS_BYTES;
+};
+
+struct ConvParams {
+  const int64_t* ids;      // gather form: [n_seq*S] token ids, or null
+  const float* table;      // [num_rows][D]
+  int64_t num_rows;
+  const u16* x_pad;        // dense form: bf16 seqpad [n_seq*(S+1)+1][KP] (columns >= D are ignored)
+  const u16* Wc;           // bf16 [3][NPC][KP]  (tap, output row, k)
+  const float* bc;         // f32 [NPC], or null (data-gradient form: no bias)
+  u16* out;                // bf16 [n_seq*S][KP], plain token layout
+  u16* x_save;             // gather form, training: bf16 seqpad copy of the dropout-masked tokens (col D = 1.0), or null
+  int relu_drop;           // 1: out = dropout2(relu(y)), col D = 1.0, cols > D zero;  0: out = y (cols >= D untouched)
+  int64_t n_seq;
+  int64_t tok_offset;      // added to the token index in the dropout counters (keeps title / abstract streams apart)
+  DropCfg dc;
+};
+
+template <int S, int NSEQ>
+__global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
+  using Gm = ConvGeom<S, NSEQ>;
+  NR_SMEM_DECL(smem);
+  u16* Xs = (u16*)smem;
+  int* ids_s = (int*)(smem + Gm::X_BYTES);
+  const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
+  const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
+
+  // ---- stage the seqpad tile -------------------------------------------------------------------------------------
+  if (p.ids != nullptr) {
+    for (int r = tid; r < Gm::TOK; r += WG) {
+      int v = -1;
+      if (tok0 + r < tok_total) {
+        int64_t id = p.ids[tok0 + r];
+        id = id < 0 ? 0 : (id >= p.num_rows ? p.num_rows - 1 : id);
+        v = (int)id;
+      }
+      ids_s[r] = v;
+    }
+    for (int i = tid; i < Gm::X_BYTES / 16; i += WG) *(u16x8*)(Xs + i * 8) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    constexpr int TOTAL = Gm::TOK * D4;
+    constexpr int U = 8;
+    for (int base = 0; base < TOTAL; base += WG * U) {
+      f32x4 v[U];
+      int rr[U], cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * WG + tid;
+        const int r = i / D4, c = i - r * D4;
+        rr[u] = r; cc[u] = c;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < TOTAL) {
+          const int id = ids_s[r];
+          if (id >= 0) v[u] = *(const f32x4*)(p.table + ((size_t)id * D4 + c) * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * WG + tid;
+        if (i < TOTAL) {
+          f32x4 x = v[u];
+          if (p.dc.enabled) {
+            uint32_t keep = drop_keep4(p.dc, 1u, (uint64_t)(p.tok_offset + tok0 + rr[u]) * D4 + cc[u]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * p.dc.scale : 0.0f;
+          }
+          const int row = rr[u] + rr[u] / S + 1;
+          *(u16x4*)(Xs + row * XS + cc[u] * 4) = pack4(x);
+        }
+      }
+    }
+    __syncthreads();
+    if (p.x_save != nullptr) {          // keep the masked bf16 tokens for the weight-gradient GEMMs (col D = 1.0 -> bias gradient)
+      constexpr int PCS = KP / 8;
+      for (int i = tid; i < Gm::TOK * PCS; i += WG) {
+        const int r = i / PCS, c = i - r * PCS;
+        if (tok0 + r >= tok_total) continue;
+        const int row = r + r / S + 1;
+        u16x8 v = *(const u16x8*)(Xs + row * XS + c * 8);
+        if (c == D / 8) v[D % 8] = 0x3F80;
+        *(u16x8*)(p.x_save + (seq0 * (S + 1) + row) * KP + c * 8) = v;
+      }
+    }
+  } else {
+    constexpr int PCS = XS / 8;         // 41 pieces per LDS row (incl. stride padding)
+    const int64_t rows_total = p.n_seq * (S + 1) + 1;
+    for (int i = tid; i < Gm::PR * PCS; i += WG) {
+      const int r = i / PCS, c = i - r * PCS;
+      const int64_t gr = seq0 * (S + 1) + r;
+      u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (c * 8 < D && gr < rows_total) {
+        v = *(const u16x8*)(p.x_pad + gr * KP + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c * 8 + j < D) ? v[j] : (u16)0;
+      }
+      *(u16x8*)(Xs + r * XS + c * 8) = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- GEMM over the three taps ----------------------------------------------------------------------------------
+  const int w_eff = (w + (int)blockIdx.x) & 3;
+  for (int cg = 0; cg < (NTF + 1) / 2; ++cg) {
+    int G, mb, me;
+    unit_range(NTF, Gm::MT, w_eff, 4, cg, G, mb, me);
+    if (mb >= me) continue;
+    const int wr0 = (2 * cg) * 16, wr1 = (G == 2) ? wr0 + 16 : wr0;     // G == 1: second column is a dead duplicate
+    f32x4 acc[Gm::MT][2];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b0 = p.bc ? *(const f32x4*)(p.bc + wr0 + 4 * g) : zero4, b1 = p.bc ? *(const f32x4*)(p.bc + wr1 + 4 * g) : zero4;
+#pragma unroll
+    for (int mi = 0; mi < Gm::MT; ++mi) { acc[mi][0] = b0; acc[mi][1] = b1; }
+    int rowoff[Gm::MT];
+#pragma unroll
+    for (int mi = 0; mi < Gm::MT; ++mi) {
+      int t = (mb + mi) * 16 + li;
+      t = t < Gm::TOK ? t : Gm::TOK - 1;
+      rowoff[mi] = (t + t / S) * XS + g * 8;          // seqpad row of tap 0 (= row(t) - 1)
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < 3; ++tap) {
+      u16x8 wf[2][KSTEPS];
+      const u16* wp0 = p.Wc + ((size_t)tap * NPC + wr0 + li) * KP + g * 8;
+      const u16* wp1 = p.Wc + ((size_t)tap * NPC + wr1 + li) * KP + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) { wf[0][ks] = *(const u16x8*)(wp0 + ks * 32); wf[1][ks] = *(const u16x8*)(wp1 + ks * 32); }
+#pragma unroll
+      for (int mi = 0; mi < Gm::MT; ++mi) {
+        if (mb + mi < me) {
+          const u16* xp = Xs + rowoff[mi] + tap * XS;
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u16x8 xf = *(const u16x8*)(xp + ks * 32);
+            acc[mi][0] = mfma_16x16x32_bf16(wf[0][ks], xf, acc[mi][0]);
+            if (G == 2) acc[mi][1] = mfma_16x16x32_bf16(wf[1][ks], xf, acc[mi][1]);
+          }
+        }
+      }
+    }
+    // epilogue: lane holds filters ncol + 4g .. +3 of token m*16 + li
+#pragma unroll
+    for (int mi = 0; mi < Gm::MT; ++mi) {
+      if (mb + mi < me) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j < G) {
+            const int t = (mb + mi) * 16 + li;
+            const int col = (j == 0 ? wr0 : wr1) + 4 * g;
+            const int64_t tok = tok0 + t;
+            if (t < Gm::TOK && tok < tok_total && col < D) {
+              f32x4 y = acc[mi][j];
+              if (p.relu_drop) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+                if (p.dc.enabled) {
+                  uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)(p.tok_offset + tok) * D4 + (col >> 2));
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) y[r] = ((keep >> r) & 1u) ? y[r] * p.dc.scale : 0.0f;
+                }
+              }
+              *(u16x4*)(p.out + tok * KP + col) = pack4(y);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (p.relu_drop) {      // K padding of the activation rows: col D = 1.0 (bias-gradient column), cols D+1..KP = 0
+    constexpr int PADQ = (KP - D) / 4;
+    for (int i = tid; i < Gm::TOK * PADQ; i += WG) {
+      const int r = i / PADQ, c = i - r * PADQ;
+      const int64_t tok = tok0 + r;
+      if (tok < tok_total) *(u16x4*)(p.out + tok * KP + D + c * 4) = u16x4{(u16)(c == 0 ? 0x3F80 : 0), 0, 0, 0};
+    }
+  }
+}
+
+// ---- weight packing: Conv2d weight f32 [F][1][3][D] + bias -> forward operand Wc[tap][f][d] and data-gradient operand
+// Wd[tap'][d][f] = W[f][2 - tap'][d], both bf16 [3][NPC][KP] zero padded; bc f32 [NPC].
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ W, const float* __restrict__ b, int F_, int D_,
+                                                        u16* __restrict__ Wc, u16* __restrict__ Wd, float* __restrict__ bc) {
+  const int total = 3 * NPC * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tap = i / (NPC * KP), rem = i - tap * NPC * KP;
+    const int row = rem / KP, k = rem - row * KP;
+    float fwd = 0.0f, bwd = 0.0f;
+    if (row < F_ && k < D_) fwd = W[((size_t)row * 3 + tap) * D_ + k];                 // Wc[tap][f=row][d=k]
+    if (row < D_ && k < F_) bwd = W[((size_t)k * 3 + (2 - tap)) * D_ + row];           // Wd[tap][d=row][f=k]
+    Wc[i] = f2bf(fwd);
+    if (Wd != nullptr) Wd[i] = f2bf(bwd);
+    if (i < NPC) bc[i] = i < F_ ? b[i] : 0.0f;
+  }
+}
+
+// ---- gradient of the activation stage: dY = (dact_gemm + attn_w (x) g_out) * [act != 0] * scale, written in seqpad
+// layout for the weight-gradient GEMMs and the data-gradient convolution.  act is the saved forward output
+// dropout2(relu(y)): act == 0 <=> dropped or y <= 0 (relu'(0) = 0 as in torch), in both cases the gradient is 0.
+__global__ __launch_bounds__(256) void conv_act_bwd_kernel(const u16* __restrict__ act, const u16* __restrict__ dact_gemm, int ldc,
+                                                           const float* __restrict__ attn_w, const float* __restrict__ g_out,
+                                                           int64_t g_stride, u16* __restrict__ dy_pad, int64_t n_seq, int S, float scale) {
+  const int64_t total = n_seq * S * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tok = i / D4;
+    const int c = (int)(i - tok * D4);
+    const int64_t seq = tok / S;
+    const u16x4 a = *(const u16x4*)(act + tok * KP + c * 4);
+    const u16x4 dg = *(const u16x4*)(dact_gemm + tok * ldc + c * 4);
+    const f32x4 go = *(const f32x4*)(g_out + seq * g_stride + c * 4);
+    const float wt = attn_w[tok];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (a[j] & 0x7FFF) ? (bf2f(dg[j]) + wt * go[j]) * scale : 0.0f;
+    *(u16x4*)(dy_pad + (tok + seq + 1) * KP + c * 4) = pack4(o);
+  }
+}
+
+// ---- gradient w.r.t. the input of an additive-attention pooling that is not followed by one of the fused backward
+// kernels: dx[tok][:] = dgemm[tok][:] + attn_w[tok] * g_out[seq][:]  (additive.py:50-52 backward), fp32 output.
+// view_major != 0 stores row tok at (tok % S) * n_seq + tok / S, i.e. S contiguous [n_seq][D] blocks.
+__global__ __launch_bounds__(256) void additive_dx_kernel(const u16* __restrict__ dgemm, int ldc, const float* __restrict__ attn_w,
+                                                          const float* __restrict__ g_out, float* __restrict__ dx, int64_t n_seq, int S,
+                                                          int view_major) {
+  const int64_t total = n_seq * S * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tok = i / D4;
+    const int c = (int)(i - tok * D4);
+    const int64_t seq = tok / S;
+    const u16x4 dg = *(const u16x4*)(dgemm + tok * ldc + c * 4);
+    const f32x4 go = *(const f32x4*)(g_out + (seq * D4 + c) * 4);
+    const float wt = attn_w[tok];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = bf2f(dg[j]) + wt * go[j];
+    const int64_t orow = view_major ? (tok - seq * S) * n_seq + seq : tok;
+    *(f32x4*)(dx + (orow * D4 + c) * 4) = o;
+  }
+}
+
+}  // namespace nr

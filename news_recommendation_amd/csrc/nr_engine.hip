@@ -4,6 +4,8 @@
 #include "k_mhsa_fwd.h"
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
+#include "k_conv.h"
+#include "k_naml.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -124,12 +126,18 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   return check_launch("nr_mhsa_fwd");
 }
 
-int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out,
-                    float* attn_w, int64_t n_seq, int S, void* stream) {
-  if (!ctx || !Wap || !bap || !qvp || !out || n_seq < 0) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
+int nr_supported_pool_len(int S) { return (S == 4 || S == 20 || S == 50) ? 1 : 0; }
+int nr_supported_conv_len(int S) { return (S == 20 || S == 50) ? 1 : 0; }
+
+int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
+                       uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || (!out && !out_b) || n_seq < 0) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
+  if ((out && (out_stride < NR_D || (out_stride & 3))) || (out_b && (out_b_stride < NR_KP || (out_b_stride & 7))))
+    return fail(NR_ERR_BADARG, "nr_additive_fwd: bad output stride");
   if (n_seq == 0) return NR_OK;
   nr::AdditiveParams p;
-  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.attn_w = attn_w; p.n_seq = n_seq;
+  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
+  p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq;
   if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;
@@ -140,10 +148,21 @@ int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
     using G = nr::AddGeom<50, NSEQ>;
     if (allow_smem(nr::additive_fwd_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 4) {
+    constexpr int NSEQ = 20;
+    using G = nr::AddGeom<4, NSEQ>;
+    if (allow_smem(nr::additive_fwd_kernel<4, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_fwd_kernel<4, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
   } else {
-    return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd: sequence length not instantiated (20, 50)");
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd: sequence length not instantiated (4, 20, 50)");
   }
   return check_launch("nr_additive_fwd");
+}
+
+int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out,
+                    float* attn_w, int64_t n_seq, int S, void* stream) {
+  if (!out) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
+  return nr_additive_fwd_ex(ctx, Wap, bap, qvp, out, NR_D, nullptr, 0, attn_w, n_seq, S, stream);
 }
 
 int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
@@ -180,6 +199,7 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
   if (S == 20) return (n_seq + 3) / 4;
   if (S == 50) return n_seq;
+  if (S == 4) return (n_seq + 19) / 20;
   return -1;
 }
 
@@ -201,8 +221,13 @@ int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
     using G = nr::AddGeom<50, NSEQ>;
     if (allow_smem(nr::additive_bwd_kernel<50, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_bwd_kernel<50, NSEQ>), n_seq, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else if (S == 4) {
+    constexpr int NSEQ = 20;
+    using G = nr::AddGeom<4, NSEQ>;
+    if (allow_smem(nr::additive_bwd_kernel<4, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_bwd_kernel<4, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
   } else {
-    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd: sequence length not instantiated (20, 50)");
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd: sequence length not instantiated (4, 20, 50)");
   }
   return check_launch("nr_additive_bwd");
 }
@@ -237,9 +262,21 @@ int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, cons
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: dropout probability out of range");
   if (n_tokens == 0) return NR_OK;
   const int64_t waves = (n_tokens + nr::SC_CH - 1) / nr::SC_CH;
-  NR_LAUNCH(nr::embed_scatter_sorted_kernel, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, ldx, grad_table,
-            num_rows, n_tokens, make_drop(p_drop, seed));
+  NR_LAUNCH(nr::embed_scatter_sorted_kernel<nr::u16>, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, (int64_t)ldx,
+            grad_table, num_rows, n_tokens, make_drop(p_drop, seed), 0);
   return check_launch("nr_embed_scatter_sorted");
+}
+
+int nr_scatter_sorted_f32(const int64_t* ids_sorted, const int64_t* perm, const float* src, int64_t ld, float* dst, int64_t num_rows,
+                          int64_t n, int pad_row, void* stream) {
+  if (!ids_sorted || !perm || !src || !dst || num_rows <= 0 || n < 0 || ld < NR_D || (ld & 3) || n >= (1LL << 31) ||
+      num_rows >= (1LL << 31) || pad_row < -1)
+    return fail(NR_ERR_BADARG, "nr_scatter_sorted_f32: bad argument");
+  if (n == 0) return NR_OK;
+  const int64_t waves = (n + nr::SC_CH - 1) / nr::SC_CH;
+  NR_LAUNCH(nr::embed_scatter_sorted_kernel<float>, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, src, ld, dst, num_rows, n,
+            make_drop(0.0f, 0), pad_row);
+  return check_launch("nr_scatter_sorted_f32");
 }
 
 int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user, int64_t B, int C, int d,
@@ -268,6 +305,110 @@ int nr_score_csr(const float* news, const float* users, const int32_t* cand_idx,
   NR_LAUNCH(nr::score_csr_kernel, (nnz + 3) / 4, 256, 0, (hipStream_t)stream, news, users, cand_idx, cand_ptr, user_idx, out,
             n_impr, nnz, d / 4);
   return check_launch("nr_score_csr");
+}
+
+// ---- convolutional text encoder (NAML / LSTUR) ----------------------------------------------------------------------
+int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uint16_t* Wd, float* bc, void* stream) {
+  if (!W || !b || !Wc || !bc) return fail(NR_ERR_BADARG, "nr_pack_conv: null pointer");
+  if (F <= 0 || F > NR_D || D <= 0 || D > NR_D) return fail(NR_ERR_UNSUPPORTED, "nr_pack_conv: num_filters and word_embedding_dim must be <= 300");
+  NR_LAUNCH(nr::pack_conv_kernel, 256, 256, 0, (hipStream_t)stream, W, b, F, D, Wc, Wd, bc);
+  return check_launch("nr_pack_conv");
+}
+
+static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what) {
+  if (S == 20) {
+    constexpr int NSEQ = 4;
+    using G = nr::ConvGeom<20, NSEQ>;
+    if (allow_smem(nr::conv3_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
+    NR_LAUNCH((nr::conv3_kernel<20, NSEQ>), (p.n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 50) {
+    constexpr int NSEQ = 2;
+    using G = nr::ConvGeom<50, NSEQ>;
+    if (allow_smem(nr::conv3_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
+    NR_LAUNCH((nr::conv3_kernel<50, NSEQ>), (p.n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    return fail(NR_ERR_UNSUPPORTED, "conv3: sequence length not instantiated (20, 50)");
+  }
+  return check_launch(what);
+}
+
+int nr_conv3_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
+                 uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, int64_t tok_offset, void* stream) {
+  if (!ids || !table || num_rows <= 0 || !Wc || !bc || !act || n_seq < 0 || tok_offset < 0) return fail(NR_ERR_BADARG, "nr_conv3_fwd: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_conv3_fwd: dropout probability out of range");
+  if (n_seq == 0) return NR_OK;
+  nr::ConvParams p;
+  p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_pad = nullptr; p.Wc = Wc; p.bc = bc; p.out = act; p.x_save = x_save;
+  p.relu_drop = 1; p.n_seq = n_seq; p.tok_offset = tok_offset; p.dc = make_drop(p_drop, seed);
+  return launch_conv(p, S, stream, "nr_conv3_fwd");
+}
+
+int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int64_t n_seq, int S, void* stream) {
+  if (!dy_pad || !Wd || !dx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_conv3_dgrad: bad argument");
+  if (n_seq == 0) return NR_OK;
+  nr::ConvParams p;
+  p.ids = nullptr; p.table = nullptr; p.num_rows = 0; p.x_pad = dy_pad; p.Wc = Wd; p.bc = nullptr; p.out = dx; p.x_save = nullptr;
+  p.relu_drop = 0; p.n_seq = n_seq; p.tok_offset = 0; p.dc = make_drop(0.0f, 0);
+  return launch_conv(p, S, stream, "nr_conv3_dgrad");
+}
+
+int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, const float* attn_w, const float* g_out, int64_t g_stride,
+                    uint16_t* dy_pad, int64_t n_seq, int S, float p_drop, void* stream) {
+  if (!act || !dact_gemm || !attn_w || !g_out || !dy_pad || n_seq < 0 || S <= 0 || ldc < NR_D || (ldc & 3) || g_stride < NR_D || (g_stride & 3))
+    return fail(NR_ERR_BADARG, "nr_conv_act_bwd: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_conv_act_bwd: dropout probability out of range");
+  if (n_seq == 0) return NR_OK;
+  NR_LAUNCH(nr::conv_act_bwd_kernel, grid_for(n_seq * S * (NR_D / 4), 256, 8192), 256, 0, (hipStream_t)stream, act, dact_gemm, ldc, attn_w,
+            g_out, g_stride, dy_pad, n_seq, S, 1.0f / (1.0f - p_drop));
+  return check_launch("nr_conv_act_bwd");
+}
+
+int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const float* g_out, float* dx, int64_t n_seq, int S,
+                   int view_major, void* stream) {
+  if (!dgemm || !attn_w || !g_out || !dx || n_seq < 0 || S <= 0 || ldc < NR_D || (ldc & 3)) return fail(NR_ERR_BADARG, "nr_additive_dx: bad argument");
+  if (n_seq == 0) return NR_OK;
+  NR_LAUNCH(nr::additive_dx_kernel, grid_for(n_seq * S * (NR_D / 4), 256, 8192), 256, 0, (hipStream_t)stream, dgemm, ldc, attn_w, g_out, dx,
+            n_seq, S, view_major);
+  return check_launch("nr_additive_dx");
+}
+
+int nr_element_table_fwd(const float* emb, int ncat, int dcat, const float* W0, const float* b0, const float* W1, const float* b1, float* E,
+                         void* stream) {
+  if (!emb || !W0 || !b0 || !W1 || !b1 || !E || ncat <= 0 || dcat <= 0) return fail(NR_ERR_BADARG, "nr_element_table_fwd: bad argument");
+  NR_LAUNCH(nr::element_table_fwd_kernel, grid_for(2LL * ncat * NR_D, 256, 2048), 256, 0, (hipStream_t)stream, emb, ncat, dcat, W0, b0, W1, b1, E, NR_D);
+  return check_launch("nr_element_table_fwd");
+}
+
+int nr_element_table_bwd(const float* emb, int ncat, int dcat, const float* W0, const float* W1, const float* E, const float* dE, float* dW,
+                         float* db, float* demb, void* stream) {
+  if (!emb || !W0 || !W1 || !E || !dE || !dW || !db || !demb || ncat <= 0 || dcat <= 0) return fail(NR_ERR_BADARG, "nr_element_table_bwd: bad argument");
+  NR_LAUNCH(nr::element_table_bwd_kernel, grid_for(2LL * NR_D * dcat + 2 * NR_D + (int64_t)ncat * dcat, 256, 2048), 256, 0, (hipStream_t)stream,
+            emb, ncat, dcat, W0, W1, E, dE, NR_D, dW, db, demb);
+  return check_launch("nr_element_table_bwd");
+}
+
+int nr_views_fill(const int64_t* cat, const int64_t* sub, const float* E, int ncat, uint16_t* views, int64_t T, void* stream) {
+  if (!cat || !sub || !E || !views || ncat <= 0 || T < 0) return fail(NR_ERR_BADARG, "nr_views_fill: bad argument");
+  if (T == 0) return NR_OK;
+  NR_LAUNCH(nr::views_fill_kernel, grid_for(T * 2 * (NR_KP / 4), 256, 4096), 256, 0, (hipStream_t)stream, cat, sub, E, ncat, views, T);
+  return check_launch("nr_views_fill");
+}
+
+int nr_rows_scatter_add(const int64_t* ids, const float* src, int64_t ld, const float* row_scale, float* dst, int64_t num_rows, int d,
+                        int64_t n, int pad_row, void* stream) {
+  if (!ids || !src || !dst || num_rows <= 0 || d <= 0 || ld < d || n < 0) return fail(NR_ERR_BADARG, "nr_rows_scatter_add: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::rows_scatter_add_kernel, grid_for(n * d, 256, 4096), 256, 0, (hipStream_t)stream, ids, src, ld, row_scale, dst, num_rows, d, n, pad_row);
+  return check_launch("nr_rows_scatter_add");
+}
+
+int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_rows, int d, const float* row_scale, float* out, int64_t ldo,
+                           int64_t n, void* stream) {
+  if (!ids || !table || !out || num_rows <= 0 || d <= 0 || (d & 3) || ldo < d || (ldo & 3) || n < 0)
+    return fail(NR_ERR_BADARG, "nr_gather_rows_strided: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::gather_rows_strided_kernel, grid_for(n * (d / 4), 256, 4096), 256, 0, (hipStream_t)stream, ids, table, num_rows, d, row_scale, out, ldo, n);
+  return check_launch("nr_gather_rows_strided");
 }
 
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream) {

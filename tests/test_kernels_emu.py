@@ -40,3 +40,22 @@ def test_attn_bwd_persistent_loop(be, monkeypatch):
     kc.check_attn_bwd(be, S=20, n_seq=4, p_drop=0.2)
     monkeypatch.setenv('NR_ATTN_BWD_MAX_WGS', '1')
     kc.check_attn_bwd(be, S=50, n_seq=1)
+
+
+# ---- NAML / LSTUR kernels ------------------------------------------------------------------------------------------
+from tests import kernel_checks_conv as kcc  # noqa: E402
+
+
+def test_pack_conv(be): kcc.check_pack_conv(be)
+def test_pack_conv_small(be): kcc.check_pack_conv(be, D=60, Fn=48)
+def test_conv_fwd_s20(be): kcc.check_conv_fwd(be, S=20, n_seq=6)
+def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=5, p_drop=0.2, tok_offset=140)
+def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=3, p_drop=0.2)
+def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
+def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
+def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be)
+def test_additive_ex_s4(be): kcc.check_additive_ex(be, S=4, n_seq=23)
+def test_additive_ex_s20(be): kcc.check_additive_ex(be, S=20, n_seq=5)
+def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be)
+def test_element_tables(be): kcc.check_element_tables(be, ncat=37, dcat=20, T=50)
+def test_row_scatters(be): kcc.check_row_scatters(be)

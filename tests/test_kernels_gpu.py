@@ -42,3 +42,21 @@ def test_attn_bwd_persistent_loop(be, monkeypatch):
     kc.check_attn_bwd(be, S=50, n_seq=9)
     monkeypatch.delenv('NR_ATTN_BWD_MAX_WGS')
     kc.check_attn_bwd(be, S=20, n_seq=2500)          # > 1536 workgroups of pairs: the production grid loops too
+
+
+# ---- NAML / LSTUR kernels ------------------------------------------------------------------------------------------
+from tests import kernel_checks_conv as kcc  # noqa: E402
+
+
+def test_pack_conv(be): kcc.check_pack_conv(be)
+def test_conv_fwd_s20(be): kcc.check_conv_fwd(be, S=20, n_seq=1027, V=5000)
+def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=515, V=5000, p_drop=0.2, tok_offset=140)
+def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=203, V=5000, p_drop=0.2)
+def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=515)
+def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=131)
+def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be, S=20, n_seq=1027)
+def test_additive_ex_s4(be): kcc.check_additive_ex(be, S=4, n_seq=2047)
+def test_additive_ex_s50(be): kcc.check_additive_ex(be, S=50, n_seq=131)
+def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be, n_seq=2047)
+def test_element_tables(be): kcc.check_element_tables(be)
+def test_row_scatters(be): kcc.check_row_scatters(be, n=54321, rows=275)
