@@ -105,14 +105,16 @@ __global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
     }
     __syncthreads();
     if (p.x_save != nullptr) {          // keep the masked bf16 tokens for the weight-gradient GEMMs (col D = 1.0 -> bias gradient)
+      // every seqpad row of this workgroup incl. the zero separators (the shared ones are written twice, with zeros)
       constexpr int PCS = KP / 8;
-      for (int i = tid; i < Gm::TOK * PCS; i += WG) {
-        const int r = i / PCS, c = i - r * PCS;
-        if (tok0 + r >= tok_total) continue;
-        const int row = r + r / S + 1;
+      const int64_t rows_total = p.n_seq * (S + 1) + 1;
+      for (int i = tid; i < Gm::PR * PCS; i += WG) {
+        const int row = i / PCS, c = i - row * PCS;
+        const int64_t gr = seq0 * (S + 1) + row;
+        if (gr >= rows_total) continue;
         u16x8 v = *(const u16x8*)(Xs + row * XS + c * 8);
-        if (c == D / 8) v[D % 8] = 0x3F80;
-        *(u16x8*)(p.x_save + (seq0 * (S + 1) + row) * KP + c * 8) = v;
+        if (c == D / 8 && (row % (S + 1)) != 0 && gr < rows_total - 1) v[D % 8] = 0x3F80;
+        *(u16x8*)(p.x_save + gr * KP + c * 8) = v;
       }
     }
   } else {

@@ -1,0 +1,51 @@
+"""NAML -- interface of src/model/NAML/__init__.py:7-93."""
+import torch
+
+from .news_encoder import NewsEncoder
+from .user_encoder import UserEncoder
+from ..general.click_predictor.dot_product import DotProductClickPredictor
+
+ATTRS = ('title', 'abstract', 'category', 'subcategory')
+
+
+class NAML(torch.nn.Module):
+    """Input 1 + K candidate news and a list of user clicked news, produce the click logits."""
+
+    def __init__(self, config, pretrained_word_embedding=None):
+        super().__init__()
+        self.config = config
+        self.news_encoder = NewsEncoder(config, pretrained_word_embedding)
+        self.user_encoder = UserEncoder(config)
+        self.click_predictor = DotProductClickPredictor()
+
+    def forward(self, candidate_news, clicked_news):
+        """candidate_news: list[1+K] of {"category": [B], "subcategory": [B], "title": [B, Lt], "abstract": [B, La]},
+        clicked_news: list[N] of the same (train.py:202-203) -> [B, 1+K].  The reference encodes the 1+K+N positions one by
+        one (__init__.py:44-48); here all B*(1+K+N) news are stacked and encoded by one kernel chain."""
+        cand = {k: torch.stack([x[k] for x in candidate_news], dim=1) for k in ATTRS}
+        click = {k: torch.stack([x[k] for x in clicked_news], dim=1) for k in ATTRS}
+        return self.forward_ids(cand, click)
+
+    def forward_ids(self, cand, click):
+        """Same on stacked id tensors: dicts of int64 [B, C, ...] / [B, N, ...] (host or device resident)."""
+        dev = self.user_encoder.additive_attention.linear.weight.device
+        B, C = cand['category'].shape
+        N = click['category'].shape[1]
+
+        def flat(k):
+            a, b = cand[k], click[k]
+            return torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0).to(dev, non_blocking=True).contiguous()
+        vec, vec_b = self.news_encoder.encode(flat('title'), flat('abstract'), flat('category'), flat('subcategory'))
+        candidate_news_vector = vec[:B * C].view(B, C, -1)
+        clicked_news_vector = vec[B * C:].view(B, N, -1)
+        user_vector = self.user_encoder(clicked_news_vector, vec_b[B * C:])
+        return self.click_predictor(candidate_news_vector, user_vector)
+
+    def get_news_vector(self, news):
+        return self.news_encoder(news)
+
+    def get_user_vector(self, clicked_news_vector):
+        return self.user_encoder(clicked_news_vector)
+
+    def get_prediction(self, news_vector, user_vector):
+        return self.click_predictor(news_vector.unsqueeze(dim=0), user_vector.unsqueeze(dim=0)).squeeze(dim=0)

@@ -1,0 +1,358 @@
+"""Host wrappers (autograd) of the convolutional news encoders: NAML (title + abstract text encoders, category /
+subcategory element encoders, final attention over the 4 views) and LSTUR (category / subcategory embedding rows ++
+title text encoder).  Same rules as ops.py: all encoder math runs in the HIP kernels of libnr_engine.so, PyTorch owns
+memory, streams and autograd bookkeeping, and the only library calls are plain bf16 GEMMs of the backward pass.
+No CPU path.
+"""
+import torch
+
+from . import ops
+from .ops import (_lib, _stream, _call, _ptr, _f32c, _bf16, _mm, _timed, _workspace, _require_cuda, pack_additive,
+                  _BF16_AS_I16, NR_D, NR_KP, NR_QP)
+
+CHUNK = 2048          # rows per batched-GEMM chunk of the conv weight gradient
+
+
+def check_conv_dims(config_like_d, num_filters, window, qdim):
+    if config_like_d != NR_D or num_filters != NR_D:
+        raise NotImplementedError(f"the HIP conv kernels are instantiated for word_embedding_dim = num_filters = {NR_D} "
+                                  f"(got {config_like_d}, {num_filters})")
+    if window != 3:
+        raise NotImplementedError(f"window_size must be 3 (got {window})")
+    if not (0 < qdim <= NR_QP):
+        raise NotImplementedError(f"query_vector_dim must be in [1, {NR_QP}] (got {qdim})")
+
+
+def pack_conv(W, b):
+    """Conv2d(1,F,(3,D)) parameters -> (Wc, Wd, bc) bf16/f32 operands; redone every call (live parameters)."""
+    dev = W.device
+    Wc = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+    Wd = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+    bc = torch.empty(NR_KP, dtype=torch.float32, device=dev)
+    Wf, bf = _f32c(W), _f32c(b)
+    _call('nr_pack_conv', _lib().nr_pack_conv, _ptr(Wf), _ptr(bf), W.shape[0], W.shape[3], _ptr(Wc), _ptr(Wd), _ptr(bc), _stream())
+    return Wc, Wd, bc
+
+
+def _seqpad_alloc(n_seq, S):
+    rp = n_seq * (S + 1) + 1
+    nc = (rp + CHUNK - 1) // CHUNK
+    return rp, nc, nc * CHUNK
+
+
+class _TextState:
+    """What one text encoder keeps between forward and backward."""
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wap', 'bap', 'qvp', 'qdim', 'tok_offset')
+
+
+def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag):
+    """gather -> dropout -> conv3 -> relu -> dropout -> additive pooling for ids int64 [n_seq, S] on the GPU.
+    Pooled vectors go to `out` (f32 rows of stride out_stride, may be None) and/or `out_b` (bf16 ctx rows)."""
+    lib = _lib()
+    n_seq, S = ids.shape
+    if not lib.nr_supported_conv_len(S):
+        raise NotImplementedError(f"text length {S} is not instantiated in the HIP conv kernels (20, 50)")
+    dev = table.device
+    st = _TextState()
+    st.S, st.n_seq, st.tok_offset, st.qdim = S, n_seq, tok_offset, Wa.shape[0]
+    Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
+    st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
+    st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
+    xs_ptr = None
+    st.xstore = None
+    if need_grad:
+        rp, nc, ra = _seqpad_alloc(n_seq, S)
+        st.xstore = torch.empty(ra + 2, NR_KP, dtype=_BF16_AS_I16, device=dev)       # row 0 = the "-1" row of the tap shift
+        st.xstore[0].zero_()
+        st.xstore[rp + 1:].zero_()
+        xs_ptr = st.xstore.data_ptr() + NR_KP * 2
+    tab = table.detach()
+    assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
+    _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
+          n_seq, S, p, seed, tok_offset, _stream())
+    st.aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+    _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_ex, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
+          out_b, out_b_stride, _ptr(st.aw), n_seq, S, _stream())
+    return st
+
+
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag):
+    """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
+    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][D]); the caller adds the direct term aw (x) g."""
+    lib = _lib()
+    dev = ctx_b.device
+    ntok = n_seq * S
+    nwg = lib.nr_additive_bwd_grid(n_seq, S)
+    dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+    dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
+          _ptr(dq_part), n_seq, S, _stream())
+    d_qv = dq_part.sum(dim=0)[:qdim]
+    dpre_b = _bf16(dpre)
+    dWa_ext = ops._wgrad(dpre_b, _bf16(ctx_b), f'gemm_dWa[{tag}]')
+    dgemm = _mm(dpre_b, _bf16(Wap)[:, :NR_D], f'gemm_dctx[{tag}]')
+    return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
+
+
+def text_bwd(st, g, g_stride, p, dx_out, tag):
+    """Backward of text_fwd for pooled-vector gradients g (f32 device pointer/tensor rows of stride g_stride).
+    Writes the token gradient (bf16 [n_seq*S][KP]) into dx_out and returns (d_conv_w, d_conv_b, d_Wa, d_ba, d_qv)."""
+    lib = _lib()
+    n_seq, S = st.n_seq, st.S
+    dev = st.act.device
+    # additive backward needs contiguous [n_seq][D] gradients
+    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag)
+    rp, nc, ra = _seqpad_alloc(n_seq, S)
+    dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
+    _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_D, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
+          n_seq, S, p, _stream())
+    dy_b = _bf16(dy).view(nc, CHUNK, NR_KP).transpose(1, 2)
+    xs_b = _bf16(st.xstore)
+
+    def wgrad():
+        taps = []
+        for w in range(3):          # dW[:, w, :] = dY^T @ X[row + w - 1]: the tap shift is a row offset into the seqpad store
+            xw = xs_b[w:w + ra].view(nc, CHUNK, NR_KP)
+            taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
+        return taps
+    taps = _timed(f'gemm_dWconv[{tag}]', wgrad)
+    d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
+    d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
+    _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
+    return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
+
+
+def embed_scatter(ids_list, dx, table, p, seed):
+    """d word_embedding: one sort + one segmented reduction over all token streams (rows of dx follow ids_list order)."""
+    lib = _lib()
+    ids = torch.cat([i.reshape(-1) for i in ids_list])
+    d_table = torch.zeros_like(table, dtype=torch.float32)
+    ids_sorted, perm = _timed('sort_ids', lambda: torch.sort(ids))
+    _call('nr_embed_scatter_sorted', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dx), NR_KP, _ptr(d_table),
+          table.shape[0], ids.numel(), p, seed, _stream())
+    return d_table
+
+
+def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row):
+    """dst[id] = sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row)."""
+    dst = torch.zeros(num_rows, NR_D, dtype=torch.float32, device=src.device)
+    ids_sorted, perm = torch.sort(ids.reshape(-1))
+    _call('nr_scatter_sorted_f32', _lib().nr_scatter_sorted_f32, _ptr(ids_sorted), _ptr(perm), src.data_ptr() + col0 * 4, ld, _ptr(dst),
+          num_rows, ids.numel(), pad_row, _stream())
+    return dst
+
+
+# ----------------------------------------------------------------------------------------------------------
+# NAML news encoder (src/model/NAML/news_encoder.py:50-115)
+# ----------------------------------------------------------------------------------------------------------
+class _NamlNewsFn(torch.autograd.Function):
+    """news vectors f32 [T, D] (+ a bf16 ctx-layout copy for the next pooling level) from title / abstract ids and
+    category / subcategory ids.  View order in the stack: title, abstract, category, subcategory (the reference's order
+    depends on set iteration; the final attention is permutation invariant)."""
+
+    @staticmethod
+    def forward(ctx, title, abstract, cat, sub, table, cat_table,
+                cw_t, cb_t, Wa_t, ba_t, qv_t, cw_a, cb_a, Wa_a, ba_a, qv_a,
+                W_c, b_c, W_s, b_s, Wa_f, ba_f, qv_f, p, seed):
+        lib = _lib()
+        dev = table.device
+        T = title.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        views = torch.empty(T * 4, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        vstride = 4 * NR_KP
+        n_title_tok = title.numel()
+        st_t = text_fwd(title, table, cw_t, cb_t, Wa_t, ba_t, qv_t, p, seed, 0, need_grad, None, NR_D, views.data_ptr(), vstride, 'title')
+        st_a = text_fwd(abstract, table, cw_a, cb_a, Wa_a, ba_a, qv_a, p, seed, n_title_tok, need_grad, None, NR_D,
+                        views.data_ptr() + NR_KP * 2, vstride, 'abstract')
+        ncat, dcat = cat_table.shape
+        E = torch.empty(2, ncat, NR_D, dtype=torch.float32, device=dev)
+        embf, Wc_, bc_, Ws_, bs_ = _f32c(cat_table), _f32c(W_c), _f32c(b_c), _f32c(W_s), _f32c(b_s)
+        _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(bc_), _ptr(Ws_), _ptr(bs_), _ptr(E), _stream())
+        _call('nr_views_fill', lib.nr_views_fill, _ptr(cat), _ptr(sub), _ptr(E), ncat, _ptr(views), T, _stream())
+        Wap, bap, qvp = pack_additive(Wa_f, ba_f, qv_f)
+        out = torch.empty(T, NR_D, dtype=torch.float32, device=dev)
+        out_b = torch.empty(T, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        aw = torch.empty(T, 4, dtype=torch.float32, device=dev)
+        _call('nr_additive_fwd[views]', lib.nr_additive_fwd_ex, _ptr(views), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, _ptr(out_b), NR_KP,
+              _ptr(aw), T, 4, _stream())
+        if need_grad:
+            ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp)
+            ctx.st = (st_t, st_a)
+            ctx.meta = (p, seed, Wa_f.shape[0])
+        ctx.mark_non_differentiable(out_b)
+        return out, out_b
+
+    @staticmethod
+    def backward(ctx, g_out, _g_b):
+        lib = _lib()
+        title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp = ctx.saved_tensors
+        st_t, st_a = ctx.st
+        p, seed, qdim = ctx.meta
+        dev = views.device
+        T = title.shape[0]
+        g_out = g_out.to(torch.float32).contiguous()
+        # final attention over the 4 views
+        d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views')
+        gv = _workspace('gviews', (4, T, NR_D), torch.float32, dev)               # view-major: 4 contiguous [T][D] blocks
+        _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
+        # element encoders: reduce per category row, then the tiny table backward
+        ncat, dcat = embf.shape
+        dE = torch.stack([_sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1), _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1)])
+        dW = torch.empty(2, NR_D, dcat, dtype=torch.float32, device=dev)
+        db = torch.empty(2, NR_D, dtype=torch.float32, device=dev)
+        demb = torch.empty(ncat, dcat, dtype=torch.float32, device=dev)
+        _call('nr_element_table_bwd', lib.nr_element_table_bwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(Ws_), _ptr(E), _ptr(dE), _ptr(dW), _ptr(db),
+              _ptr(demb), _stream())
+        # text encoders; token gradients of both texts land in one buffer -> one embedding scatter
+        nt, na = title.numel(), abstract.numel()
+        dx = _workspace('dx_tok', (nt + na, NR_KP), _BF16_AS_I16, dev)
+        gt = text_bwd(st_t, gv[0], NR_D, p, dx.data_ptr(), 'title')
+        ga = text_bwd(st_a, gv[1], NR_D, p, dx.data_ptr() + nt * NR_KP * 2, 'abstract')
+        d_table = embed_scatter([title, abstract], dx, table, p, seed) if ctx.needs_input_grad[4] else None
+        ctx.st = None
+        return (None, None, None, None, d_table, demb, *gt, *ga, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None)
+
+
+def naml_news(title, abstract, cat, sub, table, cat_table, text_t, text_a, elem_c, elem_s, final_att, p_drop, training):
+    _require_cuda(table, "word_embedding.weight")
+    p = float(p_drop) if training else 0.0
+    seed = ops.new_seed() if p > 0 else 0
+    a_t, a_a = text_t.additive_attention, text_a.additive_attention
+    return _NamlNewsFn.apply(title, abstract, cat, sub, table, cat_table,
+                             text_t.CNN.weight, text_t.CNN.bias, a_t.linear.weight, a_t.linear.bias, a_t.attention_query_vector,
+                             text_a.CNN.weight, text_a.CNN.bias, a_a.linear.weight, a_a.linear.bias, a_a.attention_query_vector,
+                             elem_c.linear.weight, elem_c.linear.bias, elem_s.linear.weight, elem_s.linear.bias,
+                             final_att.linear.weight, final_att.linear.bias, final_att.attention_query_vector, p, seed)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# additive pooling of dense vectors that already exist as bf16 ctx rows (NAML user encoder, user_encoder.py:18)
+# ----------------------------------------------------------------------------------------------------------
+class _PoolFn(torch.autograd.Function):
+    """out[n, D] = AdditiveAttention(x) for x f32 [n, S, D] whose bf16 ctx-layout copy x_b [n*S][KP] is supplied by the producer
+    (no re-quantisation pass); gradient flows to x."""
+
+    @staticmethod
+    def forward(ctx, x, x_b, Wa, ba, qv):
+        lib = _lib()
+        n, S, _ = x.shape
+        if not lib.nr_supported_pool_len(S):
+            raise NotImplementedError(f"sequence length {S} is not instantiated in the pooling kernels (4, 20, 50)")
+        dev = x.device
+        Wap, bap, qvp = pack_additive(Wa, ba, qv)
+        out = torch.empty(n, NR_D, dtype=torch.float32, device=dev)
+        aw = torch.empty(n, S, dtype=torch.float32, device=dev)
+        _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_ex, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
+              _ptr(aw), n, S, _stream())
+        ctx.save_for_backward(x_b, aw, Wap, bap, qvp)
+        ctx.qdim = Wa.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        x_b, aw, Wap, bap, qvp = ctx.saved_tensors
+        n, S = aw.shape
+        g = g.to(torch.float32).contiguous()
+        d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}')
+        dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
+        _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_D, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
+        return dx, None, d_Wa, d_ba, d_qv
+
+
+def pool_rows(x, x_b, additive):
+    _require_cuda(x, "clicked_news_vector")
+    return _PoolFn.apply(x, x_b, additive.linear.weight, additive.linear.bias, additive.attention_query_vector)
+
+
+def to_ctx_rows(x):
+    """f32 [n, S, D] -> bf16 ctx-layout rows [n*S][KP] (col D = 1.0); only for callers that do not already hold such a copy
+    (evaluate.py hands get_user_vector a freshly stacked f32 tensor)."""
+    n, S, d = x.shape
+    cb = torch.zeros(n * S, NR_KP, dtype=torch.bfloat16, device=x.device)
+    cb[:, :NR_D] = x.detach().reshape(n * S, d).to(torch.bfloat16)
+    cb[:, NR_D] = 1.0
+    return cb.view(_BF16_AS_I16)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# LSTUR news encoder (src/model/LSTUR/news_encoder.py:32-76): [category row | subcategory row | title vector]
+# ----------------------------------------------------------------------------------------------------------
+class _LsturNewsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, title, cat, sub, table, cat_table, cw, cb, Wa, ba, qv, p, seed):
+        lib = _lib()
+        dev = table.device
+        T = title.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        out = torch.empty(T, 3 * NR_D, dtype=torch.float32, device=dev)
+        ct = _f32c(cat_table)
+        for j, ids in enumerate((cat, sub)):
+            _call('nr_gather_rows_strided', lib.nr_gather_rows_strided, _ptr(ids), _ptr(ct), ct.shape[0], NR_D, None, out.data_ptr() + j * NR_D * 4,
+                  3 * NR_D, T, _stream())
+        st = text_fwd(title, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr() + 2 * NR_D * 4, 3 * NR_D, None, 0, 'title')
+        if need_grad:
+            ctx.save_for_backward(title, cat, sub, table)
+            ctx.st = st
+            ctx.meta = (p, seed, cat_table.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        title, cat, sub, table = ctx.saved_tensors
+        st = ctx.st
+        p, seed, ncat = ctx.meta
+        dev = g.device
+        g = g.to(torch.float32).contiguous()
+        T = title.shape[0]
+        # category_embedding (padding_idx = 0): two segmented reductions over column blocks of g
+        d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0) + _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0)
+        g_title = g[:, 2 * NR_D:].contiguous()
+        dx = _workspace('dx_tok', (title.numel(), NR_KP), _BF16_AS_I16, dev)
+        gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title')
+        d_table = embed_scatter([title], dx, table, p, seed) if ctx.needs_input_grad[3] else None
+        ctx.st = None
+        return (None, None, None, d_table, d_cat, *gt, None, None)
+
+
+def lstur_news(title, cat, sub, table, cat_table, conv, additive, p_drop, training):
+    _require_cuda(table, "word_embedding.weight")
+    p = float(p_drop) if training else 0.0
+    seed = ops.new_seed() if p > 0 else 0
+    return _LsturNewsFn.apply(title, cat, sub, table, cat_table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
+                              additive.attention_query_vector, p, seed)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# one text view on its own (NAML TextEncoder.forward used directly)
+# ----------------------------------------------------------------------------------------------------------
+class _TextFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, cw, cb, Wa, ba, qv, p, seed):
+        need_grad = any(ctx.needs_input_grad)
+        out = torch.empty(ids.shape[0], NR_D, dtype=torch.float32, device=table.device)
+        st = text_fwd(ids, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr(), NR_D, None, 0, 'text')
+        if need_grad:
+            ctx.save_for_backward(ids, table)
+            ctx.st = st
+            ctx.meta = (p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, table = ctx.saved_tensors
+        p, seed = ctx.meta
+        g = g.to(torch.float32).contiguous()
+        dx = _workspace('dx_tok', (ids.numel(), NR_KP), _BF16_AS_I16, g.device)
+        gt = text_bwd(ctx.st, g, NR_D, p, dx.data_ptr(), 'text')
+        d_table = embed_scatter([ids], dx, table, p, seed) if ctx.needs_input_grad[1] else None
+        ctx.st = None
+        return (None, d_table, *gt, None, None)
+
+
+def text_only(ids, table, conv, additive, p_drop, training):
+    _require_cuda(table, "word_embedding.weight")
+    p = float(p_drop) if training else 0.0
+    seed = ops.new_seed() if p > 0 else 0
+    return _TextFn.apply(ids.contiguous(), table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
+                         additive.attention_query_vector, p, seed)

@@ -134,4 +134,6 @@ def random_lstur_params(seed, num_words, d, num_categories, num_users, num_filte
         'user_encoder.gru.bias_hh_l0': un(3 * dh, a=k),
         'user_embedding.weight': rn(num_users, dh, std=emb_std),
     }
+    for k in ('news_encoder.word_embedding.weight', 'news_encoder.category_embedding.weight', 'user_embedding.weight'):
+        p[k][0] = 0        # padding_idx=0 rows are zero-initialised by nn.Embedding (pretrained_word_embedding=None path)
     return p

@@ -69,7 +69,7 @@ def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0
     ids[1] = 0
     Wc, _, bc = pack_conv(be, W, b, False)
     act = be.poison((n_seq * S, NR_KP), np.uint16)
-    xs = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16)
+    xs = be.poison((seqpad_rows(n_seq, S), NR_KP), np.uint16)      # the kernel writes the separator rows too
     ck(be, be.lib.nr_conv3_fwd(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
                                n_seq, S, p_drop, seed, tok_offset, be.stream))
     be.sync()
