@@ -186,6 +186,29 @@ int nr_rows_scatter_add(const int64_t* ids, const float* src, int64_t ld, const 
 int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_rows, int d, const float* row_scale, float* out,
                            int64_t ldo, int64_t n, void* stream);
 
+/* ---- LSTUR user encoder: nn.GRU(3F, H) over the packed click history (src/model/LSTUR/user_encoder.py:11-14,27-45) ----
+ * Padded sizes for hidden size Hd: Hg = Hd up to 16 (gate stride), Hp = Hd+1 up to 32 (h row length, col Hd of bf16 h rows = 1.0),
+ * Kp = 3*Hg up to 32 (dGh row length).  One launch per time step; the input projection gi = x W_ih^T (f32 [B*N][3*Hg], row
+ * b*N + t, gate q of unit j at column q*Hg + j, no bias) is one plain GEMM done by the caller. */
+int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp);
+/* W f32 [3*Hd][K] (weight_ih_l0 / weight_hh_l0, gate order r,z,n) -> dst bf16 [3*Hg][Kpad] (row q*Hg+j) and, if not NULL,
+ * dstT bf16 [Kpad][Kp] with dstT[k][q*Hg+j] = W[q*Hd+j][k] (operand of the hidden-state gradient). */
+int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, void* stream);
+/* f32 rows [n][d] (stride ld) -> bf16 rows [n][dp]: col d = 1.0 when d < dp, rest 0 (MFMA / GEMM operand form of dense vectors). */
+int nr_rows_to_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream);
+/* Step t of the GRU forward for all B samples: reads h_{t-1} (bf16 operand + f32 state), writes h_t (both); samples with
+ * t >= len[b] keep their state (pack_padded_sequence: the first len[b] slots are consumed, len >= 1).  gates (training):
+ * bf16 [B][4][Hg] = r, z, n, q = Gh_n + b_hn of this step for nr_gru_bwd_step; NULL for inference. */
+int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_b,
+                    uint16_t* h_out_b, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t, void* stream);
+/* Step t of the backward sweep (t = T-1 .. 0, then t = -1): dh_t = carry_next + dgh_next @ W_hh (g_last when first != 0);
+ * for t >= 0 it then writes the gate gradients of step t: dgi row b*N+t of bf16 [B*N][Kp] = [dr|dz|dn] pre-activations,
+ * dgh bf16 [B][Kp] = [dr|dz|dn*r] and carry f32 [B][Hp] = dh_t * z_t (dh_t for finished samples); for t = -1 carry
+ * receives dh_0 (gradient of the initial state = the user_embedding row in the 'ini' method). */
+int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* carry_next, const uint16_t* WhhT, const uint16_t* gates,
+                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, float* carry, int B, int N, int Hd, int t,
+                    int first, void* stream);
+
 /* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
  * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream);

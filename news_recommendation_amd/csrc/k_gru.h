@@ -1,0 +1,199 @@
+// LSTUR user encoder: one-layer GRU over the click history (src/model/LSTUR/user_encoder.py:11-14,27-45; nn.GRU gate order
+// r, z, n), one kernel launch per time step (the steps are sequentially dependent; the launches are queued back to back on
+// one stream).  The input projection x W_ih^T of ALL steps is hoisted into one plain GEMM by the caller (gi, fp32).
+//
+// Padded layouts (Hd = hidden size, I = input size):
+//   Hg = Hd rounded up to 16        gate stride: gate q of unit j lives at column / row q*Hg + j
+//   Hp = (Hd+1) rounded up to 32    K extent of h rows; column Hd of every bf16 h row holds 1.0 (bias-gradient column)
+//   Kp = 3*Hg rounded up to 32      K extent of the dGh rows
+// Forward step t:   Gh = h_{t-1} W_hh^T on MFMA (A = W_hh rows of the unit tile for the three gates, B = h^T of 16 samples):
+//   a lane ends up with 4 consecutive hidden units of one sample for all three gates -> the gate math is in-lane.
+//   r = s(gi_r + b_ir + Gh_r + b_hr), z likewise, q = Gh_n + b_hn, n = tanh(gi_n + b_in + r q), h = (1-z) n + z h_{t-1};
+//   samples with t >= length keep their state (pack_padded_sequence semantics: the first `length` slots are consumed).
+// Backward step t:  dh_t = carry_{t+1} + dGh_{t+1} W_hh (MFMA, A = W_hh^T rows of the unit tile, B = dGh^T), then the gate
+//   derivatives of step t for the same (sample, units) in the epilogue; writes dGi_t, dGh_t and carry_t = dh_t z_t.
+#pragma once
+#include "nr_common.h"
+
+namespace nr {
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+struct GruFwdParams {
+  const float* gi;        // [B*N][3*Hg] f32, row b*N + t  (x_t W_ih^T, no bias)
+  const u16* Whh;         // bf16 [3*Hg][Hp]
+  const float* b_ih;      // [3*Hd]
+  const float* b_hh;      // [3*Hd]
+  const int* len;         // [B], >= 1
+  const u16* h_in_b;      // bf16 [B][Hp]
+  u16* h_out_b;           // bf16 [B][Hp]
+  const float* h_in_f;    // f32 [B][Hp]
+  float* h_out_f;         // f32 [B][Hp]
+  u16* gates;             // training: bf16 [B][4][Hg] of this step (r, z, n, q), or null
+  int B, N, Hd, Hg, Hp, t;
+};
+
+__global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
+  const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  const int s0 = ((int)blockIdx.x * 4 + w) * 16;
+  if (s0 >= p.B) return;
+  const int j0 = (int)blockIdx.y * 16;
+  const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
+  const u16* hp = p.h_in_b + (size_t)sb * p.Hp + g * 8;
+  const u16* w0 = p.Whh + (size_t)(j0 + li) * p.Hp + g * 8;
+  const u16* w1 = w0 + (size_t)p.Hg * p.Hp;
+  const u16* w2 = w1 + (size_t)p.Hg * p.Hp;
+  f32x4 ar = f32x4{0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+  const int ksteps = p.Hp / 32;
+#pragma unroll 2
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const u16x8 hf = *(const u16x8*)(hp + ks * 32);
+    ar = mfma_16x16x32_bf16(*(const u16x8*)(w0 + ks * 32), hf, ar);
+    az = mfma_16x16x32_bf16(*(const u16x8*)(w1 + ks * 32), hf, az);
+    an = mfma_16x16x32_bf16(*(const u16x8*)(w2 + ks * 32), hf, an);
+  }
+  // lane: sample s0 + li, units j0 + 4g + r
+  const int s = s0 + li, jb = j0 + 4 * g;
+  if (s >= p.B) return;
+  const bool active = p.t < p.len[s];
+  const float* gi = p.gi + ((size_t)s * p.N + p.t) * 3 * p.Hg + jb;
+  const f32x4 gir = *(const f32x4*)gi, giz = *(const f32x4*)(gi + p.Hg), gin = *(const f32x4*)(gi + 2 * p.Hg);
+  const f32x4 ho = *(const f32x4*)(p.h_in_f + (size_t)s * p.Hp + jb);
+  f32x4 hn, rr, zz, nn, qq;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = jb + r;
+    const bool ok = j < p.Hd;
+    const float bir = ok ? p.b_ih[j] : 0.f, biz = ok ? p.b_ih[p.Hd + j] : 0.f, bin = ok ? p.b_ih[2 * p.Hd + j] : 0.f;
+    const float bhr = ok ? p.b_hh[j] : 0.f, bhz = ok ? p.b_hh[p.Hd + j] : 0.f, bhn = ok ? p.b_hh[2 * p.Hd + j] : 0.f;
+    rr[r] = fast_sigmoid(gir[r] + bir + ar[r] + bhr);
+    zz[r] = fast_sigmoid(giz[r] + biz + az[r] + bhz);
+    qq[r] = an[r] + bhn;
+    nn[r] = fast_tanh(gin[r] + bin + rr[r] * qq[r]);
+    const float v = active ? (1.0f - zz[r]) * nn[r] + zz[r] * ho[r] : ho[r];
+    hn[r] = ok ? v : 0.0f;
+  }
+  if (jb < p.Hd) {         // the 4 units straddle Hd only at the very end, where the row padding absorbs them
+    *(f32x4*)(p.h_out_f + (size_t)s * p.Hp + jb) = hn;
+    u16x4 hb = pack4(hn);
+    if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;        // column Hd = 1.0
+    *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
+    if (jb + 4 == p.Hd) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;    // Hd % 4 == 0: the lane owning the last units also sets column Hd
+  }
+  if (p.gates != nullptr && jb < p.Hg) {
+    u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
+    *(u16x4*)gp = pack4(rr);
+    *(u16x4*)(gp + p.Hg) = pack4(zz);
+    *(u16x4*)(gp + 2 * p.Hg) = pack4(nn);
+    *(u16x4*)(gp + 3 * p.Hg) = pack4(qq);
+  }
+}
+
+struct GruBwdParams {
+  const float* g_last;     // [B][Hd] gradient of the returned hidden state (used when first != 0)
+  const u16* dgh_next;     // bf16 [B][Kp]: dGh of step t+1
+  const float* carry_next; // f32 [B][Hp]: dh_{t+1} z_{t+1} (or dh_{t+1} for finished samples)
+  const u16* WhhT;         // bf16 [Hp][Kp]: WhhT[j][q*Hg + i] = W_hh[q*Hd + i][j]
+  const u16* gates;        // bf16 [B][4][Hg] of step t; null for the final call (t = -1: only dh_0 is produced)
+  const u16* h_prev_b;     // bf16 [B][Hp] = h_{t-1}
+  const int* len;
+  u16* dgi;                // bf16 [B*N][Kp]: row b*N + t receives [dr_pre | dz_pre | dn_pre]
+  u16* dgh;                // bf16 [B][Kp] of step t: [dr_pre | dz_pre | dn_pre * r]
+  float* carry;            // f32 [B][Hp] of step t; for t = -1 it receives dh_0
+  int B, N, Hd, Hg, Hp, Kp, t, first;
+};
+
+__global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
+  const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  const int s0 = ((int)blockIdx.x * 4 + w) * 16;
+  if (s0 >= p.B) return;
+  const int j0 = (int)blockIdx.y * 16;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!p.first) {
+    const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
+    const u16* dp = p.dgh_next + (size_t)sb * p.Kp + g * 8;
+    const u16* wp = p.WhhT + (size_t)(j0 + li) * p.Kp + g * 8;
+    const int ksteps = p.Kp / 32;
+#pragma unroll 4
+    for (int ks = 0; ks < ksteps; ++ks)
+      acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32), *(const u16x8*)(dp + ks * 32), acc);
+  }
+  const int s = s0 + li, jb = j0 + 4 * g;
+  if (s >= p.B || jb >= p.Hg) return;
+  f32x4 dh;
+  if (p.first) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = jb + r < p.Hd ? p.g_last[(size_t)s * p.Hd + jb + r] : 0.0f;
+  } else {
+    dh = acc + *(const f32x4*)(p.carry_next + (size_t)s * p.Hp + jb);
+  }
+  if (p.gates == nullptr) {                    // t = -1: dh_0
+    *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = dh;
+    return;
+  }
+  const bool active = p.t < p.len[s];
+  f32x4 d_r = f32x4{0.f, 0.f, 0.f, 0.f}, d_z = d_r, d_n = d_r, d_nr = d_r, cy = dh;
+  if (active) {
+    const u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
+    const u16x4 rb = *(const u16x4*)gp, zb = *(const u16x4*)(gp + p.Hg), nb = *(const u16x4*)(gp + 2 * p.Hg), qb = *(const u16x4*)(gp + 3 * p.Hg);
+    const u16x4 hb = *(const u16x4*)(p.h_prev_b + (size_t)s * p.Hp + jb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = jb + r < p.Hd;
+      const float rr = bf2f(rb[r]), zz = bf2f(zb[r]), nn = bf2f(nb[r]), qq = bf2f(qb[r]), hp = bf2f(hb[r]);
+      const float dn = dh[r] * (1.0f - zz);
+      const float dz = dh[r] * (hp - nn);
+      const float dnp = dn * (1.0f - nn * nn);
+      const float drp = dnp * qq * rr * (1.0f - rr);
+      const float dzp = dz * zz * (1.0f - zz);
+      d_r[r] = ok ? drp : 0.0f;
+      d_z[r] = ok ? dzp : 0.0f;
+      d_n[r] = ok ? dnp : 0.0f;
+      d_nr[r] = ok ? dnp * rr : 0.0f;
+      cy[r] = dh[r] * zz;
+    }
+  }
+  *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = cy;
+  u16* gi = p.dgi + ((size_t)s * p.N + p.t) * p.Kp + jb;
+  *(u16x4*)gi = pack4(d_r);
+  *(u16x4*)(gi + p.Hg) = pack4(d_z);
+  *(u16x4*)(gi + 2 * p.Hg) = pack4(d_n);
+  u16* gh = p.dgh + (size_t)s * p.Kp + jb;
+  *(u16x4*)gh = pack4(d_r);
+  *(u16x4*)(gh + p.Hg) = pack4(d_z);
+  *(u16x4*)(gh + 2 * p.Hg) = pack4(d_nr);
+}
+
+// ---- operand packing --------------------------------------------------------------------------------------------------
+// W f32 [3*Hd][K] (nn.GRU weight_ih_l0 / weight_hh_l0) -> dst bf16 [3*Hg][Kpad]: row q*Hg + j = W[q*Hd + j][:], zero padded.
+// dstT (optional) bf16 [Kpad_rows = Hp][Kp]: dstT[k][q*Hg + j] = W[q*Hd + j][k]   (the data-gradient operand).
+__global__ __launch_bounds__(256) void pack_gru_kernel(const float* __restrict__ W, int Hd, int K, int Hg, int Kpad, u16* __restrict__ dst,
+                                                       u16* __restrict__ dstT, int Trows, int Kp) {
+  const int n1 = 3 * Hg * Kpad;
+  const int n2 = dstT ? Trows * Kp : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int row = i / Kpad, k = i - row * Kpad;
+      const int q = row / Hg, j = row - q * Hg;
+      dst[i] = f2bf((j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
+    } else {
+      const int i2 = i - n1;
+      const int k = i2 / Kp, c = i2 - k * Kp;
+      const int q = c / Hg, j = c - q * Hg;
+      dstT[i2] = f2bf((q < 3 && j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
+    }
+  }
+}
+
+// f32 rows [n][d] (row stride lds_) -> bf16 rows [n][dp]: cols < d converted, col d = 1.0 (when d < dp), rest 0.
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, int64_t lds_, int d, u16* __restrict__ dst, int dp,
+                                                           int64_t n) {
+  const int64_t total = n * dp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dp;
+    const int c = (int)(i - r * dp);
+    dst[i] = c < d ? f2bf(src[r * lds_ + c]) : (u16)(c == d ? 0x3F80 : 0);
+  }
+}
+
+}  // namespace nr

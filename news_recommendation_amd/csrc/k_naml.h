@@ -122,4 +122,18 @@ __global__ __launch_bounds__(256) void gather_rows_strided_kernel(const int64_t*
   }
 }
 
+// scalar variant for widths that are not a multiple of 4 (LSTUR 'con': user rows of 1.5 F = 450 floats)
+__global__ __launch_bounds__(256) void gather_rows_strided_scalar_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                                         int64_t num_rows, int d, const float* __restrict__ row_scale,
+                                                                         float* __restrict__ out, int64_t ldo, int64_t n) {
+  const int64_t total = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / d;
+    const int c = (int)(i - r * d);
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= num_rows ? num_rows - 1 : id);
+    out[r * ldo + c] = table[id * d + c] * (row_scale ? row_scale[r] : 1.0f);
+  }
+}
+
 }  // namespace nr

@@ -6,6 +6,7 @@
 #include "k_bwd.h"
 #include "k_conv.h"
 #include "k_naml.h"
+#include "k_gru.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -404,11 +405,65 @@ int nr_rows_scatter_add(const int64_t* ids, const float* src, int64_t ld, const 
 
 int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_rows, int d, const float* row_scale, float* out, int64_t ldo,
                            int64_t n, void* stream) {
-  if (!ids || !table || !out || num_rows <= 0 || d <= 0 || (d & 3) || ldo < d || (ldo & 3) || n < 0)
-    return fail(NR_ERR_BADARG, "nr_gather_rows_strided: bad argument");
+  if (!ids || !table || !out || num_rows <= 0 || d <= 0 || ldo < d || n < 0) return fail(NR_ERR_BADARG, "nr_gather_rows_strided: bad argument");
   if (n == 0) return NR_OK;
+  if ((d & 3) || (ldo & 3) || ((uintptr_t)out & 15) || ((uintptr_t)table & 15)) {
+    NR_LAUNCH(nr::gather_rows_strided_scalar_kernel, grid_for(n * d, 256, 4096), 256, 0, (hipStream_t)stream, ids, table, num_rows, d, row_scale, out,
+              ldo, n);
+    return check_launch("nr_gather_rows_strided");
+  }
   NR_LAUNCH(nr::gather_rows_strided_kernel, grid_for(n * (d / 4), 256, 4096), 256, 0, (hipStream_t)stream, ids, table, num_rows, d, row_scale, out, ldo, n);
   return check_launch("nr_gather_rows_strided");
+}
+
+// ---- LSTUR GRU user encoder --------------------------------------------------------------------------------------------
+static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp) {
+  if (Hd <= 0 || !Hg || !Hp || !Kp) return fail(NR_ERR_BADARG, "nr_gru_dims: bad argument");
+  *Hg = ceil_to(Hd, 16); *Hp = ceil_to(Hd + 1, 32); *Kp = ceil_to(3 * *Hg, 32);
+  return NR_OK;
+}
+
+int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, void* stream) {
+  if (!W || !dst || Hd <= 0 || K <= 0 || Kpad < K || (Kpad & 31)) return fail(NR_ERR_BADARG, "nr_pack_gru: bad argument");
+  const int Hg = ceil_to(Hd, 16), Kp = ceil_to(3 * Hg, 32);
+  NR_LAUNCH(nr::pack_gru_kernel, 1024, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp);
+  return check_launch("nr_pack_gru");
+}
+
+int nr_rows_to_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream) {
+  if (!src || !dst || d <= 0 || dp < d || ld < d || n < 0) return fail(NR_ERR_BADARG, "nr_rows_to_bf16: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::rows_to_bf16_kernel, grid_for(n * dp, 256, 8192), 256, 0, (hipStream_t)stream, src, ld, d, dst, dp, n);
+  return check_launch("nr_rows_to_bf16");
+}
+
+int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_b,
+                    uint16_t* h_out_b, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t, void* stream) {
+  if (!gi || !Whh || !b_ih || !b_hh || !len || !h_in_b || !h_out_b || !h_in_f || !h_out_f || B < 0 || N <= 0 || Hd <= 0 || t < 0 || t >= N)
+    return fail(NR_ERR_BADARG, "nr_gru_fwd_step: bad argument");
+  if (B == 0) return NR_OK;
+  nr::GruFwdParams p;
+  p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_b = h_in_b; p.h_out_b = h_out_b; p.h_in_f = h_in_f;
+  p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
+  NR_LAUNCH2(nr::gru_fwd_step_kernel, (B + 63) / 64, p.Hg / 16, nr::WG, 0, (hipStream_t)stream, p);
+  return check_launch("nr_gru_fwd_step");
+}
+
+int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* carry_next, const uint16_t* WhhT, const uint16_t* gates,
+                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, float* carry, int B, int N, int Hd, int t,
+                    int first, void* stream) {
+  if (!WhhT || !len || !carry || B < 0 || N <= 0 || Hd <= 0 || t < -1 || t >= N) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: bad argument");
+  if (first ? !g_last : (!dgh_next || !carry_next)) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: missing upstream gradient");
+  if (t >= 0 && (!gates || !h_prev_b || !dgi || !dgh)) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: missing step buffers");
+  if (B == 0) return NR_OK;
+  nr::GruBwdParams p;
+  p.g_last = g_last; p.dgh_next = dgh_next; p.carry_next = carry_next; p.WhhT = WhhT; p.gates = t >= 0 ? gates : nullptr; p.h_prev_b = h_prev_b;
+  p.len = len; p.dgi = dgi; p.dgh = dgh; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
+  p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
+  NR_LAUNCH2(nr::gru_bwd_step_kernel, (B + 63) / 64, p.Hg / 16, nr::WG, 0, (hipStream_t)stream, p);
+  return check_launch("nr_gru_bwd_step");
 }
 
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream) {

@@ -12,6 +12,9 @@
 #define NR_LAUNCH(kern, gx, bx, smem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
 
+#define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
+
 namespace nr {
 
 typedef unsigned short u16;

@@ -1,0 +1,33 @@
+"""LSTUR NewsEncoder -- interface of src/model/LSTUR/news_encoder.py:9-76."""
+import torch
+import torch.nn as nn
+
+from news_recommendation_amd import ops_conv
+from ..general.attention.additive import AdditiveAttention
+
+
+class NewsEncoder(torch.nn.Module):
+    def __init__(self, config, pretrained_word_embedding):
+        super().__init__()
+        self.config = config
+        ops_conv.check_conv_dims(config.word_embedding_dim, config.num_filters, config.window_size, config.query_vector_dim)
+        if pretrained_word_embedding is None:
+            self.word_embedding = nn.Embedding(config.num_words, config.word_embedding_dim, padding_idx=0)
+        else:
+            self.word_embedding = nn.Embedding.from_pretrained(pretrained_word_embedding, freeze=False, padding_idx=0)
+        self.category_embedding = nn.Embedding(config.num_categories, config.num_filters, padding_idx=0)
+        assert config.window_size >= 1 and config.window_size % 2 == 1
+        self.title_CNN = nn.Conv2d(1, config.num_filters, (config.window_size, config.word_embedding_dim),
+                                   padding=(int((config.window_size - 1) / 2), 0))
+        self.title_attention = AdditiveAttention(config.query_vector_dim, config.num_filters)
+
+    def encode(self, title, category, subcategory):
+        """int64 device tensors [T, L], [T], [T] -> [T, 3 * num_filters] = [category row | subcategory row | title vector]."""
+        return ops_conv.lstur_news(title, category, subcategory, self.word_embedding.weight, self.category_embedding.weight,
+                                   self.title_CNN, self.title_attention, self.config.dropout_probability, self.training)
+
+    def forward(self, news):
+        """news: {"category": [B], "subcategory": [B], "title": [B, L]} (CPU or GPU) -> [B, 3 * num_filters]."""
+        dev = self.word_embedding.weight.device
+        mv = lambda k: news[k].to(dev, non_blocking=True).contiguous()
+        return self.encode(mv('title'), mv('category'), mv('subcategory'))

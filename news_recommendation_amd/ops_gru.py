@@ -1,0 +1,132 @@
+"""Host wrappers (autograd) of the LSTUR user encoder: user_embedding row gather with whole-row masking
+(src/model/LSTUR/__init__.py:38-42,74-77) and the GRU over the click history (src/model/LSTUR/user_encoder.py:16-45).
+
+The recurrence runs in the per-step HIP kernels (csrc/k_gru.h), queued back to back on the current stream; the
+time-independent products around it are plain bf16 GEMMs: the hoisted input projection x W_ih^T, and in the backward
+dX = dGi W_ih, dW_ih = dGi^T X, dW_hh = dGh^T H.  No CPU path.
+"""
+import ctypes
+import torch
+
+from . import ops
+from .ops import _lib, _stream, _call, _ptr, _f32c, _bf16, _mm, _mm_f32, _workspace, _require_cuda, _BF16_AS_I16
+
+
+def gru_dims(Hd):
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    ops._ck(_lib().nr_gru_dims(Hd, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
+def _ceil(v, m):
+    return (v + m - 1) // m * m
+
+
+def rows_to_bf16(src, d, dp):
+    """f32 [n, >=d] (row stride = src.stride(0)) -> bf16 [n, dp] with col d = 1.0."""
+    n = src.shape[0]
+    dst = torch.empty(n, dp, dtype=_BF16_AS_I16, device=src.device)
+    _call('nr_rows_to_bf16', _lib().nr_rows_to_bf16, _ptr(src), src.stride(0), d, _ptr(dst), dp, n, _stream())
+    return dst
+
+
+class _UserRowsFn(torch.autograd.Function):
+    """out[b] = row_scale[b] * table[ids[b]]: nn.Embedding(padding_idx=0) forward fused with F.dropout2d's per-sample factor
+    keep_b / (1 - p) (row_scale = None in eval mode); backward scatters B rows into the dense table gradient, row 0 skipped."""
+
+    @staticmethod
+    def forward(ctx, ids, table, row_scale):
+        tab = _f32c(table)
+        B, d = ids.shape[0], tab.shape[1]
+        out = torch.empty(B, d, dtype=torch.float32, device=tab.device)
+        _call('nr_gather_rows_strided[user]', _lib().nr_gather_rows_strided, _ptr(ids), _ptr(tab), tab.shape[0], d, _ptr(row_scale), _ptr(out), d, B, _stream())
+        ctx.save_for_backward(ids, row_scale)
+        ctx.shape = tuple(tab.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, row_scale = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        d_table = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _call('nr_rows_scatter_add[user]', _lib().nr_rows_scatter_add, _ptr(ids), _ptr(g), g.shape[1], _ptr(row_scale), _ptr(d_table), ctx.shape[0],
+              ctx.shape[1], ids.shape[0], 0, _stream())
+        return None, d_table, None
+
+
+def user_rows(ids, table, row_scale=None):
+    _require_cuda(table, "user_embedding.weight")
+    return _UserRowsFn.apply(ids.contiguous(), table, row_scale)
+
+
+class _GruFn(torch.autograd.Function):
+    """h_last[b] = GRU state after consuming x[b, 0:len[b]] starting from h0[b] (len >= 1)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, lens_dev, T, W_ih, W_hh, b_ih, b_hh):
+        lib = _lib()
+        B, N, I = x.shape
+        Hd = W_hh.shape[1]
+        Hg, Hp, Kp = gru_dims(Hd)
+        Ip = _ceil(I + 1, 32)
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad)
+        Wih_p = torch.empty(3 * Hg, Ip, dtype=_BF16_AS_I16, device=dev)
+        Whh_p = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
+        WhhT = torch.empty(Hp, Kp, dtype=_BF16_AS_I16, device=dev) if need_grad else None
+        Wi, Wh = _f32c(W_ih), _f32c(W_hh)
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, _stream())
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), _stream())
+        bi, bh = _f32c(b_ih), _f32c(b_hh)
+        xf = _f32c(x).view(B * N, I)
+        Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
+        gi = _mm_f32(_bf16(Xb), _bf16(Wih_p).t(), 'gemm_gru_gi')                             # [B*N][3*Hg] f32 (hoisted input projection)
+        H_all = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
+        hf = [torch.zeros(B, Hp, dtype=torch.float32, device=dev), torch.empty(B, Hp, dtype=torch.float32, device=dev)]
+        if h0 is not None:
+            hf[0][:, :Hd].copy_(h0)
+        _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf[0]), Hp, Hd, _ptr(H_all[0]), Hp, B, _stream())
+        gates = torch.empty(T, B, 4, Hg, dtype=_BF16_AS_I16, device=dev) if need_grad else None
+        for t in range(T):
+            _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(H_all[t]), _ptr(H_all[t + 1]),
+                  _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]), _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
+        out = hf[T % 2][:, :Hd].contiguous()
+        if need_grad:
+            ctx.save_for_backward(Xb, H_all, gates, lens_dev, Wih_p, WhhT)
+            ctx.meta = (B, N, I, Hd, T, h0 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        Xb, H_all, gates, lens_dev, Wih_p, WhhT = ctx.saved_tensors
+        B, N, I, Hd, T, has_h0 = ctx.meta
+        Hg, Hp, Kp = gru_dims(Hd)
+        dev = g.device
+        g = g.to(torch.float32).contiguous()
+        dgi = _workspace('gru_dgi', (B * N, Kp), _BF16_AS_I16, dev, zero=True)                # K padding stays zero
+        if T < N:
+            dgi.view(B, N, Kp)[:, T:].zero_()                                                # steps nobody reached
+        dgh = _workspace('gru_dgh', (T, B, Kp), _BF16_AS_I16, dev, zero=True)
+        carry = [torch.empty(B, Hp, dtype=torch.float32, device=dev) for _ in range(2)]
+        for i, t in enumerate(range(T - 1, -2, -1)):
+            first = 1 if i == 0 else 0
+            _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dgh[t + 1]),
+                  None if first else _ptr(carry[(i + 1) % 2]), _ptr(WhhT), _ptr(gates[t]) if t >= 0 else None, _ptr(H_all[t]) if t >= 0 else None,
+                  _ptr(lens_dev), _ptr(dgi) if t >= 0 else None, _ptr(dgh[t]) if t >= 0 else None, _ptr(carry[i % 2]), B, N, Hd, t, first, _stream())
+        d_h0 = carry[T % 2][:, :Hd].contiguous() if has_h0 else None
+        dgi_b = _bf16(dgi)
+        d_x = _mm(dgi_b[:, :3 * Hg], _bf16(Wih_p)[:, :I], 'gemm_gru_dx').float().view(B, N, I) if ctx.needs_input_grad[0] else None
+        dWi = ops._wgrad(dgi_b, _bf16(Xb), 'gemm_gru_dWih')                                   # [Kp][Ip]; col I = bias gradient
+        dWh = ops._wgrad(_bf16(dgh).view(T * B, Kp), _bf16(H_all)[:T].reshape(T * B, Hp), 'gemm_gru_dWhh')     # [Kp][Hp]; col Hd = bias gradient
+        unpad = lambda m, ncol: torch.cat([m[q * Hg:q * Hg + Hd, :ncol] for q in range(3)], dim=0)
+        return (d_x, d_h0, None, None, unpad(dWi, I), unpad(dWh, Hd), unpad(dWi, I + 1)[:, I].contiguous(), unpad(dWh, Hd + 1)[:, Hd].contiguous())
+
+
+def gru_last_state(x, h0, clicked_news_length, gru):
+    """x f32 [B, N, I] on the GPU, h0 f32 [B, Hd] or None (zeros), clicked_news_length: CPU (or device) integer tensor, already >= 1."""
+    _require_cuda(x, "clicked_news_vector")
+    lens = clicked_news_length.detach().to('cpu').clamp(min=1, max=x.shape[1])
+    T = int(lens.max())
+    lens_dev = lens.to(torch.int32).to(x.device)
+    return _GruFn.apply(x, h0, lens_dev, T, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)

@@ -110,6 +110,10 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
   nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), 1, 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
                  (size_t)(smem), [&]() { kern(__VA_ARGS__); })
 
+#define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...)                                                \
+  nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), (unsigned)(gy), 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
+                 (size_t)(smem), [&]() { kern(__VA_ARGS__); })
+
 namespace nr {
 
 typedef unsigned short u16;

@@ -1,0 +1,116 @@
+"""Parity checks of the GRU step kernels (LSTUR user encoder) through the C-ABI, emulator or cuda:0.
+The per-step launches are driven exactly as the host layer drives them; the plain GEMMs around them (input projection,
+weight gradients) are done in numpy here.  Reference: the oracle's explicit recurrence (oracle/lstur_torch.py) in float64."""
+import ctypes
+import numpy as np
+import torch
+
+from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
+from tests.kernel_checks import ck
+from oracle.lstur_torch import OracleLSTURUserEncoder
+
+
+def dims(be, Hd):
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    ck(be, be.lib.nr_gru_dims(Hd, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
+def gate_pad(a, Hd, Hg):
+    """[..., 3*Hd] -> [..., 3*Hg] (gate q of unit j at q*Hg + j)."""
+    out = np.zeros(a.shape[:-1] + (3 * Hg,), dtype=a.dtype)
+    for q in range(3):
+        out[..., q * Hg:q * Hg + Hd] = a[..., q * Hd:(q + 1) * Hd]
+    return out
+
+
+def gate_unpad(a, Hd, Hg):
+    return np.concatenate([a[..., q * Hg:q * Hg + Hd] for q in range(3)], axis=-1)
+
+
+def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
+    rng = np.random.default_rng(seed)
+    Hg, Hp, Kp = dims(be, Hd)
+    assert Hg % 16 == 0 and Hp % 32 == 0 and Hp > Hd and Kp >= 3 * Hg
+    k = 1.0 / np.sqrt(Hd)
+    W_ih = rng.uniform(-k, k, size=(3 * Hd, I)).astype(np.float32)
+    W_hh = rng.uniform(-k, k, size=(3 * Hd, Hd)).astype(np.float32)
+    b_ih = rng.uniform(-k, k, size=3 * Hd).astype(np.float32)
+    b_hh = rng.uniform(-k, k, size=3 * Hd).astype(np.float32)
+    x = rng.normal(0, 0.5, size=(B, N, I)).astype(np.float32)
+    h0 = rng.normal(0, 0.5, size=(B, Hd)).astype(np.float32)
+    lens = np.asarray(lens if lens is not None else rng.integers(1, N + 1, size=B), dtype=np.int32)
+    lens[0] = N
+    T = int(lens.max())
+    # ---- operand packing through the library ----------------------------------------------------------------------
+    Whh_p = be.poison((3 * Hg, Hp), np.uint16)
+    WhhT_p = be.poison((Hp, Kp), np.uint16)
+    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_p), be.ptr(WhhT_p), be.stream))
+    be.sync()
+    Wq = bf16_round(W_hh)
+    got = bf16_to_f32(be.np(Whh_p)).reshape(3, Hg, Hp)
+    assert np.array_equal(got[:, :Hd, :Hd], Wq.reshape(3, Hd, Hd)) and not got[:, Hd:].any() and not got[:, :, Hd:].any()
+    gotT = bf16_to_f32(be.np(WhhT_p))
+    assert np.array_equal(gate_unpad(gotT[:Hd, :3 * Hg], Hd, Hg), Wq.T) and not gotT[Hd:].any() and not gotT[:, 3 * Hg:].any()
+    # ---- forward sweep ------------------------------------------------------------------------------------------------
+    gi = (bf16_round(x).astype(np.float64).reshape(B * N, I) @ bf16_round(W_ih).astype(np.float64).T).astype(np.float32)
+    h_gi = be.dev(gate_pad(gi, Hd, Hg))
+    hb_ih, hb_hh, hlen = be.dev(b_ih), be.dev(b_hh), be.dev(lens)
+    H_all = [be.empty((B, Hp), np.uint16) for _ in range(T + 1)]
+    h0p = np.zeros((B, Hp), dtype=np.float32); h0p[:, :Hd] = h0
+    hf = [be.dev(h0p), be.empty((B, Hp), np.float32)]
+    ck(be, be.lib.nr_rows_to_bf16(be.ptr(hf[0]), Hp, Hd, be.ptr(H_all[0]), Hp, B, be.stream))
+    gates = [be.poison((B, 4, Hg), np.uint16) for _ in range(T)]
+    for t in range(T):
+        ck(be, be.lib.nr_gru_fwd_step(be.ptr(h_gi), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(H_all[t]),
+                                      be.ptr(H_all[t + 1]), be.ptr(hf[t % 2]), be.ptr(hf[(t + 1) % 2]), be.ptr(gates[t]), B, N, Hd, t, be.stream))
+    be.sync()
+    h_last = be.np(hf[T % 2])[:, :Hd]
+    # reference: the oracle recurrence in float64 on the same operands
+    enc = OracleLSTURUserEncoder(Hd // 3 if Hd % 3 == 0 and I == Hd else 1, 'ini')
+    enc.gru.dh = Hd
+    to = lambda a: torch.nn.Parameter(torch.from_numpy(np.asarray(a, dtype=np.float64)))
+    enc.gru.weight_ih_l0, enc.gru.weight_hh_l0, enc.gru.bias_ih_l0, enc.gru.bias_hh_l0 = to(W_ih), to(W_hh), to(b_ih), to(b_hh)
+    xt = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    h0t = torch.from_numpy(h0.astype(np.float64)).requires_grad_(True)
+    ref = enc(h0t, torch.from_numpy(lens.astype(np.int64)), xt)
+    err = np.abs(h_last - ref.detach().numpy()).max()
+    assert err < 2e-2, f'gru fwd: max err {err:.3g}'          # bf16 operands, up to N recurrent steps
+    hb = be.np(H_all[T])
+    assert np.array_equal(hb[:, :Hd], f32_to_bf16(h_last)) and (hb[:, Hd] == 0x3F80).all() and not hb[:, Hd + 1:].any()
+    # ---- backward sweep -----------------------------------------------------------------------------------------------
+    g = rng.normal(size=(B, Hd)).astype(np.float32)
+    ref.backward(torch.from_numpy(g.astype(np.float64)))
+    hg = be.dev(g)
+    dgi0 = np.full((B * N, Kp), 0x3F80, dtype=np.uint16)              # rows t < T must be fully overwritten up to column 3*Hg;
+    dgi0[:, 3 * Hg:] = 0                                              # the K padding beyond is zero-filled once by the host
+    dgi = be.dev(dgi0)
+    dgh = [be.empty((B, Kp), np.uint16) for _ in range(T)]
+    carry = [be.poison((B, Hp), np.float32), be.poison((B, Hp), np.float32)]
+    for i, t in enumerate(range(T - 1, -2, -1)):
+        first = 1 if i == 0 else 0
+        ck(be, be.lib.nr_gru_bwd_step(be.ptr(hg) if first else None, None if first else be.ptr(dgh[t + 1]), None if first else be.ptr(carry[(i + 1) % 2]),
+                                      be.ptr(WhhT_p), be.ptr(gates[t]) if t >= 0 else None, be.ptr(H_all[t]) if t >= 0 else None, be.ptr(hlen),
+                                      be.ptr(dgi) if t >= 0 else None, be.ptr(dgh[t]) if t >= 0 else None, be.ptr(carry[i % 2]), B, N, Hd, t, first,
+                                      be.stream))
+    be.sync()
+    n_calls = T + 1
+    dh0 = be.np(carry[(n_calls - 1) % 2])[:, :Hd]
+    rel = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - b).max() / (np.abs(b).max() + 1e-30)
+    assert rel(dh0, h0t.grad.numpy()) < 3e-2, rel(dh0, h0t.grad.numpy())
+    dgi_np = bf16_to_f32(be.np(dgi)).reshape(B, N, Kp).astype(np.float64)
+    assert not dgi_np[:, :T, 3 * Hg:].any()
+    for b in range(B):
+        assert not dgi_np[b, lens[b]:T].any(), 'finished samples must contribute zero gate gradients'
+        assert (be.np(dgi).reshape(B, N, Kp)[b, T:, :3 * Hg] == 0x3F80).all()          # rows t >= T are left to the host
+    dGi = gate_unpad(dgi_np[:, :, :3 * Hg], Hd, Hg)
+    dGi[:, T:] = 0
+    dx = dGi.reshape(B * N, 3 * Hd) @ W_ih.astype(np.float64)
+    assert rel(dx.reshape(B, N, I), xt.grad.numpy()) < 3e-2
+    assert rel(dGi.reshape(B * N, -1).T @ x.reshape(B * N, I).astype(np.float64), enc.gru.weight_ih_l0.grad.numpy()) < 3e-2
+    assert rel(dGi.sum((0, 1)), enc.gru.bias_ih_l0.grad.numpy()) < 3e-2
+    dGh = np.stack([gate_unpad(bf16_to_f32(be.np(d)).astype(np.float64)[:, :3 * Hg], Hd, Hg) for d in dgh])       # [T,B,3Hd]
+    Hprev = np.stack([bf16_to_f32(be.np(H_all[t]))[:, :Hd].astype(np.float64) for t in range(T)])
+    assert rel(np.einsum('tbk,tbj->kj', dGh, Hprev), enc.gru.weight_hh_l0.grad.numpy()) < 3e-2
+    assert rel(dGh.sum((0, 1)), enc.gru.bias_hh_l0.grad.numpy()) < 3e-2
+    return err

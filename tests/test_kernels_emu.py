@@ -59,3 +59,12 @@ def test_additive_ex_s20(be): kcc.check_additive_ex(be, S=20, n_seq=5)
 def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be)
 def test_element_tables(be): kcc.check_element_tables(be, ncat=37, dcat=20, T=50)
 def test_row_scatters(be): kcc.check_row_scatters(be)
+
+
+# ---- LSTUR GRU step kernels -----------------------------------------------------------------------------------------
+from tests import kernel_checks_gru as kcg  # noqa: E402
+
+
+def test_gru_ini(be): kcg.check_gru(be, B=5, N=4, Hd=900, I=900, lens=[4, 1, 3, 2, 4])
+def test_gru_con_hidden_450(be): kcg.check_gru(be, B=3, N=3, Hd=450, I=900, seed=1)
+def test_gru_two_batch_tiles(be): kcg.check_gru(be, B=19, N=2, Hd=48, I=40, seed=2)

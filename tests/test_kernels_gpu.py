@@ -60,3 +60,11 @@ def test_additive_ex_s50(be): kcc.check_additive_ex(be, S=50, n_seq=131)
 def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be, n_seq=2047)
 def test_element_tables(be): kcc.check_element_tables(be)
 def test_row_scatters(be): kcc.check_row_scatters(be, n=54321, rows=275)
+
+
+# ---- LSTUR GRU step kernels -----------------------------------------------------------------------------------------
+from tests import kernel_checks_gru as kcg  # noqa: E402
+
+
+def test_gru_ini(be): kcg.check_gru(be, B=133, N=50, Hd=900, I=900)
+def test_gru_con_hidden_450(be): kcg.check_gru(be, B=70, N=20, Hd=450, I=900, seed=1)
