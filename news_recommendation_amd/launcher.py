@@ -40,15 +40,16 @@ def install_shims():
         sys.modules['torch.utils.tensorboard'] = mod
 
 
-def _patch_dp():
-    """Data parallelism without touching train.py: wrap the engine's NRMS constructor so every new model is
+def _patch_dp(model_name):
+    """Data parallelism without touching train.py: wrap the engine model's .to() so every new model is
     broadcast from rank 0 and gets the gradient all-reduce hooks."""
+    import importlib
     from news_recommendation_amd import dist as nrdist
     rank, world, local = nrdist.init_from_env()
     if world <= 1:
         return
-    import model.NRMS as M
-    orig_to = M.NRMS.to
+    cls = getattr(importlib.import_module(f'model.{model_name}'), model_name)
+    orig_to = cls.to
 
     def to(self, *a, **k):
         out = orig_to(self, *a, **k)
@@ -57,7 +58,7 @@ def _patch_dp():
             nrdist.attach_grad_allreduce(out)
             out._nr_dp = True
         return out
-    M.NRMS.to = to
+    cls.to = to
 
 
 def run(script, reference_src, workdir, model_name='NRMS'):
@@ -74,7 +75,7 @@ def run(script, reference_src, workdir, model_name='NRMS'):
         sys.path.insert(0, p)
     install_shims()
     os.chdir(workdir)
-    _patch_dp()
+    _patch_dp(model_name)
     runpy.run_path(os.path.join(reference_src, script + '.py'), run_name='__main__')
 
 
@@ -83,7 +84,7 @@ def main(argv=None):
     ap.add_argument('script', choices=['train', 'evaluate'])
     ap.add_argument('--reference', default=os.environ.get('NR_REFERENCE_SRC', '/root/reference/src'))
     ap.add_argument('--workdir', default='.')
-    ap.add_argument('--model', default='NRMS')
+    ap.add_argument('--model', default=os.environ.get('MODEL_NAME', 'NRMS'), choices=['NRMS', 'NAML', 'LSTUR'])
     a = ap.parse_args(argv)
     run(a.script, a.reference, a.workdir, a.model)
 

@@ -91,11 +91,12 @@ def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_imp
     import pandas as pd
     rng = np.random.default_rng(seed)
     titles = news_titles(rng, n_news, title_len, num_words)
+    abstracts = news_titles(rng, n_news, 50, num_words)
     nid = [f'N{i + 1}' for i in range(n_news)]
     news = pd.DataFrame({
         'id': nid, 'category': rng.integers(1, 10, n_news), 'subcategory': rng.integers(1, 30, n_news),
         'title': [str(list(map(int, t))) for t in titles],
-        'abstract': [str([0] * 50)] * n_news,
+        'abstract': [str(list(map(int, t))) for t in abstracts],
         'title_entities': [str([0] * title_len)] * n_news, 'abstract_entities': [str([0] * 50)] * n_news})
     users = [f'U{i + 1}' for i in range(n_users)]
     for split in ('train', 'val', 'test'):

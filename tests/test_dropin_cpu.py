@@ -43,6 +43,41 @@ def test_dropin_state_dict_matches_reference_keys():
     assert m2.news_encoder.word_embedding.padding_idx == 0
 
 
+def test_naml_lstur_dropin_state_dicts_match_reference_keys():
+    """Key names and shapes of the drop-in NAML / LSTUR equal the seeded parameter sets that oracle/make_golden_naml_lstur.py loaded
+    into the REFERENCE's own modules with load_state_dict (strict), i.e. the reference's state_dict layout."""
+    from news_recommendation_amd.dropin.model.NAML import NAML
+    from news_recommendation_amd.dropin.model.LSTUR import LSTUR
+    from oracle.naml_torch import random_naml_params
+    from oracle.lstur_torch import random_lstur_params
+
+    class NamlCfg:
+        dataset_attributes = {"news": ['category', 'subcategory', 'title', 'abstract'], "record": []}
+        num_words, word_embedding_dim, num_categories, category_embedding_dim = 321, 300, 275, 100
+        num_filters, window_size, query_vector_dim, dropout_probability = 300, 3, 200, 0.2
+    m = NAML(NamlCfg)
+    want = random_naml_params(0, 321, 300, 275, 100, 300, 3, 200)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
+    assert [n for n, _ in m.named_children()] == ['news_encoder', 'user_encoder', 'click_predictor']
+    te = m.news_encoder.text_encoders
+    assert te['title'].word_embedding is te['abstract'].word_embedding                       # one shared table, two keys
+
+    for method, width in (('ini', 900), ('con', 450)):
+        class LsturCfg:
+            dataset_attributes = {"news": ['category', 'subcategory', 'title'], "record": ['user', 'clicked_news_length']}
+            num_words, word_embedding_dim, num_categories, num_users = 321, 300, 275, 77
+            num_filters, window_size, query_vector_dim, dropout_probability, masking_probability = 300, 3, 200, 0.2, 0.5
+            long_short_term_method = method
+        m = LSTUR(LsturCfg)
+        want = random_lstur_params(0, 321, 300, 275, 77, 300, 3, 200, method)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
+        assert tuple(m.user_embedding.weight.shape) == (77, width)
+    with pytest.raises(NotImplementedError):
+        class Bad(NamlCfg):
+            num_filters = 128
+        NAML(Bad)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback():
     from news_recommendation_amd.dropin.model.NRMS import NRMS
@@ -69,15 +104,17 @@ def test_product_does_not_import_oracle_or_emulator():
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
 @pytest.mark.skipif(torch.cuda.is_available(), reason="container-only check")
-def test_launcher_runs_unchanged_reference_train_against_engine(tmp_path):
-    """train.py (unchanged, read-only) is executed by the launcher; it builds the ENGINE's NRMS, loads the data with
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_launcher_runs_unchanged_reference_train_against_engine(tmp_path, model_name):
+    """train.py (unchanged, read-only) is executed by the launcher; it builds the ENGINE's model, loads the data with
     the reference's own dataset.py and reaches the first forward, where the engine refuses to run without a GPU."""
     from news_recommendation_amd import synth
     synth.write_reference_dataset(str(tmp_path))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH=ROOT)
-    p = subprocess.run([sys.executable, '-m', 'news_recommendation_amd.launcher', 'train', '--reference', REF, '--workdir', str(tmp_path)],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    env.pop('MODEL_NAME', None)
+    p = subprocess.run([sys.executable, '-m', 'news_recommendation_amd.launcher', 'train', '--reference', REF, '--workdir', str(tmp_path),
+                        '--model', model_name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out = p.stdout + p.stderr
     assert 'Load training dataset with size 256' in out, out[-2000:]             # reference train.py:116
-    assert 'news_recommendation_amd/dropin/model/NRMS' in out, out[-2000:]       # traceback goes through OUR model
+    assert f'news_recommendation_amd/dropin/model/{model_name}' in out, out[-2000:]       # traceback goes through OUR model
     assert 'no CPU fallback' in out, out[-2000:]
