@@ -1,21 +1,22 @@
 #!/usr/bin/env python
-"""Benchmark of the NRMS hot path on MI355X: training impressions/sec (BASELINE.json metric).
+"""Benchmark of the news-recommendation hot path on MI355X: training impressions/sec (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--model NRMS|NAML|LSTUR]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of MIND-small-shaped synthetic impressions resident in HBM:
-forward (embedding gather -> news encoder for 53 titles/impression -> user encoder -> dot-product scorer),
+forward (embedding gather -> news encoder for 53 news/impression -> user encoder -> dot-product scorer),
 cross-entropy, backward, gradient all-reduce over RCCL (N > 1) and the Adam update -- everything
-src/train.py:202-233 does per batch.  Workload = BASELINE.json configs[1]: NRMS, bf16 operands / fp32 accumulate,
-batch 512 per GPU, title_len 20, 50 clicked news, d 300, vocabulary 70,976.  Weak scaling: per-GPU batch is fixed.
+src/train.py:182-233 does per batch.  Default workload = BASELINE.json configs[1]: NRMS, bf16 operands / fp32 accumulate,
+batch 512 per GPU, title_len 20, 50 clicked news, d 300, vocabulary 70,976.  --model NAML is configs[2] (title + abstract +
+category + subcategory views), --model LSTUR the single-GPU shard of configs[4].  Weak scaling: per-GPU batch is fixed.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      dominant hand-written kernel: algorithmic FLOPs per launch / HIP-event duration vs the dense
-                bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)
+                bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s); traffic = HBM bytes per launch from the committed PMC passes
   gather_roofline  the embedding gather (north_star): algorithmic bytes / duration vs 8 TB/s HBM peak
-  cpu_baseline  the oracle's torch-CPU port of the reference (oracle/nrms_torch.py) timed on this host
+  cpu_baseline  the oracle's torch-CPU port of the reference timed on this host (bounded sample)
   parity        AUC / nDCG@10 of engine vs oracle on synthetic eval impressions (N = 1 only)
 """
 import argparse
@@ -33,63 +34,145 @@ import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
-
-# algorithmic work per unit (SURVEY.md 8 d6 / DESIGN.md)
-FLOP_PER_TITLE_MHSA = 2 * 20 * 300 * 900 + 2 * 2 * 15 * 20 * 20 * 20      # QKV 10.8 M + QK^T 0.24 M + PV 0.24 M
-BYTES_PER_TOKEN_F32 = 1200                                                 # one fp32 embedding row
+BYTES_PER_TOKEN_F32 = 1200   # one fp32 embedding row
+N_NEWS = 65238               # MIND-small news count
 
 
 class Cfg:
-    """The reference's NRMSConfig knobs (src/config.py:10-45) at MIND-small shape."""
+    """The reference's BaseConfig / NRMSConfig / NAMLConfig / LSTURConfig knobs (src/config.py:10-69) at MIND-small shape."""
     num_words = 1 + 70975
+    num_categories = 1 + 274
+    num_users = 1 + 50000
     word_embedding_dim = 300
+    category_embedding_dim = 100
     num_attention_heads = 15
     query_vector_dim = 200
     dropout_probability = 0.2
     num_clicked_news_a_user = 50
     num_words_title = 20
+    num_words_abstract = 50
     negative_sampling_ratio = 2
     learning_rate = 0.0001
+    num_filters = 300
+    window_size = 3
+    long_short_term_method = 'ini'
+    masking_probability = 0.5
 
 
-def make_model(seed=0):
-    from news_recommendation_amd.dropin.model.NRMS import NRMS
-    torch.manual_seed(seed)
-    return NRMS(Cfg)
+class NamlCfg(Cfg):
+    dataset_attributes = {"news": ['category', 'subcategory', 'title', 'abstract'], "record": []}
 
 
-def synth_batches(rank, n_batches, B, device):
+class LsturCfg(Cfg):
+    dataset_attributes = {"news": ['category', 'subcategory', 'title'], "record": ['user', 'clicked_news_length']}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic news table + batches (ids resident in HBM)
+# ----------------------------------------------------------------------------------------------------------------------
+def news_table(seed, n_news):
     from news_recommendation_amd import synth
-    rng = np.random.default_rng(1000 + rank)
-    news = synth.news_titles(np.random.default_rng(0), 65238, Cfg.num_words_title, Cfg.num_words)
-    out = []
-    for _ in range(n_batches):
-        cand, hist = synth.train_batch(rng, news, B, Cfg.num_clicked_news_a_user, Cfg.negative_sampling_ratio)
-        c, h = synth.batch_token_ids(news, cand, hist)
-        out.append((torch.from_numpy(c).to(device), torch.from_numpy(h).to(device)))
-    return out
+    rng = np.random.default_rng(seed)
+    return {'title': synth.news_titles(rng, n_news, Cfg.num_words_title, Cfg.num_words),
+            'abstract': synth.news_abstracts(rng, n_news, Cfg.num_words_abstract, Cfg.num_words),
+            'category': rng.integers(1, Cfg.num_categories, size=n_news).astype(np.int64),
+            'subcategory': rng.integers(1, Cfg.num_categories, size=n_news).astype(np.int64)}
 
 
-def cpu_baseline(seconds_budget=20.0, B=128):
-    """The oracle's CPU PyTorch port of the reference NRMS (per-position encoder loop and all), one full train
-    step (forward + backward + Adam) per iteration on a bounded sample."""
-    from oracle.nrms_torch import OracleNRMS
-    from news_recommendation_amd import synth
+def take(news, attr, idx):
+    """news-index batch -> attribute tensor; padded history slots (-1) are all-zero news (dataset.py:44-60,79-83)."""
+    a = news[attr]
+    pad = np.zeros((1,) + a.shape[1:], dtype=np.int64)
+    return np.concatenate([a, pad])[np.where(idx < 0, a.shape[0], idx)]
+
+
+class Workload:
+    def __init__(self, name):
+        self.name = name
+        self.attrs = {'NRMS': ('title',), 'NAML': ('title', 'abstract', 'category', 'subcategory'),
+                      'LSTUR': ('title', 'category', 'subcategory')}[name]
+
+    def make_model(self, seed=0):
+        torch.manual_seed(seed)
+        if self.name == 'NRMS':
+            from news_recommendation_amd.dropin.model.NRMS import NRMS
+            return NRMS(Cfg)
+        if self.name == 'NAML':
+            from news_recommendation_amd.dropin.model.NAML import NAML
+            return NAML(NamlCfg)
+        from news_recommendation_amd.dropin.model.LSTUR import LSTUR
+        return LSTUR(LsturCfg)
+
+    def make_oracle(self):
+        if self.name == 'NRMS':
+            from oracle.nrms_torch import OracleNRMS
+            return OracleNRMS(Cfg.num_words, 300, 15, 200, Cfg.dropout_probability)
+        if self.name == 'NAML':
+            from oracle.naml_torch import OracleNAML
+            return OracleNAML(Cfg.num_words, 300, Cfg.num_categories, 100, 300, 3, 200, Cfg.dropout_probability)
+        from oracle.lstur_torch import OracleLSTUR
+        return OracleLSTUR(Cfg.num_words, 300, Cfg.num_categories, Cfg.num_users, 300, 3, 200, Cfg.dropout_probability, 0.5, 'ini')
+
+    def batches(self, rank, n_batches, B, device):
+        from news_recommendation_amd import synth
+        news = news_table(0, N_NEWS)
+        rng = np.random.default_rng(1000 + rank)
+        out = []
+        for _ in range(n_batches):
+            cand, hist = synth.train_batch(rng, news['title'], B, Cfg.num_clicked_news_a_user, Cfg.negative_sampling_ratio)
+            b = {'cand': {k: torch.from_numpy(take(news, k, cand)).to(device) for k in self.attrs},
+                 'click': {k: torch.from_numpy(take(news, k, hist)).to(device) for k in self.attrs}}
+            if self.name == 'LSTUR':
+                b['user'] = torch.from_numpy(rng.integers(1, Cfg.num_users, size=B).astype(np.int64)).to(device)
+                b['length'] = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))          # CPU, as the reference requires
+            out.append(b)
+        return out
+
+    def forward(self, model, b):
+        if self.name == 'NRMS':
+            return model.forward_ids(b['cand']['title'], b['click']['title'])
+        if self.name == 'NAML':
+            return model.forward_ids(b['cand'], b['click'])
+        return model.forward_ids(b['user'], b['length'].clone(), b['cand'], b['click'])
+
+    def oracle_forward(self, ref, b):
+        C, N = b['cand']['title'].shape[1], b['click']['title'].shape[1]
+        cl = [{k: b['cand'][k][:, j] for k in self.attrs} for j in range(C)]
+        hl = [{k: b['click'][k][:, j] for k in self.attrs} for j in range(N)]
+        if self.name == 'LSTUR':
+            return ref(b['user'], b['length'].clone(), cl, hl)
+        return ref(cl, hl)
+
+    def flops(self, B):
+        """Algorithmic FLOPs per launch of the kernels we know how to price (SURVEY 8 d6 / DESIGN.md)."""
+        T = B * 53
+        conv = lambda S: T * 2 * S * 900 * 300
+        return {
+            'nr_mhsa_fwd[S=20]': T * (2 * 20 * 300 * 900 + 2 * 2 * 15 * 20 * 20 * 20),
+            'nr_mhsa_fwd[S=50]': B * (2 * 50 * 300 * 900 + 2 * 2 * 15 * 50 * 50 * 20),
+            'nr_attn_bwd[S=20]': T * 15 * 6 * 2 * 20 * 20 * 20,
+            'nr_attn_bwd[S=50]': B * 15 * 6 * 2 * 50 * 50 * 20,
+            'nr_additive_fwd[S=20]': T * 2 * 20 * 300 * 200, 'nr_additive_bwd[S=20]': T * 2 * 20 * 300 * 200,
+            'nr_additive_fwd[title]': T * 2 * 20 * 300 * 200, 'nr_additive_bwd[title]': T * 2 * 20 * 300 * 200,
+            'nr_additive_fwd[abstract]': T * 2 * 50 * 300 * 200, 'nr_additive_bwd[abstract]': T * 2 * 50 * 300 * 200,
+            'nr_conv3_fwd[title]': conv(20), 'nr_conv3_dgrad[title]': conv(20),
+            'nr_conv3_fwd[abstract]': conv(50), 'nr_conv3_dgrad[abstract]': conv(50),
+            'nr_gru_fwd_step': 2 * B * 900 * 2700, 'nr_gru_bwd_step': 2 * B * 2700 * 900,
+        }
+
+
+def cpu_baseline(wl, seconds_budget=20.0, B=128):
+    """The oracle's CPU PyTorch port of the reference (per-position encoder loop and all), full train steps
+    (forward + backward + Adam) on a bounded sample."""
     torch.manual_seed(0)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # 128 threads on tiny per-title ops is slower than 32
-    m = OracleNRMS(Cfg.num_words, 300, 15, 200, Cfg.dropout_probability).train()
+    m = wl.make_oracle().train()
     opt = torch.optim.Adam(m.parameters(), lr=Cfg.learning_rate)
-    rng = np.random.default_rng(7)
-    news = synth.news_titles(np.random.default_rng(0), 65238, 20, Cfg.num_words)
-    cand, hist = synth.train_batch(rng, news, B)
-    c, h = synth.batch_token_ids(news, cand, hist)
-    cl = [{'title': torch.from_numpy(c[:, j])} for j in range(c.shape[1])]
-    hl = [{'title': torch.from_numpy(h[:, j])} for j in range(h.shape[1])]
+    b = wl.batches(7, 1, B, 'cpu')[0]
     crit = torch.nn.CrossEntropyLoss()
 
     def step():
-        y = m(cl, hl)
-        loss = crit(y, torch.zeros(B, dtype=torch.long))
+        loss = crit(wl.oracle_forward(m, b), torch.zeros(B, dtype=torch.long))
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -104,34 +187,42 @@ def cpu_baseline(seconds_budget=20.0, B=128):
             break
     dt = time.perf_counter() - t0
     return {"value": n * B / dt, "unit": "impressions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps (fwd+bwd+Adam) of B={B} train-shaped impressions, oracle/nrms_torch.py on CPU fp32"}
+            "sample": f"{n} train steps (fwd+bwd+Adam) of B={B} train-shaped impressions, oracle {wl.name} torch port on CPU fp32"}
 
 
-def parity_eval(model, device, n_news=4000, n_impr=1000):
-    """AUC / nDCG@10 of the engine vs the CPU oracle on the same synthetic eval-shaped impressions and weights."""
+def parity_eval(wl, model, device, n_news=4000, n_impr=1000):
+    """AUC / nDCG@10 of the engine vs the CPU oracle on the same synthetic eval-shaped impressions and weights
+    (phases A-C of src/evaluate.py:185-260: news vectors, user vectors with a zero PADDED_NEWS vector, per-impression dot products)."""
     from news_recommendation_amd import synth, ops
-    from oracle.nrms_torch import OracleNRMS
     from oracle import metrics
     rng = np.random.default_rng(3)
-    news = synth.news_titles(np.random.default_rng(2), n_news, 20, Cfg.num_words)
+    news = {k: v for k, v in news_table(2, n_news).items() if k in wl.attrs}
     hist, cands, ptr = synth.eval_impressions(rng, n_news, n_impr)
-    ref = OracleNRMS(Cfg.num_words, 300, 15, 200, 0.2)
+    users = torch.from_numpy(rng.integers(1, Cfg.num_users, size=n_impr).astype(np.int64))
+    lengths = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))
+    ref = wl.make_oracle()
     ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
     ref.eval()
+    tn = {k: torch.from_numpy(v) for k, v in news.items()}
+    sl = lambda i, n: {k: v[i:i + n] for k, v in tn.items()}
+    was_training = model.training
+    model.eval()
     with torch.no_grad():
-        t = torch.from_numpy(news)
-        nv_ref = torch.cat([ref.get_news_vector({'title': t[i:i + 1024]}) for i in range(0, n_news, 1024)])
-        nv_pad = torch.cat([nv_ref, torch.zeros(1, 300)])                      # PADDED_NEWS = zero vector (evaluate.py:203)
+        nv_ref = torch.cat([ref.get_news_vector(sl(i, 1024)) for i in range(0, n_news, 1024)])
+        D = nv_ref.shape[1]
+        nv_pad = torch.cat([nv_ref, torch.zeros(1, D)])                        # PADDED_NEWS = zero vector (evaluate.py:203)
         hidx = torch.from_numpy(np.where(hist < 0, n_news, hist))
-        uv_ref = torch.cat([ref.get_user_vector(nv_pad[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
-        was_training = model.training
-        model.eval()
-        nv = torch.cat([model.get_news_vector({'title': t[i:i + 2048]}) for i in range(0, n_news, 2048)])
-        nvp = torch.cat([nv, torch.zeros(1, 300, device=device)])
-        uv = model.get_user_vector(nvp[hidx.to(device)])
+        nv = torch.cat([model.get_news_vector(sl(i, 2048)) for i in range(0, n_news, 2048)])
+        nvp = torch.cat([nv, torch.zeros(1, D, device=device)])
+        if wl.name == 'LSTUR':
+            uv_ref = torch.cat([ref.get_user_vector(users[i:i + 256], lengths[i:i + 256].clone(), nv_pad[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
+            uv = model.get_user_vector(users, lengths.clone(), nvp[hidx.to(device)])
+        else:
+            uv_ref = torch.cat([ref.get_user_vector(nv_pad[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
+            uv = model.get_user_vector(nvp[hidx.to(device)])
         sc = ops.score_csr(nv, uv, torch.from_numpy(cands).to(device), torch.from_numpy(ptr).to(device),
                            torch.arange(n_impr, dtype=torch.int32, device=device)).cpu().numpy()
-        model.train(was_training)
+    model.train(was_training)
     sc_ref = np.concatenate([(nv_ref[cands[ptr[i]:ptr[i + 1]]] @ uv_ref[i]).numpy() for i in range(n_impr)])
     labels = synth.teacher_labels(np.random.default_rng(4), sc_ref.astype(np.float64), ptr)
     split = lambda a: [a[ptr[i]:ptr[i + 1]] for i in range(n_impr)]
@@ -139,7 +230,7 @@ def parity_eval(model, device, n_news=4000, n_impr=1000):
     auc_e, _, _, nd_e = metrics.evaluate_impressions(split(labels), split(sc))
     return {"n_impressions": n_impr, "auc_oracle": auc_r, "auc_engine": auc_e, "ndcg10_oracle": nd_r, "ndcg10_engine": nd_e,
             "abs_diff_auc": abs(auc_r - auc_e), "abs_diff_ndcg10": abs(nd_r - nd_e), "tolerance": 1e-3,
-            "max_abs_logit_err": float(np.abs(sc - sc_ref).max())}
+            "max_abs_logit_err": float(np.abs(sc - sc_ref).max()), "logit_scale": float(np.abs(sc_ref).max())}
 
 
 def main():
@@ -148,6 +239,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (impressions)')
+    ap.add_argument('--model', default='NRMS', choices=['NRMS', 'NAML', 'LSTUR'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     args = ap.parse_args()
@@ -160,8 +252,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     B = args.batch
+    wl = Workload(args.model)
 
-    model = make_model().to(device).train()
+    model = wl.make_model().to(device).train()
     nrdist.broadcast_parameters(model)
     fgb = nrdist.FlatGradBuffer(model.parameters())
     try:
@@ -169,12 +262,11 @@ def main():
     except (TypeError, RuntimeError):
         opt = torch.optim.Adam(model.parameters(), lr=Cfg.learning_rate)
     crit = torch.nn.CrossEntropyLoss()
-    batches = synth_batches(rank, 4, B, device)
+    batches = wl.batches(rank, 4, B, device)
     target = torch.zeros(B, dtype=torch.long, device=device)
 
     def step(i):
-        cand, click = batches[i % len(batches)]
-        y = model.forward_ids(cand, click)
+        y = wl.forward(model, batches[i % len(batches)])
         loss = crit(y, target)
         fgb.zero()
         loss.backward()
@@ -218,16 +310,7 @@ def main():
         return
 
     T = B * (1 + Cfg.negative_sampling_ratio + Cfg.num_clicked_news_a_user)
-    # algorithmic work per launch of the kernels we know how to price
-    flops = {
-        'nr_mhsa_fwd[S=20]': T * FLOP_PER_TITLE_MHSA,
-        'nr_mhsa_fwd[S=50]': B * (2 * 50 * 300 * 900 + 2 * 2 * 15 * 50 * 50 * 20),
-        'nr_attn_bwd[S=20]': T * 15 * 6 * 2 * 20 * 20 * 20,       # 6 products of 20x20x20 per (title, head)
-        'nr_attn_bwd[S=50]': B * 15 * 6 * 2 * 50 * 50 * 20,
-        'nr_additive_fwd[S=20]': T * 2 * 20 * 300 * 200,
-        'nr_additive_bwd[S=20]': T * 2 * 20 * 300 * 200,
-    }
-    roofline = None
+    flops = wl.flops(B)
     if dominant in flops:
         ach = flops[dominant] / (dom[1] * 1e-6) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -238,13 +321,12 @@ def main():
         ach = nbytes / (dom[1] * 1e-6) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": dom[1], "launches": dom[0], "bytes_per_launch": nbytes}
-
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes from
     # the committed rocprofv3 --pmc passes of the same workload (profiles/traffic.json, made by tools/gpu_check.sh)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             tr = json.load(f).get(dominant)
-        if tr is not None and B == 512:
+        if tr is not None and B == 512 and args.model == 'NRMS':
             roofline["traffic"] = tr["bytes"]
             roofline["traffic_source"] = tr["source"]
     except (OSError, ValueError):
@@ -252,10 +334,10 @@ def main():
 
     # the embedding gather on its own (north_star: fraction of HBM roofline for the gather)
     lib = _capi.load()
-    cand, click = batches[0]
-    ids = torch.cat([cand.reshape(-1, 20), click.reshape(-1, 20)]).contiguous()
+    b0 = batches[0]
+    ids = torch.cat([b0['cand']['title'].reshape(-1, 20), b0['click']['title'].reshape(-1, 20)]).contiguous()
     gout = torch.empty(ids.numel(), 300, device=device)
-    table = model.news_encoder.word_embedding.weight.detach()
+    table = next(p for n, p in model.named_parameters() if n.endswith('word_embedding.weight')).detach()
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), ids.numel(), 300, table.shape[0], st)
@@ -276,22 +358,25 @@ def main():
     model.eval()
     with torch.no_grad():
         for i in range(3):
-            model.forward_ids(*batches[i % len(batches)])
+            wl.forward(model, batches[i % len(batches)])
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for i in range(10):
-            model.forward_ids(*batches[i % len(batches)])
+            wl.forward(model, batches[i % len(batches)])
         torch.cuda.synchronize()
         fwd_ips = 10 * B / (time.perf_counter() - ts)
     model.train()
 
+    cfg_names = {'NRMS': "NRMS bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU (BASELINE.json configs[1])",
+                 'NAML': "NAML (title+abstract+category+subcategory views, Conv1d k=3) bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU (BASELINE.json configs[2])",
+                 'LSTUR': "LSTUR (GRU user encoder 'ini' + per-user embedding row) bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU; single-GPU shard of BASELINE.json configs[4]"}
     out = {
-        "metric": "impressions/sec (NRMS training step: fwd+bwd+allreduce+Adam)", "value": world * B * args.steps / dt,
+        "metric": f"impressions/sec ({args.model} training step: fwd+bwd+allreduce+Adam)", "value": world * B * args.steps / dt,
         "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "NRMS bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU (BASELINE.json configs[1])",
-                   "per_gpu_batch": B, "global_batch": B * world, "titles_per_impression": 53, "title_len": 20,
+        "config": {"workload": cfg_names[args.model].replace('batch 512', f'batch {B}'),
+                   "per_gpu_batch": B, "global_batch": B * world, "news_per_impression": 53, "title_len": 20, "abstract_len": 50,
                    "num_clicked": 50, "d": 300, "heads": 15, "vocab": Cfg.num_words, "dropout": Cfg.dropout_probability,
                    "parallelism": f"dp{world}"},
         "roofline": roofline,
@@ -302,9 +387,9 @@ def main():
         "kernel_breakdown_us_per_step": {k: round(v[2] / NPROF, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])},
     }
     if world == 1 and not args.no_parity:
-        out["parity"] = parity_eval(model, device)
+        out["parity"] = parity_eval(wl, model, device)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(wl)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

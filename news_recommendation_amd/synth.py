@@ -29,6 +29,14 @@ def news_titles(rng, n_news, title_len=20, num_words=70976, dist='zipf'):
     return ids.astype(np.int64)
 
 
+def news_abstracts(rng, n_news, abstract_len=50, num_words=70976):
+    """[n_news, abstract_len] int64: 8..abstract_len real tokens (mean ~35), right-padded with 0."""
+    ids = zipf_ids(rng, (n_news, abstract_len), num_words)
+    lens = np.clip(rng.normal(35, 10, size=n_news).round().astype(np.int64), 8, abstract_len)
+    ids[np.arange(abstract_len)[None, :] >= lens[:, None]] = 0
+    return ids.astype(np.int64)
+
+
 def history_lengths(rng, n, num_clicked=50):
     """clipped lognormal history lengths in [0, num_clicked], mean ~32."""
     return np.clip(rng.lognormal(3.6, 0.8, size=n).round().astype(np.int64), 0, num_clicked)
