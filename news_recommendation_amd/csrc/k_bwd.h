@@ -130,9 +130,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dc4[j] = bf2f(rg.dg[it][j]) + rg.wt[it] * rg.go[it][j];
         if (p.dc.enabled) {
-          uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dc4[j] = ((keep >> j) & 1u) ? dc4[j] * p.dc.scale : 0.0f;
+          dc4 = dc4 * drop_mul4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
         }
         *(u16x4*)(dCm + r * Gm::DS + c) = pack4(dc4);
       }
@@ -156,6 +154,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
   wave_barrier();
 
   const float inv_sqrt_dk = 1.0f / sqrtf((float)DK);
+  const float c2 = LOG2E * inv_sqrt_dk, clamp2 = EXP_CLAMP * LOG2E;       // exp(s / sqrt(dk)) = exp2(s * c2), as in the forward kernel
   const u16 ONE = 0x3F80;
   const u16x4 Z4 = u16x4{0, 0, 0, 0};
   // AL fragment over the head dim from a [token][DS] matrix: slots d = 8g + j (d >= DK are zero)
@@ -197,6 +196,9 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
     for (int t = 0; t < Gm::QT; ++t) {
       kf[t] = frag_d(Km, t * 16 + li);
       qf[t] = frag_d(Qm, t * 16 + li);
+      // free k-slot DK = key-padding mask (see the forward kernel): scores of key rows >= S come out at -29952 -> exp2 = 0.
+      // The extra "feature" only reaches output rows d = DK, which are never stored.
+      if (8 * g + 4 == DK) { qf[t][4] = ONE; kf[t][4] = (t * 16 + li < S) ? (u16)0 : BF16_NEG_BIG; }
       u16x8 cf = frag_d(dCm, t * 16 + li);
       cperm[t] = frag_dc_perm(t * 16 + li);
 #pragma unroll
@@ -242,8 +244,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
         pT[kt] = mfma_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = fast_exp(fminf(pT[kt][r] * inv_sqrt_dk, EXP_CLAMP));     // same formula as the forward kernel
-          e = (kt * 16 + 4 * g + r < S) ? e : 0.0f;
+          const float e = fast_exp2(fminf(pT[kt][r] * c2, clamp2));     // same formula as the forward kernel
           pT[kt][r] = e;
           sum += e;
         }
@@ -283,14 +284,13 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
         // A = dC AL in the permuted slot order, B = V operand of the key tile (same slot order)
         f32x4 dPN = mfma_16x16x32_bf16(cperm[qt], va[kt], f32x4{0.f, 0.f, 0.f, 0.f});
         f32x4 pv, dv4;
-        const bool keyok = kt * 16 + li < S;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = keyok && (qt * 16 + 4 * g + r < S);
-          float e = fast_exp(fminf(sN[r] * inv_sqrt_dk, EXP_CLAMP)) * rden_r[r];
+          const bool ok = qt * 16 + 4 * g + r < S;          // padded query rows; padded keys are already exact zeros
+          float e = fast_exp2(fminf(sN[r] * c2, clamp2)) * rden_r[r];
           e = ok ? e : 0.0f;
           pv[r] = e;
-          dv4[r] = ok ? e * (dPN[r] - dot_r[r]) * inv_sqrt_dk : 0.0f;
+          dv4[r] = e * (dPN[r] - dot_r[r]) * inv_sqrt_dk;
         }
         pN[qt][kt] = pack4(pv);
         dsN[qt][kt] = pack4(dv4);
@@ -469,9 +469,7 @@ __global__ __launch_bounds__(256) void gather_bf16_kernel(const int64_t* __restr
       }
       f32x4 x = *(const f32x4*)src;
       if (dc.enabled) {
-        uint32_t keep = drop_keep4(dc, 1u, (uint64_t)tok * D4 + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * dc.scale : 0.0f;
+        x = x * drop_mul4(dc, 1u, (uint64_t)tok * D4 + c);
       }
       o = pack4(x);
     } else if (c == D4) {

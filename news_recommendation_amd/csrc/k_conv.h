@@ -94,9 +94,7 @@ __global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
         if (i < TOTAL) {
           f32x4 x = v[u];
           if (p.dc.enabled) {
-            uint32_t keep = drop_keep4(p.dc, 1u, (uint64_t)(p.tok_offset + tok0 + rr[u]) * D4 + cc[u]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * p.dc.scale : 0.0f;
+            x = x * drop_mul4(p.dc, 1u, (uint64_t)(p.tok_offset + tok0 + rr[u]) * D4 + cc[u]);
           }
           const int row = rr[u] + rr[u] / S + 1;
           *(u16x4*)(Xs + row * XS + cc[u] * 4) = pack4(x);
@@ -189,9 +187,7 @@ __global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
                 if (p.dc.enabled) {
-                  uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)(p.tok_offset + tok) * D4 + (col >> 2));
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) y[r] = ((keep >> r) & 1u) ? y[r] * p.dc.scale : 0.0f;
+                  y = y * drop_mul4(p.dc, 2u, (uint64_t)(p.tok_offset + tok) * D4 + (col >> 2));
                 }
               }
               *(u16x4*)(p.out + tok * KP + col) = pack4(y);

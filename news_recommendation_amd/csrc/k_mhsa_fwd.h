@@ -145,9 +145,7 @@ __device__ __forceinline__ void stage_tokens(const MhsaParams& p, u16* Xs, int* 
       if (i < TOTAL) {
         f32x4 x = v[u];
         if (p.dc.enabled) {
-          uint32_t keep = drop_keep4(p.dc, 1u, (uint64_t)(tok0 + rr[u]) * D4 + cc[u]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * p.dc.scale : 0.0f;
+          x = x * drop_mul4(p.dc, 1u, (uint64_t)(tok0 + rr[u]) * D4 + cc[u]);
         }
         *(u16x4*)(Xs + rr[u] * XS + cc[u] * 4) = pack4(x);
       }
@@ -170,7 +168,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
 
   stage_tokens<S, NSEQ, NW>(p, Xs, (int*)Qs, seq0);
 
-  const float inv_sqrt_dk = 1.0f / sqrtf((float)DK);
+  // exp(s / sqrt(dk)) = exp2(s * c2); the clamp keeps the row sum finite in fp32
+  const float c2 = LOG2E / sqrtf((float)DK), clamp2 = EXP_CLAMP * LOG2E;
 
   for (int hg = 0; hg < NGROUPS; ++hg) {
     const int nh = (H - hg * HG) < HG ? (H - hg * HG) : HG;
@@ -236,6 +235,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
           u16x4 khi = (8 * g + 4 < DK) ? *(const u16x4*)(kp_ + 4) : z;
           u16x4 qlo = (8 * g < DK) ? *(const u16x4*)qp_ : z;
           u16x4 qhi = (8 * g + 4 < DK) ? *(const u16x4*)(qp_ + 4) : z;
+          // k-slot DK (free: DK = 20 < 32) carries the key-padding mask: q = 1, k = -big on key rows >= S, so padded keys
+          // come out of the MFMA at -29952 and exp2 turns them into exact zeros -- no per-element select
+          if (8 * g + 4 == DK) { qhi[0] = BF16_ONE; khi[0] = (t * 16 + li < S) ? (u16)0 : BF16_NEG_BIG; }
           kf[t] = cat8(klo, khi);
           qf[t] = cat8(qlo, qhi);
         }
@@ -250,8 +252,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
             sacc[kt] = mfma_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float e = fast_exp(fminf(sacc[kt][r] * inv_sqrt_dk, EXP_CLAMP));
-              e = (kt * 16 + 4 * g + r < S) ? e : 0.0f;
+              const float e = fast_exp2(fminf(sacc[kt][r] * c2, clamp2));
               sacc[kt][r] = e;
               sum += e;
             }
@@ -332,9 +333,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
               const int64_t tok = seqg * S + q;
               const int col = (hg * HG + hd) * DK + dv0;
               if (p.dc.enabled) {
-                uint32_t keep = drop_keep4(p.dc, 2u, (uint64_t)tok * D4 + (col >> 2));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = ((keep >> j) & 1u) ? acc[j] * p.dc.scale : 0.0f;
+                acc = acc * drop_mul4(p.dc, 2u, (uint64_t)tok * D4 + (col >> 2));
               }
               *(u16x4*)(p.ctx + tok * KP + col) = pack4(acc);
             }

@@ -18,39 +18,53 @@ constexpr int QP = NR_QP;          // 208
 constexpr int QS = HG * DK + 8;    // 88: LDS row stride (elements) of the per-group Q / K tiles (176 B)
 constexpr int WG = 256;            // threads per workgroup of the 4-wave kernels
 constexpr float EXP_CLAMP = 80.0f; // exp() argument clamp: keeps sum_j exp(s_j) finite in fp32 for S <= 64 (the reference overflows to inf/nan there)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr u16 BF16_NEG_BIG = 0xC6EA;   // -29952.0: pad-key marker (exp2 of it, scaled, underflows to exactly 0)
+constexpr u16 BF16_ONE = 0x3F80;
 constexpr int D4 = D / 4;          // 75 float4 per embedding row
 
 static_assert(D % 4 == 0 && DK % 4 == 0 && (HG * DK) % 16 == 0, "geometry");
 
-// ---- counter-based RNG for dropout: Philox4x32-7, one call per 4 consecutive elements -------------
-__device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                             uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = mulhi_u32(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = mulhi_u32(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+// ---- counter-based RNG for dropout: two rounds of a 32-bit avalanche mixer per 4 consecutive elements -----------------
+// The kernels are VALU-bound (rocprofv3 PMC: ~15 VALU instructions per MFMA in the forward kernel with Philox4x32-7, a third
+// of them RNG), so the generator is as cheap as a stateless one gets: counter = element quad index, key = (seed, site);
+// r0 = mix(counter, key), r1 = mix(r0, key') give 4 x 16 random bits, element j is dropped iff its 16 bits < p * 2^16.
+// mix32 is the "lowbias32" integer finaliser (xorshift-multiply, full avalanche).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
 }
 
 struct DropCfg {
   uint32_t k0, k1;     // seed
-  uint32_t thresh;     // drop iff rand32 < thresh  (thresh = p * 2^32)
+  uint32_t thresh;     // drop iff rand16 < thresh  (thresh = p * 2^16)
   float scale;         // 1/(1-p)
   int enabled;
 };
 
 // keep-flags (bit j set = keep) for elements 4*quad .. 4*quad+3 of dropout site `site`
 __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site, uint64_t quad) {
-  uint32_t r[4];
-  philox4x32_7((uint32_t)quad, (uint32_t)(quad >> 32), site, 0x6e72u, dc.k0, dc.k1, r);
+  const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
+  const uint32_t r0 = mix32((lo * 0x9E3779B1u) ^ (hi * 0xC2B2AE3Du) ^ dc.k0 ^ (site * 0x85EBCA77u));
+  const uint32_t r1 = mix32(r0 + dc.k1 + 0x68E31DA4u);
   uint32_t m = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) m |= (r[j] >= dc.thresh ? 1u : 0u) << j;
+  m |= ((r0 & 0xFFFFu) >= dc.thresh ? 1u : 0u);
+  m |= ((r0 >> 16) >= dc.thresh ? 2u : 0u);
+  m |= ((r1 & 0xFFFFu) >= dc.thresh ? 4u : 0u);
+  m |= ((r1 >> 16) >= dc.thresh ? 8u : 0u);
+  return m;
+}
+
+// the same decision as per-element multipliers (scale or 0): saves the mask round trip in the hot loops
+__device__ __forceinline__ f32x4 drop_mul4(const DropCfg& dc, uint32_t site, uint64_t quad) {
+  const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
+  const uint32_t r0 = mix32((lo * 0x9E3779B1u) ^ (hi * 0xC2B2AE3Du) ^ dc.k0 ^ (site * 0x85EBCA77u));
+  const uint32_t r1 = mix32(r0 + dc.k1 + 0x68E31DA4u);
+  f32x4 m;
+  m[0] = (r0 & 0xFFFFu) >= dc.thresh ? dc.scale : 0.0f;
+  m[1] = (r0 >> 16) >= dc.thresh ? dc.scale : 0.0f;
+  m[2] = (r1 & 0xFFFFu) >= dc.thresh ? dc.scale : 0.0f;
+  m[3] = (r1 >> 16) >= dc.thresh ? dc.scale : 0.0f;
   return m;
 }
 

@@ -34,8 +34,8 @@ nr::DropCfg make_drop(float p, uint64_t seed) {
   dc.enabled = p > 0.0f ? 1 : 0;
   dc.k0 = (uint32_t)seed;
   dc.k1 = (uint32_t)(seed >> 32);
-  double t = (double)p * 4294967296.0;
-  dc.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  double t = (double)p * 65536.0 + 0.5;
+  dc.thresh = t >= 65535.0 ? 65535u : (uint32_t)t;
   dc.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
   return dc;
 }

@@ -46,6 +46,7 @@ __device__ __forceinline__ void wave_barrier() {
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_tanh(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7 in fp32

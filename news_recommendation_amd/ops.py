@@ -172,6 +172,35 @@ def _wgrad(a, b, name):
 
 
 _ws = {}
+_side = {}
+
+
+def sort_ids_async(ids):
+    """Sort the token ids for the embedding backward on a side HIP stream, overlapped with the forward kernels (the ids are
+    known before the forward starts; the sorted order is only needed by the scatter at the very end of the backward).
+    Returns (ids_sorted, perm, event)."""
+    dev = ids.device
+    cur = torch.cuda.current_stream(dev)
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    st.wait_stream(cur)
+    with torch.cuda.stream(st):
+        ids_sorted, perm = torch.sort(ids.reshape(-1))
+        ev = torch.cuda.Event()
+        ev.record(st)
+    ids.record_stream(st)
+    return ids_sorted, perm, ev
+
+
+def sorted_ids_ready(pack):
+    """Make the current stream wait for sort_ids_async's result and hand the tensors over to it."""
+    ids_sorted, perm, ev = pack
+    cur = torch.cuda.current_stream(ids_sorted.device)
+    cur.wait_event(ev)
+    ids_sorted.record_stream(cur)
+    perm.record_stream(cur)
+    return ids_sorted, perm
 
 
 def _workspace(key, shape, dtype, device, zero=False):
@@ -230,6 +259,7 @@ class _EncoderFn(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
+            ctx.sorted = sort_ids_async(ids_c) if gather and ctx.needs_input_grad[1] else None
         return out
 
     @staticmethod
@@ -273,7 +303,7 @@ class _EncoderFn(torch.autograd.Function):
                 d_table = torch.zeros_like(table, dtype=torch.float32)
                 dXi = dX.view(_BF16_AS_I16)
                 # sort token ids so that every table row is reduced by adjacent lanes instead of contended atomics
-                ids_sorted, perm = _timed('sort_ids', lambda: torch.sort(ids.view(-1)))
+                ids_sorted, perm = sorted_ids_ready(ctx.sorted)
                 _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_D,
                       _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
         elif ctx.needs_input_grad[2]:

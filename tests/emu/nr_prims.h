@@ -183,6 +183,7 @@ __forceinline__ void wave_barrier() { nr_emu::wave_sync(); }
 
 __forceinline__ float fast_exp(float x) { return expf(x); }
 __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+__forceinline__ float fast_exp2(float x) { return exp2f(x); }
 __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 
 __forceinline__ void atomic_add(float* p, float v) { *p += v; }
