@@ -2,6 +2,7 @@
 #include "nr_common.h"
 #include "k_misc.h"
 #include "k_mhsa_fwd.h"
+#include "k_mhsa_fwd2.h"
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
 #include "k_conv.h"
@@ -98,9 +99,14 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save;
   if (S == 20) {
     constexpr int NSEQ = 4;
-    const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: "4x2" (4 waves, pair groups), "8x1", "8x2"
-    int v = var ? atoi(var) : 81;
-    if (v == 42) {
+    const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: 2 = register-resident kernel (default); LDS-tile kernels: 42, 81, 82
+    int v = var ? atoi(var) : 2;
+    if (v == 2) {
+      using G = nr::Mhsa2Geom;
+      if (allow_smem(nr::mhsa_fwd2_kernel, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
+      const int per_wg = G::TPW * G::NWAVE;
+      NR_LAUNCH(nr::mhsa_fwd2_kernel, (n_seq + per_wg - 1) / per_wg, 256, G::SMEM, (hipStream_t)stream, p);
+    } else if (v == 42) {
       constexpr int NW = 4, GS = 2;
       using G = nr::MhsaGeom<20, NSEQ, NW>;
       if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");

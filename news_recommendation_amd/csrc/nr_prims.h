@@ -12,6 +12,14 @@
 #define NR_LAUNCH(kern, gx, bx, smem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
 
+// one wave per SIMD: the whole 512-entry register file for a register-resident kernel
+#define NR_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+
+// async global -> LDS copy of 16 B per lane (global_load_lds_dwordx4): lane i's 16 B land at lds_base + 16 i (wave-uniform base,
+// lane-linear destination); completion is tracked by vmcnt and drained by the next __syncthreads()
+#define NR_GLDS16(gptr, lds_base) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
+
 #define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
 
@@ -35,6 +43,20 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
 }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// sum over the four 16-lane rows of the wave (= over lane ^ 16 and lane ^ 32), result in every lane: two VALU lane swaps
+// (v_permlane32_swap / v_permlane16_swap, gfx950) instead of two ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ float sum_rows4(float v) {
+  // inline asm: the clang builtins return only the first of the two swapped registers (ROCm 7.2).  v_permlane32_swap exchanges
+  // a[32:63] <-> b[0:31], v_permlane16_swap the odd 16-lane rows of a with the even rows of b; with a == b on entry,
+  // a + b afterwards is the pairwise sum in every lane.  s_nop covers the VALU-write -> lane-swap hazards the assembler
+  // does not see inside inline asm.
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  a += b;
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 
 // orders this wave's LDS traffic for cross-lane exchange through LDS (hardware keeps a wave's DS ops in order;

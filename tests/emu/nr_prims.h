@@ -110,6 +110,11 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
   nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), 1, 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
                  (size_t)(smem), [&]() { kern(__VA_ARGS__); })
 
+#define NR_ONE_WAVE_PER_SIMD
+
+// emulation of global_load_lds_dwordx4: every lane copies its 16 B to lds_base + 16 * lane
+#define NR_GLDS16(gptr, lds_base) memcpy((unsigned char*)(lds_base) + 16 * (threadIdx.x & 63), (const void*)(gptr), 16)
+
 #define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...)                                                \
   nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), (unsigned)(gy), 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
                  (size_t)(smem), [&]() { kern(__VA_ARGS__); })
@@ -168,6 +173,7 @@ __forceinline__ float shfl_xor(float v, int mask) {
   nr_emu::wave_sync();
   return r;
 }
+__forceinline__ float sum_rows4(float v) { v += shfl_xor(v, 32); v += shfl_xor(v, 16); return v; }
 __forceinline__ float shfl(float v, int src) {
   nr_emu::BlockState* blk = nr_emu::g_blk;
   int l = lane_id();
