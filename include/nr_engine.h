@@ -68,6 +68,12 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
                 const uint16_t* Wp, const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save,
                 uint16_t* vt_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
 
+/* Same, and additionally (x_save != NULL, training) emits the dropout-masked bf16 token matrix x_save[n_seq*S][NR_KP] (column D = 1.0,
+ * rest of the K padding 0) that the weight-gradient GEMM dW = dqkv^T @ X needs -- what nr_gather_bf16 would recompute. */
+int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense,
+                   const uint16_t* Wp, const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save,
+                   uint16_t* vt_save, uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+
 /* AdditiveAttention forward, src/model/general/attention/additive.py:27-53:
  * out[t,:] = sum_s softmax_s(tanh(ctx[t,s,:] Wa^T + ba) . qv) * ctx[t,s,:].
  * ctx bf16[n_seq*S][NR_KP]; out f32[n_seq][D]; attn_w f32[n_seq][S] (saved for backward, may be NULL). */
@@ -208,6 +214,11 @@ int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, con
 int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* carry_next, const uint16_t* WhhT, const uint16_t* gates,
                     const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, float* carry, int B, int N, int Hd, int t,
                     int first, void* stream);
+
+/* Per-impression ranking metrics of src/evaluate.py:24-42,160-168 for a CSR batch of impressions: scores f32[nnz], labels
+ * int32[nnz] (0/1), ptr int64[n_impr+1]; out f32[n_impr][4] = AUC, MRR, nDCG@5, nDCG@10 (four NaNs when an impression has a
+ * single label class: the reference's ValueError path).  Replaces the multiprocessing pool of src/evaluate.py:267-268. */
+int nr_impression_metrics(const float* scores, const int32_t* labels, const int64_t* ptr, float* out, int64_t n_impr, void* stream);
 
 /* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
  * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */

@@ -18,6 +18,7 @@ SIGNATURES = {
     'nr_pack_qkv': ([_P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     'nr_pack_additive': ([_P, _P, _P, c_int, _P, _P, _P, _P], c_int),
     'nr_mhsa_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_mhsa_fwd_ex': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_bwd_grid': ([c_int64, c_int], c_int64),
     'nr_additive_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
@@ -47,6 +48,7 @@ SIGNATURES = {
     'nr_rows_to_bf16': ([_P, c_int64, c_int, _P, c_int, c_int64, _P], c_int),
     'nr_gru_fwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_bwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    'nr_impression_metrics': ([_P, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
 }

@@ -56,6 +56,7 @@ struct MhsaParams {
   u16* q_save;             // training: [n_seq*S][KP] (cols >= D untouched) or null
   u16* k_save;             // training: [n_seq*S][KP] or null
   u16* vt_save;            // training: [n_seq][H][DK][SP4]  (dv-major V blocks) or null
+  u16* x_save;             // training, optional: [n_seq*S][KP] dropout-masked bf16 tokens, col D = 1.0 (weight-gradient GEMM operand)
   int64_t n_seq;
   DropCfg dc;
 };

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
         if (c + 4 < D) b = b * drop_mul4(p.dc, 1u, (uint64_t)tok * D4 + (c >> 2) + 1);
       }
       xf[m][ks] = cat8(pack4(a), pack4(b));
+      if (p.x_save != nullptr && tok < tok_total) {          // the weight-gradient GEMM operand, straight from the fragment registers
+        u16x8 o = xf[m][ks];
+        if (c <= D && D < c + 8) o[D - c] = BF16_ONE;        // column D = 1.0: the GEMM then also yields the bias gradient
+        *(u16x8*)(p.x_save + tok * KP + c) = o;
+      }
     }
   }
   __syncthreads();

@@ -8,6 +8,7 @@
 #include "k_conv.h"
 #include "k_naml.h"
 #include "k_gru.h"
+#include "k_eval.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -83,9 +84,19 @@ int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim
   return check_launch("nr_pack_additive");
 }
 
+int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                   const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, int64_t n_seq,
+                   int S, float p_drop, uint64_t seed, void* stream);
+
 int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
                 const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, int64_t n_seq, int S,
                 float p_drop, uint64_t seed, void* stream) {
+  return nr_mhsa_fwd_ex(ids, table, num_rows, x_dense, Wp, bp, ctx, q_save, k_save, vt_save, nullptr, n_seq, S, p_drop, seed, stream);
+}
+
+int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                   const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, int64_t n_seq,
+                   int S, float p_drop, uint64_t seed, void* stream) {
   if (!Wp || !bp || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: bad argument");
   if ((q_save != nullptr) != (k_save != nullptr) || (q_save != nullptr) != (vt_save != nullptr))
     return fail(NR_ERR_BADARG, "nr_mhsa_fwd: q_save / k_save / vt_save must be given together");
@@ -96,13 +107,15 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   nr::MhsaParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_dense = x_dense;
   p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
-  p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save;
+  p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.x_save = nullptr;
+  bool x_done = false;
   if (S == 20) {
     constexpr int NSEQ = 4;
     const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: 2 = register-resident kernel (default); LDS-tile kernels: 42, 81, 82
     int v = var ? atoi(var) : 2;
     if (v == 2) {
       using G = nr::Mhsa2Geom;
+      p.x_save = x_save; x_done = true;
       if (allow_smem(nr::mhsa_fwd2_kernel, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
       const int per_wg = G::TPW * G::NWAVE;
       NR_LAUNCH(nr::mhsa_fwd2_kernel, (n_seq + per_wg - 1) / per_wg, 256, G::SMEM, (hipStream_t)stream, p);
@@ -130,6 +143,9 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   } else {
     return fail(NR_ERR_UNSUPPORTED, "nr_mhsa_fwd: sequence length not instantiated (20, 50)");
   }
+  if (x_save != nullptr && !x_done)        // kernels that do not emit the token matrix themselves: a separate gather pass
+    NR_LAUNCH(nr::gather_bf16_kernel, grid_for(n_seq * S * (NR_KP / 4), 256, 4096), 256, 0, (hipStream_t)stream, ids, table, num_rows, x_dense,
+              x_save, n_seq * S, p.dc);
   return check_launch("nr_mhsa_fwd");
 }
 
@@ -470,6 +486,13 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
   NR_LAUNCH2(nr::gru_bwd_step_kernel, (B + 63) / 64, p.Hg / 16, nr::WG, 0, (hipStream_t)stream, p);
   return check_launch("nr_gru_bwd_step");
+}
+
+int nr_impression_metrics(const float* scores, const int32_t* labels, const int64_t* ptr, float* out, int64_t n_impr, void* stream) {
+  if (!scores || !labels || !ptr || !out || n_impr < 0) return fail(NR_ERR_BADARG, "nr_impression_metrics: bad argument");
+  if (n_impr == 0) return NR_OK;
+  NR_LAUNCH(nr::impression_metrics_kernel, (n_impr + 3) / 4, 256, 0, (hipStream_t)stream, scores, labels, ptr, out, n_impr);
+  return check_launch("nr_impression_metrics");
 }
 
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream) {

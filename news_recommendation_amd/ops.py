@@ -239,25 +239,26 @@ class _EncoderFn(torch.autograd.Function):
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
+            xb = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)       # masked bf16 tokens for dW = dqkv^T @ X (written by the kernel)
         else:
-            qs = ks = vts = None
+            qs = ks = vts = xb = None
         if gather:
             ids_c = ids.contiguous()
             tab = table.detach()
             assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
-            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd, _ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream())
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_ex, _ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), n_seq, S, p_drop, seed, _stream())
             xd = None
         else:
             ids_c = None
             xd = _f32c(x_dense)
-            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), n_seq, S, p_drop, seed, _stream())
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_ex, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), n_seq, S, p_drop, seed, _stream())
         out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
         if need_grad:
-            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp)
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, xb)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
             ctx.sorted = sort_ids_async(ids_c) if gather and ctx.needs_input_grad[1] else None
         return out
@@ -265,7 +266,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp = ctx.saved_tensors
+        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, Xb = ctx.saved_tensors
         S, p_drop, seed, n_seq, qdim, gather = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
@@ -287,11 +288,6 @@ class _EncoderFn(torch.autograd.Function):
                             n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
         # ---- weight gradients: dW_ext = dqkv^T @ [X | 1] --------------------------------------------------------------
-        Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
-        if gather:
-            _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, _ptr(ids), _ptr(table.detach()), table.shape[0], None, _ptr(Xb), ntok, p_drop, seed, _stream())
-        else:
-            _call(f'nr_gather_bf16[S={S}]', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
         dW_ext = _wgrad(dqkv_b, _bf16(Xb), f'gemm_dWqkv[S={S}]')       # [960, KP]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]

@@ -426,3 +426,28 @@ def check_score_bwd(be, B=33, C=3):
     be.sync()
     np.testing.assert_allclose(be.np(dc), dl[:, :, None] * user[:, None, :], rtol=1e-6)
     np.testing.assert_allclose(be.np(du), np.einsum('bc,bcd->bd', dl, cand), rtol=1e-5, atol=1e-5)
+
+
+def check_mhsa_x_save(be, S=20, n_seq=7, V=300, p_drop=0.2, seed=99):
+    """nr_mhsa_fwd_ex's x_save output == nr_gather_bf16 of the same ids / dropout stream (bit exact), ctx unchanged."""
+    params = make_params(20, V)
+    rng = np.random.default_rng(21)
+    ids = rng.integers(0, V, size=(n_seq, S)).astype(np.int64)
+    table = params['news_encoder.word_embedding.weight']
+    Wp, bp = pack_qkv(be, params, 'news_encoder.')
+    hi, ht = be.dev(ids), be.dev(table)
+    sp4 = (S + 3) // 4 * 4
+    outs = []
+    for with_x in (False, True):
+        ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+        sv = [be.empty((n_seq * S, NR_KP), np.uint16), be.empty((n_seq * S, NR_KP), np.uint16), be.empty((n_seq, H, 20, sp4), np.uint16)]
+        xs = be.poison((n_seq * S, NR_KP), np.uint16) if with_x else None
+        ck(be, be.lib.nr_mhsa_fwd_ex(be.ptr(hi), be.ptr(ht), V, None, be.ptr(Wp), be.ptr(bp), be.ptr(ctx), be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]),
+                                     be.ptr(xs), n_seq, S, p_drop, seed, be.stream))
+        be.sync()
+        outs.append((be.np(ctx), xs))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    Xb = be.poison((n_seq * S, NR_KP), np.uint16)
+    ck(be, be.lib.nr_gather_bf16(be.ptr(hi), be.ptr(ht), V, None, be.ptr(Xb), n_seq * S, p_drop, seed, be.stream))
+    be.sync()
+    assert np.array_equal(bf16_to_f32(be.np(outs[1][1])), bf16_to_f32(be.np(Xb)))

@@ -17,6 +17,8 @@ def test_pack(be): kc.check_pack(be)
 def test_mhsa_gather(be): kc.check_mhsa_gather(be, n_seq=6)
 def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=5, p_drop=0.2)
 def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=2)
+def test_mhsa_x_save(be): kc.check_mhsa_x_save(be)
+def test_mhsa_x_save_s50(be): kc.check_mhsa_x_save(be, S=50, n_seq=2, p_drop=0.0)
 def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=6)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=2)
 def test_score_dot(be): kc.check_score_dot(be)

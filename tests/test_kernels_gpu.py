@@ -19,6 +19,8 @@ def test_mhsa_gather(be): kc.check_mhsa_gather(be, n_seq=1027, V=5000)
 def test_mhsa_gather_small(be): kc.check_mhsa_gather(be, n_seq=3, V=300)
 def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=515, V=5000, p_drop=0.2)
 def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=131)
+def test_mhsa_x_save(be): kc.check_mhsa_x_save(be, n_seq=1027, V=5000)
+def test_mhsa_x_save_s50(be): kc.check_mhsa_x_save(be, S=50, n_seq=33, p_drop=0.0)
 def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=1027)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=131)
 def test_score_dot(be): kc.check_score_dot(be, B=513, C=3)
