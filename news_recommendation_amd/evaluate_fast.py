@@ -1,0 +1,134 @@
+"""Batched evaluation driver: same inputs and outputs as the reference's ``evaluate(model, directory, num_workers, max_count)``
+(src/evaluate.py:171-272), without its per-impression Python loop.
+
+The reference keeps one device tensor per news id in a dict, one per history string in another, then for EVERY impression
+stacks the candidate rows, calls ``model.get_prediction`` and synchronises with ``.tolist()`` (evaluate.py:245-260), and finally
+maps sklearn over the impressions in a process pool (:267-268).  Here:
+
+  phase A  news table  -> one dense matrix of news vectors (``model.get_news_vector`` on batches of ``batch_size * 16``)
+  phase B  unique click histories (first occurrence of each ``clicked_news`` string wins, :218-233) -> one dense matrix of user
+           vectors (``model.get_user_vector`` on index-gathered [B, N, D] blocks; padded slots are the zero PADDED_NEWS vector, :203-204)
+  phase C  all impressions at once: CSR candidate indices -> ``nr_score_csr`` (one launch), then ``nr_impression_metrics``
+           (one launch, one wave per impression) and a nanmean -- a single device->host copy of four numbers.
+
+``build_plan`` is pure pandas/numpy (testable without a GPU against the reference's own dataset classes); ``evaluate`` runs
+the plan on the engine.  Quirks kept on purpose: ``count == max_count`` stops BEFORE scoring that row (:247-249), unknown users
+map to id 0 (:98-102), LSTUR uses the first user id seen with a history string.
+"""
+import sys
+from ast import literal_eval
+from os import path
+
+import numpy as np
+import pandas as pd
+import torch
+
+TEXT_ATTRS = ('title', 'abstract', 'title_entities', 'abstract_entities')
+
+
+class EvalPlan:
+    """Everything phase A-C need, as flat arrays."""
+    __slots__ = ('news_ids', 'news', 'hist_idx', 'hist_len', 'hist_user', 'cand_idx', 'cand_ptr', 'labels', 'imp_user_row')
+
+
+def build_plan(directory, news_attributes, num_clicked, user2int_path='data/train/user2int.tsv', max_count=sys.maxsize):
+    """Parse ``directory/news_parsed.tsv`` and ``directory/behaviors.tsv`` exactly as NewsDataset / UserDataset / BehaviorsDataset
+    do (src/evaluate.py:51-157) into index arrays."""
+    plan = EvalPlan()
+    news = pd.read_table(path.join(directory, 'news_parsed.tsv'), usecols=['id'] + list(news_attributes),
+                         converters={a: literal_eval for a in set(news_attributes) & set(TEXT_ATTRS)})
+    news = news.drop_duplicates(subset='id', keep='first')                    # news2vector keeps the first vector of an id (:199-201)
+    plan.news_ids = news['id'].tolist()
+    nid2row = {n: i for i, n in enumerate(plan.news_ids)}
+    plan.news = {a: np.asarray(news[a].tolist(), dtype=np.int64) for a in news_attributes}
+    n_news = len(plan.news_ids)
+
+    users = pd.read_table(path.join(directory, 'behaviors.tsv'), header=None, usecols=[1, 3], names=['user', 'clicked_news'])
+    users['clicked_news'] = users['clicked_news'].fillna(' ')
+    users = users.drop_duplicates()                                             # UserDataset (:88-93)
+    user2int = dict(pd.read_table(user2int_path).values.tolist())
+    hist_row = {}
+    hist_idx, hist_len, hist_user = [], [], []
+    for user, s in zip(users['user'].tolist(), users['clicked_news'].tolist()):
+        if s in hist_row:                                                       # user2vector: first occurrence of the string wins (:231-233)
+            continue
+        hist_row[s] = len(hist_idx)
+        clicked = s.split()[:num_clicked]
+        row = np.full(num_clicked, n_news, dtype=np.int64)                      # n_news = the PADDED_NEWS zero row, LEFT padding (:120-124)
+        if clicked:
+            row[num_clicked - len(clicked):] = [nid2row[x] for x in clicked]
+        hist_idx.append(row)
+        hist_len.append(len(clicked))
+        hist_user.append(user2int.get(user, 0))                                 # unknown users -> 0 (:98-102)
+    plan.hist_idx = np.stack(hist_idx) if hist_idx else np.zeros((0, num_clicked), dtype=np.int64)
+    plan.hist_len = np.asarray(hist_len, dtype=np.int64)
+    plan.hist_user = np.asarray(hist_user, dtype=np.int64)
+
+    beh = pd.read_table(path.join(directory, 'behaviors.tsv'), header=None, usecols=range(5),
+                        names=['impression_id', 'user', 'time', 'clicked_news', 'impressions'])
+    beh['clicked_news'] = beh['clicked_news'].fillna(' ')
+    cand, labels, ptr, urow = [], [], [0], []
+    count = 0
+    for s, imps in zip(beh['clicked_news'].tolist(), beh['impressions'].tolist()):
+        count += 1
+        if count == max_count:                                                  # stops BEFORE scoring this row (:247-249)
+            break
+        for it in imps.split():
+            nid, lab = it.split('-')
+            cand.append(nid2row[nid])
+            labels.append(int(lab))
+        ptr.append(len(cand))
+        urow.append(hist_row[s])
+    plan.cand_idx = np.asarray(cand, dtype=np.int32)
+    plan.labels = np.asarray(labels, dtype=np.int32)
+    plan.cand_ptr = np.asarray(ptr, dtype=np.int64)
+    plan.imp_user_row = np.asarray(urow, dtype=np.int32)
+    return plan
+
+
+@torch.no_grad()
+def run_plan(model, plan, batch, model_name):
+    """Phases A-C on the engine; returns (per-impression metrics f32 [n_impr, 4] on the device, scores f32 [nnz])."""
+    from . import ops
+    from .ops import _lib, _call, _ptr, _stream
+    dev = next(model.parameters()).device
+    n_news = len(plan.news_ids)
+    # phase A
+    nv = []
+    for i in range(0, n_news, batch):
+        mb = {k: torch.from_numpy(v[i:i + batch]) for k, v in plan.news.items()}
+        mb['id'] = plan.news_ids[i:i + batch]
+        nv.append(model.get_news_vector(mb))
+    nv = torch.cat(nv) if nv else torch.zeros(0, 1, device=dev)
+    D = nv.shape[1]
+    nvp = torch.cat([nv, torch.zeros(1, D, dtype=nv.dtype, device=dev)])       # PADDED_NEWS (:203-204)
+    # phase B
+    hidx = torch.from_numpy(plan.hist_idx).to(dev)
+    uv = []
+    for i in range(0, hidx.shape[0], batch):
+        block = nvp[hidx[i:i + batch]]                                           # [b, N, D]
+        if model_name == 'LSTUR':
+            uv.append(model.get_user_vector(torch.from_numpy(plan.hist_user[i:i + batch]), torch.from_numpy(plan.hist_len[i:i + batch].copy()), block))
+        else:
+            uv.append(model.get_user_vector(block))
+    uv = torch.cat(uv) if uv else torch.zeros(0, D, device=dev)
+    # phase C
+    n_impr = len(plan.imp_user_row)
+    ptr = torch.from_numpy(plan.cand_ptr).to(dev)
+    scores = ops.score_csr(nv, uv, torch.from_numpy(plan.cand_idx).to(dev), ptr, torch.from_numpy(plan.imp_user_row).to(dev))
+    out = torch.empty(n_impr, 4, dtype=torch.float32, device=dev)
+    labels = torch.from_numpy(plan.labels).to(dev)
+    _call('nr_impression_metrics', _lib().nr_impression_metrics, _ptr(scores), _ptr(labels), _ptr(ptr), _ptr(out), n_impr, _stream())
+    return out, scores
+
+
+@torch.no_grad()
+def evaluate(model, directory, num_workers=0, max_count=sys.maxsize, user2int_path='data/train/user2int.tsv'):
+    """Drop-in for src/evaluate.py:171 ``evaluate``: returns (AUC, MRR, nDCG@5, nDCG@10), nan-mean over impressions (:270-272).
+    ``num_workers`` is accepted for signature compatibility (there is no process pool)."""
+    cfg = model.config
+    model_name = type(model).__name__
+    plan = build_plan(directory, cfg.dataset_attributes['news'], cfg.num_clicked_news_a_user, user2int_path, max_count)
+    out, _ = run_plan(model, plan, getattr(cfg, 'batch_size', 128) * 16, model_name)
+    m = torch.nanmean(out.double(), dim=0).cpu().numpy()
+    return float(m[0]), float(m[1]), float(m[2]), float(m[3])

@@ -61,7 +61,29 @@ def _patch_dp(model_name):
     cls.to = to
 
 
-def run(script, reference_src, workdir, model_name='NRMS'):
+def _fast_evaluate_main(model_name):
+    """`evaluate.py`'s __main__ block (src/evaluate.py:275-294) with the batched driver: newest checkpoint -> test metrics."""
+    import importlib
+    import torch
+    import evaluate as ref_eval                       # the reference's module: config, latest_checkpoint live there / in train.py
+    from news_recommendation_amd import evaluate_fast
+    config = ref_eval.config
+    Model = getattr(importlib.import_module(f'model.{model_name}'), model_name)
+    model = Model(config).to(ref_eval.device)
+    ckpt_dir = os.path.join('./checkpoint', model_name)
+    ckpts = {int(f.split('.')[-2].split('-')[-1]): f for f in os.listdir(ckpt_dir)} if os.path.isdir(ckpt_dir) else {}
+    if not ckpts:
+        print('No checkpoint file found!')
+        return
+    path = os.path.join(ckpt_dir, ckpts[max(ckpts)])
+    print(f"Load saved parameters in {path}")
+    model.load_state_dict(torch.load(path)['model_state_dict'])
+    model.eval()
+    auc, mrr, ndcg5, ndcg10 = evaluate_fast.evaluate(model, './data/test', config.num_workers)
+    print(f'AUC: {auc:.4f}\nMRR: {mrr:.4f}\nnDCG@5: {ndcg5:.4f}\nnDCG@10: {ndcg10:.4f}')
+
+
+def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False):
     here = os.path.dirname(os.path.abspath(__file__))
     repo = os.path.dirname(here)
     reference_src = os.path.abspath(reference_src)
@@ -76,6 +98,14 @@ def run(script, reference_src, workdir, model_name='NRMS'):
     install_shims()
     os.chdir(workdir)
     _patch_dp(model_name)
+    if fast_eval:
+        # the batched evaluation driver behind the reference's own name: train.py's `from evaluate import evaluate` (train.py:12)
+        # then validates with it; `launcher evaluate --fast-eval` runs evaluate.py's main logic on it
+        import evaluate as ref_eval
+        from news_recommendation_amd import evaluate_fast
+        ref_eval.evaluate = evaluate_fast.evaluate
+        if script == 'evaluate':
+            return _fast_evaluate_main(model_name)
     runpy.run_path(os.path.join(reference_src, script + '.py'), run_name='__main__')
 
 
@@ -85,8 +115,10 @@ def main(argv=None):
     ap.add_argument('--reference', default=os.environ.get('NR_REFERENCE_SRC', '/root/reference/src'))
     ap.add_argument('--workdir', default='.')
     ap.add_argument('--model', default=os.environ.get('MODEL_NAME', 'NRMS'), choices=['NRMS', 'NAML', 'LSTUR'])
+    ap.add_argument('--fast-eval', action='store_true',
+                    help="use the batched evaluation driver (evaluate_fast.py) instead of the reference's per-impression loop")
     a = ap.parse_args(argv)
-    run(a.script, a.reference, a.workdir, a.model)
+    run(a.script, a.reference, a.workdir, a.model, a.fast_eval)
 
 
 if __name__ == '__main__':

@@ -128,6 +128,6 @@ def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_imp
                 c = int(rng.integers(2, 12))
                 lab = rng.integers(0, 2, c)
                 lab[0], lab[1] = 1, 0
-                imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c), lab))
+                imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c, replace=False), lab))     # an impression lists a news once
                 f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist_str(k)}\t{imp}\n")
     return root

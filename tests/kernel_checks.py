@@ -451,3 +451,39 @@ def check_mhsa_x_save(be, S=20, n_seq=7, V=300, p_drop=0.2, seed=99):
     ck(be, be.lib.nr_gather_bf16(be.ptr(hi), be.ptr(ht), V, None, be.ptr(Xb), n_seq * S, p_drop, seed, be.stream))
     be.sync()
     assert np.array_equal(bf16_to_f32(be.np(outs[1][1])), bf16_to_f32(be.np(Xb)))
+
+
+def check_impression_metrics(be, n_impr=40, seed=5):
+    """nr_impression_metrics vs the oracle's restatement of src/evaluate.py:24-42,160-168 (pinned to the reference's own metric
+    functions by tests/golden/metrics.npz), incl. score ties and single-class impressions."""
+    from oracle import metrics as om
+    rng = np.random.default_rng(seed)
+    ys, ss = [], []
+    for i in range(n_impr):
+        n = int(rng.integers(2, 90))
+        y = rng.integers(0, 2, size=n)
+        if i % 9 == 0:
+            y[:] = 0
+        elif i % 9 == 1:
+            y[:] = 1
+        else:
+            y[0], y[-1] = 1, 0
+        s = rng.normal(size=n).astype(np.float32)
+        if i % 4 == 0:
+            s = s.round(1)                                        # ties
+        ys.append(y.astype(np.int32)); ss.append(s)
+    ptr = np.concatenate([[0], np.cumsum([len(y) for y in ys])]).astype(np.int64)
+    out = be.poison((n_impr, 4), np.float32)
+    ck(be, be.lib.nr_impression_metrics(be.ptr(be.dev(np.concatenate(ss))), be.ptr(be.dev(np.concatenate(ys))), be.ptr(be.dev(ptr)), be.ptr(out),
+                                        n_impr, be.stream))
+    be.sync()
+    got = be.np(out)
+    for i in range(n_impr):
+        ref = om.single_impression_metrics(ys[i], ss[i].astype(np.float64))
+        if np.isnan(ref[0]):
+            assert np.isnan(got[i]).all(), i
+            continue
+        assert abs(got[i][0] - ref[0]) < 1e-5, (i, got[i], ref)       # AUC: tie handling is exact (average ranks)
+        if len(np.unique(ss[i])) == len(ss[i]):                      # MRR / nDCG depend on the tie ORDER of argsort; exact without ties
+            np.testing.assert_allclose(got[i][1:], ref[1:], rtol=2e-5, atol=2e-6, err_msg=str(i))
+    return got

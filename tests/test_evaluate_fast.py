@@ -1,0 +1,144 @@
+"""Batched evaluation driver (news_recommendation_amd/evaluate_fast.py).
+
+CPU (build container only): build_plan reproduces what the reference's own NewsDataset / UserDataset / BehaviorsDataset
+(src/evaluate.py:51-157) deliver, row for row, on a synthetic data tree in the reference's file formats.
+GPU: evaluate() == the reference's evaluate() loop restated literally (dict of row tensors, one get_prediction per impression,
+oracle metrics) on the same engine model."""
+import os
+import sys
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/src'
+
+PLAN_VS_REFERENCE = r'''
+import os, sys, json
+import numpy as np
+sys.dont_write_bytecode = True
+root, ref, workdir, model_name = sys.argv[1:5]
+os.environ['MODEL_NAME'] = model_name
+sys.path.insert(0, ref); sys.path.insert(0, root)
+os.chdir(workdir)
+import evaluate as ref_eval                                  # the reference's evaluate.py (read-only)
+from news_recommendation_amd import evaluate_fast as ef
+cfg = ref_eval.config
+attrs = cfg.dataset_attributes['news']
+for max_count in (sys.maxsize, 7):
+    plan = ef.build_plan('data/val', attrs, cfg.num_clicked_news_a_user, 'data/train/user2int.tsv', max_count)
+    nd = ref_eval.NewsDataset('data/val/news_parsed.tsv')
+    assert len(nd) == len(plan.news_ids)
+    for i in range(len(nd)):
+        it = nd[i]
+        assert it['id'] == plan.news_ids[i]
+        for a in attrs:
+            assert np.array_equal(np.asarray(it[a]), plan.news[a][i]), (i, a)
+    ud = ref_eval.UserDataset('data/val/behaviors.tsv', 'data/train/user2int.tsv')
+    seen = {}
+    for i in range(len(ud)):
+        it = ud[i]
+        if it['clicked_news_string'] in seen:
+            continue
+        r = len(seen); seen[it['clicked_news_string']] = r
+        want = [len(plan.news_ids) if x == 'PADDED_NEWS' else plan.news_ids.index(x) for x in it['clicked_news']]
+        assert list(plan.hist_idx[r]) == want, r
+        assert plan.hist_len[r] == it['clicked_news_length'] and plan.hist_user[r] == it['user']
+    assert len(seen) == plan.hist_idx.shape[0]
+    bd = ref_eval.BehaviorsDataset('data/val/behaviors.tsv')
+    count = 0; k = 0
+    for i in range(len(bd)):
+        count += 1
+        if count == max_count:
+            break
+        it = bd[i]
+        c = plan.cand_idx[plan.cand_ptr[k]:plan.cand_ptr[k + 1]]
+        assert [plan.news_ids[j] for j in c] == [x.split('-')[0] for x in it['impressions']]
+        assert list(plan.labels[plan.cand_ptr[k]:plan.cand_ptr[k + 1]]) == [int(x.split('-')[1]) for x in it['impressions']]
+        assert plan.imp_user_row[k] == seen[it['clicked_news_string']]
+        k += 1
+    assert k == len(plan.imp_user_row), (k, len(plan.imp_user_row))
+    print('plan ok', model_name, max_count if max_count < 100 else 'all', k)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_plan_matches_reference_datasets(tmp_path, model_name):
+    from news_recommendation_amd import synth
+    synth.write_reference_dataset(str(tmp_path), n_val_impr=40)
+    # an unknown user and a history-less user, as in real MIND dev data
+    with open(os.path.join(tmp_path, 'data', 'val', 'behaviors.tsv'), 'a') as f:
+        f.write("9001\tU_UNKNOWN\t11/11/2019 9:00:00 AM\tN3 N4\tN5-1 N6-0\n")
+        f.write("9002\tU2\t11/11/2019 9:00:00 AM\t\tN7-0 N8-1 N9-0\n")
+        f.write("9003\tU3\t11/11/2019 9:00:00 AM\t\tN1-1 N2-0\n")
+    p = subprocess.run([sys.executable, '-c', PLAN_VS_REFERENCE, ROOT, REF, str(tmp_path), model_name],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert p.returncode == 0 and p.stdout.count('plan ok') == 2, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def reference_style_evaluate(model, plan, model_name):
+    """The loop of src/evaluate.py:193-272 restated with the reference's data structures: a dict of per-news row tensors, a dict of
+    per-history user vectors, ONE get_prediction call per impression, per-impression metrics, nanmean."""
+    from oracle import metrics as om
+    n_news = len(plan.news_ids)
+    news2vector = {}
+    B = 64
+    for i in range(0, n_news, B):
+        mb = {k: torch.from_numpy(v[i:i + B]) for k, v in plan.news.items()}
+        vec = model.get_news_vector(mb)
+        for j, v in enumerate(vec):
+            news2vector[i + j] = v
+    news2vector[n_news] = torch.zeros_like(news2vector[0])                  # PADDED_NEWS
+    user2vector = {}
+    for r in range(plan.hist_idx.shape[0]):
+        block = torch.stack([news2vector[int(x)] for x in plan.hist_idx[r]]).unsqueeze(0)
+        if model_name == 'LSTUR':
+            uv = model.get_user_vector(torch.tensor([plan.hist_user[r]]), torch.tensor([plan.hist_len[r]]), block)
+        else:
+            uv = model.get_user_vector(block)
+        user2vector[r] = uv[0]
+    res = []
+    for k in range(len(plan.imp_user_row)):
+        c = plan.cand_idx[plan.cand_ptr[k]:plan.cand_ptr[k + 1]]
+        pred = model.get_prediction(torch.stack([news2vector[int(j)] for j in c]), user2vector[int(plan.imp_user_row[k])]).tolist()
+        res.append(om.single_impression_metrics(plan.labels[plan.cand_ptr[k]:plan.cand_ptr[k + 1]], np.asarray(pred, dtype=np.float64)))
+    return np.nanmean(np.asarray(res, dtype=np.float64), axis=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_fast_evaluate_equals_reference_style_loop(tmp_path, model_name):
+    import importlib
+    import bench
+    from news_recommendation_amd import synth, evaluate_fast as ef
+    synth.write_reference_dataset(str(tmp_path), n_news=200, n_val_impr=60, num_words=500)
+    cfg = {'NRMS': bench.Cfg, 'NAML': bench.NamlCfg, 'LSTUR': bench.LsturCfg}[model_name]
+
+    class C(cfg):
+        num_words = 500
+        num_users = 41
+        num_categories = 30
+        batch_size = 4
+    if model_name == 'NRMS':
+        C.dataset_attributes = {"news": ['title'], "record": []}
+    cls = getattr(importlib.import_module(f'news_recommendation_amd.dropin.model.{model_name}'), model_name)
+    torch.manual_seed(0)
+    m = cls(C).to('cuda:0').eval()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        fast = ef.evaluate(m, './data/val', 0)
+        plan = ef.build_plan('./data/val', C.dataset_attributes['news'], C.num_clicked_news_a_user)
+        with torch.no_grad():
+            slow = reference_style_evaluate(m, plan, model_name)
+        fast7 = ef.evaluate(m, './data/val', 0, max_count=7)
+        plan7 = ef.build_plan('./data/val', C.dataset_attributes['news'], C.num_clicked_news_a_user, max_count=7)
+        assert len(plan7.imp_user_row) == 6                                  # count == max_count stops BEFORE scoring row 7
+    finally:
+        os.chdir(cwd)
+    # same vectors, same scorer arithmetic (fp32 dot products), fp32 vs fp64 metric accumulation
+    np.testing.assert_allclose(np.asarray(fast), slow, rtol=2e-4, atol=2e-5)
+    assert all(np.isfinite(fast)) and all(np.isfinite(fast7)) and 0.0 <= fast[0] <= 1.0

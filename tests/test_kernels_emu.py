@@ -23,6 +23,7 @@ def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=6)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=2)
 def test_score_dot(be): kc.check_score_dot(be)
 def test_score_csr(be): kc.check_score_csr(be)
+def test_impression_metrics(be): kc.check_impression_metrics(be)
 def test_bad_args(be): kc.check_bad_args(be)
 def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=3)
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0.2)

@@ -25,6 +25,7 @@ def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=1027)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=131)
 def test_score_dot(be): kc.check_score_dot(be, B=513, C=3)
 def test_score_csr(be): kc.check_score_csr(be, n_news=5000, n_users=300, n_impr=1000)
+def test_impression_metrics(be): kc.check_impression_metrics(be, n_impr=3001)
 def test_bad_args(be): kc.check_bad_args(be)
 def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=203)
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=0.2)
