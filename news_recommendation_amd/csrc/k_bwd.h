@@ -249,8 +249,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
           sum += e;
         }
       }
-      sum += shfl_xor(sum, 16);
-      sum += shfl_xor(sum, 32);
+      sum = sum_rows4(sum);
       const float rden = fast_rcp(sum + 1e-8f);
       float dot = 0.0f;
       f32x4 dPT[Gm::QT];
@@ -261,8 +260,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dot += pT[kt][r] * dPT[kt][r];
       }
-      dot += shfl_xor(dot, 16);
-      dot += shfl_xor(dot, 32);
+      dot = sum_rows4(dot);
 #pragma unroll
       for (int kt = 0; kt < Gm::QT; ++kt) {
         f32x4 ds;

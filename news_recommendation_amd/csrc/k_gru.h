@@ -114,9 +114,17 @@ __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
     const u16* dp = p.dgh_next + (size_t)sb * p.Kp + g * 8;
     const u16* wp = p.WhhT + (size_t)(j0 + li) * p.Kp + g * 8;
     const int ksteps = p.Kp / 32;
-#pragma unroll 4
-    for (int ks = 0; ks < ksteps; ++ks)
+    // four independent accumulators: a single one would serialise the 86 MFMAs of the K loop on the accumulate dependency
+    f32x4 a1 = acc, a2 = acc, a3 = acc;
+    int ks = 0;
+    for (; ks + 4 <= ksteps; ks += 4) {
       acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32), *(const u16x8*)(dp + ks * 32), acc);
+      a1 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 32), *(const u16x8*)(dp + ks * 32 + 32), a1);
+      a2 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 64), *(const u16x8*)(dp + ks * 32 + 64), a2);
+      a3 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 96), *(const u16x8*)(dp + ks * 32 + 96), a3);
+    }
+    for (; ks < ksteps; ++ks) acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32), *(const u16x8*)(dp + ks * 32), acc);
+    acc = (acc + a1) + (a2 + a3);
   }
   const int s = s0 + li, jb = j0 + 4 * g;
   if (s >= p.B || jb >= p.Hg) return;
