@@ -4,7 +4,12 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libnr_engine.so
-# -amdgpu-mfma-vgpr-form: MFMA results land in ordinary VGPRs (no v_accvgpr_read copy per accumulator register; the kernels are VALU-bound)
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I. -Wno-unused-value -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form=1 \
-  ${NR_EXTRA_FLAGS:-} nr_engine.hip -o $OUT
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -Wno-unused-value -Wno-pass-failed ${NR_EXTRA_FLAGS:-}"
+mkdir -p _obj
+# -amdgpu-mfma-vgpr-form: MFMA results land in ordinary VGPRs (no v_accvgpr_read copy per accumulator register; the kernels are
+# VALU-bound).  Not for nr_mhsa2.hip: that kernel holds > 256 registers per lane and uses the AGPR half as storage.
+$HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -c nr_engine.hip -o _obj/nr_engine.o &
+$HIPCC $COMMON -c nr_mhsa2.hip -o _obj/nr_mhsa2.o &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC _obj/nr_engine.o _obj/nr_mhsa2.o -o $OUT
 echo "built $(realpath $OUT)"

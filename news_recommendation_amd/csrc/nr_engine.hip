@@ -2,7 +2,6 @@
 #include "nr_common.h"
 #include "k_misc.h"
 #include "k_mhsa_fwd.h"
-#include "k_mhsa_fwd2.h"
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
 #include "k_conv.h"
@@ -12,6 +11,12 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+
+namespace nr {
+// defined in nr_mhsa2.hip: its own translation unit because the register-resident kernel wants the AGPR half of the register
+// file as storage (default MFMA form), while every other kernel is built with -amdgpu-mfma-vgpr-form
+int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream);
+}
 
 namespace {
 
@@ -114,11 +119,8 @@ int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, con
     const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: 2 = register-resident kernel (default); LDS-tile kernels: 42, 81, 82
     int v = var ? atoi(var) : 2;
     if (v == 2) {
-      using G = nr::Mhsa2Geom;
       p.x_save = x_save; x_done = true;
-      if (allow_smem(nr::mhsa_fwd2_kernel, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-      const int per_wg = G::TPW * G::NWAVE;
-      NR_LAUNCH(nr::mhsa_fwd2_kernel, (n_seq + per_wg - 1) / per_wg, 256, G::SMEM, (hipStream_t)stream, p);
+      if (nr::launch_mhsa_fwd2(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
     } else if (v == 42) {
       constexpr int NW = 4, GS = 2;
       using G = nr::MhsaGeom<20, NSEQ, NW>;

@@ -79,6 +79,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 
 template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }   // streaming store: not re-read soon
 
 inline int set_max_dynamic_lds(const void* kernel, int bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;

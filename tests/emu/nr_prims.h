@@ -195,6 +195,7 @@ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __forceinline__ void atomic_add(float* p, float v) { *p += v; }
 
 template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }
+template <typename T> __forceinline__ void st_nt(T* p, T v) { *p = v; }
 
 inline int set_max_dynamic_lds(const void*, int) { return 0; }
 
