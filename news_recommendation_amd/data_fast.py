@@ -1,0 +1,75 @@
+"""GPU-resident training data: the reference's ``BaseDataset`` (src/dataset.py:17-85) builds 53 dicts of
+small tensors per sample in Python and the default collate restacks them per batch in 4 worker processes -- at ~85 k
+impressions/s the engine would starve behind it.  Here the two training files are parsed ONCE:
+
+  news_parsed.tsv       -> one int64 device tensor per attribute, ``[n_news + 1, ...]``; the extra last row is the all-zero
+                           padding news of dataset.py:44-60
+  behaviors_parsed.tsv  -> index arrays: candidates ``[M, 1+K]`` (positive first, data_preprocess.py:63-66), LEFT-padded history
+                           ``[M, N]`` (dataset.py:79-83), user id ``[M]``, clicked_news_length ``[M]``
+
+A batch is then two index gathers on the device and feeds ``model.forward_ids`` (the same stacked-id entry point the
+reference-format ``forward(list-of-dicts)`` reduces to).  Same sample semantics as BaseDataset.__getitem__.
+"""
+from ast import literal_eval
+
+import numpy as np
+import pandas as pd
+import torch
+
+TEXT_ATTRS = ('title', 'abstract', 'title_entities', 'abstract_entities')
+
+
+class TrainData:
+    def __init__(self, behaviors_path, news_path, config, device, rank=0, world=1):
+        attrs = list(config.dataset_attributes['news'])
+        N = config.num_clicked_news_a_user
+        news = pd.read_table(news_path, index_col='id', usecols=['id'] + attrs,
+                             converters={a: literal_eval for a in set(attrs) & set(TEXT_ATTRS)})
+        nid2row = {n: i for i, n in enumerate(news.index)}
+        self.n_news = len(news)
+        self.news = {}
+        for a in attrs:
+            t = np.asarray(news[a].tolist(), dtype=np.int64)
+            pad = np.zeros((1,) + t.shape[1:], dtype=np.int64)
+            self.news[a] = torch.from_numpy(np.concatenate([t, pad])).to(device)
+        beh = pd.read_table(behaviors_path)
+        beh = beh.iloc[rank::world]                                  # data parallel: every rank owns a strided shard of the samples
+        cand, hist, length = [], [], []
+        for c, h in zip(beh['candidate_news'].tolist(), beh['clicked_news'].tolist()):
+            cand.append([nid2row[x] for x in c.split()])
+            clicked = [nid2row[x] for x in str(h).split()[:N]] if isinstance(h, str) else []
+            length.append(len(clicked))
+            hist.append([self.n_news] * (N - len(clicked)) + clicked)
+        self.cand = torch.tensor(cand, dtype=torch.int64, device=device)
+        self.hist = torch.tensor(hist, dtype=torch.int64, device=device)
+        self.length = torch.tensor(length, dtype=torch.int64)          # stays on the host (LSTUR packs with CPU lengths)
+        self.user = torch.tensor(beh['user'].tolist(), dtype=torch.int64, device=device) if 'user' in beh else None
+        self.device = device
+
+    def __len__(self):
+        return self.cand.shape[0]
+
+    def batches(self, batch_size, generator=None):
+        """One shuffled pass, drop_last (DataLoader(shuffle=True, drop_last=True), train.py:118-124)."""
+        perm = torch.randperm(len(self), generator=generator)
+        for i in range(0, len(self) - batch_size + 1, batch_size):
+            yield self.batch(perm[i:i + batch_size])
+
+    def batch(self, idx):
+        di = idx.to(self.device)
+        c, h = self.cand[di], self.hist[di]
+        b = {'cand': {a: t[c] for a, t in self.news.items()}, 'click': {a: t[h] for a, t in self.news.items()}}
+        if self.user is not None:
+            b['user'] = self.user[di]
+        b['length'] = self.length[idx]
+        return b
+
+
+def forward_batch(model, b):
+    """Logits [B, 1+K] of a TrainData batch through the model's stacked-id entry point."""
+    name = type(model).__name__
+    if name == 'NRMS':
+        return model.forward_ids(b['cand']['title'], b['click']['title'])
+    if name == 'LSTUR':
+        return model.forward_ids(b['user'], b['length'].clone(), b['cand'], b['click'])
+    return model.forward_ids(b['cand'], b['click'])

@@ -1,0 +1,158 @@
+"""Training driver with the reference's ``train()`` semantics (src/train.py:67-279) on GPU-resident data.
+
+    python -m news_recommendation_amd.train_fast --workdir RUN_DIR --model NRMS [--reference /path/to/reference/src] [--set k=v ...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m news_recommendation_amd.train_fast ...
+
+Same files (``./data/train/{behaviors_parsed,news_parsed}.tsv``, ``pretrained_word_embedding.npy``, ``./data/val``), same
+hyper-parameters (the reference's ``config.py`` with ``--reference``, else default_config.py), same loop: Adam(lr), CrossEntropy
+against class 0, ``num_epochs * len(dataset) // batch_size`` iterations with reshuffling, loss lines every
+``num_batches_show_loss``, validation every ``num_batches_validate`` on ./data/val (max_count 200000) with early stopping
+(patience 5) on -AUC, and checkpoints ``./checkpoint/<MODEL>/ckpt-<step>.pth`` in the reference's format (resumable by either
+trainer, loadable by ``evaluate.py``).  Different on purpose: the input pipeline (data_fast.py), validation (evaluate_fast.py),
+and data parallelism (each rank a shard of the samples, one flat RCCL all-reduce per step; rank 0 validates and saves).
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+class EarlyStopping:
+    """src/train.py:27-51."""
+
+    def __init__(self, patience=5):
+        self.patience, self.counter, self.best_loss = patience, 0, float('inf')
+
+    def __call__(self, val_loss):
+        if val_loss < self.best_loss:
+            self.counter, self.best_loss = 0, val_loss
+            return False, True
+        self.counter += 1
+        return self.counter >= self.patience, False
+
+
+def latest_checkpoint(directory):
+    """src/train.py:54-64."""
+    if not os.path.exists(directory):
+        return None
+    ck = {int(x.split('.')[-2].split('-')[-1]): x for x in os.listdir(directory)}
+    return os.path.join(directory, ck[max(ck)]) if ck else None
+
+
+def load_config(model_name, reference_src, overrides):
+    if reference_src:
+        os.environ['MODEL_NAME'] = model_name
+        sys.path.insert(0, os.path.abspath(reference_src))
+        sys.dont_write_bytecode = True
+        base = getattr(importlib.import_module('config'), f'{model_name}Config')
+    else:
+        from news_recommendation_amd import default_config
+        base = getattr(default_config, f'{model_name}Config')
+    cfg = type(f'{model_name}Config', (base,), {})
+    for kv in overrides:
+        k, v = kv.split('=', 1)
+        old = getattr(base, k)
+        setattr(cfg, k, type(old)(v) if not isinstance(old, bool) else v == 'True')
+    return cfg
+
+
+def train(model_name, config, workdir='.', max_steps=None, log=print):
+    from news_recommendation_amd import dist as nrdist, evaluate_fast
+    from news_recommendation_amd.data_fast import TrainData, forward_batch
+    import torch.distributed as dist
+    rank, world, local = nrdist.init_from_env()
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    os.chdir(workdir)
+    Model = getattr(importlib.import_module(f'news_recommendation_amd.dropin.model.{model_name}'), model_name)
+    try:
+        pre = torch.from_numpy(np.load('./data/train/pretrained_word_embedding.npy')).float()
+    except FileNotFoundError:
+        pre = None
+    model = Model(config, pre).to(device)
+    nrdist.broadcast_parameters(model)
+    data = TrainData('data/train/behaviors_parsed.tsv', 'data/train/news_parsed.tsv', config, device, rank, world)
+    n_total = len(data) * world
+    if rank == 0:
+        log(f"Load training dataset with size {n_total}.")
+    criterion = torch.nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=config.learning_rate)
+    early_stopping = EarlyStopping()
+    step = 0
+    ckdir = os.path.join('./checkpoint', model_name)
+    if rank == 0:
+        os.makedirs(ckdir, exist_ok=True)
+    path = latest_checkpoint(ckdir)
+    if path is not None:
+        log(f"Load saved parameters in {path}")
+        ck = torch.load(path, map_location=device)
+        early_stopping(ck['early_stop_value'])
+        step = ck['step']
+        model.load_state_dict(ck['model_state_dict'])
+        optimizer.load_state_dict(ck['optimizer_state_dict'])
+    model.train()
+    per_rank_batch = config.batch_size                       # weak scaling: config.batch_size impressions per GPU and step
+    n_iter = config.num_epochs * len(data) // per_rank_batch
+    if max_steps is not None:
+        n_iter = min(n_iter, max_steps)
+    it = data.batches(per_rank_batch)
+    target = torch.zeros(per_rank_batch, dtype=torch.long, device=device)
+    loss_full, t0, seen = [], time.time(), 0
+    for i in range(1, n_iter + 1):
+        try:
+            b = next(it)
+        except StopIteration:
+            it = data.batches(per_rank_batch)
+            b = next(it)
+        step += 1
+        loss = criterion(forward_batch(model, b), target)
+        optimizer.zero_grad()
+        loss.backward()
+        nrdist.allreduce_grads_mean(model)
+        optimizer.step()
+        seen += per_rank_batch * world
+        if i % config.num_batches_show_loss == 0 or i == n_iter:
+            loss_full.append(loss.item())
+            if rank == 0:
+                log(f"Time {time.strftime('%H:%M:%S', time.gmtime(time.time() - t0))}, batches {i}, current loss {loss_full[-1]:.4f}, "
+                    f"average loss: {np.mean(loss_full):.4f}, {seen / (time.time() - t0):.0f} impressions/s")
+        if i % config.num_batches_validate == 0:
+            stop = torch.zeros(1, device=device)
+            if rank == 0:
+                model.eval()
+                auc, mrr, n5, n10 = evaluate_fast.evaluate(model, './data/val', config.num_workers, 200000)
+                model.train()
+                log(f"Time {time.strftime('%H:%M:%S', time.gmtime(time.time() - t0))}, batches {i}, validation AUC: {auc:.4f}, "
+                    f"validation MRR: {mrr:.4f}, validation nDCG@5: {n5:.4f}, validation nDCG@10: {n10:.4f}, ")
+                early_stop, get_better = early_stopping(-auc)
+                if early_stop:
+                    log('Early stop.')
+                    stop += 1
+                elif get_better:
+                    torch.save({'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(), 'step': step,
+                                'early_stop_value': -auc}, f"./checkpoint/{model_name}/ckpt-{step}.pth")
+            if world > 1:
+                dist.broadcast(stop, src=0)
+            if stop.item() > 0:
+                break
+    torch.cuda.synchronize()
+    return {'steps': i, 'impressions_per_s': seen / max(time.time() - t0, 1e-9), 'last_loss': float(loss.item()), 'model': model}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--workdir', default='.')
+    ap.add_argument('--model', default=os.environ.get('MODEL_NAME', 'NRMS'), choices=['NRMS', 'NAML', 'LSTUR'])
+    ap.add_argument('--reference', default=None, help="reference checkout's src/ directory: use its config.py")
+    ap.add_argument('--set', nargs='*', default=[], metavar='KNOB=VALUE', help='override config attributes')
+    ap.add_argument('--max-steps', type=int, default=None)
+    a = ap.parse_args(argv)
+    train(a.model, load_config(a.model, a.reference, a.set), a.workdir, a.max_steps)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,89 @@
+"""GPU-resident training data + fast trainer.  CPU (build container): default_config mirrors the reference's
+config.py and TrainData reproduces BaseDataset's samples.  GPU: a short run trains, validates with the batched evaluator,
+writes a reference-format checkpoint and resumes from it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/src'
+
+DATA_VS_REFERENCE = r'''
+import os, sys
+import numpy as np, torch
+sys.dont_write_bytecode = True
+root, ref, workdir, model_name = sys.argv[1:5]
+os.environ['MODEL_NAME'] = model_name
+sys.path.insert(0, ref); sys.path.insert(0, root)
+os.chdir(workdir)
+import config as ref_config
+import dataset as ref_dataset                                   # the reference's dataset.py (read-only)
+from news_recommendation_amd import default_config
+from news_recommendation_amd.data_fast import TrainData
+rc = getattr(ref_config, model_name + 'Config'); dc = getattr(default_config, model_name + 'Config')
+for k in dir(dc):
+    if not k.startswith('_'):
+        assert getattr(rc, k) == getattr(dc, k), k
+ds = ref_dataset.BaseDataset('data/train/behaviors_parsed.tsv', 'data/train/news_parsed.tsv')
+td = TrainData('data/train/behaviors_parsed.tsv', 'data/train/news_parsed.tsv', rc, 'cpu')
+assert len(ds) == len(td)
+idx = torch.tensor([0, 3, len(ds) - 1, 7])
+b = td.batch(idx)
+for j, i in enumerate(idx.tolist()):
+    it = ds[i]
+    for c in range(len(it['candidate_news'])):
+        for a in rc.dataset_attributes['news']:
+            assert torch.equal(torch.as_tensor(it['candidate_news'][c][a]), b['cand'][a][j, c]), (i, c, a)
+    for n in range(rc.num_clicked_news_a_user):
+        for a in rc.dataset_attributes['news']:
+            assert torch.equal(torch.as_tensor(it['clicked_news'][n][a]), b['click'][a][j, n]), (i, n, a)
+    if 'user' in rc.dataset_attributes['record']:
+        assert it['user'] == int(b['user'][j]) and it['clicked_news_length'] == int(b['length'][j])
+shard = TrainData('data/train/behaviors_parsed.tsv', 'data/train/news_parsed.tsv', rc, 'cpu', rank=1, world=2)
+assert len(shard) == len(ds) // 2 and torch.equal(shard.cand[0], td.cand[1])
+print('data ok', model_name, len(ds))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_train_data_matches_reference_dataset(tmp_path, model_name):
+    from news_recommendation_amd import synth
+    synth.write_reference_dataset(str(tmp_path))
+    p = subprocess.run([sys.executable, '-c', DATA_VS_REFERENCE, ROOT, REF, str(tmp_path), model_name],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert p.returncode == 0 and 'data ok' in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_fast_trainer_trains_validates_checkpoints_and_resumes(tmp_path, model_name):
+    from news_recommendation_amd import synth, train_fast
+    synth.write_reference_dataset(str(tmp_path), n_news=300, n_train=512, n_val_impr=40, num_words=500)
+    over = ['batch_size=64', 'num_words=500', 'num_users=41', 'num_categories=30', 'learning_rate=0.002', 'num_epochs=6',
+            'num_batches_show_loss=4', 'num_batches_validate=16']
+    cfg = train_fast.load_config(model_name, None, over)
+    lines = []
+    cwd = os.getcwd()
+    try:
+        torch.manual_seed(0)
+        r = train_fast.train(model_name, cfg, str(tmp_path), log=lines.append)
+        assert r['steps'] == 48
+        losses = [float(l.split('current loss ')[1].split(',')[0]) for l in lines if 'current loss' in l]
+        assert losses[-1] < losses[0] - 0.05, losses                      # it learns the (fixed) synthetic clicks
+        assert sum('validation AUC' in l for l in lines) == 3
+        ck = sorted(os.listdir(os.path.join(tmp_path, 'checkpoint', model_name)))
+        assert ck and all(c.startswith('ckpt-') and c.endswith('.pth') for c in ck)
+        sd = torch.load(os.path.join(tmp_path, 'checkpoint', model_name, ck[-1]), map_location='cpu')
+        assert set(sd) == {'model_state_dict', 'optimizer_state_dict', 'step', 'early_stop_value'}      # train.py:264-277
+        assert set(sd['model_state_dict']) == set(r['model'].state_dict())
+        lines.clear()
+        os.chdir(cwd)
+        r2 = train_fast.train(model_name, cfg, str(tmp_path), max_steps=2, log=lines.append)
+        assert any('Load saved parameters' in l for l in lines) and r2['steps'] == 2
+    finally:
+        os.chdir(cwd)
