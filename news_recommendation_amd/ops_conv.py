@@ -10,7 +10,7 @@ from . import ops
 from .ops import (_lib, _stream, _call, _ptr, _f32c, _bf16, _mm, _timed, _workspace, _require_cuda, pack_additive,
                   _BF16_AS_I16, NR_D, NR_KP, NR_QP)
 
-CHUNK = 2048          # rows per batched-GEMM chunk of the conv weight gradient
+WGRAD_CHUNKS = 64     # batched-GEMM chunks of the conv weight gradient ([320 x rows]^T x [rows x 320] per tap: ~4 output tiles each)
 
 
 def check_conv_dims(config_like_d, num_filters, window, qdim):
@@ -35,9 +35,11 @@ def pack_conv(W, b):
 
 
 def _seqpad_alloc(n_seq, S):
+    """(seqpad rows, chunk count, allocated rows = chunk count x chunk rows)."""
     rp = n_seq * (S + 1) + 1
-    nc = (rp + CHUNK - 1) // CHUNK
-    return rp, nc, nc * CHUNK
+    nc = WGRAD_CHUNKS if rp >= WGRAD_CHUNKS * 512 else max(1, rp // 512)
+    chunk = ((rp + nc - 1) // nc + 7) // 8 * 8
+    return rp, nc, nc * chunk
 
 
 class _TextState:
@@ -106,14 +108,17 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_D, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
           n_seq, S, p, _stream())
-    dy_b = _bf16(dy).view(nc, CHUNK, NR_KP).transpose(1, 2)
+    dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
     xs_b = _bf16(st.xstore)
 
     def wgrad():
         taps = []
         for w in range(3):          # dW[:, w, :] = dY^T @ X[row + w - 1]: the tap shift is a row offset into the seqpad store
-            xw = xs_b[w:w + ra].view(nc, CHUNK, NR_KP)
-            taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
+            xw = xs_b[w:w + ra].view(nc, ra // nc, NR_KP)
+            try:
+                taps.append(torch.bmm(dy_b, xw, out_dtype=torch.float32).sum(dim=0))
+            except (TypeError, RuntimeError):
+                taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
         return taps
     taps = _timed(f'gemm_dWconv[{tag}]', wgrad)
     d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
