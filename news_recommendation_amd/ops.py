@@ -294,10 +294,10 @@ class _EncoderFn(torch.autograd.Function):
         dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
         dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
-        dctx_gemm = _mm(dpre_b, Wap_b[:, :NR_D], f'gemm_dctx[S={S}]')             # [ntok, D] bf16
+        dctx_gemm = _mm(dpre_b, Wap_b, f'gemm_dctx[S={S}]')                       # [ntok, KP] bf16 (full padded width: the contiguous operand runs ~5 % faster)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
-        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(dqkv),
+        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                             n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
         # ---- weight gradients: dW_ext = dqkv^T @ [X | 1] --------------------------------------------------------------
@@ -305,7 +305,8 @@ class _EncoderFn(torch.autograd.Function):
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
-        dX = _mm(dqkv_b, _bf16(Wp)[:, :NR_D], f'gemm_dX[S={S}]')          # [ntok, D] bf16
+        WpT = _bf16(Wp).t().contiguous()                                   # [KP, 960]: the 'linear' operand form is the fastest hipBLASLt path here
+        dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:
@@ -313,10 +314,10 @@ class _EncoderFn(torch.autograd.Function):
                 dXi = dX.view(_BF16_AS_I16)
                 # sort token ids so that every table row is reduced by adjacent lanes instead of contended atomics
                 ids_sorted, perm = sorted_ids_ready(ctx.sorted)
-                _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_D,
+                _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_KP,
                       _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
         elif ctx.needs_input_grad[2]:
-            d_x = dX.float().view(n_seq, S, NR_D)
+            d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)
 
 

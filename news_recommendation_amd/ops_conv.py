@@ -80,7 +80,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
 
 def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
-    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][D]); the caller adds the direct term aw (x) g."""
+    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g."""
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
@@ -92,7 +92,7 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag):
     d_qv = dq_part.sum(dim=0)[:qdim]
     dpre_b = _bf16(dpre)
     dWa_ext = ops._wgrad(dpre_b, _bf16(ctx_b), f'gemm_dWa[{tag}]')
-    dgemm = _mm(dpre_b, _bf16(Wap)[:, :NR_D], f'gemm_dctx[{tag}]')
+    dgemm = _mm(dpre_b, _bf16(Wap), f'gemm_dctx[{tag}]')                 # [ntok, KP]: full padded width (contiguous operand)
     return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
 
 
@@ -106,7 +106,7 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag)
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
-    _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_D, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
+    _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_KP, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
           n_seq, S, p, _stream())
     dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
     xs_b = _bf16(st.xstore)
@@ -206,7 +206,7 @@ class _NamlNewsFn(torch.autograd.Function):
         # final attention over the 4 views
         d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views')
         gv = _workspace('gviews', (4, T, NR_D), torch.float32, dev)               # view-major: 4 contiguous [T][D] blocks
-        _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_D, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
+        _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
         # element encoders: reduce per category row, then the tiny table backward
         ncat, dcat = embf.shape
         dE = torch.stack([_sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1), _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1)])
@@ -268,7 +268,7 @@ class _PoolFn(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}')
         dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
-        _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_D, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
+        _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
         return dx, None, d_Wa, d_ba, d_qv
 
 
