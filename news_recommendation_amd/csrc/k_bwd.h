@@ -75,8 +75,11 @@ struct AttnBwdRegs {
 //           a second tile fills slots j >= 4).  So everything that contracts over the ROW index of a CL tile is free.
 //   Transposes LDS->CL are done by the matrix core itself: CL(M) = AL(M) x Identity.
 // No scattered LDS writes, one wave barrier per pair.
+#ifndef NR_ATTN_OCC
+#define NR_ATTN_OCC 1      // minimum workgroups per CU the register allocation must allow (tuning knob)
+#endif
 template <int S, int WPB>
-__global__ __launch_bounds__(WPB * 64) void attn_bwd_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwdParams p) {
   using Gm = AttnBwdGeom<S, WPB>;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;

@@ -209,12 +209,12 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
     constexpr int WPB = 4;
     using G = nr::AttnBwdGeom<20, WPB>;
     if (allow_smem(nr::attn_bwd_kernel<20, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 3 * 2), WPB * 64, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 24), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 50) {
     constexpr int WPB = 2;
     using G = nr::AttnBwdGeom<50, WPB>;
     if (allow_smem(nr::attn_bwd_kernel<50, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::attn_bwd_kernel<50, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 2 * 2), WPB * 64, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::attn_bwd_kernel<50, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 8), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else {
     return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd: sequence length not instantiated (20, 50)");
   }
