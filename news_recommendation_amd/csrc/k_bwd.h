@@ -370,8 +370,8 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
   // three lanes per token, 25 quads (100 columns) each; partials combined through LDS (dqp is still free here)
   {
     float* dwp = dqp;                                   // [3][ROWS] scratch (4*QP floats >= 3*ROWS)
-    const int tok = tid / 3, part = tid - tok * 3;
-    if (tok < Gm::TOK) {
+    for (int idx = tid; idx < Gm::TOK * 3; idx += WG) {
+      const int tok = idx / 3, part = idx - tok * 3;
       const int seq = tok / S;
       float a = 0.0f;
       if (seq0 + seq < p.n_seq) {

@@ -169,7 +169,7 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 50) {
-    constexpr int NSEQ = 1;
+    constexpr int NSEQ = 1;          // (2 sequences per workgroup measured no faster for 27k abstracts and 2x slower for 512 histories)
     using G = nr::AddGeom<50, NSEQ>;
     if (allow_smem(nr::additive_fwd_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
@@ -245,7 +245,7 @@ int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
     constexpr int NSEQ = 1;
     using G = nr::AddGeom<50, NSEQ>;
     if (allow_smem(nr::additive_bwd_kernel<50, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_bwd_kernel<50, NSEQ>), n_seq, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::additive_bwd_kernel<50, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
   } else if (S == 4) {
     constexpr int NSEQ = 20;
     using G = nr::AddGeom<4, NSEQ>;

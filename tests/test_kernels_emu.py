@@ -20,7 +20,7 @@ def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=2)
 def test_mhsa_x_save(be): kc.check_mhsa_x_save(be)
 def test_mhsa_x_save_s50(be): kc.check_mhsa_x_save(be, S=50, n_seq=2, p_drop=0.0)
 def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=6)
-def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=2)
+def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=3)
 def test_score_dot(be): kc.check_score_dot(be)
 def test_score_csr(be): kc.check_score_csr(be)
 def test_impression_metrics(be): kc.check_impression_metrics(be)
@@ -29,7 +29,7 @@ def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=3)
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0.2)
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=1)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=6)
-def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=2)
+def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=3)
 def test_gather_bf16(be): kc.check_gather_bf16(be)
 def test_scatter_add(be): kc.check_scatter_add(be)
 def test_score_bwd(be): kc.check_score_bwd(be)
