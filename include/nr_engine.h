@@ -112,6 +112,14 @@ int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
                     const float* attn_w, const float* g_out, uint16_t* dpre, float* dq_part, int64_t n_seq, int S,
                     void* stream);
 
+/* nr_additive_bwd that also emits the GEMM part of the input gradient, dctx bf16[n_seq*S][NR_KP] (columns < D) = dpre @ Wa, from
+ * WaT bf16[NR_KP][NR_QKP] = Wa^T (nr_pack_additive_t); saves the caller one [tokens x 208] x [208 x 300] library GEMM and a pass over dpre. */
+#define NR_QKP 224     /* NR_QP rounded up to the MFMA k-step */
+int nr_pack_additive_t(const float* Wa, int qdim, uint16_t* WaT, void* stream);
+int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w,
+                       const float* g_out, uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx, int64_t n_seq, int S,
+                       void* stream);
+
 /* Token matrix for the weight-gradient GEMM dW = dqkv^T @ Xb: Xb bf16[n_tokens][NR_KP] = dropout1(table[ids]) (or
  * dense f32 rows), column D = 1.0 (bias gradient), rest 0. */
 int nr_gather_bf16(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, uint16_t* Xb,

@@ -341,6 +341,8 @@ struct AdditiveBwdParams {
   const float* g_out;    // [n_seq][D]
   u16* dpre;             // [n_seq*S][QP] bf16
   float* dq_part;        // [gridDim.x][QP]  per-workgroup partial gradient of the query vector
+  const u16* WaT;        // optional: bf16 [KP][QKP] = Wa^T (pack_additive_t) -> the kernel also emits dctx = dpre @ Wa
+  u16* dctx;             // optional: bf16 [n_seq*S][KP] (columns < D written)
   int64_t n_seq;
 };
 
@@ -445,6 +447,53 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
   __syncthreads();
   for (int n = tid; n < QP; n += WG)
     p.dq_part[(int64_t)blockIdx.x * QP + n] = dqp[n] + dqp[QP + n] + dqp[2 * QP + n] + dqp[3 * QP + n];
+
+  // ---- fused input-gradient product dctx[tok][:] = dpre[tok][:] @ Wa (the GEMM part of d ctx; the direct term attn_w (x) g_out is
+  //      added by the consumer).  The workgroup's dpre tile was just written to global memory by its own waves (L2-hot): it is
+  //      re-read into the LDS region of the no longer needed ctx tile as the MFMA B operand; A = rows of Wa^T straight from L2.
+  if (p.dctx != nullptr) {
+    constexpr int PS2 = QKP + 8;            // 232: conflict-free b128 fragment reads
+    constexpr int PC2 = PS2 / 8;            // 29 16-B pieces per LDS row
+    constexpr int KS2 = QKP / 32;           // 7 k-steps
+    u16* Ps = Xs;
+    // (the barrier above is a workgroup-scope release/acquire; all waves of the workgroup share this CU's L1, so the re-read sees
+    //  their stores -- an agent-scope fence here costs an L2 writeback per workgroup and made the kernel 5x slower)
+    for (int i = tid; i < Gm::ROWS * PC2; i += WG) {
+      const int r = i / PC2, c = i - r * PC2;
+      u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < QP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.dpre + (tok0 + r) * QP + c * 8);
+      *(u16x8*)(Ps + r * PS2 + c * 8) = v;
+    }
+    __syncthreads();
+    constexpr int NTD = (D + 15) / 16;      // 19 output column tiles
+    for (int cg = 0; cg < (NTD + 1) / 2; ++cg) {
+      int G, mb, me;
+      unit_range(NTD, Gm::MT, w_eff, 4, cg, G, mb, me);
+      if (mb >= me) continue;
+      const int wr0 = (2 * cg) * 16, wr1 = G == 2 ? wr0 + 16 : wr0;
+      u16x8 wf[2][KS2];
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        wf[0][ks] = *(const u16x8*)(p.WaT + (size_t)(wr0 + li) * QKP + ks * 32 + g * 8);
+        wf[1][ks] = *(const u16x8*)(p.WaT + (size_t)(wr1 + li) * QKP + ks * 32 + g * 8);
+      }
+      for (int m = mb; m < me; ++m) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const u16* xp = Ps + (m * 16 + li) * PS2 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          const u16x8 xf = *(const u16x8*)(xp + ks * 32);
+          a0 = mfma_16x16x32_bf16(wf[0][ks], xf, a0);
+          if (G == 2) a1 = mfma_16x16x32_bf16(wf[1][ks], xf, a1);
+        }
+        const int r_ = m * 16 + li;
+        if (r_ < Gm::TOK && tok0 + r_ < tok_total) {
+          if (wr0 + 4 * g < D) *(u16x4*)(p.dctx + (tok0 + r_) * KP + wr0 + 4 * g) = pack4(a0);
+          if (G == 2 && wr1 + 4 * g < D) *(u16x4*)(p.dctx + (tok0 + r_) * KP + wr1 + 4 * g) = pack4(a1);
+        }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restr
   }
 }
 
+// AdditiveAttention.linear weight transposed for the fused input-gradient product of additive_bwd: WaT bf16 [KP][QKP] with
+// WaT[d][q] = Wa[q][d], zero padded (QKP = QP rounded up to the MFMA k-step of 32).
+constexpr int QKP = (QP + 31) / 32 * 32;    // 224
+__global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __restrict__ Wa, int qdim, u16* __restrict__ WaT) {
+  const int total = KP * QKP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int d = i / QKP, q = i - d * QKP;
+    WaT[i] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
+  }
+}
+
 // ---- K7: dot-product scorers -------------------------------------------------------------------------------
 // one wave per (b, c) pair; lanes stride the feature dim with float4 loads, shuffle-reduce.
 __device__ __forceinline__ float wave_sum(float v) {

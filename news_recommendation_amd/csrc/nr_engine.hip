@@ -228,14 +228,31 @@ int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
   return -1;
 }
 
+int nr_pack_additive_t(const float* Wa, int qdim, uint16_t* WaT, void* stream) {
+  if (!Wa || !WaT) return fail(NR_ERR_BADARG, "nr_pack_additive_t: null pointer");
+  if (qdim <= 0 || qdim > NR_QP) return fail(NR_ERR_UNSUPPORTED, "nr_pack_additive_t: query_vector_dim must be in [1,208]");
+  NR_LAUNCH(nr::pack_additive_t_kernel, 64, 256, 0, (hipStream_t)stream, Wa, qdim, WaT);
+  return check_launch("nr_pack_additive_t");
+}
+
+int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w,
+                       const float* g_out, uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx, int64_t n_seq, int S,
+                       void* stream);
+
 int nr_additive_bwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w,
                     const float* g_out, uint16_t* dpre, float* dq_part, int64_t n_seq, int S, void* stream) {
-  if (!ctx || !Wap || !bap || !qvp || !attn_w || !g_out || !dpre || !dq_part || n_seq < 0)
+  return nr_additive_bwd_ex(ctx, Wap, bap, qvp, attn_w, g_out, dpre, dq_part, nullptr, nullptr, n_seq, S, stream);
+}
+
+int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w,
+                       const float* g_out, uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx, int64_t n_seq, int S,
+                       void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || !attn_w || !g_out || !dpre || !dq_part || n_seq < 0 || ((WaT == nullptr) != (dctx == nullptr)))
     return fail(NR_ERR_BADARG, "nr_additive_bwd: bad argument");
   if (n_seq == 0) return NR_OK;
   nr::AdditiveBwdParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
-  p.dq_part = dq_part; p.n_seq = n_seq;
+  p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq;
   if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;

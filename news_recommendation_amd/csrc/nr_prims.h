@@ -67,6 +67,10 @@ __device__ __forceinline__ void wave_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// agent-scope release + acquire: this wave's global stores are visible device-wide and its L1 is invalidated, so data written to
+// global memory by other waves (before a barrier) is re-read from L2, never from a stale L1 line
+__device__ __forceinline__ void fence_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

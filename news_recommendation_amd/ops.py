@@ -126,6 +126,14 @@ def pack_additive(Wa, ba, qv):
     return Wap, bap, qvp
 
 
+def pack_additive_t(Wa):
+    """Wa^T as the bf16 [KP][QKP] operand of the fused input-gradient product inside nr_additive_bwd_ex."""
+    WaT = torch.empty(NR_KP, 224, dtype=_BF16_AS_I16, device=Wa.device)
+    a = _f32c(Wa)
+    _call('nr_pack_additive_t', _lib().nr_pack_additive_t, _ptr(a), Wa.shape[0], _ptr(WaT), _stream())
+    return WaT
+
+
 def _bf16(t_i16):
     return t_i16.view(torch.bfloat16)
 
@@ -248,6 +256,7 @@ class _EncoderFn(torch.autograd.Function):
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
+        WaT = pack_additive_t(Wa) if need_grad else None
         if need_grad:
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
@@ -271,7 +280,7 @@ class _EncoderFn(torch.autograd.Function):
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
         if need_grad:
-            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, xb)
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, xb, WaT)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
             ctx.sorted = sort_ids_async(ids_c) if gather and ctx.needs_input_grad[1] else None
         return out
@@ -279,7 +288,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, Xb = ctx.saved_tensors
+        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, Xb, WaT = ctx.saved_tensors
         S, p_drop, seed, n_seq, qdim, gather = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
@@ -288,13 +297,13 @@ class _EncoderFn(torch.autograd.Function):
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
         dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
-                                _ptr(dq_part), n_seq, S, _stream())
+        dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
+        _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
+                                _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
         dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
         dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
-        dctx_gemm = _mm(dpre_b, Wap_b, f'gemm_dctx[S={S}]')                       # [ntok, KP] bf16 (full padded width: the contiguous operand runs ~5 % faster)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),

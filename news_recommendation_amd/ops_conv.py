@@ -44,7 +44,7 @@ def _seqpad_alloc(n_seq, S):
 
 class _TextState:
     """What one text encoder keeps between forward and backward."""
-    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wap', 'bap', 'qvp', 'qdim', 'tok_offset')
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset')
 
 
 def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag):
@@ -59,6 +59,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     st.S, st.n_seq, st.tok_offset, st.qdim = S, n_seq, tok_offset, Wa.shape[0]
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
+    st.WaT = ops.pack_additive_t(Wa) if need_grad else None
     st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
     xs_ptr = None
     st.xstore = None
@@ -78,7 +79,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
     Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g."""
     lib = _lib()
@@ -87,12 +88,12 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag):
     nwg = lib.nr_additive_bwd_grid(n_seq, S)
     dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
     dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
-          _ptr(dq_part), n_seq, S, _stream())
+    dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
+    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_ex, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
+          _ptr(dq_part), _ptr(WaT), _ptr(dgemm), n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
     dpre_b = _bf16(dpre)
     dWa_ext = ops._wgrad(dpre_b, _bf16(ctx_b), f'gemm_dWa[{tag}]')
-    dgemm = _mm(dpre_b, _bf16(Wap), f'gemm_dctx[{tag}]')                 # [ntok, KP]: full padded width (contiguous operand)
     return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
 
 
@@ -103,7 +104,7 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     n_seq, S = st.n_seq, st.S
     dev = st.act.device
     # additive backward needs contiguous [n_seq][D] gradients
-    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag)
+    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT)
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_KP, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
@@ -181,13 +182,14 @@ class _NamlNewsFn(torch.autograd.Function):
         _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(bc_), _ptr(Ws_), _ptr(bs_), _ptr(E), _stream())
         _call('nr_views_fill', lib.nr_views_fill, _ptr(cat), _ptr(sub), _ptr(E), ncat, _ptr(views), T, _stream())
         Wap, bap, qvp = pack_additive(Wa_f, ba_f, qv_f)
+        WaT = ops.pack_additive_t(Wa_f) if need_grad else None
         out = torch.empty(T, NR_D, dtype=torch.float32, device=dev)
         out_b = torch.empty(T, NR_KP, dtype=_BF16_AS_I16, device=dev)
         aw = torch.empty(T, 4, dtype=torch.float32, device=dev)
         _call('nr_additive_fwd[views]', lib.nr_additive_fwd_ex, _ptr(views), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, _ptr(out_b), NR_KP,
               _ptr(aw), T, 4, _stream())
         if need_grad:
-            ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp)
+            ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT)
             ctx.st = (st_t, st_a)
             ctx.meta = (p, seed, Wa_f.shape[0])
             ctx.sorted = sort_tokens_async([title, abstract]) if ctx.needs_input_grad[4] else None
@@ -197,14 +199,14 @@ class _NamlNewsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_b):
         lib = _lib()
-        title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp = ctx.saved_tensors
+        title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT = ctx.saved_tensors
         st_t, st_a = ctx.st
         p, seed, qdim = ctx.meta
         dev = views.device
         T = title.shape[0]
         g_out = g_out.to(torch.float32).contiguous()
         # final attention over the 4 views
-        d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views')
+        d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views', WaT)
         gv = _workspace('gviews', (4, T, NR_D), torch.float32, dev)               # view-major: 4 contiguous [T][D] blocks
         _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
         # element encoders: reduce per category row, then the tiny table backward
@@ -256,17 +258,17 @@ class _PoolFn(torch.autograd.Function):
         aw = torch.empty(n, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_ex, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
               _ptr(aw), n, S, _stream())
-        ctx.save_for_backward(x_b, aw, Wap, bap, qvp)
+        ctx.save_for_backward(x_b, aw, Wap, bap, qvp, ops.pack_additive_t(Wa))
         ctx.qdim = Wa.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib()
-        x_b, aw, Wap, bap, qvp = ctx.saved_tensors
+        x_b, aw, Wap, bap, qvp, WaT = ctx.saved_tensors
         n, S = aw.shape
         g = g.to(torch.float32).contiguous()
-        d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}')
+        d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}', WaT)
         dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
         _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
         return dx, None, d_Wa, d_ba, d_qv

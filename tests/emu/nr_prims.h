@@ -186,6 +186,7 @@ __forceinline__ float shfl(float v, int src) {
 }
 
 __forceinline__ void wave_barrier() { nr_emu::wave_sync(); }
+__forceinline__ void fence_agent() {}
 
 __forceinline__ float fast_exp(float x) { return expf(x); }
 __forceinline__ float fast_tanh(float x) { return tanhf(x); }

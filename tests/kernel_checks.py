@@ -330,9 +330,24 @@ def check_additive_bwd(be, S=20, n_seq=6):
     nwg = be.lib.nr_additive_bwd_grid(n_seq, S)
     dpre = be.empty((n_seq * S, NR_QP), np.uint16)
     dqp = be.poison((nwg, NR_QP), np.float32)
-    ck(be, be.lib.nr_additive_bwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)),
-                                  be.ptr(dpre), be.ptr(dqp), n_seq, S, be.stream))
+    a_ = 'news_encoder.additive_attention.'
+    WaT = be.poison((NR_KP, 224), np.uint16)
+    ck(be, be.lib.nr_pack_additive_t(be.ptr(be.dev(params[a_ + 'linear.weight'])), 200, be.ptr(WaT), be.stream))
+    dctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    ck(be, be.lib.nr_additive_bwd_ex(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)),
+                                     be.ptr(dpre), be.ptr(dqp), be.ptr(WaT), be.ptr(dctx), n_seq, S, be.stream))
     be.sync()
+    # fused input-gradient product: dctx[:, :D] = bf16(dpre) @ bf16(Wa), bit-level inputs as the kernel sees them
+    wat = be.np(WaT)
+    assert np.array_equal(wat[:NR_D, :200], f32_to_bf16(params[a_ + 'linear.weight']).T) and not wat[NR_D:].any() and not wat[:, 200:].any()
+    dref = bf16_to_f32(be.np(dpre)).astype(np.float64)[:, :200] @ bf16_round(params[a_ + 'linear.weight']).astype(np.float64)
+    close_bf16(bf16_to_f32(be.np(dctx)[:, :NR_D]), dref, f'additive_bwd fused dctx S={S}', rel=2.0 ** -7, floor=1e-3)
+    # and the plain entry point gives the same dpre / dq
+    dpre2 = be.empty((n_seq * S, NR_QP), np.uint16); dqp2 = be.poison((nwg, NR_QP), np.float32)
+    ck(be, be.lib.nr_additive_bwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)),
+                                  be.ptr(dpre2), be.ptr(dqp2), n_seq, S, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(dpre), be.np(dpre2)) and np.array_equal(be.np(dqp), be.np(dqp2))
     a = 'news_encoder.additive_attention.'
     x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)
     W = bf16_round(params[a + 'linear.weight']).astype(np.float64)
