@@ -49,9 +49,10 @@ struct ConvParams {
   DropCfg dc;
 };
 
-template <int S, int NSEQ>
-__global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
+template <int S, int NSEQ, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
   using Gm = ConvGeom<S, NSEQ>;
+  constexpr int WG = NW * 64;          // shadows nr::WG: this kernel runs with 4 or 8 waves
   NR_SMEM_DECL(smem);
   u16* Xs = (u16*)smem;
   int* ids_s = (int*)(smem + Gm::X_BYTES);
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(WG, 2) void conv3_kernel(ConvParams p) {
   }
 
   // ---- GEMM over the three taps ----------------------------------------------------------------------------------
-  const int w_eff = (w + (int)blockIdx.x) & 3;
+  const int w_eff = (w + (int)blockIdx.x) % NW;
   for (int cg = 0; cg < (NTF + 1) / 2; ++cg) {
     int G, mb, me;
-    unit_range(NTF, Gm::MT, w_eff, 4, cg, G, mb, me);
+    unit_range(NTF, Gm::MT, w_eff, NW, cg, G, mb, me);
     if (mb >= me) continue;
     const int wr0 = (2 * cg) * 16, wr1 = (G == 2) ? wr0 + 16 : wr0;     // G == 1: second column is a dead duplicate
     f32x4 acc[Gm::MT][2];

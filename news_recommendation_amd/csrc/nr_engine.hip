@@ -57,6 +57,14 @@ int grid_for(int64_t work, int per_block, int cap) {
 template <typename K>
 int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
 
+template <int S, int NSEQ, int NW>
+int launch_conv_t(nr::ConvParams& p, void* stream) {
+  using G = nr::ConvGeom<S, NSEQ>;
+  if (allow_smem(nr::conv3_kernel<S, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
+  NR_LAUNCH((nr::conv3_kernel<S, NSEQ, NW>), (p.n_seq + NSEQ - 1) / NSEQ, NW * 64, G::SMEM, (hipStream_t)stream, p);
+  return NR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -358,16 +366,17 @@ int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uin
 }
 
 static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what) {
+  // tuning knob NR_CONV_VARIANT: 0 = 4 waves on 4 titles / 2 abstracts (two workgroups per CU); 1 (default) = 8 waves on 8 titles /
+  // 4 abstracts (one workgroup per CU, the filter bank is re-read from L2 half as often: ~10 % faster at B = 512)
+  const char* var = getenv("NR_CONV_VARIANT");
+  const int v = var ? atoi(var) : 1;
+  int rc;
   if (S == 20) {
-    constexpr int NSEQ = 4;
-    using G = nr::ConvGeom<20, NSEQ>;
-    if (allow_smem(nr::conv3_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
-    NR_LAUNCH((nr::conv3_kernel<20, NSEQ>), (p.n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+    rc = v == 1 ? launch_conv_t<20, 8, 8>(p, stream) : launch_conv_t<20, 4, 4>(p, stream);
+    if (rc) return rc;
   } else if (S == 50) {
-    constexpr int NSEQ = 2;
-    using G = nr::ConvGeom<50, NSEQ>;
-    if (allow_smem(nr::conv3_kernel<50, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
-    NR_LAUNCH((nr::conv3_kernel<50, NSEQ>), (p.n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
+    rc = v == 1 ? launch_conv_t<50, 4, 8>(p, stream) : launch_conv_t<50, 2, 4>(p, stream);
+    if (rc) return rc;
   } else {
     return fail(NR_ERR_UNSUPPORTED, "conv3: sequence length not instantiated (20, 50)");
   }
