@@ -13,17 +13,19 @@
 
 namespace nr {
 
-template <int S, int NSEQ>
+template <int S, int NSEQ, int NW = 4>
 struct AddGeom {
+  static constexpr int THREADS = NW * 64;
   static constexpr int TOK = S * NSEQ;
   static constexpr int MT = (TOK + 15) / 16;
   static constexpr int ROWS = MT * 16;
   static constexpr int X_BYTES = ROWS * XS * 2;
-  static constexpr int SC_BYTES = 4 * ROWS * 4;     // per-wave partial scores
+  static constexpr int SC_BYTES = NW * ROWS * 4;    // per-wave partial scores
   static constexpr int W_BYTES = ROWS * 4;          // softmax weights
   static constexpr int SMEM = X_BYTES + SC_BYTES + W_BYTES;
   static constexpr int NTQ = QP / 16;               // 13 n-tiles of the query dim
-  static constexpr int BWD_SMEM = X_BYTES + 4 * QP * 4 + ROWS * 4;   // backward: tile + dq partials + ds
+  static constexpr int DQ_FLOATS = NW * QP > 3 * ROWS ? NW * QP : 3 * ROWS;     // dq partials, also the 3 x ROWS scratch of the dw pass
+  static constexpr int BWD_SMEM = X_BYTES + DQ_FLOATS * 4 + ROWS * 4;   // backward: tile + dq partials + ds
 };
 
 struct AdditiveParams {
@@ -39,9 +41,10 @@ struct AdditiveParams {
   int64_t n_seq;
 };
 
-template <int S, int NSEQ>
-__global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
-  using Gm = AddGeom<S, NSEQ>;
+template <int S, int NSEQ, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p) {
+  using Gm = AddGeom<S, NSEQ, NW>;
+  constexpr int WG = NW * 64;          // shadows nr::WG: 4 or 8 waves
   NR_SMEM_DECL(smem);
   u16* Xs = (u16*)smem;
   float* sc = (float*)(smem + Gm::X_BYTES);            // [4][ROWS]
@@ -58,15 +61,15 @@ __global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
     if (c < KP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.ctx + (tok0 + r) * KP + c * 8);
     *(u16x8*)(Xs + r * XS + c * 8) = v;
   }
-  for (int i = tid; i < 4 * Gm::ROWS; i += WG) sc[i] = 0.0f;
+  for (int i = tid; i < NW * Gm::ROWS; i += WG) sc[i] = 0.0f;
   __syncthreads();
 
   // ---- scores: sum_n tanh(x.Wa[n] + ba[n]) * qv[n] ---------------------------------------------------------
-  const int w_eff = (w + (int)blockIdx.x) & 3;
+  const int w_eff = (w + (int)blockIdx.x) % NW;
   float* myrow = sc + w * Gm::ROWS;
   for (int cg = 0; cg < (Gm::NTQ + 1) / 2; ++cg) {
     int G, mb, me;
-    unit_range(Gm::NTQ, Gm::MT, w_eff, 4, cg, G, mb, me);
+    unit_range(Gm::NTQ, Gm::MT, w_eff, NW, cg, G, mb, me);
     if (mb >= me) continue;
     auto epi = [&](int wr, int m, f32x4 acc) {          // acc already holds x.Wa[n] + ba[n] (bias = accumulator init)
       f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
@@ -90,10 +93,15 @@ __global__ __launch_bounds__(WG, 2) void additive_fwd_kernel(AdditiveParams p) {
   __syncthreads();
 
   // ---- softmax over the S tokens of each sequence (one wave per sequence) ---------------------------------
-  for (int seq = w; seq < NSEQ; seq += 4) {
+  for (int seq = w; seq < NSEQ; seq += NW) {
     const int r = seq * S + l;
     const bool live = l < S;
-    float v = live ? (sc[r] + sc[Gm::ROWS + r] + sc[2 * Gm::ROWS + r] + sc[3 * Gm::ROWS + r]) : -3.0e38f;
+    float v = -3.0e38f;
+    if (live) {
+      v = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) v += sc[ww * Gm::ROWS + r];
+    }
     float mx = v;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, shfl_xor(mx, m));

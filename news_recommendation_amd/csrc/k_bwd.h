@@ -346,13 +346,14 @@ struct AdditiveBwdParams {
   int64_t n_seq;
 };
 
-template <int S, int NSEQ>
-__global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p) {
-  using Gm = AddGeom<S, NSEQ>;
+template <int S, int NSEQ, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams p) {
+  using Gm = AddGeom<S, NSEQ, NW>;
+  constexpr int WG = NW * 64;          // shadows nr::WG: 4 or 8 waves
   NR_SMEM_DECL(smem);
   u16* Xs = (u16*)smem;
-  float* dqp = (float*)(smem + Gm::X_BYTES);                 // [4][QP]   
-  float* dsv = (float*)(smem + Gm::X_BYTES + 4 * QP * 4);    // [ROWS]
+  float* dqp = (float*)(smem + Gm::X_BYTES);                 // [NW][QP]
+  float* dsv = (float*)(smem + Gm::X_BYTES + Gm::DQ_FLOATS * 4);    // [ROWS]
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
   const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
@@ -364,14 +365,14 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
     if (c < KP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.ctx + (tok0 + r) * KP + c * 8);
     *(u16x8*)(Xs + r * XS + c * 8) = v;
   }
-  for (int i = tid; i < 4 * QP; i += WG) dqp[i] = 0.0f;
+  for (int i = tid; i < Gm::DQ_FLOATS; i += WG) dqp[i] = 0.0f;
   for (int i = tid; i < Gm::ROWS; i += WG) dsv[i] = 0.0f;
   __syncthreads();
 
   // ---- dw[tok] = g_out . x[tok];  ds = w * (dw - sum_s w dw)  (softmax backward) -------------------------------
   // three lanes per token, 25 quads (100 columns) each; partials combined through LDS (dqp is still free here)
   {
-    float* dwp = dqp;                                   // [3][ROWS] scratch (4*QP floats >= 3*ROWS)
+    float* dwp = dqp;                                   // [3][ROWS] scratch (DQ_FLOATS >= 3*ROWS)
     for (int idx = tid; idx < Gm::TOK * 3; idx += WG) {
       const int tok = idx / 3, part = idx - tok * 3;
       const int seq = tok / S;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
       dwp[part * Gm::ROWS + tok] = a;
     }
     __syncthreads();
-    for (int seq = w; seq < NSEQ; seq += 4) {
+    for (int seq = w; seq < NSEQ; seq += NW) {
       const bool live = l < S && seq0 + seq < p.n_seq;
       const int r = seq * S + l;
       const float mydw = live ? dwp[r] + dwp[Gm::ROWS + r] + dwp[2 * Gm::ROWS + r] : 0.0f;
@@ -398,15 +399,15 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
       if (l < S) dsv[r] = wt * (mydw - tot);
     }
     __syncthreads();
-    for (int i = tid; i < 4 * QP; i += WG) dqp[i] = 0.0f;
+    for (int i = tid; i < Gm::DQ_FLOATS; i += WG) dqp[i] = 0.0f;
   }
   __syncthreads();
 
   // ---- recompute t = tanh(x Wa^T + ba); dpre = ds * qv * (1 - t^2); dq += ds * t ---------------------------------
-  const int w_eff = (w + (int)blockIdx.x) & 3;
+  const int w_eff = (w + (int)blockIdx.x) % NW;
   for (int cg = 0; cg < (Gm::NTQ + 1) / 2; ++cg) {
     int G, mb, me;
-    unit_range(Gm::NTQ, Gm::MT, w_eff, 4, cg, G, mb, me);
+    unit_range(Gm::NTQ, Gm::MT, w_eff, NW, cg, G, mb, me);
     if (mb >= me) continue;
     f32x4 dqa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto epi = [&](int j, int wr, int m, f32x4 acc) {   // acc = x.Wa[n] + ba[n] (bias = accumulator init)
@@ -446,7 +447,12 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
   }
   __syncthreads();
   for (int n = tid; n < QP; n += WG)
-    p.dq_part[(int64_t)blockIdx.x * QP + n] = dqp[n] + dqp[QP + n] + dqp[2 * QP + n] + dqp[3 * QP + n];
+  {
+    float a = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) a += dqp[ww * QP + n];
+    p.dq_part[(int64_t)blockIdx.x * QP + n] = a;
+  }
 
   // ---- fused input-gradient product dctx[tok][:] = dpre[tok][:] @ Wa (the GEMM part of d ctx; the direct term attn_w (x) g_out is
   //      added by the consumer).  The workgroup's dpre tile was just written to global memory by its own waves (L2-hot): it is
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(WG, 2) void additive_bwd_kernel(AdditiveBwdParams p
     constexpr int NTD = (D + 15) / 16;      // 19 output column tiles
     for (int cg = 0; cg < (NTD + 1) / 2; ++cg) {
       int G, mb, me;
-      unit_range(NTD, Gm::MT, w_eff, 4, cg, G, mb, me);
+      unit_range(NTD, Gm::MT, w_eff, NW, cg, G, mb, me);
       if (mb >= me) continue;
       const int wr0 = (2 * cg) * 16, wr1 = G == 2 ? wr0 + 16 : wr0;
       u16x8 wf[2][KS2];

@@ -54,6 +54,13 @@ int grid_for(int64_t work, int per_block, int cap) {
   return (int)b;
 }
 
+// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 0 = 4 waves on 4 titles (two workgroups per CU), 1 = 8 waves on 8 titles
+int add_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <typename K>
 int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
 
@@ -171,7 +178,12 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
   p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq;
-  if (S == 20) {
+  if (S == 20 && add_variant() == 1) {
+    constexpr int NSEQ = 8, NW = 8;
+    using G = nr::AddGeom<20, NSEQ, NW>;
+    if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
@@ -230,7 +242,7 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
-  if (S == 20) return (n_seq + 3) / 4;
+  if (S == 20) return add_variant() == 1 ? (n_seq + 7) / 8 : (n_seq + 3) / 4;
   if (S == 50) return n_seq;
   if (S == 4) return (n_seq + 19) / 20;
   return -1;
@@ -261,7 +273,12 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveBwdParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
   p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq;
-  if (S == 20) {
+  if (S == 20 && add_variant() == 1) {
+    constexpr int NSEQ = 8, NW = 8;
+    using G = nr::AddGeom<20, NSEQ, NW>;
+    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ, NW>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;
     if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
