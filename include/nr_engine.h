@@ -203,25 +203,35 @@ int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_r
 /* ---- LSTUR user encoder: nn.GRU(3F, H) over the packed click history (src/model/LSTUR/user_encoder.py:11-14,27-45) ----
  * Padded sizes for hidden size Hd: Hg = Hd up to 16 (gate stride), Hp = Hd+1 up to 32 (h row length, col Hd of bf16 h rows = 1.0),
  * Kp = 3*Hg up to 32 (dGh row length).  One launch per time step; the input projection gi = x W_ih^T (f32 [B*N][3*Hg], row
- * b*N + t, gate q of unit j at column q*Hg + j, no bias) is one plain GEMM done by the caller. */
+ * b*N + t, gate q of unit j at column q*Hg + j, no bias) is one plain GEMM done by the caller.
+ * "Tile order" of a bf16 operand M[R][K] (R up to 16, K % 32 == 0) is the layout the step kernels read: each 16 x 32 block
+ * (row tile, k-step) stored as the 64 lanes' 16-byte MFMA fragments back to back, element (r, k) at
+ * ((r/16)*(K/32) + k/32)*512 + ((k%32)/8)*128 + (r%16)*8 + k%8 -- one contiguous 1 KB request per wave and k-step. */
 int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp);
 /* W f32 [3*Hd][K] (weight_ih_l0 / weight_hh_l0, gate order r,z,n) -> dst bf16 [3*Hg][Kpad] (row q*Hg+j) and, if not NULL,
- * dstT bf16 [Kpad][Kp] with dstT[k][q*Hg+j] = W[q*Hd+j][k] (operand of the hidden-state gradient). */
-int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, void* stream);
+ * dstT bf16 [Kpad][Kp] with dstT[k][q*Hg+j] = W[q*Hd+j][k] (operand of the hidden-state gradient).  tiled != 0: both in tile
+ * order (W_hh for the step kernels); 0: row-major (W_ih for the hoisted GEMMs). */
+int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, int tiled, void* stream);
 /* f32 rows [n][d] (stride ld) -> bf16 rows [n][dp]: col d = 1.0 when d < dp, rest 0 (MFMA / GEMM operand form of dense vectors). */
 int nr_rows_to_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream);
-/* Step t of the GRU forward for all B samples: reads h_{t-1} (bf16 operand + f32 state), writes h_t (both); samples with
- * t >= len[b] keep their state (pack_padded_sequence: the first len[b] slots are consumed, len >= 1).  gates (training):
- * bf16 [B][4][Hg] = r, z, n, q = Gh_n + b_hn of this step for nr_gru_bwd_step; NULL for inference. */
-int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_b,
-                    uint16_t* h_out_b, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t, void* stream);
+/* bf16 rows [n][K] row-major -> tile order [n up to 16][K], padding rows zero (h_0 for the first forward step). */
+int nr_tile_rows_bf16(const uint16_t* src, int n, int K, uint16_t* dst, void* stream);
+/* Step t of the GRU forward for all B samples: reads h_{t-1} (h_in_t: bf16 operand in tile order [B up to 16][Hp], h_in_f: f32
+ * state [B][Hp]), writes h_t as h_out_t (tile order, zero-initialised by the caller once: padding is never written), h_out_f and,
+ * if not NULL, h_out_b (row-major bf16 [B][Hp] with col Hd = 1.0: what the backward sweep and the W_hh gradient GEMM read);
+ * samples with t >= len[b] keep their state (pack_padded_sequence: the first len[b] slots are consumed, len >= 1).  Whh in tile
+ * order (nr_pack_gru tiled).  gates (training): bf16 [B][4][Hg] = r, z, n, q = Gh_n + b_hn of this step; NULL for inference. */
+int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_t,
+                    uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t,
+                    void* stream);
 /* Step t of the backward sweep (t = T-1 .. 0, then t = -1): dh_t = carry_next + dgh_next @ W_hh (g_last when first != 0);
  * for t >= 0 it then writes the gate gradients of step t: dgi row b*N+t of bf16 [B*N][Kp] = [dr|dz|dn] pre-activations,
  * dgh bf16 [B][Kp] = [dr|dz|dn*r] and carry f32 [B][Hp] = dh_t * z_t (dh_t for finished samples); for t = -1 carry
- * receives dh_0 (gradient of the initial state = the user_embedding row in the 'ini' method). */
+ * receives dh_0 (gradient of the initial state = the user_embedding row in the 'ini' method).  dgh_next and WhhT are in tile
+ * order; dgh_t receives dgh of this step in tile order ([B up to 16][Kp], zero-initialised once by the caller) for the next launch. */
 int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* carry_next, const uint16_t* WhhT, const uint16_t* gates,
-                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, float* carry, int B, int N, int Hd, int t,
-                    int first, void* stream);
+                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, uint16_t* dgh_t, float* carry, int B, int N,
+                    int Hd, int t, int first, void* stream);
 
 /* Per-impression ranking metrics of src/evaluate.py:24-42,160-168 for a CSR batch of impressions: scores f32[nnz], labels
  * int32[nnz] (0/1), ptr int64[n_impr+1]; out f32[n_impr][4] = AUC, MRR, nDCG@5, nDCG@10 (four NaNs when an impression has a

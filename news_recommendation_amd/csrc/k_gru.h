@@ -17,59 +17,129 @@
 
 namespace nr {
 
+// "Tile order" of a bf16 MFMA operand M[R][K] (R % 16 == 0, K % 32 == 0): the 16 x 32 block (row tile, k-step) is stored as the 64
+// lanes' 16-byte fragments back to back, i.e. element (r, k) sits at tile_off(r, k, K).  A wave then fetches one operand fragment
+// per k-step as ONE contiguous 1 KB request.  From row-major rows the same fragment is 64 separate 16-byte pieces in 16 different
+// cache lines with consecutive lanes in different rows, which the texture-address unit serialises: the step kernels ran at 4x their
+// L1 request-rate floor that way (22 us), independent of prefetch depth, XCD locality or occupancy.
+__device__ __host__ __forceinline__ size_t tile_off(int r, int k, int K) {
+  return ((size_t)(r >> 4) * (K >> 5) + (k >> 5)) * 512 + (((k & 31) >> 3) * 16 + (r & 15)) * 8 + (k & 7);
+}
+
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+// Workgroup -> (unit tile, sample group) mapping shared by both step kernels.  Workgroups are dealt round-robin to the 8 XCDs
+// (linear id % 8), each with a private 4 MB L2.  W_hh (5 MB at Hd = 900) is the big operand and is the same at every step: XCD c
+// takes the unit tiles c, c + 8, c + 16, ... for ALL sample groups, so that it reads (and keeps L2-resident from one step launch to
+// the next) only its eighth of the weight rows; the hidden state of the step (1 MB) is what every XCD re-reads.  The 1-D grid holds
+// 8 * ceil(n_tiles / 8) * n_groups workgroups; the ones past the last unit tile exit at once.
+__device__ __forceinline__ bool gru_tile_of_wg(int n_tiles, int n_groups, int& tile, int& group) {
+  const int L = (int)blockIdx.x, c = L & 7, s = L >> 3;
+  tile = c + 8 * (s / n_groups);
+  group = s % n_groups;
+  return tile < n_tiles;
+}
+__host__ inline int gru_grid(int n_tiles, int n_groups) { return 8 * ((n_tiles + 7) / 8) * n_groups; }
 
 struct GruFwdParams {
   const float* gi;        // [B*N][3*Hg] f32, row b*N + t  (x_t W_ih^T, no bias)
-  const u16* Whh;         // bf16 [3*Hg][Hp]
+  const u16* Whh;         // bf16 [3*Hg][Hp], tile order
   const float* b_ih;      // [3*Hd]
   const float* b_hh;      // [3*Hd]
   const int* len;         // [B], >= 1
-  const u16* h_in_b;      // bf16 [B][Hp]
-  u16* h_out_b;           // bf16 [B][Hp]
+  const u16* h_in_t;      // bf16 [ceil16(B)][Hp], tile order
+  u16* h_out_b;           // bf16 [B][Hp] row-major (operand of the W_hh gradient GEMM and of the backward sweep), or null
+  u16* h_out_t;           // bf16 [ceil16(B)][Hp], tile order: the next step's operand
   const float* h_in_f;    // f32 [B][Hp]
   float* h_out_f;         // f32 [B][Hp]
   u16* gates;             // training: bf16 [B][4][Hg] of this step (r, z, n, q), or null
   int B, N, Hd, Hg, Hp, t;
 };
 
+#ifndef NR_GRU_DEPTH
+#define NR_GRU_DEPTH 8
+#endif
+// The step is latency-bound (PMC: 87 % of wave cycles waiting on memory with ~2 waves per SIMD): with a rolled k-loop every wave
+// walks a chain of Hp/32 L2 round trips.  KS_CT > 0: the k-step count is a compile-time constant (Hp / 32 for the reference's
+// hidden sizes); the loop is fully unrolled into a register pipeline with NR_GRU_DEPTH k-steps (4 x 16-byte loads each) in
+// flight, pinned by sched_barriers (left alone the scheduler sinks every load next to its MFMA to save registers).
+// KS_CT = 0: generic rolled loop.
+template <int KS_CT>
 __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
-  const int s0 = ((int)blockIdx.x * 4 + w) * 16;
+  int tile, group;
+  if (!gru_tile_of_wg(p.Hg / 16, (p.B + 63) / 64, tile, group)) return;
+  const int s0 = (group * 4 + w) * 16;
   if (s0 >= p.B) return;
-  const int j0 = (int)blockIdx.y * 16;
+  const int j0 = tile * 16;
   const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
-  const u16* hp = p.h_in_b + (size_t)sb * p.Hp + g * 8;
-  const u16* w0 = p.Whh + (size_t)(j0 + li) * p.Hp + g * 8;
+  // fragment pointers in tile order: k-step ks of an operand tile is the 1 KB at + ks * 512 elements
+  const u16* hp = p.h_in_t + (size_t)(s0 >> 4) * p.Hp * 16 + l * 8;
+  const u16* w0 = p.Whh + (size_t)tile * p.Hp * 16 + l * 8;
   const u16* w1 = w0 + (size_t)p.Hg * p.Hp;
   const u16* w2 = w1 + (size_t)p.Hg * p.Hp;
   f32x4 ar = f32x4{0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
-  const int ksteps = p.Hp / 32;
-#pragma unroll 2
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const u16x8 hf = *(const u16x8*)(hp + ks * 32);
-    ar = mfma_16x16x32_bf16(*(const u16x8*)(w0 + ks * 32), hf, ar);
-    az = mfma_16x16x32_bf16(*(const u16x8*)(w1 + ks * 32), hf, az);
-    an = mfma_16x16x32_bf16(*(const u16x8*)(w2 + ks * 32), hf, an);
-  }
-  // lane: sample s0 + li, units j0 + 4g + r
-  const int s = s0 + li, jb = j0 + 4 * g;
-  if (s >= p.B) return;
-  const bool active = p.t < p.len[s];
-  const float* gi = p.gi + ((size_t)s * p.N + p.t) * 3 * p.Hg + jb;
+  // epilogue operands (lane: sample s0 + li, units j0 + 4g + r) are requested before the k pipeline so that their round trip overlaps it
+  const int jb = j0 + 4 * g;
+  const int len_s = p.len[sb];
+  const float* gi = p.gi + ((size_t)sb * p.N + p.t) * 3 * p.Hg + jb;
   const f32x4 gir = *(const f32x4*)gi, giz = *(const f32x4*)(gi + p.Hg), gin = *(const f32x4*)(gi + 2 * p.Hg);
-  const f32x4 ho = *(const f32x4*)(p.h_in_f + (size_t)s * p.Hp + jb);
+  const f32x4 ho = *(const f32x4*)(p.h_in_f + (size_t)sb * p.Hp + jb);
+  f32x4 b_ir, b_hr, b_iz, b_hz, b_in, b_hn;            // raw values: nothing below may wait on them before the k pipeline has been issued
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = jb + r < p.Hd ? jb + r : p.Hd - 1;
+    b_ir[r] = p.b_ih[j]; b_hr[r] = p.b_hh[j];
+    b_iz[r] = p.b_ih[p.Hd + j]; b_hz[r] = p.b_hh[p.Hd + j];
+    b_in[r] = p.b_ih[2 * p.Hd + j]; b_hn[r] = p.b_hh[2 * p.Hd + j];
+  }
+  if (KS_CT > 0) {
+    constexpr int D = NR_GRU_DEPTH;
+    u16x8 fh[D], f0[D], f1[D], f2[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < KS_CT) {
+        fh[i] = *(const u16x8*)(hp + i * 512);
+        f0[i] = *(const u16x8*)(w0 + i * 512);
+        f1[i] = *(const u16x8*)(w1 + i * 512);
+        f2[i] = *(const u16x8*)(w2 + i * 512);
+      }
+    NR_SCHED_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < KS_CT; ++ks) {
+      const int sl = ks % D;
+      ar = mfma_16x16x32_bf16(f0[sl], fh[sl], ar);
+      az = mfma_16x16x32_bf16(f1[sl], fh[sl], az);
+      an = mfma_16x16x32_bf16(f2[sl], fh[sl], an);
+      if (ks + D < KS_CT) {
+        fh[sl] = *(const u16x8*)(hp + (ks + D) * 512);
+        f0[sl] = *(const u16x8*)(w0 + (ks + D) * 512);
+        f1[sl] = *(const u16x8*)(w1 + (ks + D) * 512);
+        f2[sl] = *(const u16x8*)(w2 + (ks + D) * 512);
+      }
+      NR_SCHED_BARRIER();
+    }
+  } else {
+    const int ksteps = p.Hp / 32;
+#pragma unroll 2
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const u16x8 hf = *(const u16x8*)(hp + ks * 512);
+      ar = mfma_16x16x32_bf16(*(const u16x8*)(w0 + ks * 512), hf, ar);
+      az = mfma_16x16x32_bf16(*(const u16x8*)(w1 + ks * 512), hf, az);
+      an = mfma_16x16x32_bf16(*(const u16x8*)(w2 + ks * 512), hf, an);
+    }
+  }
+  const int s = s0 + li;
+  if (s >= p.B) return;
+  const bool active = p.t < len_s;
   f32x4 hn, rr, zz, nn, qq;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int j = jb + r;
-    const bool ok = j < p.Hd;
-    const float bir = ok ? p.b_ih[j] : 0.f, biz = ok ? p.b_ih[p.Hd + j] : 0.f, bin = ok ? p.b_ih[2 * p.Hd + j] : 0.f;
-    const float bhr = ok ? p.b_hh[j] : 0.f, bhz = ok ? p.b_hh[p.Hd + j] : 0.f, bhn = ok ? p.b_hh[2 * p.Hd + j] : 0.f;
-    rr[r] = fast_sigmoid(gir[r] + bir + ar[r] + bhr);
-    zz[r] = fast_sigmoid(giz[r] + biz + az[r] + bhz);
-    qq[r] = an[r] + bhn;
-    nn[r] = fast_tanh(gin[r] + bin + rr[r] * qq[r]);
+    const bool ok = jb + r < p.Hd;                    // units >= Hd: zero weight rows and gi columns, their h stays 0
+    rr[r] = fast_sigmoid(gir[r] + b_ir[r] + ar[r] + b_hr[r]);
+    zz[r] = fast_sigmoid(giz[r] + b_iz[r] + az[r] + b_hz[r]);
+    qq[r] = an[r] + b_hn[r];
+    nn[r] = fast_tanh(gin[r] + b_in[r] + rr[r] * qq[r]);
     const float v = active ? (1.0f - zz[r]) * nn[r] + zz[r] * ho[r] : ho[r];
     hn[r] = ok ? v : 0.0f;
   }
@@ -77,8 +147,12 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
     *(f32x4*)(p.h_out_f + (size_t)s * p.Hp + jb) = hn;
     u16x4 hb = pack4(hn);
     if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;        // column Hd = 1.0
-    *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
-    if (jb + 4 == p.Hd) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;    // Hd % 4 == 0: the lane owning the last units also sets column Hd
+    *(u16x4*)(p.h_out_t + tile_off(s, jb, p.Hp)) = hb;
+    if (p.h_out_b != nullptr) *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
+    if (jb + 4 == p.Hd) {                                          // Hd % 4 == 0: the lane owning the last units also sets column Hd
+      p.h_out_t[tile_off(s, p.Hd, p.Hp)] = 0x3F80;
+      if (p.h_out_b != nullptr) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
+    }
   }
   if (p.gates != nullptr && jb < p.Hg) {
     u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
@@ -91,60 +165,100 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
 
 struct GruBwdParams {
   const float* g_last;     // [B][Hd] gradient of the returned hidden state (used when first != 0)
-  const u16* dgh_next;     // bf16 [B][Kp]: dGh of step t+1
+  const u16* dgh_next;     // bf16 [ceil16(B)][Kp], tile order: dGh of step t+1
   const float* carry_next; // f32 [B][Hp]: dh_{t+1} z_{t+1} (or dh_{t+1} for finished samples)
-  const u16* WhhT;         // bf16 [Hp][Kp]: WhhT[j][q*Hg + i] = W_hh[q*Hd + i][j]
+  const u16* WhhT;         // bf16 [Hp][Kp], tile order: WhhT[j][q*Hg + i] = W_hh[q*Hd + i][j]
   const u16* gates;        // bf16 [B][4][Hg] of step t; null for the final call (t = -1: only dh_0 is produced)
   const u16* h_prev_b;     // bf16 [B][Hp] = h_{t-1}
   const int* len;
   u16* dgi;                // bf16 [B*N][Kp]: row b*N + t receives [dr_pre | dz_pre | dn_pre]
-  u16* dgh;                // bf16 [B][Kp] of step t: [dr_pre | dz_pre | dn_pre * r]
+  u16* dgh;                // bf16 [B][Kp] of step t: [dr_pre | dz_pre | dn_pre * r], row-major (operand of the W_hh gradient GEMM)
+  u16* dgh_t;              // the same in tile order [ceil16(B)][Kp]: the next launch's operand
   float* carry;            // f32 [B][Hp] of step t; for t = -1 it receives dh_0
   int B, N, Hd, Hg, Hp, Kp, t, first;
 };
 
+template <int KS_CT>
 __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
-  const int s0 = ((int)blockIdx.x * 4 + w) * 16;
+  int tile, group;
+  if (!gru_tile_of_wg(p.Hg / 16, (p.B + 63) / 64, tile, group)) return;
+  const int s0 = (group * 4 + w) * 16;
   if (s0 >= p.B) return;
-  const int j0 = (int)blockIdx.y * 16;
+  const int j0 = tile * 16;
+  const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!p.first) {
-    const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
-    const u16* dp = p.dgh_next + (size_t)sb * p.Kp + g * 8;
-    const u16* wp = p.WhhT + (size_t)(j0 + li) * p.Kp + g * 8;
+  // epilogue operands of lane (sample s0 + li, units j0 + 4g + r), requested ahead of the k pipeline
+  const int jb = j0 + 4 * g, jc = jb < p.Hg ? jb : 0;
+  const int len_s = p.len[sb];
+  f32x4 cn = acc;
+  u16x4 rb = u16x4{0, 0, 0, 0}, zb = rb, nb = rb, qb = rb, hb = rb;
+  if (!p.first) cn = *(const f32x4*)(p.carry_next + (size_t)sb * p.Hp + jc);
+  if (p.gates != nullptr) {
+    const u16* gp = p.gates + (size_t)sb * 4 * p.Hg + jc;
+    rb = *(const u16x4*)gp; zb = *(const u16x4*)(gp + p.Hg); nb = *(const u16x4*)(gp + 2 * p.Hg); qb = *(const u16x4*)(gp + 3 * p.Hg);
+    hb = *(const u16x4*)(p.h_prev_b + (size_t)sb * p.Hp + jc);
+  }
+  if (KS_CT > 0 && !p.first) {
+    // same register pipeline as the forward step (see there): 2 x 16-byte loads per k-step, 2 * NR_GRU_DEPTH k-steps in flight
+    constexpr int D = 2 * NR_GRU_DEPTH;
+    const u16* dp = p.dgh_next + (size_t)(s0 >> 4) * p.Kp * 16 + l * 8;
+    const u16* wp = p.WhhT + (size_t)tile * p.Kp * 16 + l * 8;
+    u16x8 fd[D], fw[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < KS_CT) {
+        fw[i] = *(const u16x8*)(wp + i * 512);
+        fd[i] = *(const u16x8*)(dp + i * 512);
+      }
+    NR_SCHED_BARRIER();
+    f32x4 a1 = acc, a2 = acc, a3 = acc;
+#pragma unroll
+    for (int ks = 0; ks < KS_CT; ++ks) {
+      const int sl = ks % D;
+      if ((ks & 3) == 0) acc = mfma_16x16x32_bf16(fw[sl], fd[sl], acc);
+      else if ((ks & 3) == 1) a1 = mfma_16x16x32_bf16(fw[sl], fd[sl], a1);
+      else if ((ks & 3) == 2) a2 = mfma_16x16x32_bf16(fw[sl], fd[sl], a2);
+      else a3 = mfma_16x16x32_bf16(fw[sl], fd[sl], a3);
+      if (ks + D < KS_CT) {
+        fw[sl] = *(const u16x8*)(wp + (ks + D) * 512);
+        fd[sl] = *(const u16x8*)(dp + (ks + D) * 512);
+      }
+      NR_SCHED_BARRIER();
+    }
+    acc = (acc + a1) + (a2 + a3);
+  } else if (!p.first) {
+    const u16* dp = p.dgh_next + (size_t)(s0 >> 4) * p.Kp * 16 + l * 8;
+    const u16* wp = p.WhhT + (size_t)tile * p.Kp * 16 + l * 8;
     const int ksteps = p.Kp / 32;
     // four independent accumulators: a single one would serialise the 86 MFMAs of the K loop on the accumulate dependency
     f32x4 a1 = acc, a2 = acc, a3 = acc;
     int ks = 0;
     for (; ks + 4 <= ksteps; ks += 4) {
-      acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32), *(const u16x8*)(dp + ks * 32), acc);
-      a1 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 32), *(const u16x8*)(dp + ks * 32 + 32), a1);
-      a2 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 64), *(const u16x8*)(dp + ks * 32 + 64), a2);
-      a3 = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32 + 96), *(const u16x8*)(dp + ks * 32 + 96), a3);
+      acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 512), *(const u16x8*)(dp + ks * 512), acc);
+      a1 = mfma_16x16x32_bf16(*(const u16x8*)(wp + (ks + 1) * 512), *(const u16x8*)(dp + (ks + 1) * 512), a1);
+      a2 = mfma_16x16x32_bf16(*(const u16x8*)(wp + (ks + 2) * 512), *(const u16x8*)(dp + (ks + 2) * 512), a2);
+      a3 = mfma_16x16x32_bf16(*(const u16x8*)(wp + (ks + 3) * 512), *(const u16x8*)(dp + (ks + 3) * 512), a3);
     }
-    for (; ks < ksteps; ++ks) acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 32), *(const u16x8*)(dp + ks * 32), acc);
+    for (; ks < ksteps; ++ks) acc = mfma_16x16x32_bf16(*(const u16x8*)(wp + ks * 512), *(const u16x8*)(dp + ks * 512), acc);
     acc = (acc + a1) + (a2 + a3);
   }
-  const int s = s0 + li, jb = j0 + 4 * g;
+  const int s = s0 + li;
   if (s >= p.B || jb >= p.Hg) return;
   f32x4 dh;
   if (p.first) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh[r] = jb + r < p.Hd ? p.g_last[(size_t)s * p.Hd + jb + r] : 0.0f;
   } else {
-    dh = acc + *(const f32x4*)(p.carry_next + (size_t)s * p.Hp + jb);
+    dh = acc + cn;
   }
   if (p.gates == nullptr) {                    // t = -1: dh_0
     *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = dh;
     return;
   }
-  const bool active = p.t < p.len[s];
+  const bool active = p.t < len_s;
   f32x4 d_r = f32x4{0.f, 0.f, 0.f, 0.f}, d_z = d_r, d_n = d_r, d_nr = d_r, cy = dh;
   if (active) {
-    const u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
-    const u16x4 rb = *(const u16x4*)gp, zb = *(const u16x4*)(gp + p.Hg), nb = *(const u16x4*)(gp + 2 * p.Hg), qb = *(const u16x4*)(gp + 3 * p.Hg);
-    const u16x4 hb = *(const u16x4*)(p.h_prev_b + (size_t)s * p.Hp + jb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = jb + r < p.Hd;
@@ -166,29 +280,34 @@ __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
   *(u16x4*)gi = pack4(d_r);
   *(u16x4*)(gi + p.Hg) = pack4(d_z);
   *(u16x4*)(gi + 2 * p.Hg) = pack4(d_n);
+  const u16x4 pr = pack4(d_r), pz = pack4(d_z), pn = pack4(d_nr);
   u16* gh = p.dgh + (size_t)s * p.Kp + jb;
-  *(u16x4*)gh = pack4(d_r);
-  *(u16x4*)(gh + p.Hg) = pack4(d_z);
-  *(u16x4*)(gh + 2 * p.Hg) = pack4(d_nr);
+  *(u16x4*)gh = pr;
+  *(u16x4*)(gh + p.Hg) = pz;
+  *(u16x4*)(gh + 2 * p.Hg) = pn;
+  *(u16x4*)(p.dgh_t + tile_off(s, jb, p.Kp)) = pr;
+  *(u16x4*)(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp)) = pz;
+  *(u16x4*)(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp)) = pn;
 }
 
 // ---- operand packing --------------------------------------------------------------------------------------------------
 // W f32 [3*Hd][K] (nn.GRU weight_ih_l0 / weight_hh_l0) -> dst bf16 [3*Hg][Kpad]: row q*Hg + j = W[q*Hd + j][:], zero padded.
 // dstT (optional) bf16 [Kpad_rows = Hp][Kp]: dstT[k][q*Hg + j] = W[q*Hd + j][k]   (the data-gradient operand).
+// tiled != 0: both in tile order (step-kernel operands); 0: row-major (GEMM operand).
 __global__ __launch_bounds__(256) void pack_gru_kernel(const float* __restrict__ W, int Hd, int K, int Hg, int Kpad, u16* __restrict__ dst,
-                                                       u16* __restrict__ dstT, int Trows, int Kp) {
+                                                       u16* __restrict__ dstT, int Trows, int Kp, int tiled) {
   const int n1 = 3 * Hg * Kpad;
   const int n2 = dstT ? Trows * Kp : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
     if (i < n1) {
       const int row = i / Kpad, k = i - row * Kpad;
       const int q = row / Hg, j = row - q * Hg;
-      dst[i] = f2bf((j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
+      dst[tiled ? tile_off(row, k, Kpad) : (size_t)i] = f2bf((j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
     } else {
       const int i2 = i - n1;
       const int k = i2 / Kp, c = i2 - k * Kp;
       const int q = c / Hg, j = c - q * Hg;
-      dstT[i2] = f2bf((q < 3 && j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
+      dstT[tiled ? tile_off(k, c, Kp) : (size_t)i2] = f2bf((q < 3 && j < Hd && k < K) ? W[((size_t)q * Hd + j) * K + k] : 0.0f);
     }
   }
 }
@@ -201,6 +320,15 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restri
     const int64_t r = i / dp;
     const int c = (int)(i - r * dp);
     dst[i] = c < d ? f2bf(src[r * lds_ + c]) : (u16)(c == d ? 0x3F80 : 0);
+  }
+}
+
+// bf16 rows [n][K] row-major -> tile order [ceil16(n)][K] (rows >= n zero).
+__global__ __launch_bounds__(256) void tile_rows_kernel(const u16* __restrict__ src, int n, int K, u16* __restrict__ dst) {
+  const int64_t total = (int64_t)((n + 15) & ~15) * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), k = (int)(i - (int64_t)r * K);
+    dst[tile_off(r, k, K)] = r < n ? src[i] : (u16)0;
   }
 }
 

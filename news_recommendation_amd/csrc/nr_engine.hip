@@ -492,10 +492,10 @@ int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp) {
   return NR_OK;
 }
 
-int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, void* stream) {
+int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, int tiled, void* stream) {
   if (!W || !dst || Hd <= 0 || K <= 0 || Kpad < K || (Kpad & 31)) return fail(NR_ERR_BADARG, "nr_pack_gru: bad argument");
   const int Hg = ceil_to(Hd, 16), Kp = ceil_to(3 * Hg, 32);
-  NR_LAUNCH(nr::pack_gru_kernel, 1024, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp);
+  NR_LAUNCH(nr::pack_gru_kernel, 1024, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp, tiled);
   return check_launch("nr_pack_gru");
 }
 
@@ -506,30 +506,42 @@ int nr_rows_to_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, 
   return check_launch("nr_rows_to_bf16");
 }
 
-int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_b,
-                    uint16_t* h_out_b, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t, void* stream) {
-  if (!gi || !Whh || !b_ih || !b_hh || !len || !h_in_b || !h_out_b || !h_in_f || !h_out_f || B < 0 || N <= 0 || Hd <= 0 || t < 0 || t >= N)
+int nr_tile_rows_bf16(const uint16_t* src, int n, int K, uint16_t* dst, void* stream) {
+  if (!src || !dst || n < 0 || K <= 0 || (K & 31)) return fail(NR_ERR_BADARG, "nr_tile_rows_bf16: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::tile_rows_kernel, grid_for((int64_t)ceil_to(n, 16) * K, 256, 8192), 256, 0, (hipStream_t)stream, src, n, K, dst);
+  return check_launch("nr_tile_rows_bf16");
+}
+
+int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_t,
+                    uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t,
+                    void* stream) {
+  if (!gi || !Whh || !b_ih || !b_hh || !len || !h_in_t || !h_out_t || !h_in_f || !h_out_f || B < 0 || N <= 0 || Hd <= 0 || t < 0 || t >= N)
     return fail(NR_ERR_BADARG, "nr_gru_fwd_step: bad argument");
   if (B == 0) return NR_OK;
   nr::GruFwdParams p;
-  p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_b = h_in_b; p.h_out_b = h_out_b; p.h_in_f = h_in_f;
+  p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_t = h_in_t; p.h_out_b = h_out_b; p.h_out_t = h_out_t; p.h_in_f = h_in_f;
   p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
-  NR_LAUNCH2(nr::gru_fwd_step_kernel, (B + 63) / 64, p.Hg / 16, nr::WG, 0, (hipStream_t)stream, p);
+  if (p.Hp == 29 * 32) NR_LAUNCH2(nr::gru_fwd_step_kernel<29>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
+  else if (p.Hp == 15 * 32) NR_LAUNCH2(nr::gru_fwd_step_kernel<15>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
+  else NR_LAUNCH2(nr::gru_fwd_step_kernel<0>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);
   return check_launch("nr_gru_fwd_step");
 }
 
 int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* carry_next, const uint16_t* WhhT, const uint16_t* gates,
-                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, float* carry, int B, int N, int Hd, int t,
-                    int first, void* stream) {
+                    const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, uint16_t* dgh_t, float* carry, int B, int N,
+                    int Hd, int t, int first, void* stream) {
   if (!WhhT || !len || !carry || B < 0 || N <= 0 || Hd <= 0 || t < -1 || t >= N) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: bad argument");
   if (first ? !g_last : (!dgh_next || !carry_next)) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: missing upstream gradient");
-  if (t >= 0 && (!gates || !h_prev_b || !dgi || !dgh)) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: missing step buffers");
+  if (t >= 0 && (!gates || !h_prev_b || !dgi || !dgh || !dgh_t)) return fail(NR_ERR_BADARG, "nr_gru_bwd_step: missing step buffers");
   if (B == 0) return NR_OK;
   nr::GruBwdParams p;
   p.g_last = g_last; p.dgh_next = dgh_next; p.carry_next = carry_next; p.WhhT = WhhT; p.gates = t >= 0 ? gates : nullptr; p.h_prev_b = h_prev_b;
-  p.len = len; p.dgi = dgi; p.dgh = dgh; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
+  p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t = dgh_t; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
   p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
-  NR_LAUNCH2(nr::gru_bwd_step_kernel, (B + 63) / 64, p.Hg / 16, nr::WG, 0, (hipStream_t)stream, p);
+  if (p.Kp == 86 * 32) NR_LAUNCH2(nr::gru_bwd_step_kernel<86>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
+  else if (p.Kp == 44 * 32) NR_LAUNCH2(nr::gru_bwd_step_kernel<44>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
+  else NR_LAUNCH2(nr::gru_bwd_step_kernel<0>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);
   return check_launch("nr_gru_bwd_step");
 }
 

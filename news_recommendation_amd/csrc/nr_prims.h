@@ -13,6 +13,7 @@
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
 
 // one wave per SIMD: the whole 512-entry register file for a register-resident kernel
+#define NR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define NR_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 // async global -> LDS copy of 16 B per lane (global_load_lds_dwordx4): lane i's 16 B land at lds_base + 16 i (wave-uniform base,

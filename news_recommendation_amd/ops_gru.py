@@ -75,8 +75,8 @@ class _GruFn(torch.autograd.Function):
         Whh_p = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
         WhhT = torch.empty(Hp, Kp, dtype=_BF16_AS_I16, device=dev) if need_grad else None
         Wi, Wh = _f32c(W_ih), _f32c(W_hh)
-        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, _stream())
-        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), _stream())
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, 0, _stream())            # row-major: GEMM operand
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), 1, _stream())     # tile order: step-kernel operands
         bi, bh = _f32c(b_ih), _f32c(b_hh)
         xf = _f32c(x).view(B * N, I)
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
@@ -87,9 +87,12 @@ class _GruFn(torch.autograd.Function):
             hf[0][:, :Hd].copy_(h0)
         _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf[0]), Hp, Hd, _ptr(H_all[0]), Hp, B, _stream())
         gates = torch.empty(T, B, 4, Hg, dtype=_BF16_AS_I16, device=dev) if need_grad else None
+        ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)               # step-to-step operand, tile order
+        _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(H_all[0]), B, Hp, _ptr(ht[0]), _stream())
         for t in range(T):
-            _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(H_all[t]), _ptr(H_all[t + 1]),
-                  _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]), _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
+            _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht[t % 2]),
+                  _ptr(H_all[t + 1]) if need_grad else None, _ptr(ht[(t + 1) % 2]), _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]),
+                  _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
         out = hf[T % 2][:, :Hd].contiguous()
         if need_grad:
             ctx.save_for_backward(Xb, H_all, gates, lens_dev, Wih_p, WhhT)
@@ -109,11 +112,13 @@ class _GruFn(torch.autograd.Function):
             dgi.view(B, N, Kp)[:, T:].zero_()                                                # steps nobody reached
         dgh = _workspace('gru_dgh', (T, B, Kp), _BF16_AS_I16, dev, zero=True)
         carry = [torch.empty(B, Hp, dtype=torch.float32, device=dev) for _ in range(2)]
+        dght = _workspace('gru_dgh_t', (2, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)  # step-to-step operand, tile order
         for i, t in enumerate(range(T - 1, -2, -1)):
             first = 1 if i == 0 else 0
-            _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dgh[t + 1]),
+            _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dght[(i + 1) % 2]),
                   None if first else _ptr(carry[(i + 1) % 2]), _ptr(WhhT), _ptr(gates[t]) if t >= 0 else None, _ptr(H_all[t]) if t >= 0 else None,
-                  _ptr(lens_dev), _ptr(dgi) if t >= 0 else None, _ptr(dgh[t]) if t >= 0 else None, _ptr(carry[i % 2]), B, N, Hd, t, first, _stream())
+                  _ptr(lens_dev), _ptr(dgi) if t >= 0 else None, _ptr(dgh[t]) if t >= 0 else None, _ptr(dght[i % 2]) if t >= 0 else None,
+                  _ptr(carry[i % 2]), B, N, Hd, t, first, _stream())
         d_h0 = carry[T % 2][:, :Hd].contiguous() if has_h0 else None
         dgi_b = _bf16(dgi)
         d_x = _mm(dgi_b[:, :3 * Hg], _bf16(Wih_p)[:, :I], 'gemm_gru_dx').float().view(B, N, I) if ctx.needs_input_grad[0] else None

@@ -110,6 +110,7 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
   nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), 1, 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \
                  (size_t)(smem), [&]() { kern(__VA_ARGS__); })
 
+#define NR_SCHED_BARRIER() ((void)0)
 #define NR_ONE_WAVE_PER_SIMD
 
 // emulation of global_load_lds_dwordx4: every lane copies its 16 B to lds_base + 16 * lane

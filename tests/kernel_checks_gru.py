@@ -28,6 +28,11 @@ def gate_unpad(a, Hd, Hg):
     return np.concatenate([a[..., q * Hg:q * Hg + Hd] for q in range(3)], axis=-1)
 
 
+def untile(a, R, K):
+    """Tile order (include/nr_engine.h) -> row-major [R][K]: blocks (row tile, k-step) of 64 lane fragments (g, li) x 8."""
+    return np.asarray(a).reshape(R // 16, K // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(R, K)
+
+
 def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     rng = np.random.default_rng(seed)
     Hg, Hp, Kp = dims(be, Hd)
@@ -45,12 +50,15 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     # ---- operand packing through the library ----------------------------------------------------------------------
     Whh_p = be.poison((3 * Hg, Hp), np.uint16)
     WhhT_p = be.poison((Hp, Kp), np.uint16)
-    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_p), be.ptr(WhhT_p), be.stream))
+    Whh_rm, WhhT_rm = be.poison((3 * Hg, Hp), np.uint16), be.poison((Hp, Kp), np.uint16)
+    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_rm), be.ptr(WhhT_rm), 0, be.stream))
+    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_p), be.ptr(WhhT_p), 1, be.stream))
     be.sync()
     Wq = bf16_round(W_hh)
-    got = bf16_to_f32(be.np(Whh_p)).reshape(3, Hg, Hp)
+    got = bf16_to_f32(be.np(Whh_rm)).reshape(3, Hg, Hp)
     assert np.array_equal(got[:, :Hd, :Hd], Wq.reshape(3, Hd, Hd)) and not got[:, Hd:].any() and not got[:, :, Hd:].any()
-    gotT = bf16_to_f32(be.np(WhhT_p))
+    assert np.array_equal(untile(be.np(Whh_p), 3 * Hg, Hp), be.np(Whh_rm)) and np.array_equal(untile(be.np(WhhT_p), Hp, Kp), be.np(WhhT_rm))
+    gotT = bf16_to_f32(be.np(WhhT_rm))
     assert np.array_equal(gate_unpad(gotT[:Hd, :3 * Hg], Hd, Hg), Wq.T) and not gotT[Hd:].any() and not gotT[:, 3 * Hg:].any()
     # ---- forward sweep ------------------------------------------------------------------------------------------------
     gi = (bf16_round(x).astype(np.float64).reshape(B * N, I) @ bf16_round(W_ih).astype(np.float64).T).astype(np.float32)
@@ -61,10 +69,18 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     hf = [be.dev(h0p), be.empty((B, Hp), np.float32)]
     ck(be, be.lib.nr_rows_to_bf16(be.ptr(hf[0]), Hp, Hd, be.ptr(H_all[0]), Hp, B, be.stream))
     gates = [be.poison((B, 4, Hg), np.uint16) for _ in range(T)]
-    for t in range(T):
-        ck(be, be.lib.nr_gru_fwd_step(be.ptr(h_gi), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(H_all[t]),
-                                      be.ptr(H_all[t + 1]), be.ptr(hf[t % 2]), be.ptr(hf[(t + 1) % 2]), be.ptr(gates[t]), B, N, Hd, t, be.stream))
+    B16 = (B + 15) // 16 * 16
+    ht = [be.poison((B16, Hp), np.uint16), be.dev(np.zeros((B16, Hp), dtype=np.uint16))]
+    ck(be, be.lib.nr_tile_rows_bf16(be.ptr(H_all[0]), B, Hp, be.ptr(ht[0]), be.stream))
     be.sync()
+    t0 = untile(be.np(ht[0]), B16, Hp)
+    assert np.array_equal(t0[:B], be.np(H_all[0])) and not t0[B:].any()
+    for t in range(T):
+        ck(be, be.lib.nr_gru_fwd_step(be.ptr(h_gi), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(ht[t % 2]),
+                                      be.ptr(H_all[t + 1]), be.ptr(ht[(t + 1) % 2]), be.ptr(hf[t % 2]), be.ptr(hf[(t + 1) % 2]), be.ptr(gates[t]),
+                                      B, N, Hd, t, be.stream))
+    be.sync()
+    assert np.array_equal(untile(be.np(ht[T % 2]), B16, Hp)[:B], be.np(H_all[T]))          # both forms of h_T agree
     h_last = be.np(hf[T % 2])[:, :Hd]
     # reference: the oracle recurrence in float64 on the same operands
     enc = OracleLSTURUserEncoder(Hd // 3 if Hd % 3 == 0 and I == Hd else 1, 'ini')
@@ -87,12 +103,17 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     dgi = be.dev(dgi0)
     dgh = [be.empty((B, Kp), np.uint16) for _ in range(T)]
     carry = [be.poison((B, Hp), np.float32), be.poison((B, Hp), np.float32)]
+    dght = [be.dev(np.zeros((B16, Kp), dtype=np.uint16)) for _ in range(2)]
     for i, t in enumerate(range(T - 1, -2, -1)):
         first = 1 if i == 0 else 0
-        ck(be, be.lib.nr_gru_bwd_step(be.ptr(hg) if first else None, None if first else be.ptr(dgh[t + 1]), None if first else be.ptr(carry[(i + 1) % 2]),
-                                      be.ptr(WhhT_p), be.ptr(gates[t]) if t >= 0 else None, be.ptr(H_all[t]) if t >= 0 else None, be.ptr(hlen),
-                                      be.ptr(dgi) if t >= 0 else None, be.ptr(dgh[t]) if t >= 0 else None, be.ptr(carry[i % 2]), B, N, Hd, t, first,
-                                      be.stream))
+        ck(be, be.lib.nr_gru_bwd_step(be.ptr(hg) if first else None, None if first else be.ptr(dght[(i + 1) % 2]),
+                                      None if first else be.ptr(carry[(i + 1) % 2]), be.ptr(WhhT_p), be.ptr(gates[t]) if t >= 0 else None,
+                                      be.ptr(H_all[t]) if t >= 0 else None, be.ptr(hlen), be.ptr(dgi) if t >= 0 else None,
+                                      be.ptr(dgh[t]) if t >= 0 else None, be.ptr(dght[i % 2]) if t >= 0 else None, be.ptr(carry[i % 2]), B, N, Hd, t,
+                                      first, be.stream))
+        if t >= 0 and t in (T - 1, 0):
+            be.sync()
+            assert np.array_equal(untile(be.np(dght[i % 2]), B16, Kp)[:B, :3 * Hg], be.np(dgh[t])[:, :3 * Hg])
     be.sync()
     n_calls = T + 1
     dh0 = be.np(carry[(n_calls - 1) % 2])[:, :Hd]
