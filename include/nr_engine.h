@@ -45,7 +45,12 @@ int nr_gather_rows_f32(const int64_t* ids, const float* table, float* out, int64
 
 /* Pack the three nn.Linear(D,D) of MultiHeadSelfAttention (src/model/general/attention/multihead_self.py:36-38)
  * into the bf16 operand layout of the kernels: Wp bf16[3*NR_NP][NR_KP] (Q rows, then K, then V; zero padded),
- * bp f32[3*NR_NP].  Must be re-run whenever the fp32 parameters change (optimizer step). */
+ * bp f32[3*NR_NP].  Must be re-run whenever the fp32 parameters change (optimizer step).
+ * TILE ORDER: every packed bf16 weight operand of this library (Wp, Wap, WaT, Wc, Wd, tiled W_hh / W_hh^T) is stored as 16 x 32
+ * blocks (row tile, k-step) of the 64 lanes' 16-byte MFMA fragments back to back: element (r, k) of M[R][K] (R % 16 == 0,
+ * K % 32 == 0) sits at ((r/16)*(K/32) + k/32)*512 + ((k%32)/8)*128 + (r%16)*8 + k%8.  A wave fetches one fragment as one
+ * contiguous 1 KB request; from row-major rows the same fragment is 64 scattered 16-byte pieces, which the texture-address unit
+ * serialises (measured 2-4x on the kernels bound by these loads).  "[R][K]" below names the logical matrix. */
 int nr_pack_qkv(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
                 const float* bv, uint16_t* Wp, float* bp, void* stream);
 /* Same for AdditiveAttention.linear (src/model/general/attention/additive.py:17): Wa f32[qdim][D] ->
@@ -204,9 +209,7 @@ int nr_gather_rows_strided(const int64_t* ids, const float* table, int64_t num_r
  * Padded sizes for hidden size Hd: Hg = Hd up to 16 (gate stride), Hp = Hd+1 up to 32 (h row length, col Hd of bf16 h rows = 1.0),
  * Kp = 3*Hg up to 32 (dGh row length).  One launch per time step; the input projection gi = x W_ih^T (f32 [B*N][3*Hg], row
  * b*N + t, gate q of unit j at column q*Hg + j, no bias) is one plain GEMM done by the caller.
- * "Tile order" of a bf16 operand M[R][K] (R up to 16, K % 32 == 0) is the layout the step kernels read: each 16 x 32 block
- * (row tile, k-step) stored as the 64 lanes' 16-byte MFMA fragments back to back, element (r, k) at
- * ((r/16)*(K/32) + k/32)*512 + ((k%32)/8)*128 + (r%16)*8 + k%8 -- one contiguous 1 KB request per wave and k-step. */
+ * The step-to-step operands (h_t, dGh_t) are exchanged in tile order too (see nr_pack_qkv), rows padded up to 16. */
 int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp);
 /* W f32 [3*Hd][K] (weight_ih_l0 / weight_hh_l0, gate order r,z,n) -> dst bf16 [3*Hg][Kpad] (row q*Hg+j) and, if not NULL,
  * dstT bf16 [Kpad][Kp] with dstT[k][q*Hg+j] = W[q*Hd+j][k] (operand of the hidden-state gradient).  tiled != 0: both in tile

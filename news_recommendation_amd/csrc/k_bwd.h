@@ -480,8 +480,8 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
       u16x8 wf[2][KS2];
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        wf[0][ks] = *(const u16x8*)(p.WaT + (size_t)(wr0 + li) * QKP + ks * 32 + g * 8);
-        wf[1][ks] = *(const u16x8*)(p.WaT + (size_t)(wr1 + li) * QKP + ks * 32 + g * 8);
+        wf[0][ks] = *(const u16x8*)(p.WaT + (size_t)wr0 * QKP + ks * 512 + l * 8);      // tile order
+        wf[1][ks] = *(const u16x8*)(p.WaT + (size_t)wr1 * QKP + ks * 512 + l * 8);
       }
       for (int m = mb; m < me; ++m) {
         f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;

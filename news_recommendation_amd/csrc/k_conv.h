@@ -39,7 +39,7 @@ struct ConvParams {
   const float* table;      // [num_rows][D]
   int64_t num_rows;
   const u16* x_pad;        // dense form: bf16 seqpad [n_seq*(S+1)+1][KP] (columns >= D are ignored)
-  const u16* Wc;           // bf16 [3][NPC][KP]  (tap, output row, k)
+  const u16* Wc;           // bf16 [3][NPC][KP]  (tap, output row, k), each tap matrix in tile order
   const float* bc;         // f32 [NPC], or null (data-gradient form: no bias)
   u16* out;                // bf16 [n_seq*S][KP], plain token layout
   u16* x_save;             // gather form, training: bf16 seqpad copy of the dropout-masked tokens (col D = 1.0), or null
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
 #pragma unroll 1
     for (int tap = 0; tap < 3; ++tap) {
       u16x8 wf[2][KSTEPS];
-      const u16* wp0 = p.Wc + ((size_t)tap * NPC + wr0 + li) * KP + g * 8;
-      const u16* wp1 = p.Wc + ((size_t)tap * NPC + wr1 + li) * KP + g * 8;
+      const u16* wp0 = p.Wc + ((size_t)tap * NPC + wr0) * KP + l * 8;      // tile order: k-step ks of a row tile = + ks * 512
+      const u16* wp1 = p.Wc + ((size_t)tap * NPC + wr1) * KP + l * 8;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) { wf[0][ks] = *(const u16x8*)(wp0 + ks * 32); wf[1][ks] = *(const u16x8*)(wp1 + ks * 32); }
+      for (int ks = 0; ks < KSTEPS; ++ks) { wf[0][ks] = *(const u16x8*)(wp0 + ks * 512); wf[1][ks] = *(const u16x8*)(wp1 + ks * 512); }
 #pragma unroll
       for (int mi = 0; mi < Gm::MT; ++mi) {
         if (mb + mi < me) {
@@ -219,8 +219,9 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     float fwd = 0.0f, bwd = 0.0f;
     if (row < F_ && k < D_) fwd = W[((size_t)row * 3 + tap) * D_ + k];                 // Wc[tap][f=row][d=k]
     if (row < D_ && k < F_) bwd = W[((size_t)k * 3 + (2 - tap)) * D_ + row];           // Wd[tap][d=row][f=k]
-    Wc[i] = f2bf(fwd);
-    if (Wd != nullptr) Wd[i] = f2bf(bwd);
+    const size_t o = (size_t)tap * NPC * KP + tile_off(row, k, KP);      // each tap matrix [NPC][KP] in tile order
+    Wc[o] = f2bf(fwd);
+    if (Wd != nullptr) Wd[o] = f2bf(bwd);
     if (i < NPC) bc[i] = i < F_ ? b[i] : 0.0f;
   }
 }

@@ -17,15 +17,6 @@
 
 namespace nr {
 
-// "Tile order" of a bf16 MFMA operand M[R][K] (R % 16 == 0, K % 32 == 0): the 16 x 32 block (row tile, k-step) is stored as the 64
-// lanes' 16-byte fragments back to back, i.e. element (r, k) sits at tile_off(r, k, K).  A wave then fetches one operand fragment
-// per k-step as ONE contiguous 1 KB request.  From row-major rows the same fragment is 64 separate 16-byte pieces in 16 different
-// cache lines with consecutive lanes in different rows, which the texture-address unit serialises: the step kernels ran at 4x their
-// L1 request-rate floor that way (22 us), independent of prefetch depth, XCD locality or occupancy.
-__device__ __host__ __forceinline__ size_t tile_off(int r, int k, int K) {
-  return ((size_t)(r >> 4) * (K >> 5) + (k >> 5)) * 512 + (((k & 31) >> 3) * 16 + (r & 15)) * 8 + (k & 7);
-}
-
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
 // Workgroup -> (unit tile, sample group) mapping shared by both step kernels.  Workgroups are dealt round-robin to the 8 XCDs

@@ -70,9 +70,9 @@ __device__ __forceinline__ void proj_block(const u16* __restrict__ Wp, const int
   u16x8 wf[G][KSTEPS];
 #pragma unroll
   for (int j = 0; j < G; ++j) {
-    const u16* wp = Wp + (size_t)(wrow[j] + li) * KP + g * 8;
+    const u16* wp = Wp + (size_t)wrow[j] * KP + l * 8;          // tile order (nr_common.h): row tile wrow/16, k-step ks at + ks * 512
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) wf[j][ks] = *(const u16x8*)(wp + ks * 32);
+    for (int ks = 0; ks < KSTEPS; ++ks) wf[j][ks] = *(const u16x8*)(wp + ks * 512);
   }
   for (int m = m_begin; m < m_end; ++m) {
     f32x4 acc[G];

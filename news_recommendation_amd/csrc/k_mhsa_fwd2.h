@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
   // LDS image is FRAGMENT-MAJOR: block (nt, ks) = 1 KiB holding, lane-linear, the 16 B that lane (li, g) needs as its MFMA
   // operand fragment W[row 16 nt + li][32 ks + 8 g .. +7].  Reads are one conflict-free ds_read_b128 at block + 16 lane.
   auto chunk_fetch = [&](int c, int buf) {
-    const u16* src = p.Wp + ((size_t)(c % 3) * NP + (size_t)(c / 3) * Gm::CH_ROWS) * KP + (size_t)li * KP + g * 8;
+    const u16* src = p.Wp + ((size_t)(c % 3) * NP + (size_t)(c / 3) * Gm::CH_ROWS) * KP + l * 8;       // Wp is in tile order already
     unsigned char* dst = smem + buf * Gm::CH_BYTES;
     for (int blk = w; blk < 5 * KSTEPS; blk += Gm::NWAVE) {       // 50 blocks per chunk, 12-13 per wave
       const int nt = blk / KSTEPS, ks = blk - nt * KSTEPS;
-      NR_GLDS16(src + (size_t)nt * 16 * KP + ks * 32, dst + blk * 1024);
+      NR_GLDS16(src + (size_t)nt * 16 * KP + ks * 512, dst + blk * 1024);
     }
   };
   chunk_fetch(0, 0);

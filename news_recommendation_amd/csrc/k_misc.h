@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__
     int which = row / NP, n = row - which * NP;
     const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
     float v = (n < D && k < D) ? W[n * D + k] : 0.0f;
-    Wp[i] = f2bf(v);
+    Wp[tile_off(row, k, KP)] = f2bf(v);
     if (k == 0) {
       const float* b = which == 0 ? bq : (which == 1 ? bk : bv);
       bp[row] = n < D ? b[n] : 0.0f;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restr
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int n = i / KP, k = i - n * KP;
     float v = (n < qdim && k < D) ? Wa[n * D + k] : 0.0f;
-    Wap[i] = f2bf(v);
+    Wap[tile_off(n, k, KP)] = f2bf(v);
     if (k == 0) {
       bap[n] = n < qdim ? ba[n] : 0.0f;
       qvp[n] = n < qdim ? qv[n] : 0.0f;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __res
   const int total = KP * QKP;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int d = i / QKP, q = i - d * QKP;
-    WaT[i] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
+    WaT[tile_off(d, q, QKP)] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
   }
 }
 

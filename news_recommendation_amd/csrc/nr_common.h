@@ -99,4 +99,14 @@ __device__ __forceinline__ u16x8 cat8(u16x4 lo, u16x4 hi) {
   return o;
 }
 
+// "Tile order" of a bf16 MFMA operand M[R][K] (R % 16 == 0, K % 32 == 0): the 16 x 32 block (row tile, k-step) is stored as the 64
+// lanes' 16-byte fragments back to back, i.e. element (r, k) sits at tile_off(r, k, K).  A wave then fetches one operand fragment
+// per k-step as ONE contiguous 1 KB request.  From row-major rows the same fragment is 64 separate 16-byte pieces in 16 different
+// cache lines with consecutive lanes in different rows, which the texture-address unit serialises: the GRU step kernels ran at 4x their
+// L1 request-rate floor that way (22 us), independent of prefetch depth, XCD locality or occupancy.  Every packed weight operand
+// (Wp, Wap, WaT, Wc/Wd, W_hh) is stored this way; wave fragment (row tile T, k-step ks) = base + (T * (K/32) + ks) * 512 + lane * 8.
+__device__ __host__ __forceinline__ size_t tile_off(int r, int k, int K) {
+  return ((size_t)(r >> 4) * (K >> 5) + (k >> 5)) * 512 + (((k & 31) >> 3) * 16 + (r & 15)) * 8 + (k & 7);
+}
+
 }  // namespace nr

@@ -106,6 +106,12 @@ def new_seed():
 # weight packing (fp32 parameters -> zero-padded bf16 MFMA operands); re-done every call so the kernels
 # always see the live parameter storage the optimizer updates in place
 # ----------------------------------------------------------------------------------------------------------
+def untile(t, R, K):
+    """Packed weight operands are stored in the kernels' "tile order" (include/nr_engine.h): 16 x 32 blocks of 64 lane fragments.
+    Returns the row-major [R, K] matrix (a copy) for the library GEMMs that take the same weights."""
+    return t.view(R // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(R, K)
+
+
 def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
     dev = Wq.device
     Wp = torch.empty(3 * NR_NP, NR_KP, dtype=_BF16_AS_I16, device=dev)
@@ -301,7 +307,7 @@ class _EncoderFn(torch.autograd.Function):
         _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                                 _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
-        dpre_b, ctx_b, Wap_b = _bf16(dpre), _bf16(cbuf), _bf16(Wap)
+        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
         dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
@@ -314,7 +320,7 @@ class _EncoderFn(torch.autograd.Function):
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
-        WpT = _bf16(Wp).t().contiguous()                                   # [KP, 960]: the 'linear' operand form is the fastest hipBLASLt path here
+        WpT = _bf16(untile(Wp, 3 * NR_NP, NR_KP)).t().contiguous()                                   # [KP, 960]: the 'linear' operand form is the fastest hipBLASLt path here
         dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
         d_table = d_x = None
         if gather:
@@ -440,7 +446,7 @@ class _MhsaFn(torch.autograd.Function):
         dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
-        dX = torch.mm(dqkv_b, _bf16(Wp)[:, :NR_D]).float().view(n_seq, S, NR_D)
+        dX = torch.mm(dqkv_b, _bf16(untile(Wp, 3 * NR_NP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D)
         return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2]
 
 
@@ -486,7 +492,7 @@ class _AdditiveFn(torch.autograd.Function):
         _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
         qdim = ctx.qdim
         dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
-        dx = torch.mm(_bf16(dpre), _bf16(Wap)[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
+        dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
         return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim]
 
 

@@ -62,13 +62,18 @@ def pack_additive(be, params, prefix):
     return Wap, bap, qvp
 
 
+def untile(a, R, K):
+    """Tile order (include/nr_engine.h) -> row-major [R][K]: blocks (row tile, k-step) of 64 lane fragments (g, li) x 8."""
+    return np.asarray(a).reshape(R // 16, K // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(R, K)
+
+
 def check_pack(be):
     params = make_params(3)
     Wp, bp = pack_qkv(be, params, 'news_encoder.')
     Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
     be.sync()
     m = 'news_encoder.multihead_self_attention.'
-    Wp, bp = be.np(Wp), be.np(bp)
+    Wp, bp = untile(be.np(Wp), 3 * NR_NP, NR_KP), be.np(bp)
     for i, n in enumerate(('W_Q', 'W_K', 'W_V')):
         blk = Wp[i * NR_NP:(i + 1) * NR_NP]
         assert np.array_equal(blk[:NR_D, :NR_D], f32_to_bf16(params[m + n + '.weight']))
@@ -76,7 +81,7 @@ def check_pack(be):
         assert np.array_equal(bp[i * NR_NP:i * NR_NP + NR_D], params[m + n + '.bias'])
         assert not bp[i * NR_NP + NR_D:(i + 1) * NR_NP].any()
     a = 'news_encoder.additive_attention.'
-    Wap = be.np(Wap)
+    Wap = untile(be.np(Wap), NR_QP, NR_KP)
     assert np.array_equal(Wap[:200, :NR_D], f32_to_bf16(params[a + 'linear.weight']))
     assert not Wap[200:].any() and not Wap[:, NR_D:].any()
     assert np.array_equal(be.np(bap)[:200], params[a + 'linear.bias']) and not be.np(bap)[200:].any()
@@ -338,7 +343,7 @@ def check_additive_bwd(be, S=20, n_seq=6):
                                      be.ptr(dpre), be.ptr(dqp), be.ptr(WaT), be.ptr(dctx), n_seq, S, be.stream))
     be.sync()
     # fused input-gradient product: dctx[:, :D] = bf16(dpre) @ bf16(Wa), bit-level inputs as the kernel sees them
-    wat = be.np(WaT)
+    wat = untile(be.np(WaT), NR_KP, 224)
     assert np.array_equal(wat[:NR_D, :200], f32_to_bf16(params[a_ + 'linear.weight']).T) and not wat[NR_D:].any() and not wat[:, 200:].any()
     dref = bf16_to_f32(be.np(dpre)).astype(np.float64)[:, :200] @ bf16_round(params[a_ + 'linear.weight']).astype(np.float64)
     close_bf16(bf16_to_f32(be.np(dctx)[:, :NR_D]), dref, f'additive_bwd fused dctx S={S}', rel=2.0 ** -7, floor=1e-3)

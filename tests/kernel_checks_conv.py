@@ -5,7 +5,7 @@ import numpy as np
 from news_recommendation_amd._capi import NR_D, NR_KP, NR_QP
 from oracle import nrms_numpy as onp
 from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
-from tests.kernel_checks import ck, export_mask, close_bf16
+from tests.kernel_checks import ck, export_mask, close_bf16, untile
 
 F = NR_D
 
@@ -29,7 +29,8 @@ def check_pack_conv(be, D=NR_D, Fn=NR_D):
     W, b = conv_params(1, D, Fn)
     Wc, Wd, bc = pack_conv(be, W, b)
     be.sync()
-    Wc, Wd, bc = be.np(Wc), be.np(Wd), be.np(bc)
+    Wc, Wd = (np.stack([untile(m[t], NR_KP, NR_KP) for t in range(3)]) for m in (be.np(Wc), be.np(Wd)))
+    bc = be.np(bc)
     for t in range(3):
         assert np.array_equal(Wc[t, :Fn, :D], f32_to_bf16(W[:, 0, t, :]))
         assert np.array_equal(Wd[t, :D, :Fn], f32_to_bf16(W[:, 0, 2 - t, :].T))

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
-from tests.kernel_checks import ck
+from tests.kernel_checks import untile, ck
 from oracle.lstur_torch import OracleLSTURUserEncoder
 
 
@@ -26,11 +26,6 @@ def gate_pad(a, Hd, Hg):
 
 def gate_unpad(a, Hd, Hg):
     return np.concatenate([a[..., q * Hg:q * Hg + Hd] for q in range(3)], axis=-1)
-
-
-def untile(a, R, K):
-    """Tile order (include/nr_engine.h) -> row-major [R][K]: blocks (row tile, k-step) of 64 lane fragments (g, li) x 8."""
-    return np.asarray(a).reshape(R // 16, K // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(R, K)
 
 
 def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
