@@ -47,6 +47,7 @@ struct ConvParams {
   int64_t n_seq;
   int64_t tok_offset;      // added to the token index in the dropout counters (keeps title / abstract streams apart)
   DropCfg dc;
+  int debug;               // profiling only (NR_CONV_DEBUG): 1 = skip the token gather, 2 = skip the GEMM, 4 = skip the output stores
 };
 
 template <int S, int NSEQ, int NW>
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (i < TOTAL) {
           const int id = ids_s[r];
-          if (id >= 0) v[u] = *(const f32x4*)(p.table + ((size_t)id * D4 + c) * 4);
+          if (id >= 0 && !(p.debug & 1)) v[u] = *(const f32x4*)(p.table + ((size_t)id * D4 + c) * 4);
         }
       }
 #pragma unroll
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
         const int i = base + u * WG + tid;
         if (i < TOTAL) {
           f32x4 x = v[u];
-          if (p.dc.enabled) {
+          if (p.dc.enabled && !(p.debug & 16)) {
             x = x * drop_mul4(p.dc, 1u, (uint64_t)(p.tok_offset + tok0 + rr[u]) * D4 + cc[u]);
           }
           const int row = rr[u] + rr[u] / S + 1;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
       }
     }
     __syncthreads();
-    if (p.x_save != nullptr) {          // keep the masked bf16 tokens for the weight-gradient GEMMs (col D = 1.0 -> bias gradient)
+    if (p.x_save != nullptr && !(p.debug & 8)) {          // keep the masked bf16 tokens for the weight-gradient GEMMs (col D = 1.0 -> bias gradient)
       // every seqpad row of this workgroup incl. the zero separators (the shared ones are written twice, with zeros)
       constexpr int PCS = KP / 8;
       const int64_t rows_total = p.n_seq * (S + 1) + 1;
@@ -134,55 +135,68 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
   }
 
   // ---- GEMM over the three taps ----------------------------------------------------------------------------------
+  // A wave owns a contiguous range of (filter-tile pair, token tile) units (unit_range).  Per pair it walks its token tiles in
+  // chunks of MC: the chunk's accumulators stay in registers across the three taps, the filter fragments of one tap (G x KSTEPS,
+  // tile order: coalesced 1 KB loads) are held for the whole chunk, and the X fragments of one token tile are fetched from LDS as
+  // ONE batch of KSTEPS reads ahead of its MFMAs (sched_barrier).  G is a compile-time constant here: with a runtime G the
+  // compiler put a branch between the two MFMAs of every k-step and waited for each ds_read right before its MFMA
+  // (lgkmcnt(0) per k-step): the matrix pipe idled ~60 % of the GEMM phase.
   const int w_eff = (w + (int)blockIdx.x) % NW;
-  for (int cg = 0; cg < (NTF + 1) / 2; ++cg) {
-    int G, mb, me;
-    unit_range(NTF, Gm::MT, w_eff, NW, cg, G, mb, me);
-    if (mb >= me) continue;
-    const int wr0 = (2 * cg) * 16, wr1 = (G == 2) ? wr0 + 16 : wr0;     // G == 1: second column is a dead duplicate
-    f32x4 acc[Gm::MT][2];
+  auto gemm = [&](auto GC, int cg, int mb, int me) {
+    constexpr int G = decltype(GC)::value;
+    constexpr int MC = (Gm::MT + 1) / 2;
+    const int wr[2] = {(2 * cg) * 16, (2 * cg) * 16 + 16};
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 b0 = p.bc ? *(const f32x4*)(p.bc + wr0 + 4 * g) : zero4, b1 = p.bc ? *(const f32x4*)(p.bc + wr1 + 4 * g) : zero4;
+    f32x4 bias[G];
 #pragma unroll
-    for (int mi = 0; mi < Gm::MT; ++mi) { acc[mi][0] = b0; acc[mi][1] = b1; }
-    int rowoff[Gm::MT];
+    for (int j = 0; j < G; ++j) bias[j] = p.bc ? *(const f32x4*)(p.bc + wr[j] + 4 * g) : zero4;
+    for (int c0 = mb; c0 < me; c0 += MC) {
+      f32x4 acc[MC][G];
+      int rowoff[MC];
 #pragma unroll
-    for (int mi = 0; mi < Gm::MT; ++mi) {
-      int t = (mb + mi) * 16 + li;
-      t = t < Gm::TOK ? t : Gm::TOK - 1;
-      rowoff[mi] = (t + t / S) * XS + g * 8;          // seqpad row of tap 0 (= row(t) - 1)
-    }
+      for (int mi = 0; mi < MC; ++mi) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[mi][j] = bias[j];
+        int t = (c0 + mi) * 16 + li;
+        t = t < Gm::TOK ? t : Gm::TOK - 1;
+        rowoff[mi] = (t + t / S) * XS + g * 8;          // seqpad row of tap 0 (= row(t) - 1)
+      }
 #pragma unroll 1
-    for (int tap = 0; tap < 3; ++tap) {
-      u16x8 wf[2][KSTEPS];
-      const u16* wp0 = p.Wc + ((size_t)tap * NPC + wr0) * KP + l * 8;      // tile order: k-step ks of a row tile = + ks * 512
-      const u16* wp1 = p.Wc + ((size_t)tap * NPC + wr1) * KP + l * 8;
+      for (int tap = (p.debug & 2) ? 3 : 0; tap < 3; ++tap) {
+        u16x8 wf[G][KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) { wf[0][ks] = *(const u16x8*)(wp0 + ks * 512); wf[1][ks] = *(const u16x8*)(wp1 + ks * 512); }
+        for (int j = 0; j < G; ++j) {
+          const u16* wp = p.Wc + ((size_t)tap * NPC + wr[j]) * KP + l * 8;      // tile order: k-step ks of a row tile = + ks * 512
 #pragma unroll
-      for (int mi = 0; mi < Gm::MT; ++mi) {
-        if (mb + mi < me) {
-          const u16* xp = Xs + rowoff[mi] + tap * XS;
+          for (int ks = 0; ks < KSTEPS; ++ks) wf[j][ks] = *(const u16x8*)(wp + ks * 512);
+        }
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u16x8 xf = *(const u16x8*)(xp + ks * 32);
-            acc[mi][0] = mfma_16x16x32_bf16(wf[0][ks], xf, acc[mi][0]);
-            if (G == 2) acc[mi][1] = mfma_16x16x32_bf16(wf[1][ks], xf, acc[mi][1]);
+        for (int mi = 0; mi < MC; ++mi) {
+          if (c0 + mi < me) {
+            const u16* xp = Xs + rowoff[mi] + tap * XS;
+            u16x8 xf[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) xf[ks] = *(const u16x8*)(xp + ks * 32);
+            NR_SCHED_BARRIER();
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+              for (int j = 0; j < G; ++j) acc[mi][j] = mfma_16x16x32_bf16(wf[j][ks], xf[ks], acc[mi][j]);
+            }
+            NR_SCHED_BARRIER();
           }
         }
       }
-    }
-    // epilogue: lane holds filters ncol + 4g .. +3 of token m*16 + li
+      // epilogue: lane holds filters col .. col+3 of token m*16 + li
 #pragma unroll
-    for (int mi = 0; mi < Gm::MT; ++mi) {
-      if (mb + mi < me) {
+      for (int mi = 0; mi < MC; ++mi) {
+        if (c0 + mi < me) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (j < G) {
-            const int t = (mb + mi) * 16 + li;
-            const int col = (j == 0 ? wr0 : wr1) + 4 * g;
+          for (int j = 0; j < G; ++j) {
+            const int t = (c0 + mi) * 16 + li;
+            const int col = wr[j] + 4 * g;
             const int64_t tok = tok0 + t;
-            if (t < Gm::TOK && tok < tok_total && col < D) {
+            if (t < Gm::TOK && tok < tok_total && col < D && !(p.debug & 4)) {
               f32x4 y = acc[mi][j];
               if (p.relu_drop) {
 #pragma unroll
@@ -197,8 +211,15 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
         }
       }
     }
+  };
+  for (int cg = 0; cg < (NTF + 1) / 2; ++cg) {
+    int G, mb, me;
+    unit_range(NTF, Gm::MT, w_eff, NW, cg, G, mb, me);
+    if (mb >= me) continue;
+    if (G == 2) gemm(std::integral_constant<int, 2>{}, cg, mb, me);
+    else gemm(std::integral_constant<int, 1>{}, cg, mb, me);
   }
-  if (p.relu_drop) {      // K padding of the activation rows: col D = 1.0 (bias-gradient column), cols D+1..KP = 0
+  if (p.relu_drop && !(p.debug & 32)) {      // K padding of the activation rows: col D = 1.0 (bias-gradient column), cols D+1..KP = 0
     constexpr int PADQ = (KP - D) / 4;
     for (int i = tid; i < Gm::TOK * PADQ; i += WG) {
       const int r = i / PADQ, c = i - r * PADQ;

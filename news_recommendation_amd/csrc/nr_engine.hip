@@ -54,7 +54,8 @@ int grid_for(int64_t work, int per_block, int cap) {
   return (int)b;
 }
 
-// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 0 = 4 waves on 4 titles (two workgroups per CU), 1 = 8 waves on 8 titles
+// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 0 (default) = forward 4 waves on 2 titles, backward 4 waves on 4 titles;
+// 1 = 8 waves on 8 titles (both); 2 = 4 waves on 2 titles (both); 3 = 4 waves on 4 titles (both)
 int add_variant() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 0; }
@@ -183,6 +184,11 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
+  } else if (S == 20 && add_variant() != 3) {      // default: 2 titles per workgroup (5 workgroups per CU hide the per-tile latency chain: -14 %)
+    constexpr int NSEQ = 2;
+    using G = nr::AddGeom<20, NSEQ>;
+    if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;
@@ -242,7 +248,7 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
-  if (S == 20) return add_variant() == 1 ? (n_seq + 7) / 8 : (n_seq + 3) / 4;
+  if (S == 20) return add_variant() == 1 ? (n_seq + 7) / 8 : add_variant() == 2 ? (n_seq + 1) / 2 : (n_seq + 3) / 4;
   if (S == 50) return n_seq;
   if (S == 4) return (n_seq + 19) / 20;
   return -1;
@@ -278,6 +284,11 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_bwd_kernel<20, NSEQ, NW>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else if (S == 20 && add_variant() == 2) {
+    constexpr int NSEQ = 2;
+    using G = nr::AddGeom<20, NSEQ>;
+    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
   } else if (S == 20) {
     constexpr int NSEQ = 4;
     using G = nr::AddGeom<20, NSEQ>;
@@ -383,16 +394,17 @@ int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uin
 }
 
 static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what) {
+  { const char* d = getenv("NR_CONV_DEBUG"); p.debug = d ? atoi(d) : 0; }
   // tuning knob NR_CONV_VARIANT: 0 = 4 waves on 4 titles / 2 abstracts (two workgroups per CU); 1 (default) = 8 waves on 8 titles /
   // 4 abstracts (one workgroup per CU, the filter bank is re-read from L2 half as often: ~10 % faster at B = 512)
   const char* var = getenv("NR_CONV_VARIANT");
   const int v = var ? atoi(var) : 1;
   int rc;
   if (S == 20) {
-    rc = v == 1 ? launch_conv_t<20, 8, 8>(p, stream) : launch_conv_t<20, 4, 4>(p, stream);
+    rc = v == 1 ? launch_conv_t<20, 8, 8>(p, stream) : v == 2 ? launch_conv_t<20, 4, 8>(p, stream) : launch_conv_t<20, 4, 4>(p, stream);
     if (rc) return rc;
   } else if (S == 50) {
-    rc = v == 1 ? launch_conv_t<50, 4, 8>(p, stream) : launch_conv_t<50, 2, 4>(p, stream);
+    rc = v == 1 ? launch_conv_t<50, 4, 8>(p, stream) : v == 2 ? launch_conv_t<50, 2, 8>(p, stream) : launch_conv_t<50, 2, 4>(p, stream);
     if (rc) return rc;
   } else {
     return fail(NR_ERR_UNSUPPORTED, "conv3: sequence length not instantiated (20, 50)");

@@ -37,6 +37,16 @@ fns = {
   'additive_bwd': lambda: ck(lib.nr_additive_bwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw.data_ptr(), gout.data_ptr(), dpre.data_ptr(), dqp.data_ptr(), T, 20, st())),
   'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
 }
+if name.startswith('conv'):
+    S = 50 if 'abs' in name else 20
+    Tn = B * 53
+    idc = torch.randint(1, V, (Tn, S), generator=g).to(dev)
+    Wcv = torch.randn(300, 1, 3, 300, generator=g).mul_(0.03).to(dev); bcv = torch.zeros(300, device=dev)
+    Wc = torch.empty(3, NR_KP, NR_KP, dtype=torch.int16, device=dev); Wd = torch.empty_like(Wc); bc = torch.empty(NR_KP, device=dev)
+    ck(lib.nr_pack_conv(Wcv.data_ptr(), bcv.data_ptr(), 300, 300, Wc.data_ptr(), Wd.data_ptr(), bc.data_ptr(), st()))
+    act = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
+    xs = torch.empty(Tn * (S + 1) + 1, NR_KP, dtype=torch.int16, device=dev)
+    fns[name] = lambda: ck(lib.nr_conv3_fwd(idc.data_ptr(), table.data_ptr(), V, Wc.data_ptr(), bc.data_ptr(), act.data_ptr(), xs.data_ptr(), Tn, S, 0.2, 1, 0, st()))
 fn = fns[name]
 for _ in range(2): fn()
 torch.cuda.synchronize()
