@@ -37,6 +37,18 @@ fns = {
   'additive_bwd': lambda: ck(lib.nr_additive_bwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw.data_ptr(), gout.data_ptr(), dpre.data_ptr(), dqp.data_ptr(), T, 20, st())),
   'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
 }
+if name.endswith('50'):          # abstract-shaped pooling: 27 k sequences of 50 ctx rows
+    S = 50; Tn = B * 53
+    ctx50 = torch.randn(Tn * S, NR_KP, generator=g).mul_(0.3).to(torch.bfloat16).view(torch.int16).to(dev)
+    nv50 = torch.empty(Tn, NR_D, device=dev); aw50 = torch.empty(Tn, S, device=dev)
+    ck(lib.nr_additive_fwd(ctx50.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv50.data_ptr(), aw50.data_ptr(), Tn, S, st()))
+    gout50 = torch.randn(Tn, NR_D, generator=g).to(dev)
+    dpre50 = torch.empty(Tn * S, NR_QP, dtype=torch.int16, device=dev); dqp50 = torch.empty(lib.nr_additive_bwd_grid(Tn, S), NR_QP, device=dev)
+    WaT = torch.empty(NR_KP, 224, dtype=torch.int16, device=dev); dctx50 = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
+    ck(lib.nr_pack_additive_t(Wa.data_ptr(), 200, WaT.data_ptr(), st()))
+    fns['additive_fwd50'] = lambda: ck(lib.nr_additive_fwd(ctx50.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv50.data_ptr(), aw50.data_ptr(), Tn, S, st()))
+    fns['additive_bwd50'] = lambda: ck(lib.nr_additive_bwd_ex(ctx50.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw50.data_ptr(), gout50.data_ptr(),
+                                                              dpre50.data_ptr(), dqp50.data_ptr(), WaT.data_ptr(), dctx50.data_ptr(), Tn, S, st()))
 if name.startswith('conv'):
     S = 50 if 'abs' in name else 20
     Tn = B * 53
