@@ -236,6 +236,18 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
                     const uint16_t* h_prev_b, const int32_t* len, uint16_t* dgi, uint16_t* dgh, uint16_t* dgh_t, float* carry, int B, int N,
                     int Hd, int t, int first, void* stream);
 
+/* The whole recurrence in one call (the host pays one FFI crossing instead of 2T+1: at ~100 launches per LSTUR step the Python
+ * launch loop, not the GPU, set the step time on slower hosts).  Forward: steps t = 0..T-1 as nr_gru_fwd_step; h_t2 = two tile-order
+ * state buffers [2][B up to 16][Hp] (h_0 in the first, the rest zero), h_f2 = two f32 state buffers [2][B][Hp] (h_0 in the first);
+ * step t reads buffer t%2 and writes (t+1)%2, so h_T is in buffer T%2.  H_all bf16 [T+1][B][Hp] (row block t+1 receives h_t+1;
+ * block 0 = h_0 is the caller's) and gates bf16 [T][B][4][Hg] are for training, both NULL for inference.
+ * Backward: steps t = T-1..0 and the final t = -1 as nr_gru_bwd_step; dgh bf16 [T][B][Kp], dgh_t2 [2][B up to 16][Kp] (zeroed once),
+ * carry2 f32 [2][B][Hp]; launch i uses buffers i%2, so dh_0 ends in carry2 buffer T%2. */
+int nr_gru_fwd_seq(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2,
+                   uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream);
+int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
+                   uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream);
+
 /* Per-impression ranking metrics of src/evaluate.py:24-42,160-168 for a CSR batch of impressions: scores f32[nnz], labels
  * int32[nnz] (0/1), ptr int64[n_impr+1]; out f32[n_impr][4] = AUC, MRR, nDCG@5, nDCG@10 (four NaNs when an impression has a
  * single label class: the reference's ValueError path).  Replaces the multiprocessing pool of src/evaluate.py:267-268. */

@@ -50,6 +50,8 @@ SIGNATURES = {
     'nr_tile_rows_bf16': ([_P, c_int, c_int, _P, _P], c_int),
     'nr_rows_to_bf16': ([_P, c_int64, c_int, _P, c_int, c_int64, _P], c_int),
     'nr_gru_fwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    'nr_gru_fwd_seq': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    'nr_gru_bwd_seq': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_bwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_impression_metrics': ([_P, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),

@@ -55,28 +55,38 @@ struct GruFwdParams {
 // hidden sizes); the loop is fully unrolled into a register pipeline with NR_GRU_DEPTH k-steps (4 x 16-byte loads each) in
 // flight, pinned by sched_barriers (left alone the scheduler sinks every load next to its MFMA to save registers).
 // KS_CT = 0: generic rolled loop.
-template <int KS_CT>
+template <int KS_CT, int NB>
 __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
+  // NB sample tiles per wave share every W_hh fragment (NB = 2: 5 loads per 6 MFMAs instead of 4 per 3; the step is bound by the
+  // L2 -> L1 operand volume, ~15 TB/s measured)
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   int tile, group;
-  if (!gru_tile_of_wg(p.Hg / 16, (p.B + 63) / 64, tile, group)) return;
-  const int s0 = (group * 4 + w) * 16;
+  if (!gru_tile_of_wg(p.Hg / 16, (p.B + 64 * NB - 1) / (64 * NB), tile, group)) return;
+  const int s0 = (group * 4 + w) * NB * 16;
   if (s0 >= p.B) return;
-  const int j0 = tile * 16;
-  const int sb = s0 + li < p.B ? s0 + li : p.B - 1;
+  const int j0 = tile * 16, jb = j0 + 4 * g;
   // fragment pointers in tile order: k-step ks of an operand tile is the 1 KB at + ks * 512 elements
-  const u16* hp = p.h_in_t + (size_t)(s0 >> 4) * p.Hp * 16 + l * 8;
   const u16* w0 = p.Whh + (size_t)tile * p.Hp * 16 + l * 8;
   const u16* w1 = w0 + (size_t)p.Hg * p.Hp;
   const u16* w2 = w1 + (size_t)p.Hg * p.Hp;
-  f32x4 ar = f32x4{0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
-  // epilogue operands (lane: sample s0 + li, units j0 + 4g + r) are requested before the k pipeline so that their round trip overlaps it
-  const int jb = j0 + 4 * g;
-  const int len_s = p.len[sb];
-  const float* gi = p.gi + ((size_t)sb * p.N + p.t) * 3 * p.Hg + jb;
-  const f32x4 gir = *(const f32x4*)gi, giz = *(const f32x4*)(gi + p.Hg), gin = *(const f32x4*)(gi + 2 * p.Hg);
-  const f32x4 ho = *(const f32x4*)(p.h_in_f + (size_t)sb * p.Hp + jb);
-  f32x4 b_ir, b_hr, b_iz, b_hz, b_in, b_hn;            // raw values: nothing below may wait on them before the k pipeline has been issued
+  const u16* hp[NB];
+  int sb[NB], len_s[NB];
+  f32x4 gir[NB], giz[NB], gin[NB], ho[NB];
+  f32x4 ar[NB], az[NB], an[NB];
+  // epilogue operands (lane: sample s0 + 16 nb + li, units j0 + 4g + r) are requested before the k pipeline so that their round
+  // trip overlaps it; raw values: nothing below may wait on them before the pipeline has been issued
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int st = s0 + nb * 16 < p.B ? s0 + nb * 16 : s0;          // a missing second tile recomputes the first (results discarded)
+    hp[nb] = p.h_in_t + (size_t)(st >> 4) * p.Hp * 16 + l * 8;
+    sb[nb] = st + li < p.B ? st + li : p.B - 1;
+    len_s[nb] = p.len[sb[nb]];
+    const float* gi = p.gi + ((size_t)sb[nb] * p.N + p.t) * 3 * p.Hg + jb;
+    gir[nb] = *(const f32x4*)gi; giz[nb] = *(const f32x4*)(gi + p.Hg); gin[nb] = *(const f32x4*)(gi + 2 * p.Hg);
+    ho[nb] = *(const f32x4*)(p.h_in_f + (size_t)sb[nb] * p.Hp + jb);
+    ar[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; az[nb] = ar[nb]; an[nb] = ar[nb];
+  }
+  f32x4 b_ir, b_hr, b_iz, b_hz, b_in, b_hn;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = jb + r < p.Hd ? jb + r : p.Hd - 1;
@@ -85,12 +95,13 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
     b_in[r] = p.b_ih[2 * p.Hd + j]; b_hn[r] = p.b_hh[2 * p.Hd + j];
   }
   if (KS_CT > 0) {
-    constexpr int D = NR_GRU_DEPTH;
-    u16x8 fh[D], f0[D], f1[D], f2[D];
+    constexpr int D = NB == 1 ? NR_GRU_DEPTH : (NR_GRU_DEPTH * 3) / 4;
+    u16x8 fh[NB][D], f0[D], f1[D], f2[D];
 #pragma unroll
     for (int i = 0; i < D; ++i)
       if (i < KS_CT) {
-        fh[i] = *(const u16x8*)(hp + i * 512);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fh[nb][i] = *(const u16x8*)(hp[nb] + i * 512);
         f0[i] = *(const u16x8*)(w0 + i * 512);
         f1[i] = *(const u16x8*)(w1 + i * 512);
         f2[i] = *(const u16x8*)(w2 + i * 512);
@@ -99,11 +110,15 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS_CT; ++ks) {
       const int sl = ks % D;
-      ar = mfma_16x16x32_bf16(f0[sl], fh[sl], ar);
-      az = mfma_16x16x32_bf16(f1[sl], fh[sl], az);
-      an = mfma_16x16x32_bf16(f2[sl], fh[sl], an);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        ar[nb] = mfma_16x16x32_bf16(f0[sl], fh[nb][sl], ar[nb]);
+        az[nb] = mfma_16x16x32_bf16(f1[sl], fh[nb][sl], az[nb]);
+        an[nb] = mfma_16x16x32_bf16(f2[sl], fh[nb][sl], an[nb]);
+      }
       if (ks + D < KS_CT) {
-        fh[sl] = *(const u16x8*)(hp + (ks + D) * 512);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fh[nb][sl] = *(const u16x8*)(hp[nb] + (ks + D) * 512);
         f0[sl] = *(const u16x8*)(w0 + (ks + D) * 512);
         f1[sl] = *(const u16x8*)(w1 + (ks + D) * 512);
         f2[sl] = *(const u16x8*)(w2 + (ks + D) * 512);
@@ -114,43 +129,50 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
     const int ksteps = p.Hp / 32;
 #pragma unroll 2
     for (int ks = 0; ks < ksteps; ++ks) {
-      const u16x8 hf = *(const u16x8*)(hp + ks * 512);
-      ar = mfma_16x16x32_bf16(*(const u16x8*)(w0 + ks * 512), hf, ar);
-      az = mfma_16x16x32_bf16(*(const u16x8*)(w1 + ks * 512), hf, az);
-      an = mfma_16x16x32_bf16(*(const u16x8*)(w2 + ks * 512), hf, an);
-    }
-  }
-  const int s = s0 + li;
-  if (s >= p.B) return;
-  const bool active = p.t < len_s;
-  f32x4 hn, rr, zz, nn, qq;
+      const u16x8 a0 = *(const u16x8*)(w0 + ks * 512), a1 = *(const u16x8*)(w1 + ks * 512), a2 = *(const u16x8*)(w2 + ks * 512);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool ok = jb + r < p.Hd;                    // units >= Hd: zero weight rows and gi columns, their h stays 0
-    rr[r] = fast_sigmoid(gir[r] + b_ir[r] + ar[r] + b_hr[r]);
-    zz[r] = fast_sigmoid(giz[r] + b_iz[r] + az[r] + b_hz[r]);
-    qq[r] = an[r] + b_hn[r];
-    nn[r] = fast_tanh(gin[r] + b_in[r] + rr[r] * qq[r]);
-    const float v = active ? (1.0f - zz[r]) * nn[r] + zz[r] * ho[r] : ho[r];
-    hn[r] = ok ? v : 0.0f;
-  }
-  if (jb < p.Hd) {         // the 4 units straddle Hd only at the very end, where the row padding absorbs them
-    *(f32x4*)(p.h_out_f + (size_t)s * p.Hp + jb) = hn;
-    u16x4 hb = pack4(hn);
-    if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;        // column Hd = 1.0
-    *(u16x4*)(p.h_out_t + tile_off(s, jb, p.Hp)) = hb;
-    if (p.h_out_b != nullptr) *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
-    if (jb + 4 == p.Hd) {                                          // Hd % 4 == 0: the lane owning the last units also sets column Hd
-      p.h_out_t[tile_off(s, p.Hd, p.Hp)] = 0x3F80;
-      if (p.h_out_b != nullptr) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
+      for (int nb = 0; nb < NB; ++nb) {
+        const u16x8 hf = *(const u16x8*)(hp[nb] + ks * 512);
+        ar[nb] = mfma_16x16x32_bf16(a0, hf, ar[nb]);
+        az[nb] = mfma_16x16x32_bf16(a1, hf, az[nb]);
+        an[nb] = mfma_16x16x32_bf16(a2, hf, an[nb]);
+      }
     }
   }
-  if (p.gates != nullptr && jb < p.Hg) {
-    u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
-    *(u16x4*)gp = pack4(rr);
-    *(u16x4*)(gp + p.Hg) = pack4(zz);
-    *(u16x4*)(gp + 2 * p.Hg) = pack4(nn);
-    *(u16x4*)(gp + 3 * p.Hg) = pack4(qq);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int s = s0 + nb * 16 + li;
+    if (s >= p.B) continue;
+    const bool active = p.t < len_s[nb];
+    f32x4 hn, rr, zz, nn, qq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = jb + r < p.Hd;                    // units >= Hd: zero weight rows and gi columns, their h stays 0
+      rr[r] = fast_sigmoid(gir[nb][r] + b_ir[r] + ar[nb][r] + b_hr[r]);
+      zz[r] = fast_sigmoid(giz[nb][r] + b_iz[r] + az[nb][r] + b_hz[r]);
+      qq[r] = an[nb][r] + b_hn[r];
+      nn[r] = fast_tanh(gin[nb][r] + b_in[r] + rr[r] * qq[r]);
+      const float v = active ? (1.0f - zz[r]) * nn[r] + zz[r] * ho[nb][r] : ho[nb][r];
+      hn[r] = ok ? v : 0.0f;
+    }
+    if (jb < p.Hd) {         // the 4 units straddle Hd only at the very end, where the row padding absorbs them
+      *(f32x4*)(p.h_out_f + (size_t)s * p.Hp + jb) = hn;
+      u16x4 hb = pack4(hn);
+      if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;        // column Hd = 1.0
+      *(u16x4*)(p.h_out_t + tile_off(s, jb, p.Hp)) = hb;
+      if (p.h_out_b != nullptr) *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
+      if (jb + 4 == p.Hd) {                                          // Hd % 4 == 0: the lane owning the last units also sets column Hd
+        p.h_out_t[tile_off(s, p.Hd, p.Hp)] = 0x3F80;
+        if (p.h_out_b != nullptr) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
+      }
+    }
+    if (p.gates != nullptr && jb < p.Hg) {
+      u16* gp = p.gates + (size_t)s * 4 * p.Hg + jb;
+      *(u16x4*)gp = pack4(rr);
+      *(u16x4*)(gp + p.Hg) = pack4(zz);
+      *(u16x4*)(gp + 2 * p.Hg) = pack4(nn);
+      *(u16x4*)(gp + 3 * p.Hg) = pack4(qq);
+    }
   }
 }
 

@@ -534,9 +534,22 @@ int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, con
   nr::GruFwdParams p;
   p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_t = h_in_t; p.h_out_b = h_out_b; p.h_out_t = h_out_t; p.h_in_f = h_in_f;
   p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
-  if (p.Hp == 29 * 32) NR_LAUNCH2(nr::gru_fwd_step_kernel<29>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
-  else if (p.Hp == 15 * 32) NR_LAUNCH2(nr::gru_fwd_step_kernel<15>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
-  else NR_LAUNCH2(nr::gru_fwd_step_kernel<0>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);
+  // tuning knob NR_GRU_NB: sample tiles per wave in the forward step (default 2 from 256 samples up)
+  static int nbv = -1;
+  if (nbv < 0) { const char* e = getenv("NR_GRU_NB"); nbv = e ? atoi(e) : 0; }
+  const int nb = nbv > 0 ? nbv : (B >= 256 ? 2 : 1);
+  const int tiles = p.Hg / 16;
+  if (nb == 2) {
+    const int grid = nr::gru_grid(tiles, (B + 127) / 128);
+    if (p.Hp == 29 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<29, 2>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
+    else if (p.Hp == 15 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<15, 2>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
+    else NR_LAUNCH2((nr::gru_fwd_step_kernel<0, 2>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);
+  } else {
+    const int grid = nr::gru_grid(tiles, (B + 63) / 64);
+    if (p.Hp == 29 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<29, 1>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);
+    else if (p.Hp == 15 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<15, 1>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);
+    else NR_LAUNCH2((nr::gru_fwd_step_kernel<0, 1>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);
+  }
   return check_launch("nr_gru_fwd_step");
 }
 
@@ -555,6 +568,38 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   else if (p.Kp == 44 * 32) NR_LAUNCH2(nr::gru_bwd_step_kernel<44>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
   else NR_LAUNCH2(nr::gru_bwd_step_kernel<0>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);
   return check_launch("nr_gru_bwd_step");
+}
+
+int nr_gru_fwd_seq(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2,
+                   uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream) {
+  if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
+  const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
+  const size_t ht = (size_t)ceil_to(B, 16) * Hp, hf = (size_t)B * Hp;
+  for (int t = 0; t < T; ++t) {
+    const int rc = nr_gru_fwd_step(gi, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, H_all ? H_all + (size_t)(t + 1) * hf : nullptr,
+                                   h_t2 + ((t + 1) & 1) * ht, h_f2 + (t & 1) * hf, h_f2 + ((t + 1) & 1) * hf,
+                                   gates ? gates + (size_t)t * B * 4 * Hg : nullptr, B, N, Hd, t, stream);
+    if (rc) return rc;
+  }
+  return NR_OK;
+}
+
+int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
+                   uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream) {
+  if (!g_last || !gates || !H_all || !dgi || !dgh || !dgh_t2 || !carry2 || T <= 0 || T > N || B < 0 || Hd <= 0)
+    return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
+  const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32), Kp = ceil_to(3 * Hg, 32);
+  const size_t dt = (size_t)ceil_to(B, 16) * Kp, cf = (size_t)B * Hp, hb = (size_t)B * Hp, gb = (size_t)B * 4 * Hg, db = (size_t)B * Kp;
+  int i = 0;
+  for (int t = T - 1; t >= -1; --t, ++i) {
+    const int first = i == 0;
+    const int rc = nr_gru_bwd_step(first ? g_last : nullptr, first ? nullptr : dgh_t2 + ((i + 1) & 1) * dt, first ? nullptr : carry2 + ((i + 1) & 1) * cf,
+                                   WhhT, t >= 0 ? gates + (size_t)t * gb : nullptr, t >= 0 ? H_all + (size_t)t * hb : nullptr, len,
+                                   t >= 0 ? dgi : nullptr, t >= 0 ? dgh + (size_t)t * db : nullptr, t >= 0 ? dgh_t2 + (i & 1) * dt : nullptr,
+                                   carry2 + (i & 1) * cf, B, N, Hd, t, first, stream);
+    if (rc) return rc;
+  }
+  return NR_OK;
 }
 
 int nr_impression_metrics(const float* scores, const int32_t* labels, const int64_t* ptr, float* out, int64_t n_impr, void* stream) {

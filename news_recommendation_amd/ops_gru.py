@@ -82,17 +82,21 @@ class _GruFn(torch.autograd.Function):
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
         gi = _mm_f32(_bf16(Xb), _bf16(Wih_p).t(), 'gemm_gru_gi')                             # [B*N][3*Hg] f32 (hoisted input projection)
         H_all = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
-        hf = [torch.zeros(B, Hp, dtype=torch.float32, device=dev), torch.empty(B, Hp, dtype=torch.float32, device=dev)]
+        hf = torch.zeros(2, B, Hp, dtype=torch.float32, device=dev)
         if h0 is not None:
             hf[0][:, :Hd].copy_(h0)
         _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf[0]), Hp, Hd, _ptr(H_all[0]), Hp, B, _stream())
         gates = torch.empty(T, B, 4, Hg, dtype=_BF16_AS_I16, device=dev) if need_grad else None
         ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)               # step-to-step operand, tile order
         _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(H_all[0]), B, Hp, _ptr(ht[0]), _stream())
-        for t in range(T):
-            _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht[t % 2]),
-                  _ptr(H_all[t + 1]) if need_grad else None, _ptr(ht[(t + 1) % 2]), _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]),
-                  _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
+        if ops._prof is None:        # one FFI crossing for the whole recurrence (the per-step form is kept for per-kernel profiling)
+            _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht),
+                  _ptr(H_all) if need_grad else None, _ptr(hf), _ptr(gates) if need_grad else None, B, N, Hd, T, _stream())
+        else:
+            for t in range(T):
+                _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht[t % 2]),
+                      _ptr(H_all[t + 1]) if need_grad else None, _ptr(ht[(t + 1) % 2]), _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]),
+                      _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
         out = hf[T % 2][:, :Hd].contiguous()
         if need_grad:
             ctx.save_for_backward(Xb, H_all, gates, lens_dev, Wih_p, WhhT)
@@ -111,9 +115,12 @@ class _GruFn(torch.autograd.Function):
         if T < N:
             dgi.view(B, N, Kp)[:, T:].zero_()                                                # steps nobody reached
         dgh = _workspace('gru_dgh', (T, B, Kp), _BF16_AS_I16, dev, zero=True)
-        carry = [torch.empty(B, Hp, dtype=torch.float32, device=dev) for _ in range(2)]
+        carry = torch.empty(2, B, Hp, dtype=torch.float32, device=dev)
         dght = _workspace('gru_dgh_t', (2, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)  # step-to-step operand, tile order
-        for i, t in enumerate(range(T - 1, -2, -1)):
+        if ops._prof is None:
+            _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
+                  _ptr(dght), _ptr(carry), B, N, Hd, T, _stream())
+        for i, t in enumerate(range(T - 1, -2, -1) if ops._prof is not None else ()):
             first = 1 if i == 0 else 0
             _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dght[(i + 1) % 2]),
                   None if first else _ptr(carry[(i + 1) % 2]), _ptr(WhhT), _ptr(gates[t]) if t >= 0 else None, _ptr(H_all[t]) if t >= 0 else None,

@@ -76,6 +76,21 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
                                       B, N, Hd, t, be.stream))
     be.sync()
     assert np.array_equal(untile(be.np(ht[T % 2]), B16, Hp)[:B], be.np(H_all[T]))          # both forms of h_T agree
+    # the whole recurrence in one call (nr_gru_fwd_seq) = the same launches: bit-identical state, saved states and gates
+    ht2 = np.zeros((2, B16, Hp), dtype=np.uint16); ht2[0] = be.np(ht[0]) if T % 2 == 0 else 0
+    ht2_d = be.dev(ht2)
+    ck(be, be.lib.nr_tile_rows_bf16(be.ptr(H_all[0]), B, Hp, be.ptr(ht2_d), be.stream))
+    hf2 = np.zeros((2, B, Hp), dtype=np.float32); hf2[0] = h0p
+    hf2_d = be.dev(hf2)
+    Hs = np.zeros((T + 1, B, Hp), dtype=np.uint16); Hs[0] = be.np(H_all[0])
+    Hs_d = be.dev(Hs)
+    gs_d = be.poison((T, B, 4, Hg), np.uint16)
+    ck(be, be.lib.nr_gru_fwd_seq(be.ptr(h_gi), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(ht2_d), be.ptr(Hs_d), be.ptr(hf2_d),
+                                 be.ptr(gs_d), B, N, Hd, T, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(hf2_d)[T % 2], be.np(hf[T % 2]))
+    assert all(np.array_equal(be.np(Hs_d)[t], be.np(H_all[t])) for t in range(T + 1))
+    assert all(np.array_equal(be.np(gs_d)[t], be.np(gates[t])) for t in range(T))
     h_last = be.np(hf[T % 2])[:, :Hd]
     # reference: the oracle recurrence in float64 on the same operands
     enc = OracleLSTURUserEncoder(Hd // 3 if Hd % 3 == 0 and I == Hd else 1, 'ini')
@@ -112,6 +127,14 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     be.sync()
     n_calls = T + 1
     dh0 = be.np(carry[(n_calls - 1) % 2])[:, :Hd]
+    # nr_gru_bwd_seq: same launches in one call
+    dgi2 = be.dev(dgi0); dgh2 = be.dev(np.zeros((T, B, Kp), dtype=np.uint16))
+    dght2 = be.dev(np.zeros((2, B16, Kp), dtype=np.uint16)); carry2 = be.poison((2, B, Hp), np.float32)
+    ck(be, be.lib.nr_gru_bwd_seq(be.ptr(hg), be.ptr(WhhT_p), be.ptr(gs_d), be.ptr(Hs_d), be.ptr(hlen), be.ptr(dgi2), be.ptr(dgh2), be.ptr(dght2),
+                                 be.ptr(carry2), B, N, Hd, T, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(carry2)[T % 2][:, :Hd], be.np(carry[T % 2])[:, :Hd]) and np.array_equal(be.np(dgi2), be.np(dgi))
+    assert all(np.array_equal(be.np(dgh2)[t][:, :3 * Hg], be.np(dgh[t])[:, :3 * Hg]) for t in range(T))
     rel = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - b).max() / (np.abs(b).max() + 1e-30)
     assert rel(dh0, h0t.grad.numpy()) < 3e-2, rel(dh0, h0t.grad.numpy())
     dgi_np = bf16_to_f32(be.np(dgi)).reshape(B, N, Kp).astype(np.float64)
