@@ -136,8 +136,8 @@ int nr_embed_scatter_add(const int64_t* ids, const uint16_t* dx, int ldx, float*
                          int64_t n_tokens, float p_drop, uint64_t seed, void* stream);
 
 /* Same result without contended atomics: the caller passes the token ids sorted ascending together with the
- * permutation (ids_sorted[i] = ids[perm[i]]); each table row is reduced in registers and written once.
- * grad_table must be zero on entry (rows are stored, not accumulated, unless a run spans two waves). */
+ * permutation (ids_sorted[i] = ids[perm[i]]); each table row is reduced in registers and ADDED to grad_table once (read, add,
+ * write; atomics only where a run spans two waves), so grad_table may be a zeroed scratch or the parameter's live gradient. */
 int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, const uint16_t* dx, int ldx,
                             float* grad_table, int64_t num_rows, int64_t n_tokens, float p_drop, uint64_t seed,
                             void* stream);
@@ -194,7 +194,7 @@ int nr_element_table_bwd(const float* emb, int ncat, int dcat, const float* W0, 
 int nr_views_fill(const int64_t* cat, const int64_t* sub, const float* E, int ncat, uint16_t* views, int64_t T, void* stream);
 
 /* Segmented row reduction dst[ids[i]] += src[perm-order rows] for D-wide f32 rows (ids sorted ascending with their permutation,
- * as nr_embed_scatter_sorted; dst zero on entry); rows with id <= pad_row are skipped (-1: none). */
+ * as nr_embed_scatter_sorted: accumulated into dst); rows with id <= pad_row are skipped (-1: none). */
 int nr_scatter_sorted_f32(const int64_t* ids_sorted, const int64_t* perm, const float* src, int64_t ld, float* dst, int64_t num_rows,
                           int64_t n, int pad_row, void* stream);
 /* Generic atomic row scatter-add, any width d: dst[ids[i]][0:d] += row_scale[i] * src[i][0:d] (row_scale may be NULL). */

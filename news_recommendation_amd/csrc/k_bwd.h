@@ -560,7 +560,8 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* _
 // Sorted variant: positions are sorted by id (ids_sorted ascending, perm = original token index), so all
 // contributions to one table row are adjacent.  One wave reduces CH consecutive positions in registers (lane =
 // one 4-column quad, lanes 0..10 a second quad) and writes each finished row once; only rows whose run touches
-// the chunk boundary (and may continue in a neighbour wave) use atomics.  grad_table must start zeroed.
+// the chunk boundary (and may continue in a neighbour wave) use atomics.  The result is ADDED to grad_table (a row that only this
+// wave touches is read, added and written back), so the destination may be the live .grad buffer of the parameter.
 constexpr int SC_CH = 32;
 __device__ __forceinline__ f32x4 ld_row4(const u16* p) { u16x4 v = *(const u16x4*)p; return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
 __device__ __forceinline__ f32x4 ld_row4(const float* p) { return *(const f32x4*)p; }
@@ -597,8 +598,8 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
         for (int j = 0; j < 4; ++j) atomic_add(dst + 256 + j, a1[j]);
       }
     } else {
-      *(f32x4*)dst = a0;
-      if (two) *(f32x4*)(dst + 256) = a1;
+      *(f32x4*)dst = *(const f32x4*)dst + a0;
+      if (two) *(f32x4*)(dst + 256) = *(const f32x4*)(dst + 256) + a1;
     }
   };
   bool first = true;

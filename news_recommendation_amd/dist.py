@@ -43,6 +43,9 @@ class FlatGradBuffer:
     """All parameter gradients as views into one contiguous fp32 buffer.
 
     * ``zero()`` replaces ``optimizer.zero_grad()`` (keeps the views alive),
+    * the parameters are marked ``_nr_inplace_grad``: the engine's embedding-table backward then accumulates into the view directly
+      instead of returning a dense table-sized tensor for autograd to add (only valid with this explicit zero / all-reduce protocol:
+      no autograd hook fires for a gradient that is not returned),
     * ``allreduce_mean()`` is the single collective of the step (sum then divide by world size).
     """
 
@@ -55,6 +58,7 @@ class FlatGradBuffer:
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            p._nr_inplace_grad = True        # ops.grad_target(): the table scatters accumulate straight into these views
             off += n
         self.nbytes = total * 4
 

@@ -202,6 +202,20 @@ _ws = {}
 _side = {}
 
 
+def grad_target(param):
+    """Where a large table gradient goes.  Default: a fresh zeroed tensor handed back to autograd (which then adds it into
+    ``param.grad``: for the 85 MB word table that is a 85 MB fill plus a 255 MB read-add-write per step, 180 / 540 MB for LSTUR's user
+    table).  A trainer that owns persistent gradient buffers (``dist.FlatGradBuffer``: explicit zero() and all-reduce, no autograd
+    hooks on the parameter) marks its parameters with ``_nr_inplace_grad``; the scatter kernels (which accumulate) then write straight
+    into ``param.grad`` and the backward returns None for the table.  Returns (tensor to accumulate into, value to return)."""
+    g = getattr(param, 'grad', None)
+    if (getattr(param, '_nr_inplace_grad', False) and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+            and g.shape == param.shape and g.device == param.device):
+        return g, None
+    d = torch.zeros(param.shape, dtype=torch.float32, device=param.device)
+    return d, d
+
+
 def sort_ids_async(ids):
     """Sort the token ids for the embedding backward on a side HIP stream, overlapped with the forward kernels (the ids are
     known before the forward starts; the sorted order is only needed by the scatter at the very end of the backward).
@@ -294,6 +308,7 @@ class _EncoderFn(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, xb, WaT)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
+            ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
             ctx.sorted = sort_ids_async(ids_c) if gather and ctx.needs_input_grad[1] else None
         return out
 
@@ -331,12 +346,12 @@ class _EncoderFn(torch.autograd.Function):
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:
-                d_table = torch.zeros_like(table, dtype=torch.float32)
+                dst, d_table = grad_target(ctx.table_param)
                 dXi = dX.view(_BF16_AS_I16)
                 # sort token ids so that every table row is reduced by adjacent lanes instead of contended atomics
                 ids_sorted, perm = sorted_ids_ready(ctx.sorted)
                 _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_KP,
-                      _ptr(d_table), table.shape[0], ntok, p_drop, seed, _stream())
+                      _ptr(dst), table.shape[0], ntok, p_drop, seed, _stream())
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)

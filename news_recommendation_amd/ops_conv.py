@@ -137,10 +137,10 @@ def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):
     """d word_embedding: one segmented reduction over all token streams (rows of dx follow the concatenation order of the ids
     that were sorted at forward time)."""
     lib = _lib()
-    d_table = torch.zeros_like(table, dtype=torch.float32)
+    dst, d_table = ops.grad_target(table)
     ids_sorted, perm = ops.sorted_ids_ready(sorted_pack)
     assert ids_sorted.numel() == n_tokens
-    _call('nr_embed_scatter_sorted', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dx), NR_KP, _ptr(d_table),
+    _call('nr_embed_scatter_sorted', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dx), NR_KP, _ptr(dst),
           table.shape[0], n_tokens, p, seed, _stream())
     return d_table
 
@@ -193,6 +193,7 @@ class _NamlNewsFn(torch.autograd.Function):
             ctx.st = (st_t, st_a)
             ctx.meta = (p, seed, Wa_f.shape[0])
             ctx.sorted = sort_tokens_async([title, abstract]) if ctx.needs_input_grad[4] else None
+            ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         ctx.mark_non_differentiable(out_b)
         return out, out_b
 
@@ -222,7 +223,7 @@ class _NamlNewsFn(torch.autograd.Function):
         dx = _workspace('dx_tok', (nt + na, NR_KP), _BF16_AS_I16, dev)
         gt = text_bwd(st_t, gv[0], NR_D, p, dx.data_ptr(), 'title')
         ga = text_bwd(st_a, gv[1], NR_D, p, dx.data_ptr() + nt * NR_KP * 2, 'abstract')
-        d_table = embed_scatter(ctx.sorted, nt + na, dx, table, p, seed) if ctx.needs_input_grad[4] else None
+        d_table = embed_scatter(ctx.sorted, nt + na, dx, ctx.table_param, p, seed) if ctx.needs_input_grad[4] else None
         ctx.st = None
         return (None, None, None, None, d_table, demb, *gt, *ga, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None)
 
@@ -310,6 +311,7 @@ class _LsturNewsFn(torch.autograd.Function):
             ctx.st = st
             ctx.meta = (p, seed, cat_table.shape[0])
             ctx.sorted = sort_tokens_async([title]) if ctx.needs_input_grad[3] else None
+            ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         return out
 
     @staticmethod
@@ -325,7 +327,7 @@ class _LsturNewsFn(torch.autograd.Function):
         g_title = g[:, 2 * NR_D:].contiguous()
         dx = _workspace('dx_tok', (title.numel(), NR_KP), _BF16_AS_I16, dev)
         gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title')
-        d_table = embed_scatter(ctx.sorted, title.numel(), dx, table, p, seed) if ctx.needs_input_grad[3] else None
+        d_table = embed_scatter(ctx.sorted, title.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[3] else None
         ctx.st = None
         return (None, None, None, d_table, d_cat, *gt, None, None)
 
@@ -352,6 +354,7 @@ class _TextFn(torch.autograd.Function):
             ctx.st = st
             ctx.meta = (p, seed)
             ctx.sorted = sort_tokens_async([ids]) if ctx.needs_input_grad[1] else None
+            ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         return out
 
     @staticmethod
@@ -361,7 +364,7 @@ class _TextFn(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         dx = _workspace('dx_tok', (ids.numel(), NR_KP), _BF16_AS_I16, g.device)
         gt = text_bwd(ctx.st, g, NR_D, p, dx.data_ptr(), 'text')
-        d_table = embed_scatter(ctx.sorted, ids.numel(), dx, table, p, seed) if ctx.needs_input_grad[1] else None
+        d_table = embed_scatter(ctx.sorted, ids.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[1] else None
         ctx.st = None
         return (None, d_table, *gt, None, None)
 

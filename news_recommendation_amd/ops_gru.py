@@ -42,14 +42,15 @@ class _UserRowsFn(torch.autograd.Function):
         _call('nr_gather_rows_strided[user]', _lib().nr_gather_rows_strided, _ptr(ids), _ptr(tab), tab.shape[0], d, _ptr(row_scale), _ptr(out), d, B, _stream())
         ctx.save_for_backward(ids, row_scale)
         ctx.shape = tuple(tab.shape)
+        ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         return out
 
     @staticmethod
     def backward(ctx, g):
         ids, row_scale = ctx.saved_tensors
         g = g.to(torch.float32).contiguous()
-        d_table = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        _call('nr_rows_scatter_add[user]', _lib().nr_rows_scatter_add, _ptr(ids), _ptr(g), g.shape[1], _ptr(row_scale), _ptr(d_table), ctx.shape[0],
+        dst, d_table = ops.grad_target(ctx.table_param)
+        _call('nr_rows_scatter_add[user]', _lib().nr_rows_scatter_add, _ptr(ids), _ptr(g), g.shape[1], _ptr(row_scale), _ptr(dst), ctx.shape[0],
               ctx.shape[1], ids.shape[0], 0, _stream())
         return None, d_table, None
 

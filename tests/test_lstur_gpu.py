@@ -189,3 +189,30 @@ def test_tiny_ragged_batches(model_name, B):
     fl = grad_floor(rg)
     worst = max(rel_err(q.grad.cpu().numpy(), rg[k], fl) for k, q in m.named_parameters())
     assert worst < 8e-2, worst        # one impression: a handful of tokens carries the whole gradient (bf16 operand level)
+
+
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_flat_gradient_buffer_inplace_table_gradients(model_name):
+    """dist.FlatGradBuffer marks its parameters for in-place table gradients (ops.grad_target): the embedding / user-table scatters
+    then accumulate straight into the flat views and the backward returns None for them.  Same gradients as the plain autograd
+    path, twice in a row (zero() in between), and accumulation over two backward passes without zero()."""
+    import bench
+    from news_recommendation_amd import dist as nrdist
+    wl = bench.Workload(model_name)
+    m1, m2 = wl.make_model(5).to(DEV).eval(), wl.make_model(5).to(DEV).eval()
+    m2.load_state_dict(m1.state_dict())
+    b = wl.batches(11, 1, 8, DEV)[0]
+    crit = torch.nn.CrossEntropyLoss()
+    y = torch.zeros(8, dtype=torch.long, device=DEV)
+    crit(wl.forward(m1, b), y).backward()
+    ref = {k: p.grad.clone() for k, p in m1.named_parameters()}
+    fgb = nrdist.FlatGradBuffer(m2.parameters())
+    for rep in range(2):
+        fgb.zero()
+        crit(wl.forward(m2, b), y).backward()
+        assert fgb.check_views()
+        for k, p in m2.named_parameters():
+            torch.testing.assert_close(p.grad, ref[k], rtol=1e-5, atol=1e-7, msg=k)
+    crit(wl.forward(m2, b), y).backward()                      # no zero(): gradients accumulate
+    for k, p in m2.named_parameters():
+        torch.testing.assert_close(p.grad, 2 * ref[k], rtol=1e-5, atol=1e-7, msg=k)
