@@ -35,7 +35,7 @@ class LSTUR(torch.nn.Module):
             p = float(self.config.masking_probability)
             keep = (torch.rand(ids.shape[0]) >= p).to(torch.float32)
             self.last_user_keep = keep
-            scale = (keep / (1.0 - p)).to(dev)
+            scale = (keep / (1.0 - p)).to(dev, non_blocking=True)        # a blocking copy would drain the stream every step
         return ops_gru.user_rows(ids, self.user_embedding.weight, scale)
 
     def forward(self, user, clicked_news_length, candidate_news, clicked_news):

@@ -64,6 +64,19 @@ class profile:
         return out
 
 
+def profiling(prefix):
+    """True when an active ``profile`` would record launches whose name starts with ``prefix`` (callers that can issue a whole
+    sequence of launches from one C call fall back to the per-launch form only then)."""
+    rec = _prof
+    if rec is None:
+        return False
+    return rec.only is None or any(n.startswith(prefix) for n in rec.only)
+
+
+# launches issued by the most recent whole-sequence calls, for callers that time such a call as one event pair (bench.py)
+seq_launches = {}
+
+
 def _timed(name, fn):
     rec = _prof
     if rec is None or (rec.only is not None and name not in rec.only):

@@ -90,7 +90,8 @@ class _GruFn(torch.autograd.Function):
         gates = torch.empty(T, B, 4, Hg, dtype=_BF16_AS_I16, device=dev) if need_grad else None
         ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)               # step-to-step operand, tile order
         _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(H_all[0]), B, Hp, _ptr(ht[0]), _stream())
-        if ops._prof is None:        # one FFI crossing for the whole recurrence (the per-step form is kept for per-kernel profiling)
+        ops.seq_launches['nr_gru_fwd_seq'] = T
+        if not ops.profiling('nr_gru_fwd_step'):        # one FFI crossing for the whole recurrence (per-step form: per-kernel profiling)
             _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht),
                   _ptr(H_all) if need_grad else None, _ptr(hf), _ptr(gates) if need_grad else None, B, N, Hd, T, _stream())
         else:
@@ -118,10 +119,12 @@ class _GruFn(torch.autograd.Function):
         dgh = _workspace('gru_dgh', (T, B, Kp), _BF16_AS_I16, dev, zero=True)
         carry = torch.empty(2, B, Hp, dtype=torch.float32, device=dev)
         dght = _workspace('gru_dgh_t', (2, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)  # step-to-step operand, tile order
-        if ops._prof is None:
+        per_step = ops.profiling('nr_gru_bwd_step')
+        ops.seq_launches['nr_gru_bwd_seq'] = T + 1
+        if not per_step:
             _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
                   _ptr(dght), _ptr(carry), B, N, Hd, T, _stream())
-        for i, t in enumerate(range(T - 1, -2, -1) if ops._prof is not None else ()):
+        for i, t in enumerate(range(T - 1, -2, -1) if per_step else ()):
             first = 1 if i == 0 else 0
             _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dght[(i + 1) % 2]),
                   None if first else _ptr(carry[(i + 1) % 2]), _ptr(WhhT), _ptr(gates[t]) if t >= 0 else None, _ptr(H_all[t]) if t >= 0 else None,
@@ -139,7 +142,14 @@ class _GruFn(torch.autograd.Function):
 def gru_last_state(x, h0, clicked_news_length, gru):
     """x f32 [B, N, I] on the GPU, h0 f32 [B, Hd] or None (zeros), clicked_news_length: CPU (or device) integer tensor, already >= 1."""
     _require_cuda(x, "clicked_news_vector")
-    lens = clicked_news_length.detach().to('cpu').clamp(min=1, max=x.shape[1])
-    T = int(lens.max())
-    lens_dev = lens.to(torch.int32).to(x.device)
+    N = x.shape[1]
+    if clicked_news_length.is_cuda:
+        # lengths already on the device: run all N steps (finished samples keep their state, so the result is the same) rather
+        # than fetch max(length) -- a device-to-host round trip in the middle of the step drains the stream
+        T = N
+        lens_dev = clicked_news_length.detach().clamp(min=1, max=N).to(torch.int32)
+    else:
+        lens = clicked_news_length.detach().clamp(min=1, max=N)
+        T = int(lens.max())
+        lens_dev = lens.to(torch.int32).to(x.device, non_blocking=True)
     return _GruFn.apply(x, h0, lens_dev, T, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
