@@ -8,6 +8,8 @@ the only library calls are the plain bf16 GEMMs of the backward pass
 There is no CPU path: tensors must live on a ROCm device and the HIP library
 must be built, otherwise a RuntimeError is raised.
 """
+import collections
+
 import torch
 
 from . import _capi
@@ -62,6 +64,16 @@ class profile:
             us = [a.elapsed_time(b) * 1e3 for a, b in ev]
             out[k] = (len(us), sum(us) / len(us), sum(us))
         return out
+
+
+_host_keepalive = collections.deque(maxlen=32)
+
+
+def to_device_async(t, device):
+    """Host -> device copy that does not drain the stream (``.to(device)`` without ``non_blocking`` ends in a stream synchronise).
+    The host tensor is kept referenced for a few more calls, well past the point where the copy engine has read it."""
+    _host_keepalive.append(t)
+    return t.to(device, non_blocking=True)
 
 
 def profiling(prefix):

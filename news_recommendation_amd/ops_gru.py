@@ -151,5 +151,5 @@ def gru_last_state(x, h0, clicked_news_length, gru):
     else:
         lens = clicked_news_length.detach().clamp(min=1, max=N)
         T = int(lens.max())
-        lens_dev = lens.to(torch.int32).to(x.device, non_blocking=True)
+        lens_dev = ops.to_device_async(lens.to(torch.int32), x.device)
     return _GruFn.apply(x, h0, lens_dev, T, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)

@@ -118,3 +118,26 @@ def test_launcher_runs_unchanged_reference_train_against_engine(tmp_path, model_
     assert 'Load training dataset with size 256' in out, out[-2000:]             # reference train.py:116
     assert f'news_recommendation_amd/dropin/model/{model_name}' in out, out[-2000:]       # traceback goes through OUR model
     assert 'no CPU fallback' in out, out[-2000:]
+
+
+def test_grad_target_and_profile_switches():
+    """Host-side switches of the table-gradient and whole-recurrence paths (no GPU needed)."""
+    import torch
+    from news_recommendation_amd import ops, dist as nrdist
+    p = torch.nn.Parameter(torch.zeros(5, 3))
+    dst, ret = ops.grad_target(p)                       # plain autograd: a fresh zeroed tensor is returned to autograd
+    assert ret is dst and dst.shape == p.shape and not dst.any()
+    q = torch.nn.Parameter(torch.zeros(5, 3))
+    fgb = nrdist.FlatGradBuffer([p, q])
+    dst, ret = ops.grad_target(p)                       # FlatGradBuffer: accumulate in place, nothing returned
+    assert ret is None and dst.data_ptr() == fgb.flat.data_ptr()
+    p.grad = None                                       # optimizer.zero_grad(set_to_none=True) drops the view: back to the plain path
+    dst, ret = ops.grad_target(p)
+    assert ret is dst
+    assert not ops.profiling('nr_gru_fwd_step')
+    with ops.profile():
+        assert ops.profiling('nr_gru_fwd_step')
+    with ops.profile(only={'nr_gru_bwd_seq'}):
+        assert not ops.profiling('nr_gru_bwd_step') and ops.profiling('nr_gru_bwd_seq')
+    t = ops.to_device_async(torch.arange(3), 'cpu')
+    assert t.tolist() == [0, 1, 2]
