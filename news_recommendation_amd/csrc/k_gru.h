@@ -55,15 +55,27 @@ struct GruFwdParams {
 // hidden sizes); the loop is fully unrolled into a register pipeline with NR_GRU_DEPTH k-steps (4 x 16-byte loads each) in
 // flight, pinned by sched_barriers (left alone the scheduler sinks every load next to its MFMA to save registers).
 // KS_CT = 0: generic rolled loop.
-template <int KS_CT, int NB>
+// WLDS (experimental, NR_GRU_LDS=1, KS_CT > 0 only; not yet measured on hardware): the workgroup's W_hh tile (3 gates x 16 units x
+// Hp: 87 KB at Hd = 900, contiguous 1 KB fragments in tile order) is copied global -> LDS once (global_load_lds) and shared by the
+// four waves, which otherwise each fetch their own copy from L2: 136 -> ~59 MB of L2 -> L1 traffic per step at B = 512.
+template <int KS_CT, int NB, bool WLDS = false>
 __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
   // NB sample tiles per wave share every W_hh fragment (NB = 2: 5 loads per 6 MFMAs instead of 4 per 3; the step is bound by the
   // L2 -> L1 operand volume, ~15 TB/s measured)
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   int tile, group;
   if (!gru_tile_of_wg(p.Hg / 16, (p.B + 64 * NB - 1) / (64 * NB), tile, group)) return;
-  const int s0 = (group * 4 + w) * NB * 16;
-  if (s0 >= p.B) return;
+  const int s0r = (group * 4 + w) * NB * 16;
+  const bool idle = s0r >= p.B;                                // no samples left for this wave
+  const int s0 = idle ? 0 : s0r;                               // (an idle wave of a WLDS workgroup stays for the barrier and recomputes tile 0, discarded)
+  if (WLDS && KS_CT > 0) {
+    NR_SMEM_DECL(smem);
+    for (int blk = w; blk < 3 * KS_CT; blk += 4) {            // block (gate q, k-step ks) = 1 KB, lane-linear
+      const int q = blk / KS_CT, ks = blk - q * KS_CT;
+      NR_GLDS16(p.Whh + ((size_t)q * p.Hg + tile * 16) * p.Hp + ks * 512 + l * 8, smem + blk * 1024);
+    }
+  }
+  if (idle && !(WLDS && KS_CT > 0)) return;
   const int j0 = tile * 16, jb = j0 + 4 * g;
   // fragment pointers in tile order: k-step ks of an operand tile is the 1 KB at + ks * 512 elements
   const u16* w0 = p.Whh + (size_t)tile * p.Hp * 16 + l * 8;
@@ -94,7 +106,39 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
     b_iz[r] = p.b_ih[p.Hd + j]; b_hz[r] = p.b_hh[p.Hd + j];
     b_in[r] = p.b_ih[2 * p.Hd + j]; b_hn[r] = p.b_hh[2 * p.Hd + j];
   }
-  if (KS_CT > 0) {
+  if (KS_CT > 0 && WLDS) {
+    NR_SMEM_DECL(smem);
+    const u16* wl = (const u16*)smem + l * 8;                  // fragment (q, ks) at + (q * KS_CT + ks) * 512
+    constexpr int D = NR_GRU_DEPTH;
+    u16x8 fh[NB][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < KS_CT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fh[nb][i] = *(const u16x8*)(hp[nb] + i * 512);
+      }
+    __syncthreads();                                           // drains the global -> LDS copies of all four waves
+    u16x8 a0 = *(const u16x8*)wl, a1 = *(const u16x8*)(wl + KS_CT * 512), a2 = *(const u16x8*)(wl + 2 * KS_CT * 512);
+    NR_SCHED_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < KS_CT; ++ks) {
+      const int sl = ks % D, kn = ks + 1 < KS_CT ? ks + 1 : ks;
+      const u16x8 n0 = *(const u16x8*)(wl + kn * 512), n1 = *(const u16x8*)(wl + (KS_CT + kn) * 512),
+                  n2 = *(const u16x8*)(wl + (2 * KS_CT + kn) * 512);          // next k-step's fragments in flight during the MFMAs
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        ar[nb] = mfma_16x16x32_bf16(a0, fh[nb][sl], ar[nb]);
+        az[nb] = mfma_16x16x32_bf16(a1, fh[nb][sl], az[nb]);
+        an[nb] = mfma_16x16x32_bf16(a2, fh[nb][sl], an[nb]);
+      }
+      if (ks + D < KS_CT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fh[nb][sl] = *(const u16x8*)(hp[nb] + (ks + D) * 512);
+      }
+      a0 = n0; a1 = n1; a2 = n2;
+      NR_SCHED_BARRIER();
+    }
+  } else if (KS_CT > 0) {
     constexpr int D = NB == 1 ? NR_GRU_DEPTH : (NR_GRU_DEPTH * 3) / 4;
     u16x8 fh[NB][D], f0[D], f1[D], f2[D];
 #pragma unroll
@@ -139,6 +183,7 @@ __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
       }
     }
   }
+  if (idle) return;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int s = s0 + nb * 16 + li;
@@ -190,6 +235,47 @@ struct GruBwdParams {
   float* carry;            // f32 [B][Hp] of step t; for t = -1 it receives dh_0
   int B, N, Hd, Hg, Hp, Kp, t, first;
 };
+
+// Gate derivatives of step t for lane (sample s, units jb .. jb+3) given dh_t; shared by the step kernels.
+__device__ __forceinline__ void gru_bwd_finish(const GruBwdParams& p, int s, int jb, f32x4 dh, int len_s, u16x4 rb, u16x4 zb, u16x4 nb,
+                                               u16x4 qb, u16x4 hb) {
+  if (p.gates == nullptr) {                    // t = -1: dh_0
+    *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = dh;
+    return;
+  }
+  const bool active = p.t < len_s;
+  f32x4 d_r = f32x4{0.f, 0.f, 0.f, 0.f}, d_z = d_r, d_n = d_r, d_nr = d_r, cy = dh;
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = jb + r < p.Hd;
+      const float rr = bf2f(rb[r]), zz = bf2f(zb[r]), nn = bf2f(nb[r]), qq = bf2f(qb[r]), hp = bf2f(hb[r]);
+      const float dn = dh[r] * (1.0f - zz);
+      const float dz = dh[r] * (hp - nn);
+      const float dnp = dn * (1.0f - nn * nn);
+      const float drp = dnp * qq * rr * (1.0f - rr);
+      const float dzp = dz * zz * (1.0f - zz);
+      d_r[r] = ok ? drp : 0.0f;
+      d_z[r] = ok ? dzp : 0.0f;
+      d_n[r] = ok ? dnp : 0.0f;
+      d_nr[r] = ok ? dnp * rr : 0.0f;
+      cy[r] = dh[r] * zz;
+    }
+  }
+  *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = cy;
+  u16* gi = p.dgi + ((size_t)s * p.N + p.t) * p.Kp + jb;
+  *(u16x4*)gi = pack4(d_r);
+  *(u16x4*)(gi + p.Hg) = pack4(d_z);
+  *(u16x4*)(gi + 2 * p.Hg) = pack4(d_n);
+  const u16x4 pr = pack4(d_r), pz = pack4(d_z), pn = pack4(d_nr);
+  u16* gh = p.dgh + (size_t)s * p.Kp + jb;
+  *(u16x4*)gh = pr;
+  *(u16x4*)(gh + p.Hg) = pz;
+  *(u16x4*)(gh + 2 * p.Hg) = pn;
+  *(u16x4*)(p.dgh_t + tile_off(s, jb, p.Kp)) = pr;
+  *(u16x4*)(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp)) = pz;
+  *(u16x4*)(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp)) = pn;
+}
 
 template <int KS_CT>
 __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
@@ -265,42 +351,89 @@ __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
   } else {
     dh = acc + cn;
   }
-  if (p.gates == nullptr) {                    // t = -1: dh_0
-    *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = dh;
-    return;
+  gru_bwd_finish(p, s, jb, dh, len_s, rb, zb, nb, qb, hb);
+}
+
+// Experimental (NR_GRU_LDS=1, Hd = 900 / 450; not yet measured on hardware): backward step with the workgroup's W_hh^T tile (16 rows
+// x Kp: 86 KB at Hd = 900) copied global -> LDS once and shared by the four waves, each of which takes TWO sample tiles (so that 57 x 4
+// = 228 workgroups cover B = 512 in one round at one workgroup per CU).  L2 -> L1 traffic per step 321 -> ~165 MB.
+template <int KS_CT>
+__global__ __launch_bounds__(WG) void gru_bwd_step_lds_kernel(GruBwdParams p) {
+  constexpr int NB = 2;
+  NR_SMEM_DECL(smem);
+  const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
+  int tile, group;
+  if (!gru_tile_of_wg(p.Hg / 16, (p.B + 64 * NB - 1) / (64 * NB), tile, group)) return;
+  const int s0r = (group * 4 + w) * NB * 16;
+  const bool idle = s0r >= p.B;
+  const int s0 = idle ? 0 : s0r;
+  const int j0 = tile * 16, jb = j0 + 4 * g, jc = jb < p.Hg ? jb : 0;
+  if (!p.first) {
+    for (int blk = w; blk < KS_CT; blk += 4) NR_GLDS16(p.WhhT + (size_t)tile * p.Kp * 16 + blk * 512 + l * 8, smem + blk * 1024);
   }
-  const bool active = p.t < len_s;
-  f32x4 d_r = f32x4{0.f, 0.f, 0.f, 0.f}, d_z = d_r, d_n = d_r, d_nr = d_r, cy = dh;
-  if (active) {
+  // epilogue operands of both tiles, requested ahead of the k pipeline
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u16x4 z4 = u16x4{0, 0, 0, 0};
+  int sb[NB], len_s[NB];
+  f32x4 cn[NB], acc[NB][2];
+  u16x4 rb[NB], zb[NB], nb_[NB], qb[NB], hb[NB];
+  const u16* dp[NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = jb + r < p.Hd;
-      const float rr = bf2f(rb[r]), zz = bf2f(zb[r]), nn = bf2f(nb[r]), qq = bf2f(qb[r]), hp = bf2f(hb[r]);
-      const float dn = dh[r] * (1.0f - zz);
-      const float dz = dh[r] * (hp - nn);
-      const float dnp = dn * (1.0f - nn * nn);
-      const float drp = dnp * qq * rr * (1.0f - rr);
-      const float dzp = dz * zz * (1.0f - zz);
-      d_r[r] = ok ? drp : 0.0f;
-      d_z[r] = ok ? dzp : 0.0f;
-      d_n[r] = ok ? dnp : 0.0f;
-      d_nr[r] = ok ? dnp * rr : 0.0f;
-      cy[r] = dh[r] * zz;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int st = s0 + nb * 16 < p.B ? s0 + nb * 16 : s0;
+    sb[nb] = st + li < p.B ? st + li : p.B - 1;
+    len_s[nb] = p.len[sb[nb]];
+    cn[nb] = zero4; acc[nb][0] = zero4; acc[nb][1] = zero4;
+    rb[nb] = z4; zb[nb] = z4; nb_[nb] = z4; qb[nb] = z4; hb[nb] = z4;
+    if (!p.first) cn[nb] = *(const f32x4*)(p.carry_next + (size_t)sb[nb] * p.Hp + jc);
+    if (p.gates != nullptr) {
+      const u16* gp = p.gates + (size_t)sb[nb] * 4 * p.Hg + jc;
+      rb[nb] = *(const u16x4*)gp; zb[nb] = *(const u16x4*)(gp + p.Hg); nb_[nb] = *(const u16x4*)(gp + 2 * p.Hg); qb[nb] = *(const u16x4*)(gp + 3 * p.Hg);
+      hb[nb] = *(const u16x4*)(p.h_prev_b + (size_t)sb[nb] * p.Hp + jc);
+    }
+    dp[nb] = p.dgh_next + (size_t)(st >> 4) * p.Kp * 16 + l * 8;
+  }
+  if (!p.first) {
+    constexpr int D = NR_GRU_DEPTH;
+    u16x8 fd[NB][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < KS_CT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fd[nb][i] = *(const u16x8*)(dp[nb] + i * 512);
+      }
+    __syncthreads();                                           // drains the global -> LDS copies of all four waves
+    const u16* wl = (const u16*)smem + l * 8;
+    u16x8 a = *(const u16x8*)wl;
+    NR_SCHED_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < KS_CT; ++ks) {
+      const int sl = ks % D;
+      const u16x8 an = *(const u16x8*)(wl + (ks + 1 < KS_CT ? ks + 1 : ks) * 512);      // next fragment in flight during the MFMAs
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb][ks & 1] = mfma_16x16x32_bf16(a, fd[nb][sl], acc[nb][ks & 1]);   // 4 independent chains
+      if (ks + D < KS_CT) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fd[nb][sl] = *(const u16x8*)(dp[nb] + (ks + D) * 512);
+      }
+      a = an;
+      NR_SCHED_BARRIER();
     }
   }
-  *(f32x4*)(p.carry + (size_t)s * p.Hp + jb) = cy;
-  u16* gi = p.dgi + ((size_t)s * p.N + p.t) * p.Kp + jb;
-  *(u16x4*)gi = pack4(d_r);
-  *(u16x4*)(gi + p.Hg) = pack4(d_z);
-  *(u16x4*)(gi + 2 * p.Hg) = pack4(d_n);
-  const u16x4 pr = pack4(d_r), pz = pack4(d_z), pn = pack4(d_nr);
-  u16* gh = p.dgh + (size_t)s * p.Kp + jb;
-  *(u16x4*)gh = pr;
-  *(u16x4*)(gh + p.Hg) = pz;
-  *(u16x4*)(gh + 2 * p.Hg) = pn;
-  *(u16x4*)(p.dgh_t + tile_off(s, jb, p.Kp)) = pr;
-  *(u16x4*)(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp)) = pz;
-  *(u16x4*)(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp)) = pn;
+  if (idle || jb >= p.Hg) return;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int s = s0 + nb * 16 + li;
+    if (s >= p.B) continue;
+    f32x4 dh;
+    if (p.first) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = jb + r < p.Hd ? p.g_last[(size_t)s * p.Hd + jb + r] : 0.0f;
+    } else {
+      dh = (acc[nb][0] + acc[nb][1]) + cn[nb];
+    }
+    gru_bwd_finish(p, s, jb, dh, len_s[nb], rb[nb], zb[nb], nb_[nb], qb[nb], hb[nb]);
+  }
 }
 
 // ---- operand packing --------------------------------------------------------------------------------------------------

@@ -539,7 +539,18 @@ int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, con
   if (nbv < 0) { const char* e = getenv("NR_GRU_NB"); nbv = e ? atoi(e) : 0; }
   const int nb = nbv > 0 ? nbv : (B >= 256 ? 2 : 1);
   const int tiles = p.Hg / 16;
-  if (nb == 2) {
+  static int ldsv = -1;       // NR_GRU_LDS=1: experimental W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450 only)
+  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 0; }
+  if (ldsv == 1 && nb == 2 && (p.Hp == 29 * 32 || p.Hp == 15 * 32)) {
+    const int grid = nr::gru_grid(tiles, (B + 127) / 128), smem = 3 * p.Hp * 16 * 2;
+    if (p.Hp == 29 * 32) {
+      if (allow_smem(nr::gru_fwd_step_kernel<29, 2, true>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_step: cannot reserve LDS");
+      NR_LAUNCH2((nr::gru_fwd_step_kernel<29, 2, true>), grid, 1, nr::WG, smem, (hipStream_t)stream, p);
+    } else {
+      if (allow_smem(nr::gru_fwd_step_kernel<15, 2, true>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_step: cannot reserve LDS");
+      NR_LAUNCH2((nr::gru_fwd_step_kernel<15, 2, true>), grid, 1, nr::WG, smem, (hipStream_t)stream, p);
+    }
+  } else if (nb == 2) {
     const int grid = nr::gru_grid(tiles, (B + 127) / 128);
     if (p.Hp == 29 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<29, 2>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
     else if (p.Hp == 15 * 32) NR_LAUNCH2((nr::gru_fwd_step_kernel<15, 2>), grid, 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
@@ -564,6 +575,19 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   p.g_last = g_last; p.dgh_next = dgh_next; p.carry_next = carry_next; p.WhhT = WhhT; p.gates = t >= 0 ? gates : nullptr; p.h_prev_b = h_prev_b;
   p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t = dgh_t; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
   p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
+  static int ldsv = -1;       // NR_GRU_LDS=1: experimental W_hh^T-tile-in-LDS variant (Hd = 900 / 450, from 256 samples up)
+  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 0; }
+  if (ldsv == 1 && (p.Kp == 86 * 32 || p.Kp == 44 * 32)) {
+    const int grid = nr::gru_grid(p.Hg / 16, (B + 127) / 128), smem = p.Kp * 16 * 2;
+    if (p.Kp == 86 * 32) {
+      if (allow_smem(nr::gru_bwd_step_lds_kernel<86>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_step: cannot reserve LDS");
+      NR_LAUNCH2(nr::gru_bwd_step_lds_kernel<86>, grid, 1, nr::WG, smem, (hipStream_t)stream, p);
+    } else {
+      if (allow_smem(nr::gru_bwd_step_lds_kernel<44>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_step: cannot reserve LDS");
+      NR_LAUNCH2(nr::gru_bwd_step_lds_kernel<44>, grid, 1, nr::WG, smem, (hipStream_t)stream, p);
+    }
+    return check_launch("nr_gru_bwd_step");
+  }
   if (p.Kp == 86 * 32) NR_LAUNCH2(nr::gru_bwd_step_kernel<86>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);          // Hd = 900
   else if (p.Kp == 44 * 32) NR_LAUNCH2(nr::gru_bwd_step_kernel<44>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);     // Hd = 450
   else NR_LAUNCH2(nr::gru_bwd_step_kernel<0>, nr::gru_grid(p.Hg / 16, (B + 63) / 64), 1, nr::WG, 0, (hipStream_t)stream, p);

@@ -71,3 +71,13 @@ from tests import kernel_checks_gru as kcg  # noqa: E402
 def test_gru_ini(be): kcg.check_gru(be, B=5, N=4, Hd=900, I=900, lens=[4, 1, 3, 2, 4])
 def test_gru_con_hidden_450(be): kcg.check_gru(be, B=3, N=3, Hd=450, I=900, seed=1)
 def test_gru_two_batch_tiles(be): kcg.check_gru(be, B=19, N=2, Hd=48, I=40, seed=2)
+
+
+def test_gru_lds_variant():
+    """NR_GRU_LDS=1: the W_hh / W_hh^T tile staged in LDS and two sample tiles per wave (experimental knob) against the same oracle."""
+    import subprocess, sys, os
+    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2')
+    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_gru as k; be = EmuBackend(); "
+            "k.check_gru(be, B=37, N=3, seed=4); k.check_gru(be, B=5, N=4, Hd=450, I=900, seed=5)")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
