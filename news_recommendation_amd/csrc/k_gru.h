@@ -55,7 +55,7 @@ struct GruFwdParams {
 // hidden sizes); the loop is fully unrolled into a register pipeline with NR_GRU_DEPTH k-steps (4 x 16-byte loads each) in
 // flight, pinned by sched_barriers (left alone the scheduler sinks every load next to its MFMA to save registers).
 // KS_CT = 0: generic rolled loop.
-// WLDS (experimental, NR_GRU_LDS=1, KS_CT > 0 only; not yet measured on hardware): the workgroup's W_hh tile (3 gates x 16 units x
+// WLDS (experimental, NR_GRU_LDS=1, KS_CT > 0 only; one timing run: 50 forward steps 1.36 -> 1.18 ms, GPU parity suite pending): the workgroup's W_hh tile (3 gates x 16 units x
 // Hp: 87 KB at Hd = 900, contiguous 1 KB fragments in tile order) is copied global -> LDS once (global_load_lds) and shared by the
 // four waves, which otherwise each fetch their own copy from L2: 136 -> ~59 MB of L2 -> L1 traffic per step at B = 512.
 template <int KS_CT, int NB, bool WLDS = false>
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WG) void gru_bwd_step_kernel(GruBwdParams p) {
   gru_bwd_finish(p, s, jb, dh, len_s, rb, zb, nb, qb, hb);
 }
 
-// Experimental (NR_GRU_LDS=1, Hd = 900 / 450; not yet measured on hardware): backward step with the workgroup's W_hh^T tile (16 rows
+// Experimental (NR_GRU_LDS=1, Hd = 900 / 450; one timing run: 21.4 -> 18.7 us per step, GPU parity suite pending): backward step with the workgroup's W_hh^T tile (16 rows
 // x Kp: 86 KB at Hd = 900) copied global -> LDS once and shared by the four waves, each of which takes TWO sample tiles (so that 57 x 4
 // = 228 workgroups cover B = 512 in one round at one workgroup per CU).  L2 -> L1 traffic per step 321 -> ~165 MB.
 template <int KS_CT>
