@@ -25,7 +25,8 @@ struct AddGeom {
   static constexpr int SMEM = X_BYTES + SC_BYTES + W_BYTES;
   static constexpr int NTQ = QP / 16;               // 13 n-tiles of the query dim
   static constexpr int DQ_FLOATS = NW * QP > 3 * ROWS ? NW * QP : 3 * ROWS;     // dq partials, also the 3 x ROWS scratch of the dw pass
-  static constexpr int BWD_SMEM = X_BYTES + DQ_FLOATS * 4 + ROWS * 4;   // backward: tile + dq partials + ds
+  static constexpr int G_BYTES = NSEQ * D * 4;      // backward: the workgroup's g_out rows (read 25x per token by the softmax-backward pass)
+  static constexpr int BWD_SMEM = X_BYTES + DQ_FLOATS * 4 + ROWS * 4 + G_BYTES;   // backward: tile + dq partials + ds + g_out rows
 };
 
 struct AdditiveParams {

@@ -354,10 +354,17 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
   u16* Xs = (u16*)smem;
   float* dqp = (float*)(smem + Gm::X_BYTES);                 // [NW][QP]
   float* dsv = (float*)(smem + Gm::X_BYTES + Gm::DQ_FLOATS * 4);    // [ROWS]
+  float* gl = (float*)(smem + Gm::X_BYTES + Gm::DQ_FLOATS * 4 + Gm::ROWS * 4);     // [NSEQ][D] g_out rows of this workgroup
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
   const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
 
+  // g_out rows -> LDS, coalesced, in the same round trip as the ctx tile: the dw pass below reads each row 25 times per token
+  // (as global loads that was 5 dependent L2 round trips per lane at the head of every workgroup)
+  for (int i = tid; i < NSEQ * D4; i += WG) {
+    const int seq = i / D4, c = i - seq * D4;
+    *(f32x4*)(gl + seq * D + c * 4) = seq0 + seq < p.n_seq ? *(const f32x4*)(p.g_out + (seq0 + seq) * D + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   constexpr int PCS = XS / 8;
   for (int i = tid; i < Gm::ROWS * PCS; i += WG) {
     int r = i / PCS, c = i - r * PCS;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
       const int seq = tok / S;
       float a = 0.0f;
       if (seq0 + seq < p.n_seq) {
-        const float* go = p.g_out + (seq0 + seq) * D + part * 100;
+        const float* go = gl + seq * D + part * 100;
         const u16* xr = Xs + tok * XS + part * 100;
 #pragma unroll 5
         for (int c = 0; c < 25; ++c) {
