@@ -594,6 +594,16 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
   const bool two = l < (D4 - 64);
   f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), 0));
+  // current contents of the destination row of the run in progress, requested when the run starts so that the read-add-write of
+  // flush() does not wait on a round trip per finished row
+  f32x4 pd0 = f32x4{0.f, 0.f, 0.f, 0.f}, pd1 = pd0;
+  auto peek = [&](int id) {
+    if (id <= pad_row || id >= num_rows) return;
+    const float* src = grad_table + ((int64_t)id * D4 + l) * 4;
+    pd0 = *(const f32x4*)src;
+    if (two) pd1 = *(const f32x4*)(src + 256);
+  };
+  peek(cur);
   auto flush = [&](int id, bool shared) {
     if (id <= pad_row || id >= num_rows) return;
     float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
@@ -605,36 +615,60 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
         for (int j = 0; j < 4; ++j) atomic_add(dst + 256 + j, a1[j]);
       }
     } else {
-      *(f32x4*)dst = *(const f32x4*)dst + a0;
-      if (two) *(f32x4*)(dst + 256) = *(const f32x4*)(dst + 256) + a1;
+      *(f32x4*)dst = pd0 + a0;              // not shared: no other wave touches this row, the value peeked at run start is current
+      if (two) *(f32x4*)(dst + 256) = pd1 + a1;
     }
   };
-  bool first = true;
-  for (int i = 0; i < cnt; ++i) {
-    const int id = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), i));
-    const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
-    if (id != cur) {
-      flush(cur, first && cur == id_before);
-      first = false;
-      cur = id;
-      a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
+  // The rows of the chunk are fetched in groups of four, one group ahead of the accumulation (two register sets): a plain loop
+  // walks 32 dependent load -> add round trips per wave.  Same additions in the same order: bit-identical results.
+  constexpr int GR = 4;
+  f32x4 c0[GR], c1[GR], n0[GR], n1[GR];
+  auto fetch_group = [&](int base, f32x4 (&r0)[GR], f32x4 (&r1)[GR]) {
+#pragma unroll
+    for (int u = 0; u < GR; ++u) {
+      const int i = base + u < cnt ? base + u : cnt - 1;
+      const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
+      const SRC* row = dx + (int64_t)tok * ldx;
+      r0[u] = ld_row4(row + l * 4);
+      r1[u] = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (id <= pad_row) continue;
-    const SRC* row = dx + (int64_t)tok * ldx;
-    f32x4 v0 = ld_row4(row + l * 4);
-    f32x4 v1 = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    uint32_t k0 = 0xF, k1 = 0xF;
-    float sc = 1.0f;
-    if (dc.enabled) {
-      k0 = drop_keep4(dc, 1u, (uint64_t)tok * D4 + l);
-      k1 = two ? drop_keep4(dc, 1u, (uint64_t)tok * D4 + 64 + l) : 0u;
-      sc = dc.scale;
+  };
+  fetch_group(0, c0, c1);
+  bool first = true;
+  for (int base = 0; base < cnt; base += GR) {
+    if (base + GR < cnt) fetch_group(base + GR, n0, n1);
+#pragma unroll
+    for (int u = 0; u < GR; ++u) {
+      const int i = base + u;
+      if (i < cnt) {
+        const int id = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), i));
+        const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
+        if (id != cur) {
+          flush(cur, first && cur == id_before);
+          first = false;
+          cur = id;
+          peek(cur);
+          a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
+        }
+        if (id > pad_row) {
+          const f32x4 v0 = c0[u], v1 = c1[u];
+          uint32_t k0 = 0xF, k1 = 0xF;
+          float sc = 1.0f;
+          if (dc.enabled) {
+            k0 = drop_keep4(dc, 1u, (uint64_t)tok * D4 + l);
+            k1 = two ? drop_keep4(dc, 1u, (uint64_t)tok * D4 + 64 + l) : 0u;
+            sc = dc.scale;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((k0 >> j) & 1u) a0[j] += v0[j] * sc;
+            if ((k1 >> j) & 1u) a1[j] += v1[j] * sc;
+          }
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if ((k0 >> j) & 1u) a0[j] += v0[j] * sc;
-      if ((k1 >> j) & 1u) a1[j] += v1[j] * sc;
-    }
+    for (int u = 0; u < GR; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
   }
   flush(cur, (first && cur == id_before) || cur == id_after);
 }
