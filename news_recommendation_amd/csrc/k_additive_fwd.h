@@ -72,8 +72,12 @@ __global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p)
     int G, mb, me;
     unit_range(Gm::NTQ, Gm::MT, w_eff, NW, cg, G, mb, me);
     if (mb >= me) continue;
+    // query-vector rows of this column pair: loaded once here, in the same round trip as the weight fragments (inside the epilogue
+    // the load could not be hoisted over the LDS / global stores of the token-tile loop and cost an L2 round trip per tile)
+    const int wrq0 = (2 * cg) * 16, wrq1 = G == 2 ? wrq0 + 16 : wrq0;
+    const f32x4 qv2[2] = {*(const f32x4*)(p.qvp + wrq0 + 4 * g), *(const f32x4*)(p.qvp + wrq1 + 4 * g)};
     auto epi = [&](int wr, int m, f32x4 acc) {          // acc already holds x.Wa[n] + ba[n] (bias = accumulator init)
-      f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
+      const f32x4 q4 = wr == wrq0 ? qv2[0] : qv2[1];
       float s = 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) s += fast_tanh(acc[r]) * q4[r];

@@ -417,8 +417,11 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
     unit_range(Gm::NTQ, Gm::MT, w_eff, NW, cg, G, mb, me);
     if (mb >= me) continue;
     f32x4 dqa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // query-vector rows of this column pair, loaded once per pair with the weight fragments (see additive_fwd_kernel)
+    const int wrq0 = (2 * cg) * 16, wrq1 = G == 2 ? wrq0 + 16 : wrq0;
+    const f32x4 qv2[2] = {*(const f32x4*)(p.qvp + wrq0 + 4 * g), *(const f32x4*)(p.qvp + wrq1 + 4 * g)};
     auto epi = [&](int j, int wr, int m, f32x4 acc) {   // acc = x.Wa[n] + ba[n] (bias = accumulator init)
-      f32x4 q4 = *(const f32x4*)(p.qvp + wr + 4 * g);
+      const f32x4 q4 = qv2[j];
       const int r_ = m * 16 + li;
       const float ds = dsv[r_];
       f32x4 dp;

@@ -32,7 +32,8 @@ struct Mhsa2Geom {
   static constexpr int MT = TOKW / 16;           // 5 token tiles
   static constexpr int CH_ROWS = HG * DK;        // 80 weight rows per chunk (5 n-tiles)
   static constexpr int CH_BYTES = CH_ROWS * KP * 2;   // 51,200 B: 50 fragment blocks of 1 KiB
-  static constexpr int SMEM = 2 * CH_BYTES;      // 102,400 B
+  static constexpr int B_BYTES = 3 * NP * 4;     // 3,840 B: the packed bias vector, read once per n-tile by every wave
+  static constexpr int SMEM = 2 * CH_BYTES + B_BYTES;
   static_assert(TOKW % 16 == 0 && S % 4 == 0, "geometry");
 };
 
@@ -58,6 +59,10 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
     }
   };
   chunk_fetch(0, 0);
+  // biases -> LDS (visible after the barrier that follows the token gather).  As global loads they sat in front of every n-tile's
+  // MFMA chain (load, s_waitcnt vmcnt(0), then the accumulator init): 60 exposed L2 round trips per wave at one wave per SIMD.
+  float* bl = (float*)(smem + 2 * Gm::CH_BYTES);
+  for (int i = tid; i < 3 * NP / 4; i += 256) *(f32x4*)(bl + i * 4) = *(const f32x4*)(p.bp + i * 4);
 
   // ---- gather the wave's 80 tokens into operand fragments -----------------------------------------------------------------
   u16x8 xf[MT][KSTEPS];
@@ -120,11 +125,11 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
         const int wrow = which * NP + hg * Gm::CH_ROWS + nt * 16;      // row in the packed matrix / bias vector
         f32x4 acc[MT];
         if (which < 2) {
-          const f32x4 b4 = *(const f32x4*)(p.bp + wrow + 4 * g);        // lane owns features 4g..4g+3
+          const f32x4 b4 = *(const f32x4*)(bl + wrow + 4 * g);          // lane owns features 4g..4g+3
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m] = b4;
         } else {
-          const float b1 = p.bp[wrow + li];                              // lane owns feature li
+          const float b1 = bl[wrow + li];                                // lane owns feature li
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m] = f32x4{b1, b1, b1, b1};
         }
