@@ -365,6 +365,14 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
     const int seq = i / D4, c = i - seq * D4;
     *(f32x4*)(gl + seq * D + c * 4) = seq0 + seq < p.n_seq ? *(const f32x4*)(p.g_out + (seq0 + seq) * D + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // forward attention weights of the sequences this wave reduces below: requested now, with the tile
+  constexpr int SPW = (NSEQ + NW - 1) / NW;
+  float wt_pre[SPW];
+#pragma unroll
+  for (int k = 0; k < SPW; ++k) {
+    const int seq = w + k * NW;
+    wt_pre[k] = (seq < NSEQ && l < S && seq0 + seq < p.n_seq) ? p.attn_w[(seq0 + seq) * S + l] : 0.0f;
+  }
   constexpr int PCS = XS / 8;
   for (int i = tid; i < Gm::ROWS * PCS; i += WG) {
     int r = i / PCS, c = i - r * PCS;
@@ -397,11 +405,14 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
       dwp[part * Gm::ROWS + tok] = a;
     }
     __syncthreads();
-    for (int seq = w; seq < NSEQ; seq += NW) {
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      const int seq = w + k * NW;
+      if (seq >= NSEQ) break;
       const bool live = l < S && seq0 + seq < p.n_seq;
       const int r = seq * S + l;
       const float mydw = live ? dwp[r] + dwp[Gm::ROWS + r] + dwp[2 * Gm::ROWS + r] : 0.0f;
-      const float wt = live ? p.attn_w[(seq0 + seq) * S + l] : 0.0f;
+      const float wt = wt_pre[k];
       const float tot = wave_sum(wt * mydw);
       if (l < S) dsv[r] = wt * (mydw - tot);
     }
