@@ -59,6 +59,8 @@ struct MhsaParams {
   u16* x_save;             // training, optional: [n_seq*S][KP] dropout-masked bf16 tokens, col D = 1.0 (weight-gradient GEMM operand)
   int64_t n_seq;
   DropCfg dc;
+  int debug;               // profiling only (NR_MHSA_DEBUG, mhsa_fwd2 DBG instantiation): 1 skip the token gather, 2 skip the projection
+                           // MFMAs, 4 skip the attention phase, 8 skip the training saves (Q/K/V^T/X), 16 skip the ctx stores
 };
 
 // One (column-group, token-tile range) block of the projection GEMM.  G n-tiles of W are held in registers

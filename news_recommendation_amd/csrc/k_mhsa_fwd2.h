@@ -37,8 +37,12 @@ struct Mhsa2Geom {
   static_assert(TOKW % 16 == 0 && S % 4 == 0, "geometry");
 };
 
+// DBG = true: a second instantiation with the NR_MHSA_DEBUG phase switches (MhsaParams::debug) for timing decompositions; in the
+// production instantiation (DBG = false) `dbg` is the constant 0 and every switch folds away.
+template <bool DBG>
 __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(MhsaParams p) {
   using Gm = Mhsa2Geom;
+  const int dbg = DBG ? p.debug : 0;
   constexpr int S = Gm::S, MT = Gm::MT;
   NR_SMEM_DECL(smem);
   auto wl = [&](int buf) -> u16* { return (u16*)(smem + buf * Gm::CH_BYTES); };
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int c = ks * 32 + g * 8;
-      lo[slot][ks] = (live && c < D) ? *(const f32x4*)(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      hi[slot][ks] = (live && c + 4 < D) ? *(const f32x4*)(row + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      lo[slot][ks] = (live && c < D && !(dbg & 1)) ? *(const f32x4*)(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      hi[slot][ks] = (live && c + 4 < D && !(dbg & 1)) ? *(const f32x4*)(row + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   issue(0, 0);
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
         if (c + 4 < D) b = b * drop_mul4(p.dc, 1u, (uint64_t)tok * D4 + (c >> 2) + 1);
       }
       xf[m][ks] = cat8(pack4(a), pack4(b));
-      if (p.x_save != nullptr && tok < tok_total) {          // the weight-gradient GEMM operand, straight from the fragment registers
+      if (p.x_save != nullptr && tok < tok_total && !(dbg & 8)) {   // the weight-gradient GEMM operand, straight from the fragment registers
         u16x8 o = xf[m][ks];
         if (c <= D && D < c + 8) o[D - c] = BF16_ONE;        // column D = 1.0: the GEMM then also yields the bias gradient
         *(u16x8*)(p.x_save + tok * KP + c) = o;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
         const u16* wp = Wc + (nt * KSTEPS) * 512 + l * 8;        // fragment block (nt, ks) at +512 elements per ks
         u16x8 a = *(const u16x8*)wp;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+        for (int ks = (dbg & 2) ? KSTEPS : 0; ks < KSTEPS; ++ks) {
           const u16x8 an = ks + 1 < KSTEPS ? *(const u16x8*)(wp + (ks + 1) * 512) : a;     // next fragment in flight during the MFMAs
 #pragma unroll
           for (int m = 0; m < MT; ++m)
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
         for (int m = 0; m < MT; ++m) {
           const u16x4 v = pack4(acc[m]);
           if (which == 0) qr[nt][m] = v; else if (which == 1) kr[nt][m] = v; else vr[nt][m] = v;
-          if (p.q_save != nullptr) {
+          if (p.q_save != nullptr && !(dbg & 8)) {
             if (which < 2) {               // row-major Q / K: lane = token 16m + li, features col .. col+3
               const int64_t tok = tok0 + m * 16 + li;
               const int col = hg * Gm::CH_ROWS + nt * 16 + 4 * g;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
     project(integral_constant<int, 2>{}, hg, NT, wl(c & 1));
 
     // ---- attention of the head group once Q, K, V are complete -------------------------------------------------------------
-    {
+    if (!(dbg & 4)) {
 #pragma unroll
       for (int hd = 0; hd < HG; ++hd) {
         if (hd < nh) {
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
                 const int tokl = (i0 + qj) * 16 + li;
                 const int64_t tok = tok0 + tokl;
                 const int col = hg * Gm::CH_ROWS + tt * 16 + 4 * g;
-                if (rows_mine && tokl >= sq * S && tokl < (sq + 1) * S && tok < tok_total) {
+                if (rows_mine && tokl >= sq * S && tokl < (sq + 1) * S && tok < tok_total && !(dbg & 16)) {
                   if (p.dc.enabled) acc = acc * drop_mul4(p.dc, 2u, (uint64_t)tok * D4 + (col >> 2));
                   *(u16x4*)(p.ctx + tok * KP + col) = pack4(acc);
                 }

@@ -127,7 +127,7 @@ int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, con
   if (n_seq == 0) return NR_OK;
   nr::MhsaParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_dense = x_dense;
-  p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.x_save = nullptr;
   bool x_done = false;
   if (S == 20) {

@@ -1,4 +1,5 @@
 // Translation unit of the register-resident MHSA forward kernel (k_mhsa_fwd2.h), see nr_engine.hip for why it is separate.
+#include <cstdlib>
 #include "nr_common.h"
 #include "k_mhsa_fwd2.h"
 
@@ -6,9 +7,17 @@ namespace nr {
 
 int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
   using G = Mhsa2Geom;
-  if (set_max_dynamic_lds((const void*)mhsa_fwd2_kernel, G::SMEM)) return -1;
   const int per_wg = G::TPW * G::NWAVE;
-  NR_LAUNCH(mhsa_fwd2_kernel, (p.n_seq + per_wg - 1) / per_wg, 256, G::SMEM, stream, p);
+  const char* d = getenv("NR_MHSA_DEBUG");
+  if (d != nullptr && atoi(d) != 0) {              // profiling: phase switches, see MhsaParams::debug
+    MhsaParams q = p;
+    q.debug = atoi(d);
+    if (set_max_dynamic_lds((const void*)mhsa_fwd2_kernel<true>, G::SMEM)) return -1;
+    NR_LAUNCH(mhsa_fwd2_kernel<true>, (p.n_seq + per_wg - 1) / per_wg, 256, G::SMEM, stream, q);
+    return 0;
+  }
+  if (set_max_dynamic_lds((const void*)mhsa_fwd2_kernel<false>, G::SMEM)) return -1;
+  NR_LAUNCH(mhsa_fwd2_kernel<false>, (p.n_seq + per_wg - 1) / per_wg, 256, G::SMEM, stream, p);
   return 0;
 }
 
