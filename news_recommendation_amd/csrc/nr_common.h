@@ -28,8 +28,10 @@ static_assert(D % 4 == 0 && DK % 4 == 0 && (HG * DK) % 16 == 0, "geometry");
 // ---- counter-based RNG for dropout: two rounds of a 32-bit avalanche mixer per 4 consecutive elements -----------------
 // The kernels are VALU-bound (rocprofv3 PMC: ~15 VALU instructions per MFMA in the forward kernel with Philox4x32-7, a third
 // of them RNG), so the generator is as cheap as a stateless one gets: counter = element quad index, key = (seed, site);
-// r0 = mix(counter, key), r1 = mix(r0, key') give 4 x 16 random bits, element j is dropped iff its 16 bits < p * 2^16.
-// mix32 is the "lowbias32" integer finaliser (xorshift-multiply, full avalanche).
+// r0 = mix(counter ^ key), r1 = a one-multiply remix of r0 give 4 x 16 random bits, element j is dropped iff its 16 bits < p * 2^16.
+// mix32 is the "lowbias32" integer finaliser (xorshift-multiply, full avalanche).  v_mul_lo_u32 is a QUARTER-rate instruction on
+// CDNA (16 cycles per wave): the first version spent 6 of them per quad (two on spreading the counter, two full finalisers) and the
+// ISA histogram of the training forward kernel showed ~1000 per head group, a third of its VALU time; this one spends 3.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -42,11 +44,18 @@ struct DropCfg {
   int enabled;
 };
 
+// the two 32-bit words of a quad: r0 = lowbias32 of (counter ^ key ^ site), r1 = one more multiply-xorshift of (r0 ^ key')
+__device__ __forceinline__ void drop_words(const DropCfg& dc, uint32_t site, uint64_t quad, uint32_t& r0, uint32_t& r1) {
+  const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
+  r0 = mix32(lo ^ ((hi << 16) | (hi >> 16)) ^ dc.k0 ^ (site * 0x85EBCA77u));     // (site is a literal at every call site: folded)
+  uint32_t x = (r0 ^ dc.k1) * 0x9E3779B1u;
+  r1 = x ^ (x >> 15);
+}
+
 // keep-flags (bit j set = keep) for elements 4*quad .. 4*quad+3 of dropout site `site`
 __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site, uint64_t quad) {
-  const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
-  const uint32_t r0 = mix32((lo * 0x9E3779B1u) ^ (hi * 0xC2B2AE3Du) ^ dc.k0 ^ (site * 0x85EBCA77u));
-  const uint32_t r1 = mix32(r0 + dc.k1 + 0x68E31DA4u);
+  uint32_t r0, r1;
+  drop_words(dc, site, quad, r0, r1);
   uint32_t m = 0;
   m |= ((r0 & 0xFFFFu) >= dc.thresh ? 1u : 0u);
   m |= ((r0 >> 16) >= dc.thresh ? 2u : 0u);
@@ -57,9 +66,8 @@ __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site,
 
 // the same decision as per-element multipliers (scale or 0): saves the mask round trip in the hot loops
 __device__ __forceinline__ f32x4 drop_mul4(const DropCfg& dc, uint32_t site, uint64_t quad) {
-  const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
-  const uint32_t r0 = mix32((lo * 0x9E3779B1u) ^ (hi * 0xC2B2AE3Du) ^ dc.k0 ^ (site * 0x85EBCA77u));
-  const uint32_t r1 = mix32(r0 + dc.k1 + 0x68E31DA4u);
+  uint32_t r0, r1;
+  drop_words(dc, site, quad, r0, r1);
   f32x4 m;
   m[0] = (r0 & 0xFFFFu) >= dc.thresh ? dc.scale : 0.0f;
   m[1] = (r0 >> 16) >= dc.thresh ? dc.scale : 0.0f;
