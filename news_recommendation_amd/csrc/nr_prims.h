@@ -34,7 +34,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+// wave index inside the workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes, but the compiler only knows that after
+// readfirstlane; everything derived from it (tile / sequence / pair indices, base pointers, loop bounds, branches) then runs on the
+// scalar unit instead of costing vector instructions in VALU-bound kernels.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 __device__ __forceinline__ float bf2f(u16 h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
