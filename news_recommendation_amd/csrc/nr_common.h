@@ -56,11 +56,13 @@ __device__ __forceinline__ void drop_words(const DropCfg& dc, uint32_t site, uin
 __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site, uint64_t quad) {
   uint32_t r0, r1;
   drop_words(dc, site, quad, r0, r1);
+  // 16-bit fields compared in place: (r >> 16) >= t  <=>  r >= (t << 16);  (r & 0xFFFF) >= t  <=>  (r << 16) >= (t << 16)
+  const uint32_t t16 = dc.thresh << 16;
   uint32_t m = 0;
-  m |= ((r0 & 0xFFFFu) >= dc.thresh ? 1u : 0u);
-  m |= ((r0 >> 16) >= dc.thresh ? 2u : 0u);
-  m |= ((r1 & 0xFFFFu) >= dc.thresh ? 4u : 0u);
-  m |= ((r1 >> 16) >= dc.thresh ? 8u : 0u);
+  m |= ((r0 << 16) >= t16 ? 1u : 0u);
+  m |= (r0 >= t16 ? 2u : 0u);
+  m |= ((r1 << 16) >= t16 ? 4u : 0u);
+  m |= (r1 >= t16 ? 8u : 0u);
   return m;
 }
 
@@ -68,11 +70,12 @@ __device__ __forceinline__ uint32_t drop_keep4(const DropCfg& dc, uint32_t site,
 __device__ __forceinline__ f32x4 drop_mul4(const DropCfg& dc, uint32_t site, uint64_t quad) {
   uint32_t r0, r1;
   drop_words(dc, site, quad, r0, r1);
+  const uint32_t t16 = dc.thresh << 16;            // see drop_keep4
   f32x4 m;
-  m[0] = (r0 & 0xFFFFu) >= dc.thresh ? dc.scale : 0.0f;
-  m[1] = (r0 >> 16) >= dc.thresh ? dc.scale : 0.0f;
-  m[2] = (r1 & 0xFFFFu) >= dc.thresh ? dc.scale : 0.0f;
-  m[3] = (r1 >> 16) >= dc.thresh ? dc.scale : 0.0f;
+  m[0] = (r0 << 16) >= t16 ? dc.scale : 0.0f;
+  m[1] = r0 >= t16 ? dc.scale : 0.0f;
+  m[2] = (r1 << 16) >= t16 ? dc.scale : 0.0f;
+  m[3] = r1 >= t16 ? dc.scale : 0.0f;
   return m;
 }
 
