@@ -98,16 +98,23 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const int64_t seq = pr / H;
     const int hd = (int)(pr - seq * H);
     const int64_t tok0 = seq * S;
+    // (wave-uniform 64-bit base) + (32-bit lane offset that does not depend on the pair): the per-lane 64-bit multiply-adds of
+    // `(tok0 + r) * KP` were a quarter-rate instruction per address
+    const u16* qb = p.q_save + tok0 * KP + hd * DK;
+    const u16* kb = p.k_save + tok0 * KP + hd * DK;
+    const u16* gb = p.dctx_gemm + tok0 * p.ldc + hd * DK;
+    const float* gob = p.g_out + seq * D + hd * DK;
+    const float* wb = p.attn_w + tok0;
 #pragma unroll
     for (int it = 0; it < Gm::IT; ++it) {
       const int i = it * 64 + l;
       if (i < S * Gm::PCS) {
         const int r = i / Gm::PCS, c = (i - r * Gm::PCS) * 4;
-        rg.q[it] = *(const u16x4*)(p.q_save + (tok0 + r) * KP + hd * DK + c);
-        rg.k[it] = *(const u16x4*)(p.k_save + (tok0 + r) * KP + hd * DK + c);
-        rg.dg[it] = *(const u16x4*)(p.dctx_gemm + (tok0 + r) * p.ldc + hd * DK + c);
-        rg.go[it] = *(const f32x4*)(p.g_out + seq * D + hd * DK + c);
-        rg.wt[it] = p.attn_w[tok0 + r];
+        rg.q[it] = *(const u16x4*)(qb + (r * KP + c));
+        rg.k[it] = *(const u16x4*)(kb + (r * KP + c));
+        rg.dg[it] = *(const u16x4*)(gb + (r * p.ldc + c));
+        rg.go[it] = *(const f32x4*)(gob + c);
+        rg.wt[it] = wb[r];
       }
     }
     const u16* vblk = p.vt_save + (seq * H + hd) * DK * Gm::SP4;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         // A operand rows: i = li -> d = dt*16 + li; output CL: rows d = dt*16 + 4g + r, col = token ot*16 + li
         const int tok = ot * 16 + li;
         if (d0 < DK && tok < S) {
-          u16* dst = p.dqkv + (tok0 + tok) * LDG + hd * DK + d0;
+          u16* dst = (p.dqkv + tok0 * LDG + hd * DK) + (tok * LDG + d0);
           *(u16x4*)dst = pack4(aq);
           *(u16x4*)(dst + KP) = pack4(ak);
           *(u16x4*)(dst + 2 * KP) = pack4(av);
