@@ -253,6 +253,41 @@ int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* ga
  * single label class: the reference's ValueError path).  Replaces the multiprocessing pool of src/evaluate.py:267-268. */
 int nr_impression_metrics(const float* scores, const int32_t* labels, const int64_t* ptr, float* out, int64_t n_impr, void* stream);
 
+/* ---- optimiser: torch.optim.Adam(model.parameters(), lr) of src/train.py:127-128, stepped at :227-233 (defaults: betas (0.9, 0.999),
+ * eps 1e-8, no weight decay, no amsgrad), on flat fp32 buffers.  sched f32[2 * (step + 1)] holds the per-step scalars
+ * sched[2 s] = lr / (1 - beta1^s), sched[2 s + 1] = sqrt(1 - beta2^s), computed by the host in double as torch does; `step` is 1-based.
+ * Element update: m += (g - m)(1 - beta1); v = v beta2 + (1 - beta2) g g; p -= sched[2 s] * m / (sqrt(v) / sched[2 s + 1] + eps).
+ * nr_adam_flat: one pass over n elements; g is multiplied by grad_scale on the way in (1 / world size after a summing all-reduce) and
+ * cleared when zero_grad != 0 (replaces optimizer.zero_grad(), src/train.py:229).  All four buffers 16-byte aligned. */
+int nr_adam_flat(float* p, float* g, float* m, float* v, int64_t n, const float* sched, int64_t step, double beta1, double beta2, double eps,
+                 float grad_scale, int zero_grad, void* stream);
+
+/* Row-sparse form of the same update for a table of which a step touches few rows (LSTUR user_embedding,
+ * src/model/LSTUR/__init__.py:38-42: one row per sample).  The dense recurrence is evaluated lazily and exactly: last int32[num_rows] is
+ * the step up to which (p, m, v) of a row are current (0 = the row never received a gradient: m = v = 0, dense Adam does not move it);
+ * the idle steps a row missed are replayed one by one when the row is needed.  d <= 1024.
+ *   nr_row_adam_catchup  rows ids[0..n) (repeats allowed) -> current as of step `upto`; call before the forward gathers them.
+ *   nr_row_adam_flush    every row with state -> current as of `upto` (before state_dict() / checkpoints / full-table reads).
+ *   nr_row_adam_step     optimiser step `step` for the rows that received gradients: (id, gradient row) pairs of all ranks, sorted by id
+ *                        (ids_sorted int64[n], perm = index of the pair's row in rows f32[.][ld]).  Rows of one id are summed in
+ *                        sorted-position order (deterministic), scaled by grad_scale; ids <= pad_row are skipped (padding_idx). */
+int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
+                        int64_t upto, double beta1, double beta2, double eps, void* stream);
+int nr_row_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched, int64_t upto, double beta1,
+                      double beta2, double eps, void* stream);
+int nr_row_adam_step(const int64_t* ids_sorted, const int64_t* perm, int64_t n, const float* rows, int64_t ld, float* p, float* m, float* v,
+                     int32_t* last, int64_t num_rows, int d, const float* sched, int64_t step, double beta1, double beta2, double eps,
+                     float grad_scale, int pad_row, void* stream);
+
+/* Stable sort of token ids with their positions for the embedding backward (autograd of nn.Embedding, src/model/NRMS/news_encoder.py:38;
+ * consumer: nr_embed_scatter_sorted).  ids int64[n] (values outside [0, num_rows) are clamped like the forward gather) ->
+ * ids_sorted int64[n] ascending, perm int64[n] (original position; equal ids keep their order).  LSD radix on ceil(log2(num_rows))
+ * bits in passes of <= 9 bits.  workspace: nr_sort_ids_workspace(n, num_rows) bytes (16-byte aligned), -1 if the sizes are unsupported
+ * (n < 2^31, num_rows <= 2^27). */
+int64_t nr_sort_ids_workspace(int64_t n, int64_t num_rows);
+int nr_sort_ids(const int64_t* ids, int64_t n, int64_t num_rows, int64_t* ids_sorted, int64_t* perm, void* workspace, int64_t workspace_bytes,
+                void* stream);
+
 /* Debug/verification helper: the keep-mask (1.0/0.0) the fused kernels use for dropout `site`
  * (1 = embedding output, 2 = MHSA output) over n_elem consecutive elements. */
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream);

@@ -7,7 +7,7 @@ get a RuntimeError.
 """
 import ctypes
 import os
-from ctypes import c_void_p, c_int, c_int64, c_uint64, c_float, c_char_p
+from ctypes import c_void_p, c_int, c_int64, c_uint64, c_float, c_double, c_char_p
 
 _P = c_void_p
 SIGNATURES = {
@@ -54,6 +54,13 @@ SIGNATURES = {
     'nr_gru_bwd_seq': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_bwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_impression_metrics': ([_P, _P, _P, _P, c_int64, _P], c_int),
+    'nr_adam_flat': ([_P, _P, _P, _P, c_int64, _P, c_int64, c_double, c_double, c_double, c_float, c_int, _P], c_int),
+    'nr_row_adam_catchup': ([_P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double, _P], c_int),
+    'nr_row_adam_flush': ([_P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double, _P], c_int),
+    'nr_row_adam_step': ([_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double,
+                          c_float, c_int, _P], c_int),
+    'nr_sort_ids_workspace': ([c_int64, c_int64], c_int64),
+    'nr_sort_ids': ([_P, c_int64, c_int64, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
 }

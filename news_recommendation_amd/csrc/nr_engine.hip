@@ -8,6 +8,8 @@
 #include "k_naml.h"
 #include "k_gru.h"
 #include "k_eval.h"
+#include "k_optim.h"
+#include "k_sort.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -631,6 +633,102 @@ int nr_impression_metrics(const float* scores, const int32_t* labels, const int6
   if (n_impr == 0) return NR_OK;
   NR_LAUNCH(nr::impression_metrics_kernel, (n_impr + 3) / 4, 256, 0, (hipStream_t)stream, scores, labels, ptr, out, n_impr);
   return check_launch("nr_impression_metrics");
+}
+
+// ---- optimiser (src/train.py:127-128,227-233) ------------------------------------------------------------------------------------
+static nr::AdamCfg make_adam(const float* sched, double beta1, double beta2, double eps) {
+  nr::AdamCfg c;
+  c.sched = sched; c.om_b1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.om_b2 = (float)(1.0 - beta2); c.eps = (float)eps;
+  return c;
+}
+static bool bad_betas(double b1, double b2, double eps) { return !(b1 >= 0.0 && b1 < 1.0 && b2 >= 0.0 && b2 < 1.0 && eps >= 0.0); }
+
+int nr_adam_flat(float* p, float* g, float* m, float* v, int64_t n, const float* sched, int64_t step, double beta1, double beta2, double eps,
+                 float grad_scale, int zero_grad, void* stream) {
+  if (!p || !g || !m || !v || !sched || n < 0 || step < 1 || bad_betas(beta1, beta2, eps)) return fail(NR_ERR_BADARG, "nr_adam_flat: bad argument");
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(NR_ERR_BADARG, "nr_adam_flat: buffers must be 16-byte aligned");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::adam_flat_kernel, grid_for((n + 3) / 4, 256, 256 * 16), 256, 0, (hipStream_t)stream, p, g, m, v, n,
+            make_adam(sched, beta1, beta2, eps), step, grad_scale, zero_grad);
+  return check_launch("nr_adam_flat");
+}
+
+int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
+                        int64_t upto, double beta1, double beta2, double eps, void* stream) {
+  if (!ids || !p || !m || !v || !last || !sched || n < 0 || num_rows <= 0 || d <= 0 || d > 64 * nr::ROW_EPL || upto < 0 || bad_betas(beta1, beta2, eps))
+    return fail(NR_ERR_BADARG, "nr_row_adam_catchup: bad argument");
+  if (n == 0 || upto == 0) return NR_OK;
+  NR_LAUNCH(nr::row_adam_catchup_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids, n, p, m, v, (int*)last, num_rows, d, upto,
+            make_adam(sched, beta1, beta2, eps));
+  return check_launch("nr_row_adam_catchup");
+}
+
+int nr_row_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched, int64_t upto, double beta1,
+                      double beta2, double eps, void* stream) {
+  if (!p || !m || !v || !last || !sched || num_rows <= 0 || d <= 0 || d > 64 * nr::ROW_EPL || upto < 0 || bad_betas(beta1, beta2, eps))
+    return fail(NR_ERR_BADARG, "nr_row_adam_flush: bad argument");
+  if (upto == 0) return NR_OK;
+  NR_LAUNCH(nr::row_adam_flush_kernel, grid_for(num_rows, 4, 256 * 8), 256, 0, (hipStream_t)stream, p, m, v, (int*)last, num_rows, d, upto,
+            make_adam(sched, beta1, beta2, eps));
+  return check_launch("nr_row_adam_flush");
+}
+
+int nr_row_adam_step(const int64_t* ids_sorted, const int64_t* perm, int64_t n, const float* rows, int64_t ld, float* p, float* m, float* v,
+                     int32_t* last, int64_t num_rows, int d, const float* sched, int64_t step, double beta1, double beta2, double eps,
+                     float grad_scale, int pad_row, void* stream) {
+  if (!ids_sorted || !perm || !rows || !p || !m || !v || !last || !sched || n < 0 || num_rows <= 0 || d <= 0 || d > 64 * nr::ROW_EPL ||
+      ld < d || step < 1 || pad_row < -1 || bad_betas(beta1, beta2, eps))
+    return fail(NR_ERR_BADARG, "nr_row_adam_step: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::row_adam_step_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, n, rows, ld, p, m, v, (int*)last, num_rows, d,
+            step, make_adam(sched, beta1, beta2, eps), grad_scale, pad_row);
+  return check_launch("nr_row_adam_step");
+}
+
+// ---- token-id sort for the embedding backward ---------------------------------------------------------------------------------------
+static void sort_plan(int64_t num_rows, int* passes, int* bits) {
+  int total = 1;
+  while ((1LL << total) < num_rows) ++total;
+  *passes = (total + 8) / 9;
+  *bits = (total + *passes - 1) / *passes;
+}
+
+int64_t nr_sort_ids_workspace(int64_t n, int64_t num_rows) {
+  if (n < 0 || num_rows <= 0 || n >= (1LL << 31) || num_rows > (1LL << 27)) return -1;
+  int passes, bits;
+  sort_plan(num_rows, &passes, &bits);
+  const int64_t tiles = (n + nr::SORT_TILE - 1) / nr::SORT_TILE;
+  const int64_t hist = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256;
+  const int64_t pair = ((n * 4) + 255) / 256 * 256;
+  return hist + 2 * pair * (passes > 2 ? 2 : 1);
+}
+
+int nr_sort_ids(const int64_t* ids, int64_t n, int64_t num_rows, int64_t* ids_sorted, int64_t* perm, void* workspace, int64_t workspace_bytes,
+                void* stream) {
+  const int64_t need = nr_sort_ids_workspace(n, num_rows);
+  if (!ids || !ids_sorted || !perm || need < 0 || (n > 0 && (!workspace || workspace_bytes < need)) || ((uintptr_t)workspace & 15))
+    return fail(NR_ERR_BADARG, "nr_sort_ids: bad argument");
+  if (n == 0) return NR_OK;
+  int passes, bits;
+  sort_plan(num_rows, &passes, &bits);
+  const int tiles = (int)((n + nr::SORT_TILE - 1) / nr::SORT_TILE);
+  const int64_t hist_b = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256, pair = ((n * 4) + 255) / 256 * 256;
+  unsigned char* ws = (unsigned char*)workspace;
+  uint32_t* kbuf[2] = {(uint32_t*)(ws + hist_b), passes > 2 ? (uint32_t*)(ws + hist_b + 2 * pair) : nullptr};
+  uint32_t* ibuf[2] = {(uint32_t*)(ws + hist_b + pair), passes > 2 ? (uint32_t*)(ws + hist_b + 3 * pair) : nullptr};
+  for (int ps = 0; ps < passes; ++ps) {
+    nr::SortPass s;
+    s.ids = ps == 0 ? ids : nullptr;
+    s.key_in = ps == 0 ? nullptr : kbuf[(ps - 1) & 1]; s.idx_in = ps == 0 ? nullptr : ibuf[(ps - 1) & 1];
+    const bool last_pass = ps == passes - 1;
+    s.key_out = last_pass ? nullptr : kbuf[ps & 1]; s.idx_out = last_pass ? nullptr : ibuf[ps & 1];
+    s.ids_sorted = last_pass ? ids_sorted : nullptr; s.perm = last_pass ? perm : nullptr;
+    s.hist = (int*)ws; s.n = n; s.num_rows = num_rows; s.n_tiles = tiles; s.shift = ps * bits; s.bits = bits;
+    NR_LAUNCH(nr::sort_hist_kernel, tiles, 256, nr::SORT_SMEM, (hipStream_t)stream, s);
+    NR_LAUNCH(nr::sort_scan_kernel, 1, 256, 256 * 4, (hipStream_t)stream, s.hist, (int64_t)(1 << bits) * tiles);
+    NR_LAUNCH(nr::sort_scatter_kernel, tiles, 256, nr::SORT_SMEM, (hipStream_t)stream, s);
+  }
+  return check_launch("nr_sort_ids");
 }
 
 int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, int site, void* stream) {

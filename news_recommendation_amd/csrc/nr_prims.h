@@ -85,6 +85,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ int atomic_exch(int* p, int v) { return atomicExch(p, v); }
+__device__ __forceinline__ int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
+// a value the program knows to be identical in all lanes, as a scalar (see wave_id())
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// 64-bit mask of the lanes whose predicate is true
+__device__ __forceinline__ uint64_t ballot(bool pred) { return __ballot(pred); }
 
 template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }   // streaming store: not re-read soon

@@ -14,11 +14,28 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index(local_rank=None):
+    """Index of this rank's GPU among the devices the process can SEE.  A launcher that narrows visibility to one GPU per rank
+    (``HIP_VISIBLE_DEVICES=<LOCAL_RANK>``, so that the reference's hard-coded ``cuda:0`` is the local GPU) leaves exactly one
+    visible device: the index is then 0, not LOCAL_RANK (``set_device(LOCAL_RANK)`` would be an invalid ordinal on every rank >= 1)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n == 0:
+        return 0
+    if local_rank >= n:
+        if n == 1:
+            return 0
+        raise RuntimeError(f"LOCAL_RANK={local_rank} but only {n} GPUs are visible (HIP_VISIBLE_DEVICES="
+                           f"{os.environ.get('HIP_VISIBLE_DEVICES')!r}): expose one GPU per rank or all of them")
+    return local_rank
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local device index)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = local_device_index()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -37,6 +54,8 @@ def broadcast_parameters(model, src=0):
             dist.broadcast(p.data, src=src)
         for b in model.buffers():
             dist.broadcast(b.data, src=src)
+        from . import ops
+        ops.invalidate_packed()                  # .data writes do not bump the parameters' version counters
 
 
 class FlatGradBuffer:

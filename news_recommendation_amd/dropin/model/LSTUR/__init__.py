@@ -28,6 +28,7 @@ class LSTUR(torch.nn.Module):
 
     def _user_rows(self, user, masked):
         dev = self.user_embedding.weight.device
+        ops.check_ids(user, self.user_embedding.weight.shape[0], "user id")
         ids = user.to(dev, non_blocking=True)
         scale = None
         if masked:
@@ -52,7 +53,7 @@ class LSTUR(torch.nn.Module):
 
         def flat(k):
             a, b = cand[k], click[k]
-            return torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0).to(dev, non_blocking=True).contiguous()
+            return self.news_encoder.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
         vec = self.news_encoder.encode(flat('title'), flat('category'), flat('subcategory'))       # one kernel chain for all B*(C+N) news
         candidate_news_vector = vec[:B * C].view(B, C, -1)
         clicked_news_vector = vec[B * C:].view(B, N, -1)

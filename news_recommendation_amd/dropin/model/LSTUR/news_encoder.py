@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from news_recommendation_amd import ops_conv
+from news_recommendation_amd import ops, ops_conv
 from ..general.attention.additive import AdditiveAttention
 
 
@@ -26,8 +26,14 @@ class NewsEncoder(torch.nn.Module):
         return ops_conv.lstur_news(title, category, subcategory, self.word_embedding.weight, self.category_embedding.weight,
                                    self.title_CNN, self.title_attention, self.config.dropout_probability, self.training)
 
+    def to_device(self, key, ids):
+        """Host or device id tensor of attribute `key` -> contiguous device tensor; out-of-table ids raise IndexError like nn.Embedding
+        (host tensors always, device tensors with NR_CHECK_IDS=1: ops.check_ids)."""
+        rows = (self.word_embedding if key == 'title' else self.category_embedding).weight.shape[0]
+        ops.check_ids(ids, rows, f"{key} id")
+        return ids.to(self.word_embedding.weight.device, non_blocking=True).contiguous()
+
     def forward(self, news):
         """news: {"category": [B], "subcategory": [B], "title": [B, L]} (CPU or GPU) -> [B, 3 * num_filters]."""
-        dev = self.word_embedding.weight.device
-        mv = lambda k: news[k].to(dev, non_blocking=True).contiguous()
+        mv = lambda k: self.to_device(k, news[k])
         return self.encode(mv('title'), mv('category'), mv('subcategory'))

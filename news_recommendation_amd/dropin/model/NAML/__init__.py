@@ -34,7 +34,7 @@ class NAML(torch.nn.Module):
 
         def flat(k):
             a, b = cand[k], click[k]
-            return torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0).to(dev, non_blocking=True).contiguous()
+            return self.news_encoder.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
         vec, vec_b = self.news_encoder.encode(flat('title'), flat('abstract'), flat('category'), flat('subcategory'))
         candidate_news_vector = vec[:B * C].view(B, C, -1)
         clicked_news_vector = vec[B * C:].view(B, N, -1)

@@ -26,5 +26,6 @@ class NewsEncoder(torch.nn.Module):
 
     def forward(self, news):
         """news: {"title": int64 [batch, num_words_title]} (CPU or GPU) -> [batch, word_embedding_dim]."""
+        ops.check_ids(news["title"], self.word_embedding.weight.shape[0], "title token id")
         ids = news["title"].to(self.word_embedding.weight.device, non_blocking=True)
         return self.encode_ids(ids)

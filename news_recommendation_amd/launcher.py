@@ -83,12 +83,31 @@ def _fast_evaluate_main(model_name):
     print(f'AUC: {auc:.4f}\nMRR: {mrr:.4f}\nnDCG@5: {ndcg5:.4f}\nnDCG@10: {ndcg10:.4f}')
 
 
+def narrow_visibility(env):
+    """One GPU per rank BEFORE torch is imported: the reference hard-codes ``cuda:0`` in 13 module globals, so the only
+    way to run its unchanged files on the rank's own GPU is to make that GPU the process's device 0.  If the caller already restricts
+    visibility to a list (``HIP_VISIBLE_DEVICES=4,5,6,7``) the rank takes the LOCAL_RANK-th entry of that list; a single pre-set
+    entry per process is left alone.  ``dist.local_device_index()`` then resolves the local device index to 0."""
+    if env.get('WORLD_SIZE', '1') == '1' or 'LOCAL_RANK' not in env:
+        return
+    lr = int(env['LOCAL_RANK'])
+    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        cur = env.get(var)
+        if cur:
+            devs = [d for d in cur.split(',') if d != '']
+            if len(devs) > 1:
+                if lr >= len(devs):
+                    raise RuntimeError(f"LOCAL_RANK={lr} but {var}={cur!r} lists only {len(devs)} devices")
+                env[var] = devs[lr]
+            return
+    env['HIP_VISIBLE_DEVICES'] = str(lr)
+
+
 def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False):
     here = os.path.dirname(os.path.abspath(__file__))
     repo = os.path.dirname(here)
     reference_src = os.path.abspath(reference_src)
-    if os.environ.get('WORLD_SIZE', '1') != '1' and 'LOCAL_RANK' in os.environ:
-        os.environ.setdefault('HIP_VISIBLE_DEVICES', os.environ['LOCAL_RANK'])   # cuda:0 == the local GPU
+    narrow_visibility(os.environ)
     os.environ['MODEL_NAME'] = model_name
     sys.dont_write_bytecode = True            # the reference tree is read-only
     for p in (reference_src, repo, os.path.join(here, 'dropin')):

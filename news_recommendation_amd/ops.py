@@ -9,6 +9,7 @@ There is no CPU path: tensors must live on a ROCm device and the HIP library
 must be built, otherwise a RuntimeError is raised.
 """
 import collections
+import os
 
 import torch
 
@@ -122,14 +123,28 @@ def check_dims(d_model, heads, qdim=None):
         raise NotImplementedError(f"query_vector_dim must be in [1, {NR_QP}] (got {qdim})")
 
 
+_CHECK_DEVICE_IDS = os.environ.get('NR_CHECK_IDS', '0') == '1'
+
+
+def check_ids(ids, num_rows, what="index"):
+    """nn.Embedding raises IndexError on an id outside [0, num_rows) (the kernels clamp instead of faulting).  Host-resident id
+    tensors -- what the reference's DataLoader delivers (train.py:202) -- are always checked (a cheap CPU min/max before the H2D copy);
+    device-resident ones only with NR_CHECK_IDS=1, because the check costs a stream synchronisation per call."""
+    if ids.numel() == 0 or (ids.is_cuda and not _CHECK_DEVICE_IDS):
+        return
+    lo, hi = int(ids.min()), int(ids.max())
+    if lo < 0 or hi >= num_rows:
+        raise IndexError(f"{what} out of range: got [{lo}, {hi}], table has {num_rows} rows")
+
+
 def new_seed():
     """Seed for the kernels' counter-based dropout RNG, drawn from torch's CPU generator (torch.manual_seed-able)."""
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
 # ----------------------------------------------------------------------------------------------------------
-# weight packing (fp32 parameters -> zero-padded bf16 MFMA operands); re-done every call so the kernels
-# always see the live parameter storage the optimizer updates in place (SURVEY 8 b6)
+# weight packing (fp32 parameters -> zero-padded bf16 MFMA operands) of the LIVE parameter storage the optimizer
+# updates in place (SURVEY 8 b6): re-packed whenever the parameters changed, see _packed()
 # ----------------------------------------------------------------------------------------------------------
 def untile(t, R, K):
     """Packed weight operands are stored in the kernels' "tile order" (include/nr_engine.h): 16 x 32 blocks of 64 lane fragments.
@@ -137,32 +152,67 @@ def untile(t, R, K):
     return t.view(R // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(R, K)
 
 
+# Packed operands are cached per parameter STATE: key = (storage pointer, tensor version) of every source tensor + a global epoch.
+# torch's own in-place updates (optimizer.step(), load_state_dict, .copy_) bump the version counter; code that writes parameter memory
+# behind torch's back -- the engine's fused Adam kernel, collectives on ``p.data`` -- calls ``invalidate_packed()``.  A training step packs
+# each operand once (not once per encoder call plus once per backward), evaluation packs once per model state.
+_pack_cache = collections.OrderedDict()
+_pack_epoch = 0
+_PACK_CACHE_MAX = 64
+
+
+def invalidate_packed():
+    """Parameters were modified without torch noticing (raw kernel writes / ``.data`` writes): drop every cached packed operand."""
+    global _pack_epoch
+    _pack_epoch += 1
+    _pack_cache.clear()
+
+
+def _packed(kind, tensors, build):
+    key = (kind, _pack_epoch) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        _pack_cache.move_to_end(key)
+        return hit
+    out = build()
+    _pack_cache[key] = out
+    while len(_pack_cache) > _PACK_CACHE_MAX:
+        _pack_cache.popitem(last=False)
+    return out
+
+
 def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
-    dev = Wq.device
-    Wp = torch.empty(3 * NR_NP, NR_KP, dtype=_BF16_AS_I16, device=dev)
-    bp = torch.empty(3 * NR_NP, dtype=torch.float32, device=dev)
-    args = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
-    _call('nr_pack_qkv', _lib().nr_pack_qkv, *[_ptr(a) for a in args], _ptr(Wp), _ptr(bp), _stream())
-    return Wp, bp
+    def build():
+        dev = Wq.device
+        Wp = torch.empty(3 * NR_NP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        bp = torch.empty(3 * NR_NP, dtype=torch.float32, device=dev)
+        args = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
+        _call('nr_pack_qkv', _lib().nr_pack_qkv, *[_ptr(a) for a in args], _ptr(Wp), _ptr(bp), _stream())
+        return Wp, bp
+    return _packed('qkv', (Wq, bq, Wk, bk, Wv, bv), build)
 
 
 def pack_additive(Wa, ba, qv):
-    dev = Wa.device
-    qdim = Wa.shape[0]
-    Wap = torch.empty(NR_QP, NR_KP, dtype=_BF16_AS_I16, device=dev)
-    bap = torch.empty(NR_QP, dtype=torch.float32, device=dev)
-    qvp = torch.empty(NR_QP, dtype=torch.float32, device=dev)
-    a = [_f32c(Wa), _f32c(ba), _f32c(qv)]
-    _call('nr_pack_additive', _lib().nr_pack_additive, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), qdim, _ptr(Wap), _ptr(bap), _ptr(qvp), _stream())
-    return Wap, bap, qvp
+    def build():
+        dev = Wa.device
+        qdim = Wa.shape[0]
+        Wap = torch.empty(NR_QP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        bap = torch.empty(NR_QP, dtype=torch.float32, device=dev)
+        qvp = torch.empty(NR_QP, dtype=torch.float32, device=dev)
+        a = [_f32c(Wa), _f32c(ba), _f32c(qv)]
+        _call('nr_pack_additive', _lib().nr_pack_additive, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), qdim, _ptr(Wap), _ptr(bap), _ptr(qvp), _stream())
+        return Wap, bap, qvp
+    return _packed('additive', (Wa, ba, qv), build)
 
 
 def pack_additive_t(Wa):
     """Wa^T as the bf16 [KP][QKP] operand of the fused input-gradient product inside nr_additive_bwd_ex."""
-    WaT = torch.empty(NR_KP, 224, dtype=_BF16_AS_I16, device=Wa.device)
-    a = _f32c(Wa)
-    _call('nr_pack_additive_t', _lib().nr_pack_additive_t, _ptr(a), Wa.shape[0], _ptr(WaT), _stream())
-    return WaT
+    def build():
+        WaT = torch.empty(NR_KP, 224, dtype=_BF16_AS_I16, device=Wa.device)
+        a = _f32c(Wa)
+        _call('nr_pack_additive_t', _lib().nr_pack_additive_t, _ptr(a), Wa.shape[0], _ptr(WaT), _stream())
+        return WaT
+    return _packed('additive_t', (Wa,), build)
 
 
 def _bf16(t_i16):
@@ -241,10 +291,27 @@ def grad_target(param):
     return d, d
 
 
-def sort_ids_async(ids):
+def table_grad_ready(param):
+    """Tell the owner of the gradient buffers (optim.EngineAdam) that this table's gradient is complete on the current stream."""
+    cb = getattr(param, '_nr_grad_ready', None)
+    if cb is not None:
+        cb()
+
+
+def pack_qkv_t(Wq, bq, Wk, bk, Wv, bv):
+    """[KP, 960] row-major transpose of the packed QKV operand for the library GEMM of the input gradient dX = dqkv @ W (the 'linear'
+    operand form is the fastest hipBLASLt path for it); cached on the same parameter state as pack_qkv."""
+    def build():
+        Wp, _ = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
+        return _bf16(untile(Wp, 3 * NR_NP, NR_KP)).t().contiguous()
+    return _packed('qkv_t', (Wq, bq, Wk, bk, Wv, bv), build)
+
+
+def sort_ids_async(ids, num_rows=None):
     """Sort the token ids for the embedding backward on a side HIP stream, overlapped with the forward kernels (the ids are
     known before the forward starts; the sorted order is only needed by the scatter at the very end of the backward).
-    Returns (ids_sorted, perm, event)."""
+    ``nr_sort_ids``: stable LSD radix sort on the ceil(log2(num_rows)) significant bits (2 passes for the 70,976- and 130,001-word
+    vocabularies) instead of torch.sort's 64-bit merge sort.  Returns (ids_sorted, perm, event)."""
     dev = ids.device
     cur = torch.cuda.current_stream(dev)
     st = _side.get(dev)
@@ -252,17 +319,35 @@ def sort_ids_async(ids):
         st = _side[dev] = torch.cuda.Stream(device=dev)
     st.wait_stream(cur)
     with torch.cuda.stream(st):
-        # 32-bit keys: rocPRIM's radix sort makes half the passes of the int64 sort (1.9 M NAML tokens: 284 -> 140 us)
         flat = ids.reshape(-1)
-        if flat.numel() >= (1 << 20):
-            s32, perm = torch.sort(flat.to(torch.int32))
-            ids_sorted = s32.to(torch.int64)
-        else:
-            ids_sorted, perm = torch.sort(flat)
+        n = flat.numel()
+        lib = _lib()
+        ws_bytes = lib.nr_sort_ids_workspace(n, num_rows) if num_rows is not None else -1
+        if ws_bytes < 0:
+            raise NotImplementedError(f"nr_sort_ids: {n} ids over {num_rows} rows is outside the supported range")
+        ids_sorted = torch.empty(n, dtype=torch.int64, device=dev)
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        _call('nr_sort_ids', lib.nr_sort_ids, _ptr(flat), n, num_rows, _ptr(ids_sorted), _ptr(perm), _ptr(ws), ws_bytes, st.cuda_stream)
         ev = torch.cuda.Event()
         ev.record(st)
     ids.record_stream(st)
     return ids_sorted, perm, ev
+
+
+def sort_ids(ids, num_rows):
+    """nr_sort_ids on the current stream: (ids_sorted, perm) of a flat int64 id tensor, stable."""
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    lib = _lib()
+    ws_bytes = lib.nr_sort_ids_workspace(n, num_rows)
+    if ws_bytes < 0:
+        raise NotImplementedError(f"nr_sort_ids: {n} ids over {num_rows} rows is outside the supported range")
+    ids_sorted = torch.empty(n, dtype=torch.int64, device=flat.device)
+    perm = torch.empty(n, dtype=torch.int64, device=flat.device)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=flat.device)
+    _call('nr_sort_ids', lib.nr_sort_ids, _ptr(flat), n, num_rows, _ptr(ids_sorted), _ptr(perm), _ptr(ws), ws_bytes, _stream())
+    return ids_sorted, perm
 
 
 def sorted_ids_ready(pack):
@@ -275,14 +360,34 @@ def sorted_ids_ready(pack):
     return ids_sorted, perm
 
 
+_WS_ZERO_SHAPES = 4
+
+
 def _workspace(key, shape, dtype, device, zero=False):
-    """Reusable scratch buffers that live only inside one backward call."""
-    k = (key, tuple(shape), dtype, str(device))
-    t = _ws.get(k)
-    if t is None:
-        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
-        _ws[k] = t
-    return t
+    """Reusable scratch buffers that live only inside one backward call (all users are ordered on the current stream).
+    Plain buffers: ONE flat allocation per (key, dtype, device), grown to the largest request and sliced -- a cache keyed on the shape
+    would keep a buffer per distinct batch shape forever.  ``zero=True`` buffers rely on the columns / rows the kernels never write
+    staying zero, so they are kept per shape (zeroed once when created), at most _WS_ZERO_SHAPES shapes per key, least recently used
+    evicted: a training step alternates between two shapes (user encoder, news encoder) and must not pay a fill per call."""
+    shape = tuple(int(x) for x in shape)
+    k = (key, dtype, str(device))
+    if zero:
+        lru = _ws.setdefault(k, collections.OrderedDict())
+        t = lru.get(shape)
+        if t is None:
+            t = lru[shape] = torch.zeros(shape, dtype=dtype, device=device)
+            while len(lru) > _WS_ZERO_SHAPES:
+                lru.popitem(last=False)
+        else:
+            lru.move_to_end(shape)
+        return t
+    n = 1
+    for x in shape:
+        n *= x
+    buf = _ws.get(k)
+    if buf is None or buf.numel() < n:
+        buf = _ws[k] = torch.empty(max(n, 1), dtype=dtype, device=device)
+    return buf[:n].view(shape)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -308,6 +413,7 @@ class _EncoderFn(torch.autograd.Function):
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
         WaT = pack_additive_t(Wa) if need_grad else None
+        WpT = pack_qkv_t(Wq, bq, Wk, bk, Wv, bv) if need_grad else None
         if need_grad:
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
@@ -331,16 +437,16 @@ class _EncoderFn(torch.autograd.Function):
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
         if need_grad:
-            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, xb, WaT)
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
             ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
-            ctx.sorted = sort_ids_async(ids_c) if gather and ctx.needs_input_grad[1] else None
+            ctx.sorted = sort_ids_async(ids_c, table.shape[0]) if gather and ctx.needs_input_grad[1] else None
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        ids, table, xd, cbuf, qs, ks, vts, aw, Wp, Wap, bap, qvp, Xb, WaT = ctx.saved_tensors
+        ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT = ctx.saved_tensors
         S, p_drop, seed, n_seq, qdim, gather = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
@@ -353,20 +459,14 @@ class _EncoderFn(torch.autograd.Function):
         _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                                 _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
-        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
-        d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                             n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
-        # ---- weight gradients: dW_ext = dqkv^T @ [X | 1] --------------------------------------------------------------
-        dW_ext = _wgrad(dqkv_b, _bf16(Xb), f'gemm_dWqkv[S={S}]')       # [960, KP]
-        gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
-        gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
-        # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] ---------------------------------------------------------------------
-        WpT = _bf16(untile(Wp, 3 * NR_NP, NR_KP)).t().contiguous()                                   # [KP, 960]: the 'linear' operand form is the fastest hipBLASLt path here
+        # ---- input gradient first: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
+        # data-parallel exchange; finishing it BEFORE the weight-gradient GEMMs lets its all-reduce (started by table_grad_ready on
+        # RCCL's stream) overlap with them ---------------------------------------------------------------------------------------------
         dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
         d_table = d_x = None
         if gather:
@@ -377,8 +477,16 @@ class _EncoderFn(torch.autograd.Function):
                 ids_sorted, perm = sorted_ids_ready(ctx.sorted)
                 _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_KP,
                       _ptr(dst), table.shape[0], ntok, p_drop, seed, _stream())
+                table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
+        # ---- weight gradients: two plain GEMMs, dWa_ext = dpre^T @ [ctx | 1], dW_ext = dqkv^T @ [X | 1] -----------------------------
+        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
+        dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
+        dW_ext = _wgrad(dqkv_b, _bf16(Xb), f'gemm_dWqkv[S={S}]')       # [960, KP]
+        gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
+        gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)
 
 

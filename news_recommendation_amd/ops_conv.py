@@ -24,14 +24,17 @@ def check_conv_dims(config_like_d, num_filters, window, qdim):
 
 
 def pack_conv(W, b):
-    """Conv2d(1,F,(3,D)) parameters -> (Wc, Wd, bc) bf16/f32 operands; redone every call (live parameters)."""
-    dev = W.device
-    Wc = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
-    Wd = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
-    bc = torch.empty(NR_KP, dtype=torch.float32, device=dev)
-    Wf, bf = _f32c(W), _f32c(b)
-    _call('nr_pack_conv', _lib().nr_pack_conv, _ptr(Wf), _ptr(bf), W.shape[0], W.shape[3], _ptr(Wc), _ptr(Wd), _ptr(bc), _stream())
-    return Wc, Wd, bc
+    """Conv2d(1,F,(3,D)) parameters -> (Wc, Wd, bc) bf16/f32 operands of the live parameters, cached per parameter state
+    (ops._packed)."""
+    def build():
+        dev = W.device
+        Wc = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        Wd = torch.empty(3, NR_KP, NR_KP, dtype=_BF16_AS_I16, device=dev)
+        bc = torch.empty(NR_KP, dtype=torch.float32, device=dev)
+        Wf, bf = _f32c(W), _f32c(b)
+        _call('nr_pack_conv', _lib().nr_pack_conv, _ptr(Wf), _ptr(bf), W.shape[0], W.shape[3], _ptr(Wc), _ptr(Wd), _ptr(bc), _stream())
+        return Wc, Wd, bc
+    return ops._packed('conv', (W, b), build)
 
 
 def _seqpad_alloc(n_seq, S):
@@ -128,9 +131,9 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
 
 
-def sort_tokens_async(ids_list):
+def sort_tokens_async(ids_list, num_rows):
     """Concatenate the token streams and sort them on the side stream while the forward kernels run (ops.sort_ids_async)."""
-    return ops.sort_ids_async(torch.cat([i.reshape(-1) for i in ids_list]))
+    return ops.sort_ids_async(torch.cat([i.reshape(-1) for i in ids_list]), num_rows)
 
 
 def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):
@@ -142,13 +145,14 @@ def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):
     assert ids_sorted.numel() == n_tokens
     _call('nr_embed_scatter_sorted', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dx), NR_KP, _ptr(dst),
           table.shape[0], n_tokens, p, seed, _stream())
+    ops.table_grad_ready(table)
     return d_table
 
 
 def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row):
     """dst[id] = sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row)."""
     dst = torch.zeros(num_rows, NR_D, dtype=torch.float32, device=src.device)
-    ids_sorted, perm = torch.sort(ids.reshape(-1))
+    ids_sorted, perm = ops.sort_ids(ids, num_rows)
     _call('nr_scatter_sorted_f32', _lib().nr_scatter_sorted_f32, _ptr(ids_sorted), _ptr(perm), src.data_ptr() + col0 * 4, ld, _ptr(dst),
           num_rows, ids.numel(), pad_row, _stream())
     return dst
@@ -192,7 +196,7 @@ class _NamlNewsFn(torch.autograd.Function):
             ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT)
             ctx.st = (st_t, st_a)
             ctx.meta = (p, seed, Wa_f.shape[0])
-            ctx.sorted = sort_tokens_async([title, abstract]) if ctx.needs_input_grad[4] else None
+            ctx.sorted = sort_tokens_async([title, abstract], table.shape[0]) if ctx.needs_input_grad[4] else None
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         ctx.mark_non_differentiable(out_b)
         return out, out_b
@@ -310,7 +314,7 @@ class _LsturNewsFn(torch.autograd.Function):
             ctx.save_for_backward(title, cat, sub, table)
             ctx.st = st
             ctx.meta = (p, seed, cat_table.shape[0])
-            ctx.sorted = sort_tokens_async([title]) if ctx.needs_input_grad[3] else None
+            ctx.sorted = sort_tokens_async([title], table.shape[0]) if ctx.needs_input_grad[3] else None
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         return out
 
@@ -353,7 +357,7 @@ class _TextFn(torch.autograd.Function):
             ctx.save_for_backward(ids, table)
             ctx.st = st
             ctx.meta = (p, seed)
-            ctx.sorted = sort_tokens_async([ids]) if ctx.needs_input_grad[1] else None
+            ctx.sorted = sort_tokens_async([ids], table.shape[0]) if ctx.needs_input_grad[1] else None
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
         return out
 
@@ -375,3 +379,49 @@ def text_only(ids, table, conv, additive, p_drop, training):
     seed = ops.new_seed() if p > 0 else 0
     return _TextFn.apply(ids.contiguous(), table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
                          additive.attention_query_vector, p, seed)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# one element view on its own (NAML ElementEncoder.forward used directly, src/model/NAML/news_encoder.py:40-47)
+# ----------------------------------------------------------------------------------------------------------
+class _ElementFn(torch.autograd.Function):
+    """relu(linear(embedding(ids))): the table form (one row of E per category id, nr_element_table_fwd) + a row gather."""
+
+    @staticmethod
+    def forward(ctx, ids, emb, W, b):
+        lib = _lib()
+        dev = emb.device
+        ncat, dcat = emb.shape
+        F = W.shape[0]
+        if F != NR_D:
+            raise NotImplementedError(f"ElementEncoder output dim must be {NR_D} (got {F})")
+        embf, Wf, bf = _f32c(emb), _f32c(W), _f32c(b)
+        E = torch.empty(2, ncat, NR_D, dtype=torch.float32, device=dev)
+        _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wf), _ptr(bf), _ptr(Wf), _ptr(bf), _ptr(E), _stream())
+        flat = ids.reshape(-1).contiguous()
+        out = torch.empty(flat.numel(), NR_D, dtype=torch.float32, device=dev)
+        _call('nr_gather_rows_strided', lib.nr_gather_rows_strided, _ptr(flat), _ptr(E), ncat, NR_D, None, _ptr(out), NR_D, flat.numel(), _stream())
+        ctx.save_for_backward(flat, embf, Wf, E)
+        ctx.shape = tuple(ids.shape)
+        return out.view(*ids.shape, NR_D)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        flat, embf, Wf, E = ctx.saved_tensors
+        ncat, dcat = embf.shape
+        dev = embf.device
+        g = g.reshape(-1, NR_D).to(torch.float32).contiguous()
+        dE = torch.stack([_sorted_rows_scatter(flat, g, 0, NR_D, ncat, -1), torch.zeros(ncat, NR_D, dtype=torch.float32, device=dev)])
+        dW = torch.empty(2, NR_D, dcat, dtype=torch.float32, device=dev)
+        db = torch.empty(2, NR_D, dtype=torch.float32, device=dev)
+        demb = torch.empty(ncat, dcat, dtype=torch.float32, device=dev)
+        _call('nr_element_table_bwd', lib.nr_element_table_bwd, _ptr(embf), ncat, dcat, _ptr(Wf), _ptr(Wf), _ptr(E), _ptr(dE), _ptr(dW), _ptr(db),
+              _ptr(demb), _stream())
+        return None, demb, dW[0], db[0]
+
+
+def element_only(ids, embedding, linear):
+    _require_cuda(embedding.weight, "category embedding")
+    ops.check_ids(ids, embedding.weight.shape[0], "category / subcategory id")
+    return _ElementFn.apply(ids, embedding.weight, linear.weight, linear.bias)

@@ -36,6 +36,9 @@ class _UserRowsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, table, row_scale):
+        sync = getattr(table, '_nr_row_sync', None)
+        if sync is not None:
+            sync(ids)                            # row-sparse optimiser (optim.EngineAdam): replay the idle Adam steps these rows missed
         tab = _f32c(table)
         B, d = ids.shape[0], tab.shape[1]
         out = torch.empty(B, d, dtype=torch.float32, device=tab.device)
@@ -49,6 +52,10 @@ class _UserRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         ids, row_scale = ctx.saved_tensors
         g = g.to(torch.float32).contiguous()
+        sink = getattr(ctx.table_param, '_nr_row_sink', None)
+        if sink is not None:                     # row-sparse optimiser: hand over (ids, gradient rows), never build the dense table gradient
+            sink(ids, g if row_scale is None else g * row_scale.unsqueeze(1))
+            return None, None, None
         dst, d_table = ops.grad_target(ctx.table_param)
         _call('nr_rows_scatter_add[user]', _lib().nr_rows_scatter_add, _ptr(ids), _ptr(g), g.shape[1], _ptr(row_scale), _ptr(dst), ctx.shape[0],
               ctx.shape[1], ids.shape[0], 0, _stream())
@@ -72,12 +79,15 @@ class _GruFn(torch.autograd.Function):
         Ip = _ceil(I + 1, 32)
         dev = x.device
         need_grad = any(ctx.needs_input_grad)
-        Wih_p = torch.empty(3 * Hg, Ip, dtype=_BF16_AS_I16, device=dev)
-        Whh_p = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
-        WhhT = torch.empty(Hp, Kp, dtype=_BF16_AS_I16, device=dev) if need_grad else None
-        Wi, Wh = _f32c(W_ih), _f32c(W_hh)
-        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, 0, _stream())            # row-major: GEMM operand
-        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), 1, _stream())     # tile order: step-kernel operands
+        def build():         # packed once per parameter state (ops._packed), not once per call
+            Wih_p = torch.empty(3 * Hg, Ip, dtype=_BF16_AS_I16, device=dev)
+            Whh_p = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
+            WhhT = torch.empty(Hp, Kp, dtype=_BF16_AS_I16, device=dev)
+            Wi, Wh = _f32c(W_ih), _f32c(W_hh)
+            _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, 0, _stream())            # row-major: GEMM operand
+            _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), 1, _stream())     # tile order: step-kernel operands
+            return Wih_p, Whh_p, WhhT
+        Wih_p, Whh_p, WhhT = ops._packed('gru', (W_ih, W_hh), build)
         bi, bh = _f32c(b_ih), _f32c(b_hh)
         xf = _f32c(x).view(B * N, I)
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0

@@ -1,0 +1,356 @@
+"""The optimiser step of src/train.py:127-128,227-233 -- ``Adam(model.parameters(), lr)``, ``zero_grad / backward / step`` -- fused with the
+data-parallel gradient exchange.
+
+What the reference does per step: ``optimizer.zero_grad()``, ``loss.backward()`` (53 dense 85 MB embedding gradients accumulated),
+``optimizer.step()`` (dense Adam over every parameter, one process, one device).  ``EngineAdam`` keeps exactly that update rule
+(torch.optim.Adam defaults) and the ``state_dict`` format of ``torch.optim.Adam`` (checkpoints stay interchangeable with the reference's
+``train.py:144-159,264-277``), on a memory layout made for the engine:
+
+* all DENSE parameters live in one flat fp32 buffer ``[small parameters | word-embedding table(s)]``; ``.grad`` of every parameter is a
+  view into a flat gradient buffer of the same layout, Adam moments likewise.  One kernel pass (``nr_adam_flat``) reads p, g, m, v,
+  writes p, m, v and clears g: the zero_grad pass, the ``/ world`` pass and the separate moment updates are gone.
+* data parallel (one process per GPU, RCCL over xGMI): the table bucket's all-reduce is started from inside the backward, right after
+  the embedding scatter has been enqueued (``param._nr_grad_ready``), and runs on RCCL's stream while the encoder's weight-gradient
+  GEMMs still compute; the small bucket (2.65 MB for NRMS) follows at the end.  xGMI is point-to-point (7 links per GPU): two large
+  messages, not one per parameter.
+* ROW-SPARSE tables (LSTUR ``user_embedding``, src/model/LSTUR/__init__.py:38-42: 711,223 x 900 fp32 = 2.56 GB at MIND-large scale, B
+  rows touched per step) never materialise a dense gradient: the backward hands over ``(row ids, gradient rows)``, ranks all-gather
+  those (B x 3.6 KB each instead of a 2.56 GB all-reduce), and ``nr_row_adam_*`` evaluate the dense Adam recurrence lazily and exactly
+  (csrc/k_optim.h): rows are caught up just before the forward reads them, and ``flush()`` brings the whole table up to date before
+  ``state_dict()`` / checkpoints.
+
+There is no CPU implementation: the update runs in the HIP library (``_capi.load()``).  ``lib=`` lets the GPU-less unit tests inject
+the CPU wave-emulation build of the same kernel sources (tests/emu, test infrastructure).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi, ops
+
+TABLE_MIN_NUMEL = 1 << 22          # dense parameters from 4 M elements up form their own all-reduce bucket (the embedding tables)
+_ALIGN = 64                        # flat regions start on 256-byte boundaries
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class AdamSchedule:
+    """Device table of the per-step scalars, computed in double exactly as torch's ``_single_tensor_adam`` does:
+    ``sched[2 s] = lr / (1 - beta1 ** s)``, ``sched[2 s + 1] = sqrt(1 - beta2 ** s)``."""
+
+    def __init__(self, lr, betas, device, capacity=4096):
+        self.lr, self.betas, self.device = float(lr), (float(betas[0]), float(betas[1])), device
+        self.capacity = 0
+        self.table = None
+        self.ensure(capacity - 1)
+
+    @staticmethod
+    def host_table(lr, betas, n):
+        s = np.arange(n, dtype=np.float64)
+        out = np.zeros((n, 2), dtype=np.float32)
+        if n > 1:
+            bc1 = 1.0 - np.power(betas[0], s[1:])
+            bc2 = 1.0 - np.power(betas[1], s[1:])
+            out[1:, 0] = (lr / bc1).astype(np.float32)
+            out[1:, 1] = np.sqrt(bc2).astype(np.float32)
+        return out
+
+    def ensure(self, step):
+        if step < self.capacity:
+            return
+        cap = max(4096, self.capacity)
+        while cap <= step:
+            cap *= 2
+        self.table = torch.from_numpy(self.host_table(self.lr, self.betas, cap)).to(self.device)
+        self.capacity = cap
+
+
+class _Region:
+    __slots__ = ('name', 'lo', 'hi', 'work')
+
+    def __init__(self, name, lo, hi):
+        self.name, self.lo, self.hi, self.work = name, lo, hi, None
+
+
+class _SparseTable:
+    __slots__ = ('name', 'param', 'm', 'v', 'last', 'pending', 'pad_row')
+
+
+class EngineAdam:
+    """Adam over a model's parameters with the engine's flat layout, fused update kernel, bucketed / overlapped all-reduce and
+    row-sparse tables.  Drop-in for the ``optimizer`` object of src/train.py: ``zero_grad()``, ``step()``, ``state_dict()``,
+    ``load_state_dict()``, ``param_groups``."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, row_sparse=(), overlap=True, lib=None, stream_fn=None):
+        if isinstance(model, torch.nn.Module):
+            named = list(model.named_parameters())
+            self._module = model
+        else:
+            named = list(model)
+            self._module = None
+        named = [(n, p) for n, p in named if p.requires_grad]
+        if not named:
+            raise ValueError("EngineAdam: no trainable parameters")
+        self.lib = lib if lib is not None else _capi.load()
+        self._stream_fn = stream_fn if stream_fn is not None else (lambda: torch.cuda.current_stream().cuda_stream)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.overlap = bool(overlap)
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]               # model.parameters() order == torch.optim.Adam's parameter indices
+        dev = self.params[0].device
+        self.device = dev
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("EngineAdam: all parameters must be fp32 on one device")
+        self.t = 0
+        self._uniform_rows = {}
+        self.sched = AdamSchedule(self.lr, self.betas, dev)
+
+        sparse_names = [n for n in self.names if any(n == s or n.endswith(s) for s in row_sparse)]
+        dense = [(n, p) for n, p in named if n not in sparse_names]
+        small = [(n, p) for n, p in dense if p.numel() < TABLE_MIN_NUMEL]
+        tables = [(n, p) for n, p in dense if p.numel() >= TABLE_MIN_NUMEL]
+        # ---- flat dense layout: [small | table 0 | table 1 ...], every region 256-byte aligned -------------------------------
+        self.slices = {}
+        off = 0
+        for n, p in small:
+            self.slices[n] = (off, off + p.numel())
+            off += p.numel()
+        self.regions = [_Region('small', 0, off)] if off else []
+        for n, p in tables:
+            off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+            self.slices[n] = (off, off + p.numel())
+            self.regions.append(_Region(n, off, off + p.numel()))
+            off += p.numel()
+        total = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.dense_nbytes = total * 4
+        self._table_region = {}
+        with torch.no_grad():
+            for n, p in dense:
+                lo, hi = self.slices[n]
+                self.flat_p[lo:hi].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[lo:hi].view(p.shape)            # the optimiser updates the parameter's own storage in place
+                p.grad = self.flat_g[lo:hi].view(p.shape)
+                p._nr_inplace_grad = True                            # ops.grad_target(): table scatters accumulate straight into the view
+        for r in self.regions:
+            if r.name != 'small':
+                p = dict(dense)[r.name]
+                self._table_region[id(p)] = r
+                p._nr_grad_ready = self._make_ready(r)
+        # ---- row-sparse tables ---------------------------------------------------------------------------------------------------------
+        self.sparse = []
+        for n, p in named:
+            if n in sparse_names:
+                if p.dim() != 2 or p.shape[1] > 1024 or not p.is_contiguous():
+                    raise ValueError(f"EngineAdam: row-sparse table {n} must be a contiguous [rows, d <= 1024] matrix")
+                st = _SparseTable()
+                st.name, st.param, st.pending = n, p, []
+                st.m, st.v = torch.zeros_like(p.data), torch.zeros_like(p.data)
+                st.last = torch.zeros(p.shape[0], dtype=torch.int32, device=dev)
+                st.pad_row = 0                       # nn.Embedding(padding_idx=0): row 0 receives no gradient
+                p.grad = None
+                p._nr_row_sink = self._make_sink(st)
+                p._nr_row_sync = self._make_sync(st)
+                self.sparse.append(st)
+        self.param_groups = [{'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                              'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                              'params': list(range(len(self.params)))}]
+        if self._module is not None and self.sparse:
+            self._module.register_state_dict_pre_hook(lambda *_a, **_k: self.flush())
+
+    # ---- hooks the engine's backward calls ------------------------------------------------------------------------------------------------
+    def _make_ready(self, region):
+        def ready():
+            """The table's gradient is complete (its scatter is enqueued on the current stream): start the bucket's all-reduce now."""
+            if _world() > 1 and self.overlap:
+                if region.work is not None:
+                    raise RuntimeError(f"EngineAdam(overlap=True): the gradient of {region.name} was completed twice in one step; "
+                                       "use overlap=False when a table is scattered by more than one backward call per step")
+                region.work = dist.all_reduce(self.flat_g[region.lo:region.hi], op=dist.ReduceOp.SUM, async_op=True)
+        return ready
+
+    def _make_sink(self, st):
+        def sink(ids, rows):
+            st.pending.append((ids.detach().reshape(-1), rows.detach().reshape(ids.numel(), -1)))
+        return sink
+
+    def _make_sync(self, st):
+        def sync(ids):
+            """Called by the forward before it gathers rows `ids`: replay the idle steps those rows missed."""
+            if self.t > 0:
+                p = st.param.data
+                self._ck(self.lib.nr_row_adam_catchup(ids.data_ptr(), ids.numel(), p.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+                                                      st.last.data_ptr(), p.shape[0], p.shape[1], self.sched.table.data_ptr(), self.t,
+                                                      self.betas[0], self.betas[1], self.eps, self._stream_fn()))
+        return sync
+
+    def _ck(self, rc):
+        _capi.check(self.lib, rc)
+
+    # ---- the optimiser interface -------------------------------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        """No-op in the steady state: ``step()`` clears the gradient buffer in the same pass that consumes it.  (Gradients of a backward
+        that is NOT followed by step() are dropped by ``discard_grads()``.)"""
+
+    def discard_grads(self):
+        self.flat_g.zero_()
+        for r in self.regions:
+            r.work = None
+        for st in self.sparse:
+            st.pending.clear()
+
+    def _adam(self, lo, hi, scale):
+        self._ck(self.lib.nr_adam_flat(self.flat_p.data_ptr() + lo * 4, self.flat_g.data_ptr() + lo * 4, self.flat_m.data_ptr() + lo * 4,
+                                       self.flat_v.data_ptr() + lo * 4, hi - lo, self.sched.table.data_ptr(), self.t, self.betas[0],
+                                       self.betas[1], self.eps, scale, 1, self._stream_fn()))
+
+    def step(self):
+        self.t += 1
+        self.sched.ensure(self.t)
+        ops.invalidate_packed()                  # the kernels below rewrite parameter memory behind torch's version counters
+        world = _world()
+        scale = 1.0 / world
+        if world == 1:
+            if self.regions:
+                self._adam(0, self.regions[-1].hi, 1.0)                       # one launch over [small | tables]
+        else:
+            works = []
+            for r in self.regions:                                           # tables first (already in flight when overlapped), small last
+                if r.name != 'small' and r.work is None:
+                    r.work = dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True)
+            gathered = [self._exchange_rows(st) for st in self.sparse]
+            for r in self.regions:
+                if r.name == 'small':
+                    r.work = dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True)
+            for r in sorted(self.regions, key=lambda r: r.name != 'small'):   # small bucket is the short message: update it while the table flies
+                r.work.wait()
+                r.work = None
+                self._adam(r.lo, r.hi, scale)
+            for st, (ids, rows) in zip(self.sparse, gathered):
+                self._row_step(st, ids, rows, scale)
+            return
+        for st in self.sparse:
+            if st.pending:
+                ids = torch.cat([i for i, _ in st.pending])
+                rows = torch.cat([r for _, r in st.pending])
+                st.pending.clear()
+                self._row_step(st, ids, rows, 1.0)
+
+    def _exchange_rows(self, st):
+        """All ranks' (row id, gradient row) pairs, in rank order: B x (8 + 4 d) bytes per rank instead of a table-sized all-reduce."""
+        world = _world()
+        d = st.param.shape[1]
+        if st.pending:
+            ids = torch.cat([i for i, _ in st.pending]).to(torch.int64)
+            rows = torch.cat([r for _, r in st.pending]).to(torch.float32).contiguous()
+        else:
+            ids = torch.zeros(0, dtype=torch.int64, device=self.device)
+            rows = torch.zeros(0, d, dtype=torch.float32, device=self.device)
+        st.pending.clear()
+        # Every rank normally contributes the same number of rows (fixed per-GPU batch, DataLoader(drop_last=True), src/train.py:118-124).
+        # That is verified with one tiny all-gather (a host round trip) the first time and whenever the local count changes; steady-state
+        # steps then exchange ids and rows without any host synchronisation.  Unequal counts take the padded path every step.
+        if self._uniform_rows.get(st.name) != ids.numel():
+            n = torch.tensor([ids.numel()], dtype=torch.int64, device=self.device)
+            counts = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(counts, n)
+            counts = [int(c.item()) for c in counts]
+            if all(c == counts[0] for c in counts):
+                self._uniform_rows[st.name] = counts[0]
+            else:
+                self._uniform_rows.pop(st.name, None)
+                nmax = max(counts)
+                pid = torch.zeros(nmax, dtype=torch.int64, device=self.device)       # id 0 = the padding row: skipped by the update
+                prow = torch.zeros(nmax, d, dtype=torch.float32, device=self.device)
+                pid[:ids.numel()] = ids
+                prow[:ids.numel()] = rows
+                gid = [torch.empty_like(pid) for _ in range(world)]
+                grow = [torch.empty_like(prow) for _ in range(world)]
+                dist.all_gather(gid, pid)
+                dist.all_gather(grow, prow)
+                return torch.cat([g[:c] for g, c in zip(gid, counts)]), torch.cat([g[:c] for g, c in zip(grow, counts)])
+        if ids.numel() == 0:
+            return ids, rows
+        gid = torch.empty(world * ids.numel(), dtype=torch.int64, device=self.device)
+        grow = torch.empty(world * ids.numel(), d, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(gid, ids.contiguous())
+        dist.all_gather_into_tensor(grow, rows)
+        return gid, grow
+
+    def _row_step(self, st, ids, rows, scale):
+        if ids.numel() == 0:
+            return
+        ids = ids.to(torch.int64).contiguous()
+        n, p = ids.numel(), st.param.data
+        ws_bytes = self.lib.nr_sort_ids_workspace(n, p.shape[0])
+        ids_sorted, perm = torch.empty_like(ids), torch.empty_like(ids)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=ids.device)
+        self._ck(self.lib.nr_sort_ids(ids.data_ptr(), n, p.shape[0], ids_sorted.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws_bytes,
+                                      self._stream_fn()))
+        rows = rows.contiguous()
+        self._ck(self.lib.nr_row_adam_step(ids_sorted.data_ptr(), perm.data_ptr(), n, rows.data_ptr(), rows.shape[1], p.data_ptr(),
+                                           st.m.data_ptr(), st.v.data_ptr(), st.last.data_ptr(), p.shape[0], p.shape[1],
+                                           self.sched.table.data_ptr(), self.t, self.betas[0], self.betas[1], self.eps, scale, st.pad_row,
+                                           self._stream_fn()))
+
+    def flush(self):
+        """Bring every row of the row-sparse tables up to date with the steps taken so far (before the table is read as a whole)."""
+        if self.t == 0:
+            return
+        for st in self.sparse:
+            p = st.param.data
+            self._ck(self.lib.nr_row_adam_flush(p.data_ptr(), st.m.data_ptr(), st.v.data_ptr(), st.last.data_ptr(), p.shape[0], p.shape[1],
+                                                self.sched.table.data_ptr(), self.t, self.betas[0], self.betas[1], self.eps, self._stream_fn()))
+
+    # ---- torch.optim.Adam-compatible state (src/train.py:151-152,268-275) ---------------------------------------------------------
+    def _moments(self, i):
+        n, p = self.names[i], self.params[i]
+        if n in self.slices:
+            lo, hi = self.slices[n]
+            return self.flat_m[lo:hi].view(p.shape), self.flat_v[lo:hi].view(p.shape)
+        st = next(s for s in self.sparse if s.name == n)
+        return st.m, st.v
+
+    def state_dict(self):
+        self.flush()
+        state = {}
+        if self.t > 0:
+            for i in range(len(self.params)):
+                m, v = self._moments(i)
+                state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': m.detach().clone(), 'exp_avg_sq': v.detach().clone()}
+        return {'state': state, 'param_groups': [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        n = sum(len(g['params']) for g in groups)
+        if n != len(self.params):
+            raise ValueError(f"EngineAdam.load_state_dict: {n} parameters in the checkpoint, {len(self.params)} in the model")
+        g0 = groups[0]
+        if (float(g0['lr']), tuple(map(float, g0['betas'])), float(g0['eps'])) != (self.lr, self.betas, self.eps):
+            self.lr, self.betas, self.eps = float(g0['lr']), tuple(map(float, g0['betas'])), float(g0['eps'])
+            self.sched = AdamSchedule(self.lr, self.betas, self.device)
+            self.param_groups[0].update(lr=self.lr, betas=self.betas, eps=self.eps)
+        steps = {int(float(s['step'])) for s in sd['state'].values()}
+        if len(steps) > 1:
+            raise ValueError("EngineAdam.load_state_dict: parameters with different step counts are not supported")
+        self.t = steps.pop() if steps else 0
+        self.sched.ensure(self.t)
+        with torch.no_grad():
+            for i in range(len(self.params)):
+                m, v = self._moments(i)
+                s = sd['state'].get(i)
+                if s is None:
+                    m.zero_()
+                    v.zero_()
+                else:
+                    m.copy_(s['exp_avg'].to(self.device))
+                    v.copy_(s['exp_avg_sq'].to(self.device))
+            for st in self.sparse:                      # rows with optimiser state are current as of the checkpoint's step
+                has = ((st.m != 0) | (st.v != 0)).any(dim=1)
+                st.last.copy_(has.to(torch.int32) * self.t)

@@ -195,6 +195,21 @@ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
 __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 
 __forceinline__ void atomic_add(float* p, float v) { *p += v; }
+__forceinline__ int atomic_exch(int* p, int v) { int o = *p; *p = v; return o; }
+__forceinline__ int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
+__forceinline__ int uniform(int v) { return v; }
+__forceinline__ uint64_t ballot(bool pred) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  ws.stage[l][0] = pred ? 1u : 0u;
+  nr_emu::wave_sync();
+  uint64_t m = 0;
+  int lanes = std::min(64, blk->nthreads - (blk->cur / 64) * 64);
+  for (int i = 0; i < lanes; ++i) m |= (uint64_t)(ws.stage[i][0] & 1u) << i;
+  nr_emu::wave_sync();
+  return m;
+}
 
 template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }
 template <typename T> __forceinline__ void st_nt(T* p, T v) { *p = v; }

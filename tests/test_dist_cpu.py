@@ -74,3 +74,124 @@ def test_grad_allreduce_world2(mode):
         assert not np.array_equal(loc0, loc1)
     for a, b in zip(new0, new1):
         assert np.array_equal(a, b)                     # replicas stay in lock-step after the optimizer step
+
+
+# ---- EngineAdam over gloo: bucketed all-reduce started from the backward + touched-row exchange --------------------------------------------
+class _TableFn(torch.autograd.Function):
+    """CPU stand-in for the engine's embedding backward protocol (ops._EncoderFn): the table gradient is ACCUMULATED IN PLACE into
+    ops.grad_target(param) (the flat-buffer view, nothing returned to autograd) and ops.table_grad_ready(param) is signalled as soon as it
+    is complete -- before the remaining (weight) gradients are produced."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        ctx.save_for_backward(ids)
+        ctx.table = table
+        return table.detach()[ids].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from news_recommendation_amd import ops
+        (ids,) = ctx.saved_tensors
+        dst, ret = ops.grad_target(ctx.table)
+        keep = ids != 0
+        dst.index_add_(0, ids[keep], g[keep])
+        ops.table_grad_ready(ctx.table)
+        return None, ret
+
+
+class _RowsFn(torch.autograd.Function):
+    """CPU stand-in for ops_gru._UserRowsFn (row-sparse table: sync before the read, (ids, rows) to the sink in the backward)."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        sync = getattr(table, '_nr_row_sync', None)
+        if sync is not None:
+            sync(ids)
+        ctx.save_for_backward(ids)
+        ctx.table = table
+        return table.detach()[ids].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        sink = getattr(ctx.table, '_nr_row_sink', None)
+        if sink is not None:
+            sink(ids, g)
+            return None, None
+        d = torch.zeros_like(ctx.table)
+        keep = ids != 0
+        d.index_add_(0, ids[keep], g[keep])
+        return None, d
+
+
+class _ToyRec(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.word_embedding = torch.nn.Embedding(60, 8, padding_idx=0)
+        self.user_embedding = torch.nn.Embedding(30, 8, padding_idx=0)
+        self.lin = torch.nn.Linear(8, 3)
+
+    def forward(self, words, users):
+        w = _TableFn.apply(words, self.word_embedding.weight).sum(dim=1)
+        u = _RowsFn.apply(users, self.user_embedding.weight)
+        return self.lin(w + u)
+
+
+def _toy_batches(rank, steps):
+    g = torch.Generator().manual_seed(50 + rank)
+    return [(torch.randint(0, 60, (5, 4), generator=g), torch.randint(0, 30, (5,), generator=g), torch.randint(0, 3, (5,), generator=g))
+            for _ in range(steps)]
+
+
+def _engine_worker(rank, world, port, overlap, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from news_recommendation_amd import dist as nrdist, optim
+    from tests.backends import EmuBackend
+    nrdist.init_from_env(backend='gloo')
+    optim.TABLE_MIN_NUMEL = 256                         # the toy word table (480 elements) is the "table bucket"
+    torch.manual_seed(100 + rank)
+    model = _ToyRec()
+    nrdist.broadcast_parameters(model)
+    opt = optim.EngineAdam(model, lr=1e-2, row_sparse=('user_embedding.weight',), overlap=overlap, lib=EmuBackend().lib, stream_fn=lambda: None)
+    assert [r.name for r in opt.regions] == ['small', 'word_embedding.weight']
+    for words, users, y in _toy_batches(rank, 4):
+        torch.nn.functional.cross_entropy(model(words, users), y).backward()
+        opt.step()
+        assert not opt.flat_g.any()
+    sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    q.put((rank, sd))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_engine_adam_world2_equals_single_process_mean_gradient(overlap):
+    """Two ranks, each its own shard: table all-reduce (started inside the backward when overlap=True), small-bucket all-reduce, and the
+    (row id, gradient row) all-gather for the row-sparse table must leave BOTH replicas bit-identical and equal to one process running
+    torch.optim.Adam on the mean of the two shards' gradients -- i.e. sparse exchange == dense all-reduce."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), f"replicas diverged in {k}"
+    # single-process reference: same initial weights (rank 0's init), dense torch Adam on the mean loss of both shards
+    torch.manual_seed(100)
+    ref = _ToyRec()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    b0, b1 = _toy_batches(0, 4), _toy_batches(1, 4)
+    for (w0, u0, y0), (w1, u1, y1) in zip(b0, b1):
+        opt.zero_grad()
+        loss = 0.5 * (torch.nn.functional.cross_entropy(ref(w0, u0), y0) + torch.nn.functional.cross_entropy(ref(w1, u1), y1))
+        loss.backward()
+        opt.step()
+    for k, v in ref.state_dict().items():
+        np.testing.assert_allclose(res[0][k], v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
