@@ -1,27 +1,37 @@
 #!/usr/bin/env python
 """Benchmark of the news-recommendation hot path on MI355X: training impressions/sec (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W [--model NRMS|NAML|LSTUR]
+    python bench.py --gpus 1 --steps K --warmup W [--model NRMS|NAML|LSTUR] [--shape small|large|xlarge]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of MIND-small-shaped synthetic impressions resident in HBM:
-forward (embedding gather -> news encoder for 53 news/impression -> user encoder -> dot-product scorer),
-cross-entropy, backward, gradient all-reduce over RCCL (N > 1) and the Adam update -- everything
-src/train.py:182-233 does per batch.  Default workload = BASELINE.json configs[1]: NRMS, bf16 operands / fp32 accumulate,
-batch 512 per GPU, title_len 20, 50 clicked news, d 300, vocabulary 70,976.  --model NAML is configs[2] (title + abstract +
-category + subcategory views), --model LSTUR the single-GPU shard of configs[4].  Weak scaling: per-GPU batch is fixed.
+A "step" is one pass of the hot path over one batch of MIND-shaped synthetic impressions resident in HBM: forward (embedding gather ->
+news encoder for 53 news/impression -> user encoder -> dot-product scorer), cross-entropy, backward, gradient exchange over RCCL
+(N > 1) and the Adam update -- everything src/train.py:182-233 does per batch.
+
+Workloads (BASELINE.json configs): N = 1 defaults to configs[1] -- NRMS, bf16 operands / fp32 accumulate, batch 512, MIND-small shape
+(title_len 20, 50 clicked news, d 300, vocabulary 70,976).  N > 1 defaults to the MIND-LARGE shape the multi-GPU configs name
+(configs[3] NRMS DP, configs[4] with --model LSTUR): 161,013 news, vocabulary 1 + 130,000 (knob: --vocab), 711,223 users, batch 512
+per GPU (weak scaling).  --model NAML is configs[2].  --shape overrides the default.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant hand-written kernel: algorithmic FLOPs per launch / HIP-event duration vs the dense
-                bf16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s); traffic = HBM bytes per launch from the committed PMC passes
-  gather_roofline  the embedding gather (north_star): algorithmic bytes / duration vs 8 TB/s HBM peak
-  cpu_baseline  the oracle's torch-CPU port of the reference timed on this host (bounded sample)
-  parity        AUC / nDCG@10 of engine vs oracle on synthetic eval impressions (N = 1 only)
+  roofline        dominant hand-written kernel: algorithmic FLOPs per launch / HIP-event duration vs the dense bf16 MFMA peak
+                  (MI355X_MICROARCH.md: 2.5 PFLOP/s); traffic = HBM bytes per launch from the committed PMC passes (profiles/traffic.json,
+                  keyed on a hash of the kernel source so that it cannot go stale silently)
+  gather_roofline the embedding gather (north_star) at two points: the workload's table (Infinity-Cache resident) and a > 256 MB table
+                  with uniform ids (HBM bound): algorithmic bytes / duration vs 8 TB/s
+  value_dropin    the same step through the REAL drop-in boundary: model(candidate_news, clicked_news) on the DataLoader's CPU
+                  list-of-dicts (train.py:166-203), pinned H2D copy included
+  score_eval      eval-shaped scoring throughput, phases A-C of src/evaluate.py:185-272 on the batched driver (evaluate_fast.run_plan)
+  cpu_baseline    the reference's own modules (kind "reference", when /root/reference/src exists) or the oracle's torch port (kind
+                  "port") timed on this host's cores in a GPU-hidden child process: train step, eval forward, evaluate()
+  parity          AUC / nDCG@10 of engine vs oracle on n = 1000 AND n = 5000 eval impressions, for three weight states (N = 1 only)
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,48 +45,33 @@ import torch
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 BYTES_PER_TOKEN_F32 = 1200   # one fp32 embedding row
-N_NEWS = 65238               # MIND-small news count
+REFERENCE_SRC = '/root/reference/src'
 
 
-class Cfg:
-    """The reference's BaseConfig / NRMSConfig / NAMLConfig / LSTURConfig knobs (src/config.py:10-69) at MIND-small shape."""
-    num_words = 1 + 70975
-    num_categories = 1 + 274
-    num_users = 1 + 50000
-    word_embedding_dim = 300
-    category_embedding_dim = 100
-    num_attention_heads = 15
-    query_vector_dim = 200
-    dropout_probability = 0.2
-    num_clicked_news_a_user = 50
-    num_words_title = 20
-    num_words_abstract = 50
-    negative_sampling_ratio = 2
-    learning_rate = 0.0001
-    num_filters = 300
-    window_size = 3
-    long_short_term_method = 'ini'
-    masking_probability = 0.5
-
-
-class NamlCfg(Cfg):
-    dataset_attributes = {"news": ['category', 'subcategory', 'title', 'abstract'], "record": []}
-
-
-class LsturCfg(Cfg):
-    dataset_attributes = {"news": ['category', 'subcategory', 'title'], "record": ['user', 'clicked_news_length']}
+def make_cfg(model, shape, vocab=0):
+    """The reference's BaseConfig / <Model>Config knobs (src/config.py:10-69) at the requested dataset shape."""
+    from news_recommendation_amd import default_config, synth
+    sh = dict(synth.SHAPES[shape])
+    if vocab:
+        sh['num_words'] = vocab
+    base = getattr(default_config, f'{model}Config')
+    cfg = type(f'{model}Config', (base,), {k: sh[k] for k in ('num_words', 'num_users', 'num_categories')})
+    cfg.num_news = sh['num_news']
+    cfg.eval_impressions = sh['eval_impressions']
+    cfg.shape = shape
+    return cfg
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # synthetic news table + batches (ids resident in HBM)
 # ----------------------------------------------------------------------------------------------------------------------
-def news_table(seed, n_news):
+def news_table(cfg, seed, n_news):
     from news_recommendation_amd import synth
     rng = np.random.default_rng(seed)
-    return {'title': synth.news_titles(rng, n_news, Cfg.num_words_title, Cfg.num_words),
-            'abstract': synth.news_abstracts(rng, n_news, Cfg.num_words_abstract, Cfg.num_words),
-            'category': rng.integers(1, Cfg.num_categories, size=n_news).astype(np.int64),
-            'subcategory': rng.integers(1, Cfg.num_categories, size=n_news).astype(np.int64)}
+    return {'title': synth.news_titles(rng, n_news, cfg.num_words_title, cfg.num_words),
+            'abstract': synth.news_abstracts(rng, n_news, cfg.num_words_abstract, cfg.num_words),
+            'category': rng.integers(1, cfg.num_categories, size=n_news).astype(np.int64),
+            'subcategory': rng.integers(1, cfg.num_categories, size=n_news).astype(np.int64)}
 
 
 def take(news, attr, idx):
@@ -87,43 +82,50 @@ def take(news, attr, idx):
 
 
 class Workload:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, cfg):
+        self.name, self.cfg = name, cfg
         self.attrs = {'NRMS': ('title',), 'NAML': ('title', 'abstract', 'category', 'subcategory'),
                       'LSTUR': ('title', 'category', 'subcategory')}[name]
+        self._news = None
 
-    def make_model(self, seed=0):
+    def news(self):
+        if self._news is None:
+            self._news = news_table(self.cfg, 0, self.cfg.num_news)
+        return self._news
+
+    def make_model(self, seed=0, pretrained=None):
         torch.manual_seed(seed)
-        if self.name == 'NRMS':
-            from news_recommendation_amd.dropin.model.NRMS import NRMS
-            return NRMS(Cfg)
-        if self.name == 'NAML':
-            from news_recommendation_amd.dropin.model.NAML import NAML
-            return NAML(NamlCfg)
-        from news_recommendation_amd.dropin.model.LSTUR import LSTUR
-        return LSTUR(LsturCfg)
+        import importlib
+        cls = getattr(importlib.import_module(f'news_recommendation_amd.dropin.model.{self.name}'), self.name)
+        return cls(self.cfg, pretrained)
 
     def make_oracle(self):
+        c = self.cfg
         if self.name == 'NRMS':
             from oracle.nrms_torch import OracleNRMS
-            return OracleNRMS(Cfg.num_words, 300, 15, 200, Cfg.dropout_probability)
+            return OracleNRMS(c.num_words, 300, 15, 200, c.dropout_probability)
         if self.name == 'NAML':
             from oracle.naml_torch import OracleNAML
-            return OracleNAML(Cfg.num_words, 300, Cfg.num_categories, 100, 300, 3, 200, Cfg.dropout_probability)
+            return OracleNAML(c.num_words, 300, c.num_categories, 100, 300, 3, 200, c.dropout_probability)
         from oracle.lstur_torch import OracleLSTUR
-        return OracleLSTUR(Cfg.num_words, 300, Cfg.num_categories, Cfg.num_users, 300, 3, 200, Cfg.dropout_probability, 0.5, 'ini')
+        return OracleLSTUR(c.num_words, 300, c.num_categories, c.num_users, 300, 3, 200, c.dropout_probability, 0.5, 'ini')
+
+    def make_optimizer(self, model):
+        from news_recommendation_amd.optim import EngineAdam
+        return EngineAdam(model, lr=self.cfg.learning_rate, row_sparse=('user_embedding.weight',) if self.name == 'LSTUR' else ())
 
     def batches(self, rank, n_batches, B, device):
+        """Stacked id tensors on `device` ('cpu' gives the raw material of the list-of-dicts form)."""
         from news_recommendation_amd import synth
-        news = news_table(0, N_NEWS)
+        c, news = self.cfg, self.news()
         rng = np.random.default_rng(1000 + rank)
         out = []
         for _ in range(n_batches):
-            cand, hist = synth.train_batch(rng, news['title'], B, Cfg.num_clicked_news_a_user, Cfg.negative_sampling_ratio)
+            cand, hist = synth.train_batch(rng, news['title'], B, c.num_clicked_news_a_user, c.negative_sampling_ratio)
             b = {'cand': {k: torch.from_numpy(take(news, k, cand)).to(device) for k in self.attrs},
                  'click': {k: torch.from_numpy(take(news, k, hist)).to(device) for k in self.attrs}}
             if self.name == 'LSTUR':
-                b['user'] = torch.from_numpy(rng.integers(1, Cfg.num_users, size=B).astype(np.int64)).to(device)
+                b['user'] = torch.from_numpy(rng.integers(1, c.num_users, size=B).astype(np.int64)).to(device)
                 b['length'] = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))          # CPU, as the reference requires
             out.append(b)
         return out
@@ -135,25 +137,35 @@ class Workload:
             return model.forward_ids(b['cand'], b['click'])
         return model.forward_ids(b['user'], b['length'].clone(), b['cand'], b['click'])
 
-    def oracle_forward(self, ref, b):
+    def as_dataloader_batch(self, b):
+        """What train.py:166 gets from the DataLoader: candidate_news = list[1+K] of {attr: CPU tensor [B, ...]}, clicked_news =
+        list[N] of the same (default collate; pin_memory=True, train.py:118-124)."""
         C, N = b['cand']['title'].shape[1], b['click']['title'].shape[1]
-        cl = [{k: b['cand'][k][:, j] for k in self.attrs} for j in range(C)]
-        hl = [{k: b['click'][k][:, j] for k in self.attrs} for j in range(N)]
+        pin = (lambda t: t.pin_memory()) if torch.cuda.is_available() else (lambda t: t)
+        mb = {'candidate_news': [{k: pin(b['cand'][k][:, j].contiguous()) for k in self.attrs} for j in range(C)],
+              'clicked_news': [{k: pin(b['click'][k][:, j].contiguous()) for k in self.attrs} for j in range(N)]}
         if self.name == 'LSTUR':
-            return ref(b['user'], b['length'].clone(), cl, hl)
-        return ref(cl, hl)
+            mb['user'], mb['clicked_news_length'] = b['user'], b['length']
+        return mb
+
+    def forward_dropin(self, model, mb):
+        if self.name == 'LSTUR':            # train.py:183-185
+            return model(mb['user'], mb['clicked_news_length'].clone(), mb['candidate_news'], mb['clicked_news'])
+        return model(mb['candidate_news'], mb['clicked_news'])      # train.py:202-203
 
     def flops(self, B):
         """Algorithmic FLOPs per launch of the kernels we know how to price (SURVEY 8 d6 / DESIGN.md)."""
         T = B * 53
         conv = lambda S: T * 2 * S * 900 * 300
+        mhsa20 = T * (2 * 20 * 300 * 900 + 2 * 2 * 15 * 20 * 20 * 20)
+        pool20 = T * 2 * 20 * 300 * 200
         return {
-            'nr_mhsa_fwd[S=20]': T * (2 * 20 * 300 * 900 + 2 * 2 * 15 * 20 * 20 * 20),
+            'nr_mhsa_fwd[S=20]': mhsa20, 'nr_news_fwd[S=20]': mhsa20 + pool20,
             'nr_mhsa_fwd[S=50]': B * (2 * 50 * 300 * 900 + 2 * 2 * 15 * 50 * 50 * 20),
             'nr_attn_bwd[S=20]': T * 15 * 6 * 2 * 20 * 20 * 20,
             'nr_attn_bwd[S=50]': B * 15 * 6 * 2 * 50 * 50 * 20,
-            'nr_additive_fwd[S=20]': T * 2 * 20 * 300 * 200, 'nr_additive_bwd[S=20]': T * 2 * 20 * 300 * 200,
-            'nr_additive_fwd[title]': T * 2 * 20 * 300 * 200, 'nr_additive_bwd[title]': T * 2 * 20 * 300 * 200,
+            'nr_additive_fwd[S=20]': pool20, 'nr_additive_bwd[S=20]': pool20,
+            'nr_additive_fwd[title]': pool20, 'nr_additive_bwd[title]': pool20,
             'nr_additive_fwd[abstract]': T * 2 * 50 * 300 * 200, 'nr_additive_bwd[abstract]': T * 2 * 50 * 300 * 200,
             'nr_conv3_fwd[title]': conv(20), 'nr_conv3_dgrad[title]': conv(20),
             'nr_conv3_fwd[abstract]': conv(50), 'nr_conv3_dgrad[abstract]': conv(50),
@@ -161,79 +173,165 @@ class Workload:
         }
 
 
-def cpu_baseline(wl, seconds_budget=20.0, B=128):
-    """The oracle's CPU PyTorch port of the reference (per-position encoder loop and all), full train steps
-    (forward + backward + Adam) on a bounded sample."""
-    torch.manual_seed(0)
-    torch.set_num_threads(min(32, os.cpu_count() or 1))   # 128 threads on tiny per-title ops is slower than 32
-    m = wl.make_oracle().train()
-    opt = torch.optim.Adam(m.parameters(), lr=Cfg.learning_rate)
-    b = wl.batches(7, 1, B, 'cpu')[0]
-    crit = torch.nn.CrossEntropyLoss()
-
-    def step():
-        loss = crit(wl.oracle_forward(m, b), torch.zeros(B, dtype=torch.long))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-
-    step()                                   # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        step()
-        n += 1
-        if time.perf_counter() - t0 > seconds_budget or n >= 16:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n * B / dt, "unit": "impressions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps (fwd+bwd+Adam) of B={B} train-shaped impressions, oracle {wl.name} torch port on CPU fp32"}
+# ----------------------------------------------------------------------------------------------------------------------
+# measurement legs besides the headline
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, shape, vocab, budget=24.0):
+    """The reference's CPU PyTorch path timed on this host in a child process that cannot see the GPUs."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_baseline.py'), '--model', wl.name, '--shape', shape, '--budget', str(budget)]
+    if vocab:
+        cmd += ['--vocab', str(vocab)]
+    if os.path.isdir(REFERENCE_SRC):
+        cmd += ['--reference', REFERENCE_SRC]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        return json.loads(line)
+    except Exception as e:        # noqa: BLE001 -- a failed baseline leg must not lose the measured GPU line
+        return {"value": None, "unit": "impressions/s", "cores": None, "kind": "port", "sample": f"cpu baseline child failed: {e!r}"}
 
 
-def parity_eval(wl, model, device, n_news=4000, n_impr=5000):
-    """AUC / nDCG@10 of the engine vs the CPU oracle on the same synthetic eval-shaped impressions and weights
-    (phases A-C of src/evaluate.py:185-260: news vectors, user vectors with a zero PADDED_NEWS vector, per-impression dot products).
-    5,000 impressions: the bf16-operand logit noise (rms ~1e-3 of the logit scale) flips near-tied candidate pairs at random, and on
-    1,000 impressions of a barely trained model that alone moves AUC by 1e-5 .. 1.2e-3 from one weight state to the next."""
-    from news_recommendation_amd import synth, ops
-    from oracle import metrics
-    rng = np.random.default_rng(3)
-    news = {k: v for k, v in news_table(2, n_news).items() if k in wl.attrs}
+def eval_set(wl, n_news, n_impr, seed=3):
+    from news_recommendation_amd import synth
+    rng = np.random.default_rng(seed)
+    news = {k: v for k, v in news_table(wl.cfg, 2, n_news).items() if k in wl.attrs}
     hist, cands, ptr = synth.eval_impressions(rng, n_news, n_impr)
-    users = torch.from_numpy(rng.integers(1, Cfg.num_users, size=n_impr).astype(np.int64))
-    lengths = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))
-    ref = wl.make_oracle()
-    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    ref.eval()
+    users = rng.integers(1, wl.cfg.num_users, size=n_impr).astype(np.int64)
+    return news, hist, cands, ptr, users
+
+
+def engine_scores(wl, model, device, es):
+    """Phases A-C of src/evaluate.py:185-260 on the engine: news vectors, user vectors (PADDED_NEWS = zero vector), CSR dot products."""
+    from news_recommendation_amd import ops
+    news, hist, cands, ptr, users = es
+    n_news, n_impr = news['title'].shape[0], hist.shape[0]
     tn = {k: torch.from_numpy(v) for k, v in news.items()}
-    sl = lambda i, n: {k: v[i:i + n] for k, v in tn.items()}
     was_training = model.training
     model.eval()
     with torch.no_grad():
-        nv_ref = torch.cat([ref.get_news_vector(sl(i, 1024)) for i in range(0, n_news, 1024)])
-        D = nv_ref.shape[1]
-        nv_pad = torch.cat([nv_ref, torch.zeros(1, D)])                        # PADDED_NEWS = zero vector (evaluate.py:203)
-        hidx = torch.from_numpy(np.where(hist < 0, n_news, hist))
-        nv = torch.cat([model.get_news_vector(sl(i, 2048)) for i in range(0, n_news, 2048)])
-        nvp = torch.cat([nv, torch.zeros(1, D, device=device)])
+        nv = torch.cat([model.get_news_vector({k: v[i:i + 2048] for k, v in tn.items()}) for i in range(0, n_news, 2048)])
+        nvp = torch.cat([nv, torch.zeros(1, nv.shape[1], device=device)])
+        hidx = torch.from_numpy(np.where(hist < 0, n_news, hist)).to(device)
         if wl.name == 'LSTUR':
-            uv_ref = torch.cat([ref.get_user_vector(users[i:i + 256], lengths[i:i + 256].clone(), nv_pad[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
-            uv = model.get_user_vector(users, lengths.clone(), nvp[hidx.to(device)])
+            lengths = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))
+            uv = torch.cat([model.get_user_vector(torch.from_numpy(users[i:i + 1024]), lengths[i:i + 1024].clone(), nvp[hidx[i:i + 1024]])
+                            for i in range(0, n_impr, 1024)])
         else:
-            uv_ref = torch.cat([ref.get_user_vector(nv_pad[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
-            uv = model.get_user_vector(nvp[hidx.to(device)])
+            uv = torch.cat([model.get_user_vector(nvp[hidx[i:i + 1024]]) for i in range(0, n_impr, 1024)])
         sc = ops.score_csr(nv, uv, torch.from_numpy(cands).to(device), torch.from_numpy(ptr).to(device),
                            torch.arange(n_impr, dtype=torch.int32, device=device)).cpu().numpy()
     model.train(was_training)
-    sc_ref = np.concatenate([(nv_ref[cands[ptr[i]:ptr[i + 1]]] @ uv_ref[i]).numpy() for i in range(n_impr)])
-    labels = synth.teacher_labels(np.random.default_rng(4), sc_ref.astype(np.float64), ptr)
-    split = lambda a: [a[ptr[i]:ptr[i + 1]] for i in range(n_impr)]
-    auc_r, _, _, nd_r = metrics.evaluate_impressions(split(labels), split(sc_ref))
-    auc_e, _, _, nd_e = metrics.evaluate_impressions(split(labels), split(sc))
-    return {"n_impressions": n_impr, "auc_oracle": auc_r, "auc_engine": auc_e, "ndcg10_oracle": nd_r, "ndcg10_engine": nd_e,
-            "abs_diff_auc": abs(auc_r - auc_e), "abs_diff_ndcg10": abs(nd_r - nd_e), "tolerance": 1e-3,
-            "max_abs_logit_err": float(np.abs(sc - sc_ref).max()), "rms_logit_err": float(np.sqrt(np.mean((sc - sc_ref) ** 2))),
-            "mean_logit_err": float(np.mean(sc - sc_ref)), "logit_scale": float(np.abs(sc_ref).max())}
+    return sc
+
+
+def oracle_scores(wl, state_dict, es):
+    news, hist, cands, ptr, users = es
+    n_news, n_impr = news['title'].shape[0], hist.shape[0]
+    ref = wl.make_oracle()
+    ref.load_state_dict(state_dict)
+    ref.eval()
+    tn = {k: torch.from_numpy(v) for k, v in news.items()}
+    with torch.no_grad():
+        nv = torch.cat([ref.get_news_vector({k: v[i:i + 1024] for k, v in tn.items()}) for i in range(0, n_news, 1024)])
+        nvp = torch.cat([nv, torch.zeros(1, nv.shape[1])])                     # PADDED_NEWS = zero vector (evaluate.py:203)
+        hidx = torch.from_numpy(np.where(hist < 0, n_news, hist))
+        if wl.name == 'LSTUR':
+            lengths = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))
+            uv = torch.cat([ref.get_user_vector(torch.from_numpy(users[i:i + 256]), lengths[i:i + 256].clone(), nvp[hidx[i:i + 256]])
+                            for i in range(0, n_impr, 256)])
+        else:
+            uv = torch.cat([ref.get_user_vector(nvp[hidx[i:i + 256]]) for i in range(0, n_impr, 256)])
+    return np.concatenate([(nv[cands[ptr[i]:ptr[i + 1]]] @ uv[i]).numpy() for i in range(n_impr)])
+
+
+def parity_eval(wl, states, device, n_news=4000, n_impr=5000):
+    """AUC / nDCG@10 of the engine vs the CPU oracle on the same synthetic eval-shaped impressions and the same weights, reported for
+    the first 1,000 impressions (BASELINE configs[0]) and for all 5,000, for every weight state in `states`
+    ({name: engine model}).  Labels come from a seeded teacher on the ORACLE's scores; the budget is 1e-3."""
+    from news_recommendation_amd import synth
+    from oracle import metrics
+    es = eval_set(wl, n_news, n_impr)
+    ptr = es[3]
+    out = {"tolerance": 1e-3, "n_news": n_news, "states": {}}
+    worst = {1000: [0.0, 0.0], n_impr: [0.0, 0.0]}
+    for name, model in states.items():
+        sc = engine_scores(wl, model, device, es)
+        sc_ref = oracle_scores(wl, {k: v.detach().cpu() for k, v in model.state_dict().items()}, es)
+        labels = synth.teacher_labels(np.random.default_rng(4), sc_ref.astype(np.float64), ptr)
+        st = {"max_abs_logit_err": float(np.abs(sc - sc_ref).max()), "rms_logit_err": float(np.sqrt(np.mean((sc - sc_ref) ** 2))),
+              "mean_logit_err": float(np.mean(sc - sc_ref)), "logit_scale": float(np.abs(sc_ref).max())}
+        for n in (1000, n_impr):
+            split = lambda a: [a[ptr[i]:ptr[i + 1]] for i in range(n)]
+            auc_r, _, _, nd_r = metrics.evaluate_impressions(split(labels), split(sc_ref))
+            auc_e, _, _, nd_e = metrics.evaluate_impressions(split(labels), split(sc))
+            st[f"n{n}"] = {"auc_oracle": auc_r, "auc_engine": auc_e, "ndcg10_oracle": nd_r, "ndcg10_engine": nd_e,
+                           "abs_diff_auc": abs(auc_r - auc_e), "abs_diff_ndcg10": abs(nd_r - nd_e)}
+            worst[n][0] = max(worst[n][0], abs(auc_r - auc_e))
+            worst[n][1] = max(worst[n][1], abs(nd_r - nd_e))
+        out["states"][name] = st
+    out["worst_abs_diff_auc_n1000"], out["worst_abs_diff_ndcg10_n1000"] = worst[1000]
+    out[f"worst_abs_diff_auc_n{n_impr}"], out[f"worst_abs_diff_ndcg10_n{n_impr}"] = worst[n_impr]
+    out["within_tolerance"] = bool(max(worst[1000] + worst[n_impr]) < 1e-3)
+    return out
+
+
+def score_eval(wl, model, device, n_impr_cap=100000):
+    """Eval-shaped scoring throughput: phases A (encode every news once), B (one user vector per impression history), C
+    (ragged candidate scoring + per-impression AUC / MRR / nDCG on the device) of src/evaluate.py:185-272 via evaluate_fast.run_plan,
+    on a synthetic plan of the dataset shape (all news of the shape, min(eval impressions of the shape, cap) impressions)."""
+    from news_recommendation_amd import evaluate_fast, synth
+    cfg = wl.cfg
+    n_news, n_impr = cfg.num_news, min(cfg.eval_impressions, n_impr_cap)
+    rng = np.random.default_rng(11)
+    news = wl.news()
+    hist, cands, ptr = synth.eval_impressions(rng, n_news, n_impr)
+    plan = evaluate_fast.EvalPlan()
+    plan.news_ids = [f'N{i}' for i in range(n_news)]
+    plan.news = {k: news[k] for k in cfg.dataset_attributes['news']}
+    plan.hist_idx = np.where(hist < 0, n_news, hist).astype(np.int64)
+    plan.hist_len = (hist >= 0).sum(1).astype(np.int64)
+    plan.hist_user = rng.integers(1, cfg.num_users, size=n_impr).astype(np.int64)
+    plan.cand_idx, plan.cand_ptr = cands, ptr
+    plan.labels = (rng.random(len(cands)) < 0.1).astype(np.int32)
+    plan.imp_user_row = np.arange(n_impr, dtype=np.int32)
+    was_training = model.training
+    model.eval()
+    evaluate_fast.run_plan(model, plan, 2048, wl.name)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, _ = evaluate_fast.run_plan(model, plan, 2048, wl.name)
+    m = torch.nanmean(out.double(), dim=0).cpu()
+    dt = time.perf_counter() - t0
+    model.train(was_training)
+    return {"value": n_impr / dt, "unit": "impressions/s", "impressions": n_impr, "news": n_news, "candidates": int(len(cands)),
+            "seconds": dt, "what": "phases A+B+C of src/evaluate.py:185-272 (batched driver), host index arrays -> four metric means"}
+
+
+def gather_point(lib, table, ids, device):
+    st = torch.cuda.current_stream().cuda_stream
+    gout = torch.empty(ids.numel(), 300, device=device)
+    for _ in range(3):
+        lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), ids.numel(), 300, table.shape[0], st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), ids.numel(), 300, table.shape[0], st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 10
+    nbytes = ids.numel() * (BYTES_PER_TOKEN_F32 + 8)
+    return {"avg_us": us, "tokens": ids.numel(), "table_mb": table.numel() * 4 / 1e6, "algorithmic_bytes": nbytes,
+            "achieved": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "read_plus_write_GBs": (nbytes + ids.numel() * BYTES_PER_TOKEN_F32) / (us * 1e-6) / 1e9}
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'nr_common.h'):
+        with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -243,8 +341,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (impressions)')
     ap.add_argument('--model', default='NRMS', choices=['NRMS', 'NAML', 'LSTUR'])
+    ap.add_argument('--shape', default=None, choices=['small', 'large', 'xlarge'],
+                    help='dataset shape; default: small on 1 GPU (BASELINE configs[1]/[2]), large on N > 1 (configs[3]/[4])')
+    ap.add_argument('--vocab', type=int, default=0, help='override the vocabulary size of the shape (rows of the word-embedding table)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -255,26 +357,22 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     B = args.batch
-    wl = Workload(args.model)
+    shape = args.shape or ('small' if world == 1 else 'large')
+    cfg = make_cfg(args.model, shape, args.vocab)
+    wl = Workload(args.model, cfg)
 
     model = wl.make_model().to(device).train()
     nrdist.broadcast_parameters(model)
-    fgb = nrdist.FlatGradBuffer(model.parameters())
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=Cfg.learning_rate, fused=True)
-    except (TypeError, RuntimeError):
-        opt = torch.optim.Adam(model.parameters(), lr=Cfg.learning_rate)
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (world == 1 and not args.no_parity) else None
+    opt = wl.make_optimizer(model)
     crit = torch.nn.CrossEntropyLoss()
     batches = wl.batches(rank, 4, B, device)
     target = torch.zeros(B, dtype=torch.long, device=device)
 
     def step(i):
-        y = wl.forward(model, batches[i % len(batches)])
-        loss = crit(y, target)
-        fgb.zero()
-        loss.backward()
-        fgb.allreduce_mean()
-        opt.step()
+        loss = crit(wl.forward(model, batches[i % len(batches)]), target)
+        loss.backward()                       # gradients land in the optimiser's flat buffer; the table bucket's all-reduce starts inside
+        opt.step()                            # small-bucket all-reduce, fused Adam (also clears the gradients: no zero_grad pass)
         return loss
 
     def barrier():
@@ -290,8 +388,8 @@ def main():
         for i in range(NPROF):
             step(i)
     prof = rec.summary()
-    assert fgb.check_views(), "gradient views detached from the flat buffer"
-    hand = {k: v for k, v in prof.items() if k.startswith('nr_')}
+    assert opt.check_views(), "parameter / gradient views detached from the optimiser's flat buffers"
+    hand = {k: v for k, v in prof.items() if k.startswith('nr_') and not k.startswith(('nr_pack', 'nr_sort', 'nr_adam', 'nr_row_adam'))}
     dominant = max(hand, key=lambda k: hand[k][2]) if hand else 'nr_mhsa_fwd[S=20]'
 
     barrier()
@@ -320,7 +418,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    T = B * (1 + Cfg.negative_sampling_ratio + Cfg.num_clicked_news_a_user)
+    T = B * (1 + cfg.negative_sampling_ratio + cfg.num_clicked_news_a_user)
     flops = wl.flops(B)
     if dominant in flops:
         ach = flops[dominant] / (dom[1] * 1e-6) / 1e12
@@ -332,78 +430,109 @@ def main():
         ach = nbytes / (dom[1] * 1e-6) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": dom[1], "launches": dom[0], "bytes_per_launch": nbytes}
-    # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes from
-    # the committed rocprofv3 --pmc passes of the same workload (profiles/traffic.json, made by tools/gpu_check.sh)
+    # HBM traffic of that kernel: PMC counters cannot be read from inside the process, so the per-launch figure comes from the committed
+    # rocprofv3 --pmc passes of the same workload (profiles/traffic.json, made by tools/pmc_traffic.sh); an entry only counts when it was
+    # measured on the kernel sources this library was built from (source hash) and on this workload
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             tr = json.load(f).get(dominant)
-        if tr is not None and B == 512 and args.model == 'NRMS':
+        if tr is not None and tr.get("source_hash") == kernel_source_hash() and tr.get("workload") == f"{args.model}/{shape}/B{B}":
             roofline["traffic"] = tr["bytes"]
             roofline["traffic_source"] = tr["source"]
+        elif tr is not None:
+            roofline["traffic_note"] = "profiles/traffic.json entry is for other kernel sources / another workload: not reported"
     except (OSError, ValueError):
         pass
 
-    # the embedding gather on its own (north_star: fraction of HBM roofline for the gather)
-    lib = _capi.load()
-    b0 = batches[0]
-    ids = torch.cat([b0['cand']['title'].reshape(-1, 20), b0['click']['title'].reshape(-1, 20)]).contiguous()
-    gout = torch.empty(ids.numel(), 300, device=device)
-    table = next(p for n, p in model.named_parameters() if n.endswith('word_embedding.weight')).detach()
-    st = torch.cuda.current_stream().cuda_stream
-    for _ in range(3):
-        lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), ids.numel(), 300, table.shape[0], st)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        lib.nr_gather_rows_f32(ids.data_ptr(), table.data_ptr(), gout.data_ptr(), ids.numel(), 300, table.shape[0], st)
-    e1.record()
-    torch.cuda.synchronize()
-    g_us = e0.elapsed_time(e1) * 1e3 / 10
-    g_bytes = ids.numel() * (BYTES_PER_TOKEN_F32 + 8)
-    gather = {"kernel": "nr_gather_rows_f32", "bound": "hbm", "achieved": g_bytes / (g_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": g_bytes / (g_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": g_us,
-              "algorithmic_bytes": g_bytes, "read_plus_write_GBs": (g_bytes + ids.numel() * BYTES_PER_TOKEN_F32) / (g_us * 1e-6) / 1e9,
-              "frac_read_plus_write": (g_bytes + ids.numel() * BYTES_PER_TOKEN_F32) / (g_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-              "note": "achieved / frac count the algorithmic READ bytes only (1200 B row + 8 B id per token; the 85 MB table is Infinity-Cache "
-                      "resident); the stand-alone kernel also writes the gathered rows (same volume, to HBM): read_plus_write_GBs"}
-    del gout
+    extras = {}
+    if not args.no_extras:
+        # ---- the embedding gather on its own (north_star: fraction of HBM roofline for the gather) -------------------------------------
+        lib = _capi.load()
+        b0 = batches[0]
+        ids = torch.cat([b0['cand']['title'].reshape(-1, 20), b0['click']['title'].reshape(-1, 20)]).contiguous()
+        table = next(p for n, p in model.named_parameters() if n.endswith('word_embedding.weight')).detach()
+        g_mall = gather_point(lib, table, ids, device)
+        big_rows = 400001                                                # 480 MB fp32: larger than the 256 MB Infinity Cache
+        big = torch.randn(big_rows, 300, device=device)
+        uni = torch.randint(1, big_rows, (ids.numel(),), device=device)
+        g_hbm = gather_point(lib, big, uni, device)
+        del big, uni
+        extras["gather_roofline"] = {
+            "kernel": "nr_gather_rows_f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": g_hbm["achieved"], "frac": g_hbm["frac"],
+            "hbm_point": dict(g_hbm, ids="uniform over 400,001 rows", note="table larger than the Infinity Cache: rows come from HBM"),
+            "workload_point": dict(g_mall, ids="the batch's title tokens (Zipf, 45 % padding id 0)",
+                                   note=f"the workload's {table.numel() * 4 / 1e6:.0f} MB table is Infinity-Cache resident: this is MALL, not HBM, bandwidth"),
+            "note": "achieved / frac count the algorithmic READ bytes (1200 B row + 8 B id per token); the stand-alone kernel also writes the "
+                    "gathered rows to HBM (read_plus_write_GBs).  In NRMS training the gather is fused into nr_mhsa_fwd (rows go straight into "
+                    "MFMA operand registers); this kernel is the north_star's stand-alone roofline probe"}
+        # ---- the same training step through the real boundary: model(candidate_news, clicked_news) on CPU list-of-dicts ------------------
+        cpu_batches = [wl.as_dataloader_batch(b) for b in wl.batches(rank, 2, B, 'cpu')]
 
-    # forward-only (scoring) throughput, same batches
-    model.eval()
-    with torch.no_grad():
+        def step_dropin(i):
+            loss = crit(wl.forward_dropin(model, cpu_batches[i % len(cpu_batches)]), target)
+            loss.backward()
+            opt.step()
         for i in range(3):
-            wl.forward(model, batches[i % len(batches)])
+            step_dropin(i)
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        for i in range(10):
-            wl.forward(model, batches[i % len(batches)])
+        for i in range(args.steps):
+            step_dropin(i)
         torch.cuda.synchronize()
-        fwd_ips = 10 * B / (time.perf_counter() - ts)
-    model.train()
+        dtd = time.perf_counter() - ts
+        extras["value_dropin"] = {"value": B * args.steps / dtd, "unit": "impressions/s", "ms_per_step": dtd / args.steps * 1e3,
+                                  "what": "model(candidate_news, clicked_news) on the DataLoader's pinned CPU list-of-dicts "
+                                          "(train.py:166-203): host stacking + id range check + H2D copy inside the timed step"}
+        # ---- forward-only (scoring) throughput on train-shaped batches, and eval-shaped scoring (phases A-C) ------------------------------
+        model.eval()
+        with torch.no_grad():
+            for i in range(3):
+                wl.forward(model, batches[i % len(batches)])
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(10):
+                wl.forward(model, batches[i % len(batches)])
+            torch.cuda.synchronize()
+            extras["score_impressions_per_s_fwd_only"] = 10 * B / (time.perf_counter() - ts)
+        model.train()
+        extras["score_eval"] = score_eval(wl, model, device)
 
-    cfg_names = {'NRMS': "NRMS bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU (BASELINE.json configs[1])",
-                 'NAML': "NAML (title+abstract+category+subcategory views, Conv1d k=3) bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU (BASELINE.json configs[2])",
-                 'LSTUR': "LSTUR (GRU user encoder 'ini' + per-user embedding row) bf16 on MI355X, MIND-small-shaped synthetic, batch 512 per GPU; single-GPU shard of BASELINE.json configs[4]"}
+    wname = {'NRMS': "NRMS", 'NAML': "NAML (title+abstract+category+subcategory views, Conv1d k=3)",
+             'LSTUR': "LSTUR (GRU user encoder 'ini' + per-user embedding row)"}[args.model]
+    cfgidx = {('NRMS', 'small'): "configs[1]", ('NAML', 'small'): "configs[2]", ('NRMS', 'large'): "configs[3]", ('LSTUR', 'large'): "configs[4]"}
+    tag = cfgidx.get((args.model, shape))
+    if tag in ("configs[3]", "configs[4]") and world == 1:
+        tag = f"single-GPU shard of {tag}"
     out = {
         "metric": f"impressions/sec ({args.model} training step: fwd+bwd+allreduce+Adam)", "value": world * B * args.steps / dt,
         "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": cfg_names[args.model].replace('batch 512', f'batch {B}'),
-                   "per_gpu_batch": B, "global_batch": B * world, "news_per_impression": 53, "title_len": 20, "abstract_len": 50,
-                   "num_clicked": 50, "d": 300, "heads": 15, "vocab": Cfg.num_words, "dropout": Cfg.dropout_probability,
-                   "parallelism": f"dp{world}"},
+        "config": {"workload": f"{wname} bf16 on MI355X, MIND-{shape}-shaped synthetic, batch {B} per GPU"
+                               + (f" (BASELINE.json {tag})" if tag else "") + (f", RCCL gradient exchange over xGMI, dp{world}" if world > 1 else ""),
+                   "shape": shape, "per_gpu_batch": B, "global_batch": B * world, "news_per_impression": 53, "title_len": 20, "abstract_len": 50,
+                   "num_clicked": 50, "d": 300, "heads": 15, "vocab": cfg.num_words, "num_news": cfg.num_news, "num_users": cfg.num_users,
+                   "dropout": cfg.dropout_probability, "parallelism": f"dp{world}"},
         "roofline": roofline,
-        "gather_roofline": gather,
-        "score_impressions_per_s_fwd_only": fwd_ips,
         "loss": float(loss.item()),
-        "grad_allreduce_bytes": fgb.nbytes,
+        "grad_exchange": {"dense_allreduce_bytes": opt.dense_nbytes, "buckets": [[r.name, (r.hi - r.lo) * 4] for r in opt.regions],
+                          "row_sparse_tables": [[s.name, list(s.param.shape), f"{B} (id, row) pairs per rank and step"] for s in opt.sparse]},
         "kernel_breakdown_us_per_step": {k: round(v[2] / NPROF, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])},
     }
+    out.update(extras)
     if world == 1 and not args.no_parity:
-        out["parity"] = parity_eval(wl, model, device)
+        states = {"trained": model}
+        m0 = wl.make_model().to(device)
+        m0.load_state_dict(init_state)
+        states["init"] = m0
+        torch.manual_seed(5)
+        pre = torch.randn(cfg.num_words, 300)                               # data_preprocess.py:272-277: N(0,1) rows incl. row 0
+        states["pretrained_table"] = wl.make_model(seed=1, pretrained=pre).to(device)
+        out["parity"] = parity_eval(wl, states, device)
+        del states, m0
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl)
+        out["cpu_baseline"] = cpu_baseline(wl, shape, args.vocab)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -134,8 +134,8 @@ int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, con
   bool x_done = false;
   if (S == 20) {
     constexpr int NSEQ = 4;
-    const char* var = getenv("NR_MHSA_VARIANT");     // tuning knob: 2 = register-resident kernel (default); LDS-tile kernels: 42, 81, 82
-    int v = var ? atoi(var) : 2;
+    static int v = -1;                               // tuning knob NR_MHSA_VARIANT, read once: 2 = register-resident kernel (default);
+    if (v < 0) { const char* var = getenv("NR_MHSA_VARIANT"); v = var ? atoi(var) : 2; }     // LDS-tile kernels: 42, 81, 82
     if (v == 2) {
       p.x_save = x_save; x_done = true;
       if (nr::launch_mhsa_fwd2(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
@@ -231,7 +231,7 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
   // grid (used by the tests to force many pairs per wave on small inputs).
-  const char* capenv = getenv("NR_ATTN_BWD_MAX_WGS");
+  const char* capenv = getenv("NR_ATTN_BWD_MAX_WGS");      // (re-read per call: the tests flip it inside one process)
   const int capdiv = capenv ? atoi(capenv) : 0;
   if (S == 20) {
     constexpr int WPB = 4;
@@ -396,11 +396,11 @@ int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uin
 }
 
 static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what) {
-  { const char* d = getenv("NR_CONV_DEBUG"); p.debug = d ? atoi(d) : 0; }
+  { static int dbg = -1; if (dbg < 0) { const char* d = getenv("NR_CONV_DEBUG"); dbg = d ? atoi(d) : 0; } p.debug = dbg; }
   // tuning knob NR_CONV_VARIANT: 0 = 4 waves on 4 titles / 2 abstracts (two workgroups per CU); 1 (default) = 8 waves on 8 titles /
   // 4 abstracts (one workgroup per CU, the filter bank is re-read from L2 half as often: ~10 % faster at B = 512)
-  const char* var = getenv("NR_CONV_VARIANT");
-  const int v = var ? atoi(var) : 1;
+  static int v = -1;
+  if (v < 0) { const char* var = getenv("NR_CONV_VARIANT"); v = var ? atoi(var) : 1; }
   int rc;
   if (S == 20) {
     rc = v == 1 ? launch_conv_t<20, 8, 8>(p, stream) : v == 2 ? launch_conv_t<20, 4, 8>(p, stream) : launch_conv_t<20, 4, 4>(p, stream);
@@ -541,8 +541,8 @@ int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, con
   if (nbv < 0) { const char* e = getenv("NR_GRU_NB"); nbv = e ? atoi(e) : 0; }
   const int nb = nbv > 0 ? nbv : (B >= 256 ? 2 : 1);
   const int tiles = p.Hg / 16;
-  static int ldsv = -1;       // NR_GRU_LDS=1: experimental W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450 only)
-  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 0; }
+  static int ldsv = -1;       // W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450): default since the round-1 driver run passed it on
+  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 1; }     // hardware; NR_GRU_LDS=0 selects the register-only kernels
   if (ldsv == 1 && nb == 2 && (p.Hp == 29 * 32 || p.Hp == 15 * 32)) {
     const int grid = nr::gru_grid(tiles, (B + 127) / 128), smem = 3 * p.Hp * 16 * 2;
     if (p.Hp == 29 * 32) {
@@ -577,8 +577,8 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   p.g_last = g_last; p.dgh_next = dgh_next; p.carry_next = carry_next; p.WhhT = WhhT; p.gates = t >= 0 ? gates : nullptr; p.h_prev_b = h_prev_b;
   p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t = dgh_t; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
   p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
-  static int ldsv = -1;       // NR_GRU_LDS=1: experimental W_hh^T-tile-in-LDS variant (Hd = 900 / 450, from 256 samples up)
-  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 0; }
+  static int ldsv = -1;       // W_hh^T-tile-in-LDS variant (Hd = 900 / 450): default, NR_GRU_LDS=0 selects the register-only kernel
+  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 1; }
   if (ldsv == 1 && (p.Kp == 86 * 32 || p.Kp == 44 * 32)) {
     const int grid = nr::gru_grid(p.Hg / 16, (B + 127) / 128), smem = p.Kp * 16 * 2;
     if (p.Kp == 86 * 32) {

@@ -33,6 +33,7 @@ class TrainData:
             pad = np.zeros((1,) + t.shape[1:], dtype=np.int64)
             self.news[a] = torch.from_numpy(np.concatenate([t, pad])).to(device)
         beh = pd.read_table(behaviors_path)
+        self.n_total = len(beh)                                      # samples over ALL ranks (iteration counts must not depend on the shard)
         beh = beh.iloc[rank::world]                                  # data parallel: every rank owns a strided shard of the samples
         cand, hist, length = [], [], []
         for c, h in zip(beh['candidate_news'].tolist(), beh['clicked_news'].tolist()):

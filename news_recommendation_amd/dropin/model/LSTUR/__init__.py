@@ -42,8 +42,11 @@ class LSTUR(torch.nn.Module):
     def forward(self, user, clicked_news_length, candidate_news, clicked_news):
         """user: [B], clicked_news_length: [B], candidate_news: list[1+K] of {"category": [B], "subcategory": [B], "title": [B, L]},
         clicked_news: list[N] of the same (train.py:183-185) -> [B, 1+K]."""
-        cand = {k: torch.stack([x[k] for x in candidate_news], dim=1) for k in ATTRS}
-        click = {k: torch.stack([x[k] for x in clicked_news], dim=1) for k in ATTRS}
+        ne = self.news_encoder
+        dev = self.user_embedding.weight.device
+        ops._require_cuda(self.user_embedding.weight, "LSTUR parameters")
+        cand = {k: ops.stack_to_device([x[k] for x in candidate_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
+        click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
         return self.forward_ids(user, clicked_news_length, cand, click)
 
     def forward_ids(self, user, clicked_news_length, cand, click):

@@ -26,11 +26,14 @@ class NewsEncoder(torch.nn.Module):
         return ops_conv.lstur_news(title, category, subcategory, self.word_embedding.weight, self.category_embedding.weight,
                                    self.title_CNN, self.title_attention, self.config.dropout_probability, self.training)
 
+    def table_rows(self, key):
+        """Rows of the embedding table attribute `key` indexes."""
+        return (self.word_embedding if key == 'title' else self.category_embedding).weight.shape[0]
+
     def to_device(self, key, ids):
         """Host or device id tensor of attribute `key` -> contiguous device tensor; out-of-table ids raise IndexError like nn.Embedding
         (host tensors always, device tensors with NR_CHECK_IDS=1: ops.check_ids)."""
-        rows = (self.word_embedding if key == 'title' else self.category_embedding).weight.shape[0]
-        ops.check_ids(ids, rows, f"{key} id")
+        ops.check_ids(ids, self.table_rows(key), f"{key} id")
         return ids.to(self.word_embedding.weight.device, non_blocking=True).contiguous()
 
     def forward(self, news):

@@ -1,6 +1,7 @@
 """NAML -- interface of src/model/NAML/__init__.py:7-93."""
 import torch
 
+from news_recommendation_amd import ops
 from .news_encoder import NewsEncoder
 from .user_encoder import UserEncoder
 from ..general.click_predictor.dot_product import DotProductClickPredictor
@@ -22,8 +23,11 @@ class NAML(torch.nn.Module):
         """candidate_news: list[1+K] of {"category": [B], "subcategory": [B], "title": [B, Lt], "abstract": [B, La]},
         clicked_news: list[N] of the same (train.py:202-203) -> [B, 1+K].  The reference encodes the 1+K+N positions one by
         one (__init__.py:44-48); here all B*(1+K+N) news are stacked and encoded by one kernel chain."""
-        cand = {k: torch.stack([x[k] for x in candidate_news], dim=1) for k in ATTRS}
-        click = {k: torch.stack([x[k] for x in clicked_news], dim=1) for k in ATTRS}
+        ne = self.news_encoder
+        dev = self.user_encoder.additive_attention.linear.weight.device
+        ops._require_cuda(self.user_encoder.additive_attention.linear.weight, "NAML parameters")
+        cand = {k: ops.stack_to_device([x[k] for x in candidate_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
+        click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
         return self.forward_ids(cand, click)
 
     def forward_ids(self, cand, click):

@@ -68,11 +68,14 @@ class NewsEncoder(torch.nn.Module):
                                   ee['category'].embedding.weight, te['title'], te['abstract'], ee['category'], ee['subcategory'],
                                   self.final_attention, self.config.dropout_probability, self.training)
 
+    def table_rows(self, key):
+        """Rows of the embedding table attribute `key` indexes."""
+        return (self.text_encoders['title'].word_embedding if key in ('title', 'abstract') else self.element_encoders['category'].embedding).weight.shape[0]
+
     def to_device(self, key, ids):
         """Host or device id tensor of attribute `key` -> contiguous device tensor; ids outside the embedding table raise IndexError like
         nn.Embedding (host tensors always, device tensors with NR_CHECK_IDS=1: ops.check_ids)."""
-        rows = (self.text_encoders['title'].word_embedding if key in ('title', 'abstract') else self.element_encoders['category'].embedding).weight.shape[0]
-        ops.check_ids(ids, rows, f"{key} id")
+        ops.check_ids(ids, self.table_rows(key), f"{key} id")
         return ids.to(self.final_attention.linear.weight.device, non_blocking=True).contiguous()
 
     def forward(self, news):

@@ -23,8 +23,11 @@ class NRMS(torch.nn.Module):
 
         The reference encodes the 1+K+N positions one by one (__init__.py:38-42); here all B*(1+K+N) titles are
         stacked into ONE id matrix and encoded by one kernel chain."""
-        cand = torch.stack([x["title"] for x in candidate_news], dim=1)       # [B, C, L]
-        click = torch.stack([x["title"] for x in clicked_news], dim=1)        # [B, N, L]
+        w = self.news_encoder.word_embedding.weight
+        ops._require_cuda(w, "NRMS parameters")
+        # the 1+K+N per-position CPU tensors cross PCIe as two pinned, asynchronous copies (ops.stack_to_device)
+        cand = ops.stack_to_device([x["title"] for x in candidate_news], w.device, w.shape[0], "title token id")       # [B, C, L]
+        click = ops.stack_to_device([x["title"] for x in clicked_news], w.device, w.shape[0], "title token id")        # [B, N, L]
         return self.forward_ids(cand, click)
 
     def forward_ids(self, cand, click):

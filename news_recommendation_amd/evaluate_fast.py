@@ -123,12 +123,14 @@ def run_plan(model, plan, batch, model_name):
 
 
 @torch.no_grad()
-def evaluate(model, directory, num_workers=0, max_count=sys.maxsize, user2int_path='data/train/user2int.tsv'):
+def evaluate(model, directory, num_workers=0, max_count=sys.maxsize, user2int_path='data/train/user2int.tsv', plan=None):
     """Drop-in for src/evaluate.py:171 ``evaluate``: returns (AUC, MRR, nDCG@5, nDCG@10), nan-mean over impressions (:270-272).
-    ``num_workers`` is accepted for signature compatibility (there is no process pool)."""
+    ``num_workers`` is accepted for signature compatibility (there is no process pool).  ``plan``: a build_plan() result of the same
+    directory / max_count to reuse (periodic validation parses the files once)."""
     cfg = model.config
     model_name = type(model).__name__
-    plan = build_plan(directory, cfg.dataset_attributes['news'], cfg.num_clicked_news_a_user, user2int_path, max_count)
+    if plan is None:
+        plan = build_plan(directory, cfg.dataset_attributes['news'], cfg.num_clicked_news_a_user, user2int_path, max_count)
     out, _ = run_plan(model, plan, getattr(cfg, 'batch_size', 128) * 16, model_name)
     m = torch.nanmean(out.double(), dim=0).cpu().numpy()
     return float(m[0]), float(m[1]), float(m[2]), float(m[3])

@@ -20,7 +20,7 @@ What the reference does per step: ``optimizer.zero_grad()``, ``loss.backward()``
   ``state_dict()`` / checkpoints.
 
 There is no CPU implementation: the update runs in the HIP library (``_capi.load()``).  ``lib=`` lets the GPU-less unit tests inject
-the CPU wave-emulation build of the same kernel sources (tests/emu, test infrastructure).
+a host build of the same kernel sources that the test suite owns (test infrastructure; the product never loads it).
 """
 import numpy as np
 import torch
@@ -205,7 +205,19 @@ class EngineAdam:
         for st in self.sparse:
             st.pending.clear()
 
+    def check_views(self):
+        """autograd accumulates in place into an existing .grad, so the views must still alias the flat buffers."""
+        for n, p in zip(self.names, self.params):
+            if n in self.slices:
+                lo, _ = self.slices[n]
+                if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + lo * 4 or p.data_ptr() != self.flat_p.data_ptr() + lo * 4:
+                    return False
+        return True
+
     def _adam(self, lo, hi, scale):
+        ops._timed('nr_adam_flat', lambda: self._adam_launch(lo, hi, scale))
+
+    def _adam_launch(self, lo, hi, scale):
         self._ck(self.lib.nr_adam_flat(self.flat_p.data_ptr() + lo * 4, self.flat_g.data_ptr() + lo * 4, self.flat_m.data_ptr() + lo * 4,
                                        self.flat_v.data_ptr() + lo * 4, hi - lo, self.sched.table.data_ptr(), self.t, self.betas[0],
                                        self.betas[1], self.eps, scale, 1, self._stream_fn()))

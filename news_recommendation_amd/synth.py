@@ -5,6 +5,17 @@ import numpy as np
 
 MIND_SMALL = dict(num_words=70976, num_news=65238, num_clicked=50, title_len=20, neg_k=2)
 
+# Dataset shapes.  'small' = the sizes hard-coded in the reference's src/config.py:29-33 (MIND-small after its
+# preprocessing).  'large' = MIND-large: ~161 k news, 711,222 training users (src/model/LSTUR/__init__.py:38-42 sizes user_embedding from
+# num_users: 711,223 x 900 fp32 = 2.56 GB); the reference gives no MIND-large vocabulary, 1 + 130,000 words is this project's knob
+# (156 MB fp32 table, still inside the 256 MB Infinity Cache).  'xlarge' only differs in the vocabulary: 1 + 250,000 words = 300 MB,
+# the point at which the embedding gather and the table's gradient exchange leave the cache.
+SHAPES = {
+    'small': dict(num_words=1 + 70975, num_news=65238, num_users=1 + 50000, num_categories=1 + 274, eval_impressions=73152),
+    'large': dict(num_words=1 + 130000, num_news=161013, num_users=1 + 711222, num_categories=1 + 274, eval_impressions=376471),
+    'xlarge': dict(num_words=1 + 250000, num_news=161013, num_users=1 + 711222, num_categories=1 + 274, eval_impressions=376471),
+}
+
 
 def zipf_ids(rng, shape, num_words, s=1.05):
     """Zipf(s)-distributed token ids over 1..num_words-1 (rank-frequency like natural text)."""

@@ -509,3 +509,29 @@ def check_impression_metrics(be, n_impr=40, seed=5):
         if len(np.unique(ss[i])) == len(ss[i]):                      # MRR / nDCG depend on the tie ORDER of argsort; exact without ties
             np.testing.assert_allclose(got[i][1:], ref[1:], rtol=2e-5, atol=2e-6, err_msg=str(i))
     return got
+
+
+def check_dropout_mask_statistics(be):
+    """The counter-based dropout generator (csrc/nr_common.h, 3 integer multiplies per 4 elements): keep rate, and no visible
+    correlation between neighbouring elements, the elements of a quad, sites and seeds (1 M elements: sigma ~ 1e-3)."""
+    import numpy as np
+    n = 1 << 20
+
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))
+
+    for p in (0.2, 0.5):
+        m1 = export_mask(be, n, p, 777, 1).astype(np.float64)
+        m2 = export_mask(be, n, p, 777, 2).astype(np.float64)
+        m3 = export_mask(be, n, p, 778, 1).astype(np.float64)
+        sig = np.sqrt(p * (1 - p) / n)
+        assert abs(m1.mean() - (1 - p)) < 4 * sig and abs(m2.mean() - (1 - p)) < 4 * sig
+        for k in (1, 2, 3, 4, 300, 1200):
+            assert abs(corr(m1[:-k], m1[k:])) < 5e-3, k
+        assert abs(corr(m1, m2)) < 5e-3 and abs(corr(m1, m3)) < 5e-3
+        q = m1.reshape(-1, 4)
+        assert np.all(np.abs(q.mean(0) - (1 - p)) < 5 * 2 * sig)
+        for i in range(4):
+            for j in range(i + 1, 4):
+                assert abs(corr(q[:, i], q[:, j])) < 6e-3, (i, j)

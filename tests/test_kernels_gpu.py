@@ -73,16 +73,38 @@ def test_gru_ini(be): kcg.check_gru(be, B=133, N=50, Hd=900, I=900)
 def test_gru_con_hidden_450(be): kcg.check_gru(be, B=70, N=20, Hd=450, I=900, seed=1)
 
 
-@pytest.mark.xfail(strict=False, reason="NR_GRU_LDS=1 is an opt-in variant verified on the wave emulator; this records its first on-hardware parity run")
-def test_gru_lds_variant_on_hardware():
-    """The LDS-shared W_hh / W_hh^T step kernels (NR_GRU_LDS=1, experimental knob) against the same oracle, in a subprocess because the
-    knob is read once per process.  Not part of the default path: an XPASS here is the signal to make it the default."""
+def test_gru_lds_default_large_batch(be):
+    """From 256 samples up the default step kernels stage the W_hh / W_hh^T tile in LDS (two sample tiles per wave in the forward)."""
+    kcg.check_gru(be, B=300, N=12, Hd=900, I=900, seed=3)
+    kcg.check_gru(be, B=270, N=8, Hd=450, I=900, seed=4)
+
+
+def test_gru_register_only_variant():
+    """NR_GRU_LDS=0 (the round-1 default: operands straight from L2 into registers) stays selectable; knobs are read once per process,
+    hence the subprocess."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2')
+    env = dict(os.environ, NR_GRU_LDS='0')
     code = ("from tests.backends import GpuBackend; from tests import kernel_checks_gru as k; be = GpuBackend(); "
             "k.check_gru(be, B=300, N=12, Hd=900, I=900, seed=3); k.check_gru(be, B=70, N=8, Hd=450, I=900, seed=4)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_dropout_mask_statistics(be):
+    """Keep rate and decorrelation of the counter-based dropout generator on the hardware build (same check as on the emulator)."""
+    kc.check_dropout_mask_statistics(be)
+
+
+def test_dropout_mask_bits_equal_cpu_emulation(be):
+    """The masks the GPU kernels draw are the masks the CPU build of the same sources draws, bit for bit (an independent check of the
+    hardware's integer path: mul_lo / shifts / compares of csrc/nr_common.h)."""
+    import numpy as np
+    from tests.backends import EmuBackend
+    emu = EmuBackend()
+    for p, seed, site in ((0.2, 777, 1), (0.2, 2 ** 40 + 12345, 2), (0.5, 3, 1)):
+        a = kc.export_mask(be, 100003, p, seed, site)
+        b = kc.export_mask(emu, 100003, p, seed, site)
+        assert np.array_equal(a, b)
