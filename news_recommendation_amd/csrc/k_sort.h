@@ -26,7 +26,8 @@ struct SortPass {
   uint32_t* idx_out;
   int64_t* ids_sorted;       // last pass
   int64_t* perm;
-  int* hist;                 // [bins][n_tiles]: counts after the histogram kernel, exclusive global offsets after the scan
+  int* hist;                 // [bins][n_tiles]: counts after the histogram kernel, per-digit exclusive prefixes over the tiles after the scan
+  int* bin_tot;              // [bins]: total per digit (after the scan kernel)
   int64_t n, num_rows;
   int n_tiles, shift, bits;
 };
@@ -69,6 +70,7 @@ __device__ __forceinline__ void sort_rank_wave(const SortPass& s, int64_t wave_b
 }
 
 constexpr int SORT_SMEM = 4 * SORT_MAXBINS * 4;     // one counter row per wave
+constexpr int SORT_SCATTER_SMEM = SORT_SMEM + SORT_MAXBINS * 4 + WG * 4;     // + digit bases + scan scratch
 
 __global__ __launch_bounds__(256) void sort_hist_kernel(SortPass s) {
   NR_SMEM_DECL(smem);
@@ -83,24 +85,37 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(SortPass s) {
   for (int d = threadIdx.x; d < bins; d += WG) s.hist[(size_t)d * s.n_tiles + blockIdx.x] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
 }
 
-// in-place exclusive prefix sum of data[0..n) by ONE workgroup (n = bins * n_tiles <= a few 10^5 ints, L2 resident)
-__global__ __launch_bounds__(256) void sort_scan_kernel(int* __restrict__ data, int64_t n) {
+// Exclusive prefix sums of the tile counts, one workgroup per digit: hist[d][0..n_tiles) -> in-place exclusive scan over the tiles
+// (coalesced 256-wide sweeps with a running carry), bin_tot[d] = the digit's total.  The digits' own prefix (<= 512 values) is formed by
+// every scatter workgroup in LDS.  (A single workgroup walking all bins x tiles counters took 0.49 ms per pass on MI355X: 530 dependent,
+// uncoalesced global loads per thread.)
+__device__ __forceinline__ int block_scan_incl(int* part, int t, int v) {       // Hillis-Steele over WG values; returns the inclusive sum
+  part[t] = v;
+  __syncthreads();
+  for (int off = 1; off < WG; off <<= 1) {
+    const int u = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += u;
+    __syncthreads();
+  }
+  return part[t];
+}
+
+__global__ __launch_bounds__(256) void sort_scan_kernel(int* __restrict__ hist, int* __restrict__ bin_tot, int n_tiles) {
   NR_SMEM_DECL(smem);
   int* part = (int*)smem;                            // WG ints
   const int t = threadIdx.x;
-  const int64_t chunk = (n + WG - 1) / WG, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  int sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += data[i];
-  part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < WG; off <<= 1) {          // Hillis-Steele inclusive scan of the 256 partial sums
-    const int v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  int* row = hist + (size_t)blockIdx.x * n_tiles;
+  int carry = 0;
+  for (int base = 0; base < n_tiles; base += WG) {
+    const int i = base + t;
+    const int v = i < n_tiles ? row[i] : 0;
+    const int incl = block_scan_incl(part, t, v);
+    if (i < n_tiles) row[i] = carry + incl - v;
+    carry += part[WG - 1];
+    __syncthreads();                                 // part[] is rewritten by the next sweep
   }
-  int run = part[t] - sum;
-  for (int64_t i = lo; i < hi; ++i) { const int v = data[i]; data[i] = run; run += v; }
+  if (t == 0) bin_tot[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(256) void sort_scatter_kernel(SortPass s) {
@@ -114,9 +129,20 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(SortPass s) {
   const int64_t wave_base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * 64 * SORT_KPT;
   sort_rank_wave(s, wave_base, cnt[w], key, digit, rank);
   __syncthreads();
-  // per-digit base of each wave: global offset of (digit, this tile) + the totals of the lower waves
+  // digit bases: exclusive scan of the <= 512 digit totals (two digits per thread), in LDS behind the counters
+  int* dbase = (int*)(smem + SORT_SMEM);             // [SORT_MAXBINS]
+  int* part = dbase + SORT_MAXBINS;                  // [WG]
+  {
+    const int t = threadIdx.x;
+    const int v0 = 2 * t < bins ? s.bin_tot[2 * t] : 0, v1 = 2 * t + 1 < bins ? s.bin_tot[2 * t + 1] : 0;
+    const int incl = block_scan_incl(part, t, v0 + v1);
+    dbase[2 * t] = incl - v0 - v1;
+    dbase[2 * t + 1] = incl - v1;
+  }
+  __syncthreads();
+  // per-digit base of each wave: digit base + prefix of (digit, this tile) + the totals of the lower waves
   for (int d = threadIdx.x; d < bins; d += WG) {
-    int run = s.hist[(size_t)d * s.n_tiles + blockIdx.x];
+    int run = dbase[d] + s.hist[(size_t)d * s.n_tiles + blockIdx.x];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) { const int c = cnt[ww][d]; cnt[ww][d] = run; run += c; }
   }

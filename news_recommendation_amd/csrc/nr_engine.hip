@@ -698,7 +698,7 @@ int64_t nr_sort_ids_workspace(int64_t n, int64_t num_rows) {
   int passes, bits;
   sort_plan(num_rows, &passes, &bits);
   const int64_t tiles = (n + nr::SORT_TILE - 1) / nr::SORT_TILE;
-  const int64_t hist = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256;
+  const int64_t hist = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256 + nr::SORT_MAXBINS * 4;     // tile counts + digit totals
   const int64_t pair = ((n * 4) + 255) / 256 * 256;
   return hist + 2 * pair * (passes > 2 ? 2 : 1);
 }
@@ -712,7 +712,8 @@ int nr_sort_ids(const int64_t* ids, int64_t n, int64_t num_rows, int64_t* ids_so
   int passes, bits;
   sort_plan(num_rows, &passes, &bits);
   const int tiles = (int)((n + nr::SORT_TILE - 1) / nr::SORT_TILE);
-  const int64_t hist_b = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256, pair = ((n * 4) + 255) / 256 * 256;
+  const int64_t hist_only = (((int64_t)(1 << bits) * tiles * 4) + 255) / 256 * 256, hist_b = hist_only + nr::SORT_MAXBINS * 4,
+                pair = ((n * 4) + 255) / 256 * 256;
   unsigned char* ws = (unsigned char*)workspace;
   uint32_t* kbuf[2] = {(uint32_t*)(ws + hist_b), passes > 2 ? (uint32_t*)(ws + hist_b + 2 * pair) : nullptr};
   uint32_t* ibuf[2] = {(uint32_t*)(ws + hist_b + pair), passes > 2 ? (uint32_t*)(ws + hist_b + 3 * pair) : nullptr};
@@ -723,10 +724,10 @@ int nr_sort_ids(const int64_t* ids, int64_t n, int64_t num_rows, int64_t* ids_so
     const bool last_pass = ps == passes - 1;
     s.key_out = last_pass ? nullptr : kbuf[ps & 1]; s.idx_out = last_pass ? nullptr : ibuf[ps & 1];
     s.ids_sorted = last_pass ? ids_sorted : nullptr; s.perm = last_pass ? perm : nullptr;
-    s.hist = (int*)ws; s.n = n; s.num_rows = num_rows; s.n_tiles = tiles; s.shift = ps * bits; s.bits = bits;
+    s.hist = (int*)ws; s.bin_tot = (int*)(ws + hist_only); s.n = n; s.num_rows = num_rows; s.n_tiles = tiles; s.shift = ps * bits; s.bits = bits;
     NR_LAUNCH(nr::sort_hist_kernel, tiles, 256, nr::SORT_SMEM, (hipStream_t)stream, s);
-    NR_LAUNCH(nr::sort_scan_kernel, 1, 256, 256 * 4, (hipStream_t)stream, s.hist, (int64_t)(1 << bits) * tiles);
-    NR_LAUNCH(nr::sort_scatter_kernel, tiles, 256, nr::SORT_SMEM, (hipStream_t)stream, s);
+    NR_LAUNCH(nr::sort_scan_kernel, 1 << bits, 256, 256 * 4, (hipStream_t)stream, s.hist, s.bin_tot, tiles);
+    NR_LAUNCH(nr::sort_scatter_kernel, tiles, 256, nr::SORT_SCATTER_SMEM, (hipStream_t)stream, s);
   }
   return check_launch("nr_sort_ids");
 }

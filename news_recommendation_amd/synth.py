@@ -142,3 +142,67 @@ def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_imp
                 imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c, replace=False), lab))     # an impression lists a news once
                 f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist_str(k)}\t{imp}\n")
     return root
+
+
+_WORDS = ("the of and to in a is that for it as was with be by on not he this are or his from at which but have an had they you were "
+          "their one all we can her has there been if more when will would who so no out up said what its about than into them only "
+          "new some could time these two may first then do any like my now over such our man me even most made after also did many off "
+          "before must well back through years much where your way down should because long each just state people those too how "
+          "election storm market player game police school city court team health fire president trade season coach film music").split()
+
+
+def write_raw_mind(root, n_news=40, n_users=12, n_behaviors=50, seed=0, splits=('train', 'val', 'test')):
+    """A tiny tree of RAW MIND-format files (news.tsv: id, category, subcategory, title, abstract, url, title_entities,
+    abstract_entities; behaviors.tsv: impression id, user, time, clicked news, impressions) for the preprocessing tools
+    (data_tools.py; schemas as read by src/data_preprocess.py:33-37,99-107).  Titles carry punctuation, quotes, contractions and
+    digits so that tokenisation is exercised; entities carry confidences around the 0.5 threshold."""
+    import json
+    import os
+    rng = np.random.default_rng(seed)
+    cats = ['news', 'sports', 'finance', 'health']
+    subs = ['newsus', 'football_nfl', 'markets', 'wellness', 'newspolitics', 'baseball_mlb']
+    ents = [f'Q{100 + i}' for i in range(12)]
+
+    def sentence(nw):
+        ws = [str(rng.choice(_WORDS)) for _ in range(nw)]
+        if rng.random() < 0.3:
+            ws[int(rng.integers(0, nw))] += ','
+        if rng.random() < 0.2:
+            ws[int(rng.integers(0, nw))] = f'"{ws[0]}"'
+        if rng.random() < 0.2:
+            ws.append("don't")
+        if rng.random() < 0.2:
+            ws.append(str(int(rng.integers(1, 2020))))
+        s = ' '.join(ws).capitalize()
+        return s + str(rng.choice(['.', '?', '!', '', ' ...']))
+
+    def entities(text):
+        out = []
+        for w in set(text.lower().replace(',', ' ').replace('.', ' ').split()):
+            if rng.random() < 0.15:
+                out.append({"Label": w, "Type": "O", "WikidataId": str(rng.choice(ents)), "Confidence": float(rng.choice([0.3, 0.6, 0.9, 1.0])),
+                            "OccurrenceOffsets": [0] * int(rng.integers(0, 3)), "SurfaceForms": [w]})
+        return json.dumps(out)
+    nid = [f'N{1000 + i}' for i in range(n_news)]
+    rows = []
+    for i in range(n_news):
+        title = sentence(int(rng.integers(3, 26)))
+        abstract = ' '.join(sentence(int(rng.integers(4, 30))) for _ in range(int(rng.integers(0, 4))))
+        rows.append((nid[i], str(rng.choice(cats)), str(rng.choice(subs)), title, abstract, f'https://example.invalid/{i}', entities(title),
+                     entities(abstract) if abstract and rng.random() < 0.8 else ''))
+    users = [f'U{i + 1}' for i in range(n_users)]
+    for split in splits:
+        d = os.path.join(root, 'data', split)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'news.tsv'), 'w') as f:
+            for r in rows:
+                f.write('\t'.join(r) + '\n')
+        with open(os.path.join(d, 'behaviors.tsv'), 'w') as f:
+            for i in range(n_behaviors):
+                k = int(rng.integers(0, 8))
+                hist = ' '.join(rng.choice(nid, size=k)) if k else ''
+                c = int(rng.integers(2, 9))
+                lab = (rng.random(c) < 0.3).astype(int)
+                imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c, replace=False), lab))
+                f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist}\t{imp}\n")
+    return root

@@ -115,7 +115,7 @@ def test_fast_evaluate_equals_reference_style_loop(tmp_path, model_name):
     import bench
     from news_recommendation_amd import synth, evaluate_fast as ef
     synth.write_reference_dataset(str(tmp_path), n_news=200, n_val_impr=60, num_words=500)
-    cfg = {'NRMS': bench.Cfg, 'NAML': bench.NamlCfg, 'LSTUR': bench.LsturCfg}[model_name]
+    cfg = bench.make_cfg(model_name, 'small')
 
     class C(cfg):
         num_words = 500

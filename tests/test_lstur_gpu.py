@@ -198,7 +198,7 @@ def test_flat_gradient_buffer_inplace_table_gradients(model_name):
     path, twice in a row (zero() in between), and accumulation over two backward passes without zero()."""
     import bench
     from news_recommendation_amd import dist as nrdist
-    wl = bench.Workload(model_name)
+    wl = bench.Workload(model_name, bench.make_cfg(model_name, 'small'))
     m1, m2 = wl.make_model(5).to(DEV).eval(), wl.make_model(5).to(DEV).eval()
     m2.load_state_dict(m1.state_dict())
     b = wl.batches(11, 1, 8, DEV)[0]
