@@ -10,6 +10,7 @@ must be built, otherwise a RuntimeError is raised.
 """
 import collections
 import os
+import weakref
 
 import torch
 
@@ -186,7 +187,13 @@ def check_ids(ids, num_rows, what="index"):
     device-resident ones only with NR_CHECK_IDS=1, because the check costs a stream synchronisation per call."""
     if ids.numel() == 0 or (ids.is_cuda and not _CHECK_DEVICE_IDS):
         return
-    lo, hi = int(ids.min()), int(ids.max())
+    if ids.is_cuda:
+        lo, hi = int(ids.min()), int(ids.max())
+    else:
+        # numpy on the host: torch's CPU reductions wake the whole intra-op thread pool (measured 11 ms per call on a 128-thread host
+        # whose workers had gone to sleep between training steps; numpy scans 4.3 MB in ~0.2 ms on one core)
+        a = ids.detach().numpy()
+        lo, hi = int(a.min()), int(a.max())
     if lo < 0 or hi >= num_rows:
         raise IndexError(f"{what} out of range: got [{lo}, {hi}], table has {num_rows} rows")
 
@@ -206,7 +213,7 @@ def untile(t, R, K):
     return t.view(R // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(R, K)
 
 
-# Packed operands are cached per parameter STATE: key = (storage pointer, tensor version) of every source tensor + a global epoch.
+# Packed operands are cached per parameter STATE: the source tensor objects, their storage pointers and version counters + a global epoch.
 # torch's own in-place updates (optimizer.step(), load_state_dict, .copy_) bump the version counter; code that writes parameter memory
 # behind torch's back -- the engine's fused Adam kernel, collectives on ``p.data`` -- calls ``invalidate_packed()``.  A training step packs
 # each operand once (not once per encoder call plus once per backward), evaluation packs once per model state.
@@ -223,13 +230,19 @@ def invalidate_packed():
 
 
 def _packed(kind, tensors, build):
-    key = (kind, _pack_epoch) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    """Cached build() keyed on the source tensor OBJECTS (weak references: an address / id recycled by a later model never matches), their
+    storage pointers and version counters, and the global epoch."""
+    key = (kind,) + tuple(id(t) for t in tensors)
+    state = tuple((t.data_ptr(), t._version) for t in tensors)
     hit = _pack_cache.get(key)
     if hit is not None:
-        _pack_cache.move_to_end(key)
-        return hit
+        refs, st, epoch, out = hit
+        if epoch == _pack_epoch and st == state and all(r() is t for r, t in zip(refs, tensors)):
+            _pack_cache.move_to_end(key)
+            return out
     out = build()
-    _pack_cache[key] = out
+    _pack_cache[key] = (tuple(weakref.ref(t) for t in tensors), state, _pack_epoch, out)
+    _pack_cache.move_to_end(key)
     while len(_pack_cache) > _PACK_CACHE_MAX:
         _pack_cache.popitem(last=False)
     return out
