@@ -42,6 +42,21 @@ struct AdditiveParams {
   int64_t n_seq;
 };
 
+// parameters of the pooling backward kernels (k_bwd.h additive_bwd_kernel, k_pool2.h pool2_bwd_kernel)
+struct AdditiveBwdParams {
+  const u16* ctx;        // [n_seq*S][KP]  (forward input of the additive layer)
+  const u16* Wap;        // [QP][KP]
+  const float* bap;      // [QP]
+  const float* qvp;      // [QP]
+  const float* attn_w;   // [n_seq][S]
+  const float* g_out;    // [n_seq][D]
+  u16* dpre;             // [n_seq*S][QP] bf16
+  float* dq_part;        // [gridDim.x][QP]  per-workgroup partial gradient of the query vector
+  const u16* WaT;        // optional: bf16 [KP][QKP] = Wa^T (pack_additive_t) -> the kernel also emits dctx = dpre @ Wa
+  u16* dctx;             // optional: bf16 [n_seq*S][KP] (columns < D written)
+  int64_t n_seq;
+};
+
 template <int S, int NSEQ, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p) {
   using Gm = AddGeom<S, NSEQ, NW>;

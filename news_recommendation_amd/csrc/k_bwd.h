@@ -339,19 +339,6 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct AdditiveBwdParams {
-  const u16* ctx;        // [n_seq*S][KP]  (forward input of the additive layer)
-  const u16* Wap;        // [QP][KP]
-  const float* bap;      // [QP]
-  const float* qvp;      // [QP]
-  const float* attn_w;   // [n_seq][S]
-  const float* g_out;    // [n_seq][D]
-  u16* dpre;             // [n_seq*S][QP] bf16
-  float* dq_part;        // [gridDim.x][QP]  per-workgroup partial gradient of the query vector
-  const u16* WaT;        // optional: bf16 [KP][QKP] = Wa^T (pack_additive_t) -> the kernel also emits dctx = dpre @ Wa
-  u16* dctx;             // optional: bf16 [n_seq*S][KP] (columns < D written)
-  int64_t n_seq;
-};
 
 template <int S, int NSEQ, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams p) {
@@ -513,10 +500,11 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
       }
       for (int m = mb; m < me; ++m) {
         f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        const u16* xp = Ps + (m * 16 + li) * PS2 + g * 8;
+        const u16* xp = Ps + (m * 16 + li) * PS2 + g * 4;
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
-          const u16x8 xf = *(const u16x8*)(xp + ks * 32);
+          // pair-permuted contraction index of WaT (pack_additive_t_kernel): query rows 4g..4g+3 of tiles 2 ks and 2 ks + 1
+          const u16x8 xf = cat8(*(const u16x4*)(xp + ks * 32), *(const u16x4*)(xp + ks * 32 + 16));
           a0 = mfma_16x16x32_bf16(wf[0][ks], xf, a0);
           if (G == 2) a1 = mfma_16x16x32_bf16(wf[1][ks], xf, a1);
         }

@@ -55,14 +55,18 @@ __global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restr
   }
 }
 
-// AdditiveAttention.linear weight transposed for the fused input-gradient product of additive_bwd: WaT bf16 [KP][QKP] with
-// WaT[d][q] = Wa[q][d], zero padded (QKP = QP rounded up to the MFMA k-step of 32).
-constexpr int QKP = (QP + 31) / 32 * 32;    // 224
+// AdditiveAttention.linear weight transposed for the fused input-gradient product dctx = dpre @ Wa of the pooling backward kernels:
+// WaT bf16 [KP][QKP] in tile order (QKP = QP rounded up to the MFMA k-step of 32), zero padded, with a PAIR-PERMUTED contraction
+// index: slot kappa = 32 ks + 8 g + j of row d holds Wa[q][d] with q = 16 (2 ks + j / 4) + 4 g + j % 4.  The transposed projection
+// product leaves a lane with rows 4g..4g+3 of each 16-row query tile; in this order the B fragment of k-step ks is just the lane's
+// registers of tiles 2 ks and 2 ks + 1 back to back (k_pool2.h), or two 8-byte LDS reads (additive_bwd_kernel).
 __global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __restrict__ Wa, int qdim, u16* __restrict__ WaT) {
   const int total = KP * QKP;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int d = i / QKP, q = i - d * QKP;
-    WaT[tile_off(d, q, QKP)] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
+    const int d = i / QKP, kap = i - d * QKP;
+    const int ks = kap >> 5, g = (kap & 31) >> 3, j = kap & 7;
+    const int q = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
+    WaT[tile_off(d, kap, QKP)] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
   }
 }
 

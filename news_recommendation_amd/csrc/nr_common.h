@@ -15,6 +15,7 @@ constexpr int HG = 4;              // heads per head-group (4*20 = 80 = 5 n-tile
 constexpr int NGROUPS = (H + HG - 1) / HG;   // 4 groups: 4,4,4,3 heads
 constexpr int NP = NR_NP;          // 304 rows per packed W block
 constexpr int QP = NR_QP;          // 208
+constexpr int QKP = (QP + 31) / 32 * 32;     // 224: query dim padded to the MFMA k-step (contraction dim of dctx = dpre @ Wa)
 constexpr int QS = HG * DK + 8;    // 88: LDS row stride (elements) of the per-group Q / K tiles (176 B)
 constexpr int WG = 256;            // threads per workgroup of the 4-wave kernels
 constexpr float EXP_CLAMP = 80.0f; // exp() argument clamp: keeps sum_j exp(s_j) finite in fp32 for S <= 64 (the reference overflows to inf/nan there)

@@ -18,6 +18,8 @@ namespace nr {
 // defined in nr_mhsa2.hip: its own translation unit because the register-resident kernel wants the AGPR half of the register
 // file as storage (default MFMA form), while every other kernel is built with -amdgpu-mfma-vgpr-form
 int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream);
+int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream);      // k_pool2.h, same translation unit
+int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream);
 }
 
 namespace {
@@ -56,11 +58,12 @@ int grid_for(int64_t work, int per_block, int cap) {
   return (int)b;
 }
 
-// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 0 (default) = forward 4 waves on 2 titles, backward 4 waves on 4 titles;
-// 1 = 8 waves on 8 titles (both); 2 = 4 waves on 2 titles (both); 3 = 4 waves on 4 titles (both)
+// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 4 (default) = register-resident kernels of k_pool2.h (one wave = 4 titles,
+// weights streamed through LDS); LDS-tile kernels: 0 = forward 4 waves on 2 titles, backward 4 waves on 4 titles; 1 = 8 waves on 8 titles
+// (both); 2 = 4 waves on 2 titles (both); 3 = 4 waves on 4 titles (both)
 int add_variant() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 4; }
   return v;
 }
 
@@ -181,7 +184,9 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
   p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq;
-  if (S == 20 && add_variant() == 1) {
+  if (S == 20 && add_variant() == 4) {
+    if (nr::launch_pool2_fwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
+  } else if (S == 20 && add_variant() == 1) {
     constexpr int NSEQ = 8, NW = 8;
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
@@ -250,7 +255,7 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
-  if (S == 20) return add_variant() == 1 ? (n_seq + 7) / 8 : add_variant() == 2 ? (n_seq + 1) / 2 : (n_seq + 3) / 4;
+  if (S == 20) return add_variant() == 4 ? (n_seq + 15) / 16 : add_variant() == 1 ? (n_seq + 7) / 8 : add_variant() == 2 ? (n_seq + 1) / 2 : (n_seq + 3) / 4;
   if (S == 50) return n_seq;
   if (S == 4) return (n_seq + 19) / 20;
   return -1;
@@ -281,7 +286,9 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveBwdParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
   p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq;
-  if (S == 20 && add_variant() == 1) {
+  if (S == 20 && add_variant() == 4) {
+    if (nr::launch_pool2_bwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
+  } else if (S == 20 && add_variant() == 1) {
     constexpr int NSEQ = 8, NW = 8;
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_bwd_kernel<20, NSEQ, NW>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");

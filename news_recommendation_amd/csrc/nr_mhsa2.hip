@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include "nr_common.h"
 #include "k_mhsa_fwd2.h"
+#include "k_pool2.h"
 
 namespace nr {
 
@@ -18,6 +19,23 @@ int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
   }
   if (set_max_dynamic_lds((const void*)mhsa_fwd2_kernel<false>, G::SMEM)) return -1;
   NR_LAUNCH(mhsa_fwd2_kernel<false>, (p.n_seq + per_wg - 1) / per_wg, 256, G::SMEM, stream, p);
+  return 0;
+}
+
+// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup
+int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
+  using G = Pool2Geom;
+  const int per_wg = G::TPW * G::NWAVE;
+  if (set_max_dynamic_lds((const void*)pool2_fwd_kernel, G::FWD_SMEM)) return -1;
+  NR_LAUNCH(pool2_fwd_kernel, (p.n_seq + per_wg - 1) / per_wg, 256, G::FWD_SMEM, stream, p);
+  return 0;
+}
+
+int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {
+  using G = Pool2Geom;
+  const int per_wg = G::TPW * G::NWAVE;
+  if (set_max_dynamic_lds((const void*)pool2_bwd_kernel, G::BWD_SMEM)) return -1;
+  NR_LAUNCH(pool2_bwd_kernel, (p.n_seq + per_wg - 1) / per_wg, 256, G::BWD_SMEM, stream, p);
   return 0;
 }
 

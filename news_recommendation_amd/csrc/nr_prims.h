@@ -62,6 +62,17 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return a + b;
 }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+// sum over the 16 lanes of a row (lanes with equal l >> 4), result in every lane of the row: four DPP-modified adds (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror) instead of four ds_bpermute round trips
+__device__ __forceinline__ float sum_row16(float v) {
+#define NR_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  NR_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  NR_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  NR_DPP_ADD(0x141);   // row_half_mirror: lane i <-> 7 - i inside each group of 8
+  NR_DPP_ADD(0x140);   // row_mirror: lane i <-> 15 - i
+#undef NR_DPP_ADD
+  return v;
+}
 
 // orders this wave's LDS traffic for cross-lane exchange through LDS (hardware keeps a wave's DS ops in order;
 // this only stops the compiler from moving accesses across the point)

@@ -186,6 +186,20 @@ __forceinline__ float shfl(float v, int src) {
   return r;
 }
 
+__forceinline__ float sum_row16(float v) {          // same pairing order as the DPP version: xor 1, xor 2, i <-> 7 - i, i <-> 15 - i
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  const int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  const int partner[4] = {l ^ 1, l ^ 2, (l & ~7) | (7 - (l & 7)), (l & ~15) | (15 - (l & 15))};
+  for (int s = 0; s < 4; ++s) {
+    memcpy(&ws.stage[l][0], &v, 4);
+    nr_emu::wave_sync();
+    float o; memcpy(&o, &ws.stage[partner[s]][0], 4);
+    nr_emu::wave_sync();
+    v += o;
+  }
+  return v;
+}
 __forceinline__ void wave_barrier() { nr_emu::wave_sync(); }
 __forceinline__ void fence_agent() {}
 

@@ -343,7 +343,12 @@ def check_additive_bwd(be, S=20, n_seq=6):
                                      be.ptr(dpre), be.ptr(dqp), be.ptr(WaT), be.ptr(dctx), n_seq, S, be.stream))
     be.sync()
     # fused input-gradient product: dctx[:, :D] = bf16(dpre) @ bf16(Wa), bit-level inputs as the kernel sees them
-    wat = untile(be.np(WaT), NR_KP, 224)
+    # WaT = Wa^T in tile order with the pair-permuted contraction index (csrc/k_misc.h): slot 32 ks + 8 g + j <-> q = 16 (2 ks + j // 4) + 4 g + j % 4
+    kap = np.arange(224)
+    qmap = 16 * (2 * (kap >> 5) + ((kap & 7) >> 2)) + 4 * ((kap & 31) >> 3) + (kap & 3)
+    wat = np.zeros((NR_KP, 256), dtype=np.uint16)
+    wat[:, qmap] = untile(be.np(WaT), NR_KP, 224)
+    assert sorted(qmap.tolist()) == list(range(224))
     assert np.array_equal(wat[:NR_D, :200], f32_to_bf16(params[a_ + 'linear.weight']).T) and not wat[NR_D:].any() and not wat[:, 200:].any()
     dref = bf16_to_f32(be.np(dpre)).astype(np.float64)[:, :200] @ bf16_round(params[a_ + 'linear.weight']).astype(np.float64)
     close_bf16(bf16_to_f32(be.np(dctx)[:, :NR_D]), dref, f'additive_bwd fused dctx S={S}', rel=2.0 ** -7, floor=1e-3)
