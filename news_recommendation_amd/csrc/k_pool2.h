@@ -137,15 +137,17 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
   wave_barrier();
 
   // ---- weighted sum out[title][:] = sum_s w[s] x[s][:], straight from the fragment registers: title sq lives in token tiles
-  //      (20 sq) / 16 and the next one; a lane adds its token's share, the 16 lanes of a row are summed with DPP adds -------------------
+  //      (20 sq) / 16 and the next one; a lane adds its token's share (80 partial sums: 10 k-steps x 8 features), then the 16 lanes of a
+  //      row are combined by RECURSIVE HALVING (reduce-scatter): at level b the lane keeps the half of its values that its lane-index
+  //      bit b selects and adds the partner's copy of that half -- 40 + 20 + 10 + 5 exchanges instead of the 4 x 80 of an all-reduce
+  //      butterfly (which made this phase half of the kernel's run time).  Lane li ends with values 5 li .. 5 li + 4. -------------------
+  const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
 #pragma unroll
   for (int sq = 0; sq < Gm::TPW; ++sq) {
     const int m0 = (sq * S) / 16;
-    float acc[KSTEPS][8];
+    float v[KSTEPS * 8];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[ks][j] = 0.0f;
+    for (int i = 0; i < KSTEPS * 8; ++i) v[i] = 0.0f;
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm) {
       const int m = m0 + dm;
@@ -154,27 +156,25 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[ks][j] += wm * bf2f(xf[m][ks][j]);
+        for (int j = 0; j < 8; ++j) v[ks * 8 + j] += wm * bf2f(xf[m][ks][j]);
     }
-    const bool owner = li == 0 && seq0 + sq < p.n_seq;
+    float k1[40], k2[20], k3[10], k4[5];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      f32x4 lo, hi;
+    for (int i = 0; i < 40; ++i) k1[i] = (b3 ? v[40 + i] : v[i]) + row_xchg<3>(b3 ? v[i] : v[40 + i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { lo[j] = sum_row16(acc[ks][j]); hi[j] = sum_row16(acc[ks][4 + j]); }
-      const int c = ks * 32 + g * 8;
-      if (owner) {
-        if (p.out != nullptr) {
-          float* o = p.out + (seq0 + sq) * p.out_stride + c;
-          if (c < D) *(f32x4*)o = lo;
-          if (c + 4 < D) *(f32x4*)(o + 4) = hi;
-        }
-        if (p.out_b != nullptr) {             // bf16 ctx-layout copy: cols < D data, col D = 1.0, rest of the K padding 0
-          u16* o = p.out_b + (seq0 + sq) * p.out_b_stride + c;
-          const u16x4 one = u16x4{BF16_ONE, 0, 0, 0}, zero = u16x4{0, 0, 0, 0};
-          *(u16x4*)o = c < D ? pack4(lo) : (c == D ? one : zero);
-          *(u16x4*)(o + 4) = c + 4 < D ? pack4(hi) : (c + 4 == D ? one : zero);
-        }
+    for (int i = 0; i < 20; ++i) k2[i] = (b2 ? k1[20 + i] : k1[i]) + row_xchg<2>(b2 ? k1[i] : k1[20 + i]);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) k3[i] = (b1 ? k2[10 + i] : k2[i]) + row_xchg<1>(b1 ? k2[i] : k2[10 + i]);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) k4[i] = (b0 ? k3[5 + i] : k3[i]) + row_xchg<0>(b0 ? k3[i] : k3[5 + i]);
+    if (seq0 + sq < p.n_seq) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int idx = 5 * li + i;                      // flat (k-step, feature-in-fragment) index of the value this lane ended up with
+        const int c = (idx >> 3) * 32 + g * 8 + (idx & 7);
+        if (p.out != nullptr && c < D) p.out[(seq0 + sq) * p.out_stride + c] = k4[i];
+        if (p.out_b != nullptr)                          // bf16 ctx-layout copy: cols < D data, col D = 1.0, rest of the K padding 0
+          p.out_b[(seq0 + sq) * p.out_b_stride + c] = c < D ? f2bf(k4[i]) : (c == D ? BF16_ONE : (u16)0);
       }
     }
   }

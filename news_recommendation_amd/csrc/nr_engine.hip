@@ -184,14 +184,19 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
   p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq;
-  if (S == 20 && add_variant() == 4) {
+  // NR_POOL2_FWD=1 selects the register-resident forward (k_pool2.h).  Measured at B = 512: 286 us vs 265 us for the LDS-tile kernel
+  // below -- one workgroup per CU alternates between loading its 205 KB of ctx rows and computing, with nothing to overlap either phase,
+  // while 5 small workgroups per CU interleave naturally; the BACKWARD of k_pool2.h is the default (400 us vs 570 us).
+  static int p2f = -1;
+  if (p2f < 0) { const char* e = getenv("NR_POOL2_FWD"); p2f = e ? atoi(e) : 0; }
+  if (S == 20 && add_variant() == 4 && p2f) {
     if (nr::launch_pool2_fwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
   } else if (S == 20 && add_variant() == 1) {
     constexpr int NSEQ = 8, NW = 8;
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
-  } else if (S == 20 && add_variant() != 3) {      // default: 2 titles per workgroup (5 workgroups per CU hide the per-tile latency chain: -14 %)
+  } else if (S == 20 && add_variant() != 3) {      // LDS-tile default: 2 titles per workgroup (5 workgroups per CU hide the per-tile latency chain: -14 %)
     constexpr int NSEQ = 2;
     using G = nr::AddGeom<20, NSEQ>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");

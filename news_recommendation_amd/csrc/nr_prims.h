@@ -62,15 +62,17 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return a + b;
 }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
-// sum over the 16 lanes of a row (lanes with equal l >> 4), result in every lane of the row: four DPP-modified adds (quad_perm xor 1,
-// xor 2, row_half_mirror, row_mirror) instead of four ds_bpermute round trips
+// Lane exchange inside a row of 16 lanes (lanes with equal l >> 4) as ONE DPP-modified move: MODE 0: lane ^ 1, 1: lane ^ 2 (quad_perm),
+// 2: i <-> 7 - i inside each group of 8 (row_half_mirror), 3: i <-> 15 - i (row_mirror).  Every mode pairs lanes that differ in bit
+// MODE of the lane index and agree in the higher bits: enough for butterflies and recursive halving, no ds_bpermute round trip.
+template <int MODE>
+__device__ __forceinline__ float row_xchg(float v) {
+  constexpr int ctrl = MODE == 0 ? 0xB1 : MODE == 1 ? 0x4E : MODE == 2 ? 0x141 : 0x140;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a row, result in every lane of the row
 __device__ __forceinline__ float sum_row16(float v) {
-#define NR_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-  NR_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
-  NR_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
-  NR_DPP_ADD(0x141);   // row_half_mirror: lane i <-> 7 - i inside each group of 8
-  NR_DPP_ADD(0x140);   // row_mirror: lane i <-> 15 - i
-#undef NR_DPP_ADD
+  v += row_xchg<0>(v); v += row_xchg<1>(v); v += row_xchg<2>(v); v += row_xchg<3>(v);
   return v;
 }
 

@@ -107,7 +107,11 @@ class _PinnedRing:
         elif ring['evs'][i] is not None:
             ring['evs'][i].synchronize()
         buf = ring['bufs'][i]
-        torch.stack(parts, dim=dim, out=buf)
+        # numpy does the interleave on the calling thread: torch's CPU stack / reductions wake the whole intra-op pool, which costs
+        # milliseconds per call when the workers have gone to sleep between training steps (128-thread host)
+        bn = buf.numpy()
+        for j, part in enumerate(parts):
+            bn[(slice(None),) * dim + (j,)] = part.numpy()
         out = buf.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -342,6 +346,47 @@ def _wgrad(a, b, name):
 
 _ws = {}
 _side = {}
+_wg_side = {}
+# NR_WGRAD_OVERLAP=1 puts the weight-gradient GEMMs on a second stream (see side_wgrad).  Measured on MI355X at B = 512 (NRMS 5.51 vs
+# 5.55 ms, LSTUR 6.15 vs 6.10, NAML 11.07 vs 11.06 ms per step, A/B on one box): no gain -- each of these kernels fills the GPU on its own
+# -- and in data-parallel runs the GEMMs are more useful AFTER the embedding scatter, where they cover the table all-reduce.  Off by default.
+_WGRAD_OVERLAP = os.environ.get('NR_WGRAD_OVERLAP', '0') == '1'
+
+
+class side_wgrad:
+    """Weight-gradient GEMMs on a second HIP stream.  In the backward of an encoder the chain that matters for latency is
+    pooling backward -> attention backward -> dX GEMM -> embedding scatter (-> gradient exchange); the weight gradients
+    (dpre^T @ ctx, dqkv^T @ X: plain library GEMMs, MFMA bound) only have to be ready when the backward returns.  Issued on a side
+    stream they share the GPU with the VALU / bandwidth-bound kernels of the chain instead of extending it.
+
+        sw = side_wgrad(device)
+        dWa = sw.run(lambda: _wgrad(...))      # starts after everything enqueued on the current stream so far
+        ...                                    # more work on the current stream
+        sw.join(dWa, ...)                      # current stream waits; tensors handed over to it
+    """
+
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        self.st = None
+        if _WGRAD_OVERLAP:
+            self.st = _wg_side.get(device)
+            if self.st is None:
+                self.st = _wg_side[device] = torch.cuda.Stream(device=device)
+
+    def run(self, fn):
+        if self.st is None:
+            return fn()
+        self.st.wait_stream(self.cur)
+        with torch.cuda.stream(self.st):
+            return fn()
+
+    def join(self, *tensors):
+        if self.st is None:
+            return
+        self.cur.wait_stream(self.st)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.cur)
 
 
 def grad_target(param):
@@ -526,14 +571,20 @@ class _EncoderFn(torch.autograd.Function):
         _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                                 _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         d_qv = dq_part.sum(dim=0)[:qdim]
+        sw = side_wgrad(dev)
+        # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
+        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
+        dWa_ext = sw.run(lambda: _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))       # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                             n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
-        # ---- input gradient first: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
-        # data-parallel exchange; finishing it BEFORE the weight-gradient GEMMs lets its all-reduce (started by table_grad_ready on
-        # RCCL's stream) overlap with them ---------------------------------------------------------------------------------------------
+        # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
+        Xb_b = _bf16(Xb)
+        dW_ext = sw.run(lambda: _wgrad(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))       # [960, KP]
+        # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
+        # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
         dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
         d_table = d_x = None
         if gather:
@@ -547,11 +598,8 @@ class _EncoderFn(torch.autograd.Function):
                 table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
-        # ---- weight gradients: two plain GEMMs, dWa_ext = dpre^T @ [ctx | 1], dW_ext = dqkv^T @ [X | 1] -----------------------------
-        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        dWa_ext = _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]')                      # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        sw.join(dWa_ext, dW_ext)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
-        dW_ext = _wgrad(dqkv_b, _bf16(Xb), f'gemm_dWqkv[S={S}]')       # [960, KP]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)

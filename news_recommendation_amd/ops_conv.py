@@ -82,9 +82,10 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
-    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g."""
+    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.  With ``sw`` (ops.side_wgrad) the
+    weight-gradient GEMM runs on the side stream and the CALLER joins it (before the shared dpre workspace is written again)."""
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
@@ -95,8 +96,12 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT):
     _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_ex, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
           _ptr(dq_part), _ptr(WaT), _ptr(dgemm), n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
-    dpre_b = _bf16(dpre)
-    dWa_ext = ops._wgrad(dpre_b, _bf16(ctx_b), f'gemm_dWa[{tag}]')
+    dpre_b, ctx_bb = _bf16(dpre), _bf16(ctx_b)
+    if sw is not None:
+        dWa_ext = sw.run(lambda: ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]'))
+        sw.pending.append(dWa_ext)
+    else:
+        dWa_ext = ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]')
     return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
 
 
@@ -106,8 +111,11 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     lib = _lib()
     n_seq, S = st.n_seq, st.S
     dev = st.act.device
-    # additive backward needs contiguous [n_seq][D] gradients
-    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT)
+    # additive backward needs contiguous [n_seq][D] gradients.  The two weight-gradient GEMMs of this level (pooling, conv taps) go to the
+    # side stream: they overlap with the activation backward and the data-gradient conv, and are joined before this function returns
+    sw = ops.side_wgrad(dev)
+    sw.pending = []
+    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, sw)
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_KP, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
@@ -124,10 +132,11 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
             except (TypeError, RuntimeError):
                 taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
         return taps
-    taps = _timed(f'gemm_dWconv[{tag}]', wgrad)
+    taps = sw.run(lambda: _timed(f'gemm_dWconv[{tag}]', wgrad))
+    _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
+    sw.join(*taps, *sw.pending)
     d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
     d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
-    _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
     return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
 
 

@@ -186,18 +186,20 @@ __forceinline__ float shfl(float v, int src) {
   return r;
 }
 
-__forceinline__ float sum_row16(float v) {          // same pairing order as the DPP version: xor 1, xor 2, i <-> 7 - i, i <-> 15 - i
+template <int MODE>
+__forceinline__ float row_xchg(float v) {            // partner: lane ^ 1, lane ^ 2, i <-> 7 - i (groups of 8), i <-> 15 - i (rows of 16)
   nr_emu::BlockState* blk = nr_emu::g_blk;
   const int l = lane_id();
   nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
-  const int partner[4] = {l ^ 1, l ^ 2, (l & ~7) | (7 - (l & 7)), (l & ~15) | (15 - (l & 15))};
-  for (int s = 0; s < 4; ++s) {
-    memcpy(&ws.stage[l][0], &v, 4);
-    nr_emu::wave_sync();
-    float o; memcpy(&o, &ws.stage[partner[s]][0], 4);
-    nr_emu::wave_sync();
-    v += o;
-  }
+  const int partner = MODE == 0 ? (l ^ 1) : MODE == 1 ? (l ^ 2) : MODE == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15)));
+  memcpy(&ws.stage[l][0], &v, 4);
+  nr_emu::wave_sync();
+  float o; memcpy(&o, &ws.stage[partner][0], 4);
+  nr_emu::wave_sync();
+  return o;
+}
+__forceinline__ float sum_row16(float v) {
+  v += row_xchg<0>(v); v += row_xchg<1>(v); v += row_xchg<2>(v); v += row_xchg<3>(v);
   return v;
 }
 __forceinline__ void wave_barrier() { nr_emu::wave_sync(); }

@@ -83,5 +83,16 @@ def test_gru_lds_variant():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+def test_pool2_fwd_variant():
+    """NR_POOL2_FWD=1: the register-resident pooling forward of csrc/k_pool2.h (the backward of that file is the default and is
+    covered by test_additive_bwd_s20) against the same oracle; knobs are read once per process, hence the subprocess."""
+    import subprocess, sys, os
+    env = dict(os.environ, NR_POOL2_FWD='1')
+    code = ("from tests.backends import EmuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = EmuBackend(); "
+            "k.check_additive(be, S=20, n_seq=6); k.check_additive(be, S=20, n_seq=19); kc.check_additive_ex(be, S=20, n_seq=5)")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_dropout_mask_statistics(be):
     kc.check_dropout_mask_statistics(be)

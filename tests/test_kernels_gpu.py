@@ -93,6 +93,19 @@ def test_gru_register_only_variant():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+def test_pool2_fwd_variant():
+    """NR_POOL2_FWD=1: the register-resident pooling forward (csrc/k_pool2.h; off by default, its backward is the default)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NR_POOL2_FWD='1')
+    code = ("from tests.backends import GpuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = GpuBackend(); "
+            "k.check_additive(be, S=20, n_seq=1027); k.check_additive(be, S=20, n_seq=3); kc.check_additive_ex(be, S=20, n_seq=131)")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_dropout_mask_statistics(be):
     """Keep rate and decorrelation of the counter-based dropout generator on the hardware build (same check as on the emulator)."""
     kc.check_dropout_mask_statistics(be)

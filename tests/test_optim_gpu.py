@@ -161,13 +161,17 @@ def test_engine_adam_nrms_tracks_torch_adam():
         lb = torch.nn.functional.cross_entropy(b.forward_ids(cand, click), y)
         lb.backward()
         ob.step()
-        assert abs(la.item() - lb.item()) < 2e-4 * max(1.0, abs(la.item())), (step, la.item(), lb.item())
+        # lr = 1e-3 moves every weight by ~lr per step, in a rounding-noise direction where the gradient is noise: the losses drift apart
+        # by a few 1e-4 relative per step
+        assert abs(la.item() - lb.item()) < 2e-3 * max(1.0, abs(la.item())), (step, la.item(), lb.item())
         assert ob.check_views() and not ob.flat_g.any()
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        if k.endswith('W_K.bias'):
-            continue        # analytically zero gradient (a per-query shift of the scores cancels in exp / sum): Adam amplifies pure rounding noise
-        # Adam normalises the step: a gradient element whose sign is rounding noise moves by +-lr either way, hence the atol of 2 lr
-        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=1e-3, atol=2.5e-3, err_msg=k)
+        # Adam normalises the step: a gradient element whose sign is rounding noise moves by +-lr either way, every step (4 steps x 2 lr).
+        # Two gradients ARE rounding noise here: W_K.bias (a per-query shift of the scores cancels in exp / sum) and, at initialisation,
+        # the pooling bias (sum_s ds = 0 and tanh' ~ 1): for those only the bound holds, for the others nearly all elements must agree
+        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=1e-3, atol=8.5e-3, err_msg=k)
+        if k.endswith(('W_K.bias', 'additive_attention.linear.bias')):
+            continue
         frac_close = (torch.abs(pa - pb) < 1e-5).float().mean().item()
         assert frac_close > 0.95, (k, frac_close)
     # optimiser state in torch's format round-trips into torch.optim.Adam
