@@ -7,8 +7,9 @@ How the drop-in works:
   * sys.path = [<this package>/dropin, <repo root>, <reference>/src, ...]: ``import model.NRMS`` resolves to the
     engine's ``dropin/model`` package (same class names / signatures / state_dict keys), while ``config``,
     ``dataset``, ``evaluate`` and ``train`` resolve to the reference's read-only files;
-  * two shims for this container's package set: a no-op ``torch.utils.tensorboard.SummaryWriter``
-    when tensorboard is not installed, and ``numpy.Inf`` (removed in NumPy 2, used at train.py:31);
+  * three shims for this container's package set: a no-op ``torch.utils.tensorboard.SummaryWriter``
+    when tensorboard is not installed, ``numpy.Inf`` (removed in NumPy 2, used at train.py:31), and ``torch.load``
+    defaulting to ``weights_only=False`` as it did when the reference was written (its checkpoints hold a numpy scalar);
   * cwd = RUN_DIR, which holds ./data (reference formats), ./checkpoint, ./runs -- every reference path is
     cwd-relative;
   * under torchrun (WORLD_SIZE > 1) each rank pins its own GPU (so the reference's hard-coded ``cuda:0`` is the local
@@ -26,6 +27,20 @@ def install_shims():
     import numpy
     if not hasattr(numpy, 'Inf'):
         numpy.Inf = numpy.inf
+    # torch >= 2.6 defaults torch.load(weights_only=True); the reference's checkpoints (train.py:268-275) carry a numpy scalar
+    # ('early_stop_value') and are loaded with a bare torch.load(path) (train.py:149, evaluate.py:287), which that default rejects.
+    # The reference was written for the old default: restore it for ITS OWN checkpoint files.
+    import functools
+    import torch
+    if not getattr(torch.load, '_nr_shim', False):
+        orig = torch.load
+
+        @functools.wraps(orig)
+        def load(*a, **k):
+            k.setdefault('weights_only', False)
+            return orig(*a, **k)
+        load._nr_shim = True
+        torch.load = load
     try:
         import torch.utils.tensorboard  # noqa: F401
     except Exception:
@@ -103,7 +118,21 @@ def narrow_visibility(env):
     env['HIP_VISIBLE_DEVICES'] = str(lr)
 
 
-def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False):
+def apply_overrides(model_name, overrides):
+    """``--set knob=value``: override attributes of the reference's config class IN MEMORY (src/config.py is the knob surface; its sizes
+    -- num_words, num_users, ... -- are meant to be hand-edited after preprocessing, README.md:62; the file itself stays untouched).
+    The reference's scripts pick the class up from sys.modules (train.py:19, evaluate.py:16, dataset.py:11)."""
+    if not overrides:
+        return
+    import importlib
+    cfg = getattr(importlib.import_module('config'), f'{model_name}Config')
+    for kv in overrides:
+        k, v = kv.split('=', 1)
+        old = getattr(cfg, k)
+        setattr(cfg, k, (v == 'True') if isinstance(old, bool) else type(old)(v))
+
+
+def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False, overrides=()):
     here = os.path.dirname(os.path.abspath(__file__))
     repo = os.path.dirname(here)
     reference_src = os.path.abspath(reference_src)
@@ -116,6 +145,7 @@ def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False):
         sys.path.insert(0, p)
     install_shims()
     os.chdir(workdir)
+    apply_overrides(model_name, overrides)
     _patch_dp(model_name)
     if fast_eval:
         # the batched evaluation driver behind the reference's own name: train.py's `from evaluate import evaluate` (train.py:12)
@@ -136,8 +166,9 @@ def main(argv=None):
     ap.add_argument('--model', default=os.environ.get('MODEL_NAME', 'NRMS'), choices=['NRMS', 'NAML', 'LSTUR'])
     ap.add_argument('--fast-eval', action='store_true',
                     help="use the batched evaluation driver (evaluate_fast.py) instead of the reference's per-impression loop")
+    ap.add_argument('--set', nargs='*', default=[], metavar='KNOB=VALUE', help="override attributes of the reference's config class in memory")
     a = ap.parse_args(argv)
-    run(a.script, a.reference, a.workdir, a.model, a.fast_eval)
+    run(a.script, a.reference, a.workdir, a.model, a.fast_eval, a.set)
 
 
 if __name__ == '__main__':
