@@ -73,6 +73,14 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
                 const uint16_t* Wp, const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save,
                 uint16_t* vt_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
 
+/* nr_mhsa_fwd_ex with per-sequence KEY LENGTHS: key_len int32[n_seq] (NULL: S).  Keys at positions >= key_len[seq] get zero attention
+ * weight for every query of that sequence: the `length` argument of MultiHeadSelfAttention.forward (multihead_self.py:60-70: the mask
+ * multiplies exp(scores) before the row sum).  Also how sequences shorter than an instantiated S (config knobs num_words_title,
+ * num_clicked_news_a_user) are run: zero-padded to S by the host, key_len = their length, pooled with nr_additive_fwd_v(valid). */
+int nr_mhsa_fwd_len(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                    const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save,
+                    const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+
 /* Same, and additionally (x_save != NULL, training) emits the dropout-masked bf16 token matrix x_save[n_seq*S][NR_KP] (column D = 1.0,
  * rest of the K padding 0) that the weight-gradient GEMM dW = dqkv^T @ X needs -- what nr_gather_bf16 would recompute. */
 int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense,
@@ -107,6 +115,10 @@ int nr_score_csr(const float* news, const float* users, const int32_t* cand_idx,
 int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm,
                 int ldc, const float* attn_w, const float* g_out, uint16_t* dqkv, int64_t n_seq, int S,
                 float p_drop, uint64_t seed, void* stream);
+/* nr_attn_bwd for a forward that ran with key lengths (nr_mhsa_fwd_len): the recomputed attention probabilities use the same mask. */
+int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
+                    const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                    uint64_t seed, void* stream);
 
 /* Backward of AdditiveAttention (additive.py:35-52) up to the pre-activation: dpre bf16[n_seq*S][NR_QP] and
  * per-workgroup partial sums of the query-vector gradient dq_part f32[nr_additive_bwd_grid()][NR_QP]
@@ -166,6 +178,10 @@ int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uin
  * activations) so several texts can share one seed. */
 int nr_conv3_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
                  uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
+/* nr_conv3_fwd for texts of `valid` (1..S) tokens zero-padded to an instantiated S: positions >= valid enter the convolution as zero
+ * vectors (what Conv2d's own padding puts after the last token), and are excluded downstream by nr_additive_fwd_v(valid). */
+int nr_conv3_fwd_v(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
+                   uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
 /* Data gradient of the convolution: dx bf16 [n_seq*S][NR_KP] (cols < D) from dy_pad (seqpad) and Wd. */
 int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int64_t n_seq, int S, void* stream);
 /* Gradient through dropout+relu: dy_pad[row(q,s)] = (dact_gemm[t] + attn_w[t] * g_out[q]) * [act[t] != 0] / (1 - p_drop);
@@ -178,6 +194,11 @@ int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, con
  * directly (NAML final_attention over the 4 views, news_encoder.py:108-114; NAML user encoder, user_encoder.py:18). */
 int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
                        uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, void* stream);
+/* nr_additive_fwd_ex pooling only the first `valid` (1..S) tokens of every sequence: tokens >= valid get softmax weight exactly 0
+ * (attn_w rows are written for all S positions), so they drop out of the pooled vector and -- through the zero weights -- out of
+ * every gradient of nr_additive_bwd_ex.  Sequences shorter than an instantiated S are zero-padded by the host. */
+int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
+                      uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, void* stream);
 /* Input gradient of a pooling level: dx[t][:] = dgemm[t][:] + attn_w[t] * g_out[seq(t)][:], f32 [n_seq*S][D]; view_major != 0
  * stores row t at (t % S) * n_seq + t / S (S contiguous [n_seq][D] blocks, one per view). */
 int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const float* g_out, float* dx, int64_t n_seq, int S,

@@ -19,6 +19,9 @@ SIGNATURES = {
     'nr_pack_additive': ([_P, _P, _P, c_int, _P, _P, _P, _P], c_int),
     'nr_mhsa_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_mhsa_fwd_ex': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_mhsa_fwd_len': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_attn_bwd_len': ([_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_additive_fwd_v': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_bwd_grid': ([c_int64, c_int], c_int64),
     'nr_additive_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
@@ -35,6 +38,7 @@ SIGNATURES = {
     'nr_supported_conv_len': ([c_int], c_int),
     'nr_pack_conv': ([_P, _P, c_int, c_int, _P, _P, _P, _P], c_int),
     'nr_conv3_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, c_int64, _P], c_int),
+    'nr_conv3_fwd_v': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, c_int64, _P], c_int),
     'nr_conv3_dgrad': ([_P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_conv_act_bwd': ([_P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, c_float, _P], c_int),
     'nr_additive_fwd_ex': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P], c_int),

@@ -40,6 +40,8 @@ struct AdditiveParams {
   int64_t out_b_stride;
   float* attn_w;       // [n_seq][S] or null
   int64_t n_seq;
+  int valid;           // tokens s >= valid of every sequence are excluded from the softmax (weight exactly 0); 0 or >= S: all S tokens.
+                       // Sequences shorter than an instantiated S are zero-padded by the host and pooled with valid = their length
 };
 
 // parameters of the pooling backward kernels (k_bwd.h additive_bwd_kernel, k_pool2.h pool2_bwd_kernel)
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p)
   // ---- softmax over the S tokens of each sequence (one wave per sequence) ---------------------------------
   for (int seq = w; seq < NSEQ; seq += NW) {
     const int r = seq * S + l;
-    const bool live = l < S;
+    const bool live = l < ((p.valid > 0 && p.valid < S) ? p.valid : S);
     float v = -3.0e38f;
     if (live) {
       v = 0.0f;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sum += shfl_xor(sum, m);
     float wt = e / sum;
-    if (live) {
+    if (l < S) {                              // masked tokens (valid <= l < S) get weight 0: they drop out of the sum and of every gradient
       wl[r] = wt;
       if (p.attn_w != nullptr && seq0 + seq < p.n_seq) p.attn_w[(seq0 + seq) * S + l] = wt;
     }

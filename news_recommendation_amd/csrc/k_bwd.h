@@ -54,6 +54,7 @@ struct AttnBwdParams {
   const float* g_out;    // [n_seq][D]  gradient of the pooled vector
   u16* dqkv;             // [n_seq*S][LDG] bf16 (padding columns are never written; host zero-fills once)
   int64_t n_seq;
+  const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
 };
 
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const int64_t seq = pair / H;
     const int hd = (int)(pair - seq * H);
     const int64_t tok0 = seq * S;
+    const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
     store_lds(pair);
     const int64_t next = pair + stride;
     if (next < n_pairs) load_regs(next);          // prefetch the next pair while this one is computed
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       qf[t] = frag_d(Qm, t * 16 + li);
       // free k-slot DK = key-padding mask (see the forward kernel): scores of key rows >= S come out at -29952 -> exp2 = 0.
       // The extra "feature" only reaches output rows d = DK, which are never stored.
-      if (8 * g + 4 == DK) { qf[t][4] = ONE; kf[t][4] = (t * 16 + li < S) ? (u16)0 : BF16_NEG_BIG; }
+      if (8 * g + 4 == DK) { qf[t][4] = ONE; kf[t][4] = (t * 16 + li < klen) ? (u16)0 : BF16_NEG_BIG; }
       u16x8 cf = frag_d(dCm, t * 16 + li);
       cperm[t] = frag_dc_perm(t * 16 + li);
 #pragma unroll

@@ -46,6 +46,8 @@ struct ConvParams {
   int relu_drop;           // 1: out = dropout2(relu(y)), col D = 1.0, cols > D zero;  0: out = y (cols >= D untouched)
   int64_t n_seq;
   int64_t tok_offset;      // added to the token index in the dropout counters (keeps title / abstract streams apart)
+  int valid;               // gather form: positions s >= valid of every sequence are ZERO vectors (texts shorter than S are zero-padded by
+                           // the host: the convolution then sees the reference's zero padding right after the last real token); 0: all S
   DropCfg dc;
   int debug;               // profiling only (NR_CONV_DEBUG): 1 = skip the token gather, 2 = skip the GEMM, 4 = skip the output stores
 };
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
   if (p.ids != nullptr) {
     for (int r = tid; r < Gm::TOK; r += WG) {
       int v = -1;
-      if (tok0 + r < tok_total) {
+      if (tok0 + r < tok_total && (p.valid <= 0 || (r % S) < p.valid)) {
         int64_t id = p.ids[tok0 + r];
         id = id < 0 ? 0 : (id >= p.num_rows ? p.num_rows - 1 : id);
         v = (int)id;

@@ -58,6 +58,8 @@ struct MhsaParams {
   u16* vt_save;            // training: [n_seq][H][DK][SP4]  (dv-major V blocks) or null
   u16* x_save;             // training, optional: [n_seq*S][KP] dropout-masked bf16 tokens, col D = 1.0 (weight-gradient GEMM operand)
   int64_t n_seq;
+  const int32_t* key_len;  // optional [n_seq]: keys >= key_len[seq] get zero attention weight for every query (the `length` argument of
+                           // MultiHeadSelfAttention.forward, multihead_self.py:60-70; also how sequences shorter than S are padded); null: S
   DropCfg dc;
   int debug;               // profiling only (NR_MHSA_DEBUG, mhsa_fwd2 DBG instantiation): 1 skip the token gather, 2 skip the projection
                            // MFMAs, 4 skip the attention phase, 8 skip the training saves (Q/K/V^T/X), 16 skip the ctx stores
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
       const int pidx = w + NW * i;
       if (pidx < NSEQ * nh) {
         const int seq = pidx / nh, hd = pidx - seq * nh;
+        const int klen = (p.key_len != nullptr && seq0 + seq < p.n_seq) ? clamp_len(p.key_len[seq0 + seq], S) : S;
         u16x8 kf[Gm::QT], qf[Gm::QT];
 #pragma unroll
         for (int t = 0; t < Gm::QT; ++t) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p)
           u16x4 qhi = (8 * g + 4 < DK) ? *(const u16x4*)(qp_ + 4) : z;
           // k-slot DK (free: DK = 20 < 32) carries the key-padding mask: q = 1, k = -big on key rows >= S, so padded keys
           // come out of the MFMA at -29952 and exp2 turns them into exact zeros -- no per-element select
-          if (8 * g + 4 == DK) { qhi[0] = BF16_ONE; khi[0] = (t * 16 + li < S) ? (u16)0 : BF16_NEG_BIG; }
+          if (8 * g + 4 == DK) { qhi[0] = BF16_ONE; khi[0] = (t * 16 + li < klen) ? (u16)0 : BF16_NEG_BIG; }
           kf[t] = cat8(klo, khi);
           qf[t] = cat8(qlo, qhi);
         }

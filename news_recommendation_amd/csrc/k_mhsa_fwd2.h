@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
 
   const float c2 = LOG2E / sqrtf((float)DK), clamp2 = EXP_CLAMP * LOG2E;
   constexpr int NCHUNK = 3 * NGROUPS;
+  int klen[Gm::TPW];                              // key length of each of the wave's titles (MhsaParams::key_len), S when absent
+#pragma unroll
+  for (int sq = 0; sq < Gm::TPW; ++sq)
+    klen[sq] = (p.key_len != nullptr && seq0 + sq < p.n_seq) ? uniform(clamp_len(p.key_len[seq0 + sq], S)) : S;
 
   u16x4 qr[5][MT], kr[5][MT], vr[5][MT];       // [n-tile of the head group][token tile]
 
@@ -204,12 +208,13 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(Mhs
 #pragma unroll
           for (int sq = 0; sq < Gm::TPW; ++sq) {
             const int i0 = (sq * S) / 16;             // the title's tokens live in token tiles i0, i0 + 1
+            const int kend = sq * S + klen[sq];       // keys of this title beyond its key length are masked like foreign tokens
             u16x8 ka[2], qa[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               const int i = i0 + t;
               const int tokl = i * 16 + li;           // wave-local token of this lane (A row / B column)
-              const bool mine = tokl >= sq * S && tokl < (sq + 1) * S;
+              const bool mine = tokl >= sq * S && tokl < kend;
               u16x4 klo = in_a ? kr[ta][i] : Z4, khi = in_b ? kr[tb][i] : Z4;
               u16x4 qlo = qr[ta][i], qhi = qr[tb][i];
               if (mslot_a) { klo[0] = mine ? (u16)0 : BF16_NEG_BIG; qlo[0] = BF16_ONE; }

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
   wave_barrier();
 
   // ---- softmax over the 20 tokens of each title: lane l owns token l (and l + 64 for l < 16) ---------------------------------------------
+  const int nvalid = (p.valid > 0 && p.valid < S) ? p.valid : S;       // AdditiveParams::valid
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int t = l + 64 * k;
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
       const int base = (t / S) * S;
       float mx = -3.0e38f;
 #pragma unroll
-      for (int j = 0; j < S; ++j) mx = fmaxf(mx, sc[base + j]);
+      for (int j = 0; j < S; ++j) mx = j < nvalid ? fmaxf(mx, sc[base + j]) : mx;
       float sum = 0.0f;
 #pragma unroll
-      for (int j = 0; j < S; ++j) sum += fast_exp(sc[base + j] - mx);
-      const float wt = fast_exp(sc[t] - mx) / sum;
+      for (int j = 0; j < S; ++j) sum += j < nvalid ? fast_exp(sc[base + j] - mx) : 0.0f;
+      const float wt = t - base < nvalid ? fast_exp(sc[t] - mx) / sum : 0.0f;
       wl[t] = wt;
       if (p.attn_w != nullptr && tok0 + t < tok_total) p.attn_w[tok0 + t] = wt;
     }

@@ -98,6 +98,8 @@ __device__ __forceinline__ void unit_range(int ntiles, int MT, int w, int nw, in
   if (m_end > MT) m_end = MT;
 }
 
+__device__ __forceinline__ int clamp_len(int v, int S) { return v < 0 ? 0 : (v > S ? S : v); }
+
 __device__ __forceinline__ u16x4 pack4(f32x4 v) {
   u16x4 o;
   o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);

@@ -110,9 +110,15 @@ int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim
   return check_launch("nr_pack_additive");
 }
 
+int nr_mhsa_fwd_len(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                    const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, const int32_t* key_len,
+                    int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+
 int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
                    const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, int64_t n_seq,
-                   int S, float p_drop, uint64_t seed, void* stream);
+                   int S, float p_drop, uint64_t seed, void* stream) {
+  return nr_mhsa_fwd_len(ids, table, num_rows, x_dense, Wp, bp, ctx, q_save, k_save, vt_save, x_save, nullptr, n_seq, S, p_drop, seed, stream);
+}
 
 int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
                 const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, int64_t n_seq, int S,
@@ -120,9 +126,9 @@ int nr_mhsa_fwd(const int64_t* ids, const float* table, int64_t num_rows, const 
   return nr_mhsa_fwd_ex(ids, table, num_rows, x_dense, Wp, bp, ctx, q_save, k_save, vt_save, nullptr, n_seq, S, p_drop, seed, stream);
 }
 
-int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
-                   const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, int64_t n_seq,
-                   int S, float p_drop, uint64_t seed, void* stream) {
+int nr_mhsa_fwd_len(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
+                    const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, const int32_t* key_len,
+                    int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
   if (!Wp || !bp || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_mhsa_fwd: bad argument");
   if ((q_save != nullptr) != (k_save != nullptr) || (q_save != nullptr) != (vt_save != nullptr))
     return fail(NR_ERR_BADARG, "nr_mhsa_fwd: q_save / k_save / vt_save must be given together");
@@ -132,7 +138,7 @@ int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, con
   if (n_seq == 0) return NR_OK;
   nr::MhsaParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_dense = x_dense;
-  p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
+  p.Wp = Wp; p.bp = bp; p.ctx = ctx; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.debug = 0;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.x_save = nullptr;
   bool x_done = false;
   if (S == 20) {
@@ -175,15 +181,23 @@ int nr_mhsa_fwd_ex(const int64_t* ids, const float* table, int64_t num_rows, con
 int nr_supported_pool_len(int S) { return (S == 4 || S == 20 || S == 50) ? 1 : 0; }
 int nr_supported_conv_len(int S) { return (S == 20 || S == 50) ? 1 : 0; }
 
+int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
+                      uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, void* stream);
+
 int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
                        uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, void* stream) {
-  if (!ctx || !Wap || !bap || !qvp || (!out && !out_b) || n_seq < 0) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
+  return nr_additive_fwd_v(ctx, Wap, bap, qvp, out, out_stride, out_b, out_b_stride, attn_w, n_seq, S, S, stream);
+}
+
+int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
+                      uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || (!out && !out_b) || n_seq < 0 || valid < 1 || valid > S) return fail(NR_ERR_BADARG, "nr_additive_fwd: bad argument");
   if ((out && (out_stride < NR_D || (out_stride & 3))) || (out_b && (out_b_stride < NR_KP || (out_b_stride & 7))))
     return fail(NR_ERR_BADARG, "nr_additive_fwd: bad output stride");
   if (n_seq == 0) return NR_OK;
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
-  p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq;
+  p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq; p.valid = valid;
   // NR_POOL2_FWD=1 selects the register-resident forward (k_pool2.h).  Measured at B = 512: 286 us vs 265 us for the LDS-tile kernel
   // below -- one workgroup per CU alternates between loading its 205 KB of ctx rows and computing, with nothing to overlap either phase,
   // while 5 small workgroups per CU interleave naturally; the BACKWARD of k_pool2.h is the default (400 us vs 570 us).
@@ -228,16 +242,26 @@ int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, 
   return nr_additive_fwd_ex(ctx, Wap, bap, qvp, out, NR_D, nullptr, 0, attn_w, n_seq, S, stream);
 }
 
+int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
+                    const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                    uint64_t seed, void* stream);
+
 int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
                 const float* attn_w, const float* g_out, uint16_t* dqkv, int64_t n_seq, int S, float p_drop, uint64_t seed,
                 void* stream) {
+  return nr_attn_bwd_len(q_save, k_save, vt_save, dctx_gemm, ldc, attn_w, g_out, dqkv, nullptr, n_seq, S, p_drop, seed, stream);
+}
+
+int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
+                    const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                    uint64_t seed, void* stream) {
   if (!q_save || !k_save || !vt_save || !dctx_gemm || !attn_w || !g_out || !dqkv || n_seq < 0 || ldc < NR_D || (ldc & 3))
     return fail(NR_ERR_BADARG, "nr_attn_bwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_bwd: dropout probability out of range");
   if (n_seq == 0) return NR_OK;
   nr::AttnBwdParams p;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
-  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed);
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
   // grid (used by the tests to force many pairs per wave on small inputs).
@@ -426,14 +450,23 @@ static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what)
   return check_launch(what);
 }
 
+int nr_conv3_fwd_v(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
+                   uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
+
 int nr_conv3_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
                  uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, int64_t tok_offset, void* stream) {
-  if (!ids || !table || num_rows <= 0 || !Wc || !bc || !act || n_seq < 0 || tok_offset < 0) return fail(NR_ERR_BADARG, "nr_conv3_fwd: bad argument");
+  return nr_conv3_fwd_v(ids, table, num_rows, Wc, bc, act, x_save, n_seq, S, S, p_drop, seed, tok_offset, stream);
+}
+
+int nr_conv3_fwd_v(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wc, const float* bc, uint16_t* act,
+                   uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream) {
+  if (!ids || !table || num_rows <= 0 || !Wc || !bc || !act || n_seq < 0 || tok_offset < 0 || valid < 1 || valid > S)
+    return fail(NR_ERR_BADARG, "nr_conv3_fwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_conv3_fwd: dropout probability out of range");
   if (n_seq == 0) return NR_OK;
   nr::ConvParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.x_pad = nullptr; p.Wc = Wc; p.bc = bc; p.out = act; p.x_save = x_save;
-  p.relu_drop = 1; p.n_seq = n_seq; p.tok_offset = tok_offset; p.dc = make_drop(p_drop, seed);
+  p.relu_drop = 1; p.n_seq = n_seq; p.tok_offset = tok_offset; p.valid = valid; p.dc = make_drop(p_drop, seed);
   return launch_conv(p, S, stream, "nr_conv3_fwd");
 }
 
@@ -442,7 +475,7 @@ int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int
   if (n_seq == 0) return NR_OK;
   nr::ConvParams p;
   p.ids = nullptr; p.table = nullptr; p.num_rows = 0; p.x_pad = dy_pad; p.Wc = Wd; p.bc = nullptr; p.out = dx; p.x_save = nullptr;
-  p.relu_drop = 0; p.n_seq = n_seq; p.tok_offset = 0; p.dc = make_drop(0.0f, 0);
+  p.relu_drop = 0; p.n_seq = n_seq; p.tok_offset = 0; p.valid = 0; p.dc = make_drop(0.0f, 0);
   return launch_conv(p, S, stream, "nr_conv3_dgrad");
 }
 

@@ -23,8 +23,9 @@ class MultiHeadSelfAttention(nn.Module):
                 nn.init.xavier_uniform_(m.weight, gain=1)
 
     def forward(self, Q, K=None, V=None, length=None):
-        """Q: [batch, S, d_model] -> [batch, S, d_model] (heads concatenated, no output projection).
-        Only the self-attention form the reference's models use (K = V = Q, no length mask) is implemented."""
-        if K is not None or V is not None or length is not None:
-            raise NotImplementedError("only K=V=Q with length=None is used by NRMS (SURVEY.md 5.9 #3) and implemented")
-        return ops.mhsa_dense(Q, self)
+        """Q: [batch, S, d_model] (S <= 50) -> [batch, S, d_model] (heads concatenated, no output projection).  ``length`` (int tensor
+        [batch]): keys at positions >= length[b] are masked for every query (multihead_self.py:60-70).  The cross-attention form
+        (K or V different from Q) is used by none of the reference's models and is not implemented."""
+        if (K is not None and K is not Q) or (V is not None and V is not Q):
+            raise NotImplementedError("MultiHeadSelfAttention: only self-attention (K = V = Q) is implemented; no reference model passes K or V")
+        return ops.mhsa_dense(Q, self, length)

@@ -202,6 +202,29 @@ def check_ids(ids, num_rows, what="index"):
         raise IndexError(f"{what} out of range: got [{lo}, {hi}], table has {num_rows} rows")
 
 
+def padded_len(L, what="sequence length"):
+    """Instantiated sequence length that holds a sequence of L items: 20 or 50 (the kernels are templated on those).  Shorter
+    sequences are zero-padded by the host and run with key lengths / a pooling length of L, so that any num_words_title /
+    num_clicked_news_a_user in [1, 50] works (src/config.py:21-22)."""
+    if L < 1 or L > 50:
+        raise NotImplementedError(f"{what} must be in [1, 50] (got {L}): the HIP kernels are instantiated for 20 and 50 positions")
+    return 20 if L <= 20 else 50
+
+
+_len_cache = {}
+
+
+def uniform_lengths(n, L, device):
+    """int32 [n] filled with L on `device` (cached)."""
+    k = (n, L, str(device))
+    t = _len_cache.get(k)
+    if t is None:
+        if len(_len_cache) > 64:
+            _len_cache.clear()
+        t = _len_cache[k] = torch.full((n,), L, dtype=torch.int32, device=device)
+    return t
+
+
 def new_seed():
     """Seed for the kernels' counter-based dropout RNG, drawn from torch's CPU generator (torch.manual_seed-able)."""
     return int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -512,13 +535,17 @@ class _EncoderFn(torch.autograd.Function):
     (dense form, no dropout)."""
 
     @staticmethod
-    def forward(ctx, ids, table, x_dense, Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, S, p_drop, seed):
+    def forward(ctx, ids, table, x_dense, Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, S, p_drop, seed, valid=None):
+        """S: instantiated length the inputs are padded to; valid (<= S): real length -- positions >= valid are masked as attention
+        keys (nr_mhsa_fwd_len) and excluded from the pooling (nr_additive_fwd_v), so they receive and produce zero gradients."""
         lib = _lib()
         gather = ids is not None
         dev = Wq.device
         n_seq = ids.shape[0] if gather else x_dense.shape[0]
         if not lib.nr_supported_seq_len(S):
             raise NotImplementedError(f"sequence length {S} is not instantiated in the HIP kernels (20, 50)")
+        valid = S if valid is None else int(valid)
+        key_len = uniform_lengths(n_seq, valid, dev) if valid < S else None
         need_grad = any(ctx.needs_input_grad)
         Wp, bp = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
@@ -537,19 +564,20 @@ class _EncoderFn(torch.autograd.Function):
             ids_c = ids.contiguous()
             tab = table.detach()
             assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
-            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_ex, _ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), n_seq, S, p_drop, seed, _stream())
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_len, _ptr(ids_c), _ptr(tab), tab.shape[0], None, _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
             xd = None
         else:
             ids_c = None
             xd = _f32c(x_dense)
-            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_ex, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
-                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), n_seq, S, p_drop, seed, _stream())
+            _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_len, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
+                                _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
         out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-        _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
+        _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw),
+              n_seq, S, valid, _stream())
         if need_grad:
-            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT)
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
             ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
             ctx.sorted = sort_ids_async(ids_c, table.shape[0]) if gather and ctx.needs_input_grad[1] else None
@@ -558,7 +586,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT = ctx.saved_tensors
+        ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT, key_len = ctx.saved_tensors
         S, p_drop, seed, n_seq, qdim, gather = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
@@ -577,8 +605,8 @@ class _EncoderFn(torch.autograd.Function):
         dWa_ext = sw.run(lambda: _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))       # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
-        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
-                            n_seq, S, p_drop, seed, _stream())
+        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
+                            _ptr(key_len), n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)
@@ -602,7 +630,7 @@ class _EncoderFn(torch.autograd.Function):
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
-        return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None)
+        return (None, d_table, d_x, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], d_Wa, d_ba, d_qv, None, None, None, None)
 
 
 def encode_titles(ids, table, mhsa, additive, p_drop, training):
@@ -611,18 +639,26 @@ def encode_titles(ids, table, mhsa, additive, p_drop, training):
     check_dims(table.shape[1], mhsa.num_attention_heads, additive.linear.weight.shape[0])
     p = float(p_drop) if training else 0.0
     seed = new_seed() if p > 0 else 0
+    L = ids.shape[1]
+    S = padded_len(L, "num_words_title")
+    if S != L:
+        ids = torch.nn.functional.pad(ids, (0, S - L))        # padded positions: masked keys, outside the pooling
     return _EncoderFn.apply(ids, table, None, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias,
                             mhsa.W_V.weight, mhsa.W_V.bias, additive.linear.weight, additive.linear.bias,
-                            additive.attention_query_vector, ids.shape[1], p, seed)
+                            additive.attention_query_vector, S, p, seed, L)
 
 
 def encode_dense(x, mhsa, additive):
     """NRMS user encoder on a dense [n_seq, S, D] float tensor."""
     _require_cuda(x, "clicked_news_vector")
     check_dims(x.shape[2], mhsa.num_attention_heads, additive.linear.weight.shape[0])
+    N = x.shape[1]
+    S = padded_len(N, "num_clicked_news_a_user")
+    if S != N:
+        x = torch.nn.functional.pad(x, (0, 0, 0, S - N))      # zero rows: masked keys, outside the pooling; their gradient is sliced off
     return _EncoderFn.apply(None, None, x, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias,
                             mhsa.W_V.weight, mhsa.W_V.bias, additive.linear.weight, additive.linear.bias,
-                            additive.attention_query_vector, x.shape[1], 0.0, 0)
+                            additive.attention_query_vector, S, 0.0, 0, N)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -672,10 +708,11 @@ def score_csr(news_mat, user_mat, cand_idx, cand_ptr, user_idx):
 # stand-alone L0 modules (same math, un-fused entry points for callers that use the primitives directly)
 # ----------------------------------------------------------------------------------------------------------
 class _MhsaFn(torch.autograd.Function):
-    """MultiHeadSelfAttention.forward(Q) with K=V=Q, length=None (multihead_self.py:46-75) on a dense input."""
+    """MultiHeadSelfAttention.forward(Q, length=length) with K=V=Q (multihead_self.py:46-75) on a dense input already padded to an
+    instantiated length; key_len int32 [n_seq] or None."""
 
     @staticmethod
-    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv):
+    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv, key_len=None):
         lib = _lib()
         n_seq, S, _ = x.shape
         if not lib.nr_supported_seq_len(S):
@@ -691,16 +728,16 @@ class _MhsaFn(torch.autograd.Function):
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
-        _call('nr_mhsa_fwd', lib.nr_mhsa_fwd, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf), _ptr(qs), _ptr(ks), _ptr(vts),
-                            n_seq, S, 0.0, 0, _stream())
+        _call('nr_mhsa_fwd', lib.nr_mhsa_fwd_len, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf), _ptr(qs), _ptr(ks), _ptr(vts), None,
+                            _ptr(key_len), n_seq, S, 0.0, 0, _stream())
         if need_grad:
-            ctx.save_for_backward(xd, qs, ks, vts, Wp)
+            ctx.save_for_backward(xd, qs, ks, vts, Wp, key_len)
         return _bf16(cbuf)[:, :NR_D].float().view(n_seq, S, NR_D)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib()
-        xd, qs, ks, vts, Wp = ctx.saved_tensors
+        xd, qs, ks, vts, Wp, key_len = ctx.saved_tensors
         n_seq, S, _ = xd.shape
         dev = xd.device
         ntok = n_seq * S
@@ -708,7 +745,8 @@ class _MhsaFn(torch.autograd.Function):
         zw = torch.zeros(n_seq, S, dtype=torch.float32, device=dev)
         zg = torch.zeros(n_seq, NR_D, dtype=torch.float32, device=dev)
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)
-        _call('nr_attn_bwd', lib.nr_attn_bwd, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), n_seq, S, 0.0, 0, _stream())
+        _call('nr_attn_bwd', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), _ptr(key_len),
+              n_seq, S, 0.0, 0, _stream())
         dqkv_b = _bf16(dqkv)
         Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
         _call('nr_gather_bf16', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
@@ -716,24 +754,40 @@ class _MhsaFn(torch.autograd.Function):
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         dX = torch.mm(dqkv_b, _bf16(untile(Wp, 3 * NR_NP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D)
-        return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2]
+        return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], None
 
 
-def mhsa_dense(x, mhsa):
+def mhsa_dense(x, mhsa, length=None):
+    """MultiHeadSelfAttention.forward(Q, length=length), K = V = Q.  Any sequence length in [1, 50]: the input is zero-padded to an
+    instantiated length and the padding is masked as keys; `length` (int tensor [batch], multihead_self.py:60-70) masks keys per
+    sequence on top of that.  Rows of padded query positions are sliced off the result."""
     _require_cuda(x, "MultiHeadSelfAttention input")
     check_dims(x.shape[2], mhsa.num_attention_heads)
-    return _MhsaFn.apply(x, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias, mhsa.W_V.weight, mhsa.W_V.bias)
+    n_seq, L, _ = x.shape
+    S = padded_len(L, "sequence length")
+    key_len = None
+    if length is not None:
+        key_len = length.to(device=x.device, dtype=torch.int32).reshape(-1).clamp(max=L).contiguous()
+        if key_len.numel() != n_seq:
+            raise ValueError(f"length must have one entry per sequence ({n_seq}), got {key_len.numel()}")
+    elif S != L:
+        key_len = uniform_lengths(n_seq, L, x.device)
+    if S != L:
+        x = torch.nn.functional.pad(x, (0, 0, 0, S - L))
+    y = _MhsaFn.apply(x, mhsa.W_Q.weight, mhsa.W_Q.bias, mhsa.W_K.weight, mhsa.W_K.bias, mhsa.W_V.weight, mhsa.W_V.bias, key_len)
+    return y[:, :L] if S != L else y
 
 
 class _AdditiveFn(torch.autograd.Function):
     """AdditiveAttention.forward (additive.py:27-53) on a dense [n_seq, S, D] input."""
 
     @staticmethod
-    def forward(ctx, x, Wa, ba, qv):
+    def forward(ctx, x, Wa, ba, qv, valid=None):
         lib = _lib()
         n_seq, S, _ = x.shape
         if not lib.nr_supported_seq_len(S):
             raise NotImplementedError(f"sequence length {S} is not instantiated in the HIP kernels (20, 50)")
+        valid = S if valid is None else int(valid)
         dev = x.device
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cb = torch.zeros(n_seq * S, NR_KP, dtype=torch.bfloat16, device=dev)
@@ -742,7 +796,8 @@ class _AdditiveFn(torch.autograd.Function):
         cbuf = cb.view(_BF16_AS_I16)
         out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-        _call('nr_additive_fwd', lib.nr_additive_fwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), _ptr(aw), n_seq, S, _stream())
+        _call('nr_additive_fwd', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw), n_seq, S,
+              valid, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp)
         ctx.qdim = Wa.shape[0]
         return out
@@ -762,10 +817,15 @@ class _AdditiveFn(torch.autograd.Function):
         qdim = ctx.qdim
         dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
         dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
-        return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim]
+        return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim], None
 
 
 def additive_dense(x, additive):
+    """AdditiveAttention.forward on [batch, L, D], L in [1, 50]: zero-padded to an instantiated length and pooled over the first L."""
     _require_cuda(x, "AdditiveAttention input")
     check_dims(x.shape[2], NR_HEADS, additive.linear.weight.shape[0])
-    return _AdditiveFn.apply(x, additive.linear.weight, additive.linear.bias, additive.attention_query_vector)
+    L = x.shape[1]
+    S = padded_len(L, "sequence length")
+    if S != L:
+        x = torch.nn.functional.pad(x, (0, 0, 0, S - L))
+    return _AdditiveFn.apply(x, additive.linear.weight, additive.linear.bias, additive.attention_query_vector, L)

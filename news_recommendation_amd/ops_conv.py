@@ -50,11 +50,20 @@ class _TextState:
     __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset')
 
 
-def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag):
+def pad_text(ids, what):
+    """int64 [n, L] (L in [1, 50]) -> ([n, S] zero-padded to an instantiated length, L): ops.padded_len."""
+    L = ids.shape[1]
+    S = ops.padded_len(L, what)
+    return (torch.nn.functional.pad(ids, (0, S - L)) if S != L else ids).contiguous(), L
+
+
+def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag, valid=None):
     """gather -> dropout -> conv3 -> relu -> dropout -> additive pooling for ids int64 [n_seq, S] on the GPU.
-    Pooled vectors go to `out` (f32 rows of stride out_stride, may be None) and/or `out_b` (bf16 ctx rows)."""
+    Pooled vectors go to `out` (f32 rows of stride out_stride, may be None) and/or `out_b` (bf16 ctx rows).  valid (<= S): real text
+    length when the ids were zero-padded (pad_text): padded positions are zero vectors for the convolution and outside the pooling."""
     lib = _lib()
     n_seq, S = ids.shape
+    valid = S if valid is None else int(valid)
     if not lib.nr_supported_conv_len(S):
         raise NotImplementedError(f"text length {S} is not instantiated in the HIP conv kernels (20, 50)")
     dev = table.device
@@ -74,11 +83,11 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
         xs_ptr = st.xstore.data_ptr() + NR_KP * 2
     tab = table.detach()
     assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
-    _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
-          n_seq, S, p, seed, tok_offset, _stream())
+    _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd_v, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
+          n_seq, S, valid, p, seed, tok_offset, _stream())
     st.aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-    _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_ex, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
-          out_b, out_b_stride, _ptr(st.aw), n_seq, S, _stream())
+    _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_v, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
+          out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, _stream())
     return st
 
 
@@ -178,7 +187,7 @@ class _NamlNewsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, title, abstract, cat, sub, table, cat_table,
                 cw_t, cb_t, Wa_t, ba_t, qv_t, cw_a, cb_a, Wa_a, ba_a, qv_a,
-                W_c, b_c, W_s, b_s, Wa_f, ba_f, qv_f, p, seed):
+                W_c, b_c, W_s, b_s, Wa_f, ba_f, qv_f, p, seed, valid_t=None, valid_a=None):
         lib = _lib()
         dev = table.device
         T = title.shape[0]
@@ -186,9 +195,9 @@ class _NamlNewsFn(torch.autograd.Function):
         views = torch.empty(T * 4, NR_KP, dtype=_BF16_AS_I16, device=dev)
         vstride = 4 * NR_KP
         n_title_tok = title.numel()
-        st_t = text_fwd(title, table, cw_t, cb_t, Wa_t, ba_t, qv_t, p, seed, 0, need_grad, None, NR_D, views.data_ptr(), vstride, 'title')
+        st_t = text_fwd(title, table, cw_t, cb_t, Wa_t, ba_t, qv_t, p, seed, 0, need_grad, None, NR_D, views.data_ptr(), vstride, 'title', valid_t)
         st_a = text_fwd(abstract, table, cw_a, cb_a, Wa_a, ba_a, qv_a, p, seed, n_title_tok, need_grad, None, NR_D,
-                        views.data_ptr() + NR_KP * 2, vstride, 'abstract')
+                        views.data_ptr() + NR_KP * 2, vstride, 'abstract', valid_a)
         ncat, dcat = cat_table.shape
         E = torch.empty(2, ncat, NR_D, dtype=torch.float32, device=dev)
         embf, Wc_, bc_, Ws_, bs_ = _f32c(cat_table), _f32c(W_c), _f32c(b_c), _f32c(W_s), _f32c(b_s)
@@ -238,7 +247,7 @@ class _NamlNewsFn(torch.autograd.Function):
         ga = text_bwd(st_a, gv[1], NR_D, p, dx.data_ptr() + nt * NR_KP * 2, 'abstract')
         d_table = embed_scatter(ctx.sorted, nt + na, dx, ctx.table_param, p, seed) if ctx.needs_input_grad[4] else None
         ctx.st = None
-        return (None, None, None, None, d_table, demb, *gt, *ga, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None)
+        return (None, None, None, None, d_table, demb, *gt, *ga, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None, None, None)
 
 
 def naml_news(title, abstract, cat, sub, table, cat_table, text_t, text_a, elem_c, elem_s, final_att, p_drop, training):
@@ -246,11 +255,13 @@ def naml_news(title, abstract, cat, sub, table, cat_table, text_t, text_a, elem_
     p = float(p_drop) if training else 0.0
     seed = ops.new_seed() if p > 0 else 0
     a_t, a_a = text_t.additive_attention, text_a.additive_attention
+    title, valid_t = pad_text(title, "num_words_title")
+    abstract, valid_a = pad_text(abstract, "num_words_abstract")
     return _NamlNewsFn.apply(title, abstract, cat, sub, table, cat_table,
                              text_t.CNN.weight, text_t.CNN.bias, a_t.linear.weight, a_t.linear.bias, a_t.attention_query_vector,
                              text_a.CNN.weight, text_a.CNN.bias, a_a.linear.weight, a_a.linear.bias, a_a.attention_query_vector,
                              elem_c.linear.weight, elem_c.linear.bias, elem_s.linear.weight, elem_s.linear.bias,
-                             final_att.linear.weight, final_att.linear.bias, final_att.attention_query_vector, p, seed)
+                             final_att.linear.weight, final_att.linear.bias, final_att.attention_query_vector, p, seed, valid_t, valid_a)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -261,17 +272,18 @@ class _PoolFn(torch.autograd.Function):
     (no re-quantisation pass); gradient flows to x."""
 
     @staticmethod
-    def forward(ctx, x, x_b, Wa, ba, qv):
+    def forward(ctx, x, x_b, Wa, ba, qv, valid=None):
         lib = _lib()
         n, S, _ = x.shape
         if not lib.nr_supported_pool_len(S):
             raise NotImplementedError(f"sequence length {S} is not instantiated in the pooling kernels (4, 20, 50)")
+        valid = S if valid is None else int(valid)
         dev = x.device
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         out = torch.empty(n, NR_D, dtype=torch.float32, device=dev)
         aw = torch.empty(n, S, dtype=torch.float32, device=dev)
-        _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_ex, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
-              _ptr(aw), n, S, _stream())
+        _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_v, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
+              _ptr(aw), n, S, valid, _stream())
         ctx.save_for_backward(x_b, aw, Wap, bap, qvp, ops.pack_additive_t(Wa))
         ctx.qdim = Wa.shape[0]
         return out
@@ -285,12 +297,21 @@ class _PoolFn(torch.autograd.Function):
         d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}', WaT)
         dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
         _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
-        return dx, None, d_Wa, d_ba, d_qv
+        return dx, None, d_Wa, d_ba, d_qv, None
 
 
 def pool_rows(x, x_b, additive):
+    """AdditiveAttention over the N news vectors of each user (NAML user encoder); N in [1, 50]: padded to 20 / 50 with zero rows that the
+    pooling excludes (ops.padded_len)."""
     _require_cuda(x, "clicked_news_vector")
-    return _PoolFn.apply(x, x_b, additive.linear.weight, additive.linear.bias, additive.attention_query_vector)
+    n, N, d = x.shape
+    S = ops.padded_len(N, "num_clicked_news_a_user")
+    if S != N:
+        x = torch.nn.functional.pad(x, (0, 0, 0, S - N))
+        xb = torch.zeros(n, S, NR_KP, dtype=_BF16_AS_I16, device=x_b.device)
+        xb[:, :N] = x_b.view(n, N, NR_KP)
+        x_b = xb.view(n * S, NR_KP)
+    return _PoolFn.apply(x, x_b, additive.linear.weight, additive.linear.bias, additive.attention_query_vector, N)
 
 
 def to_ctx_rows(x):
@@ -308,7 +329,7 @@ def to_ctx_rows(x):
 # ----------------------------------------------------------------------------------------------------------
 class _LsturNewsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, title, cat, sub, table, cat_table, cw, cb, Wa, ba, qv, p, seed):
+    def forward(ctx, title, cat, sub, table, cat_table, cw, cb, Wa, ba, qv, p, seed, valid=None):
         lib = _lib()
         dev = table.device
         T = title.shape[0]
@@ -318,7 +339,7 @@ class _LsturNewsFn(torch.autograd.Function):
         for j, ids in enumerate((cat, sub)):
             _call('nr_gather_rows_strided', lib.nr_gather_rows_strided, _ptr(ids), _ptr(ct), ct.shape[0], NR_D, None, out.data_ptr() + j * NR_D * 4,
                   3 * NR_D, T, _stream())
-        st = text_fwd(title, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr() + 2 * NR_D * 4, 3 * NR_D, None, 0, 'title')
+        st = text_fwd(title, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr() + 2 * NR_D * 4, 3 * NR_D, None, 0, 'title', valid)
         if need_grad:
             ctx.save_for_backward(title, cat, sub, table)
             ctx.st = st
@@ -342,15 +363,16 @@ class _LsturNewsFn(torch.autograd.Function):
         gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title')
         d_table = embed_scatter(ctx.sorted, title.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[3] else None
         ctx.st = None
-        return (None, None, None, d_table, d_cat, *gt, None, None)
+        return (None, None, None, d_table, d_cat, *gt, None, None, None)
 
 
 def lstur_news(title, cat, sub, table, cat_table, conv, additive, p_drop, training):
     _require_cuda(table, "word_embedding.weight")
     p = float(p_drop) if training else 0.0
     seed = ops.new_seed() if p > 0 else 0
+    title, valid = pad_text(title, "num_words_title")
     return _LsturNewsFn.apply(title, cat, sub, table, cat_table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
-                              additive.attention_query_vector, p, seed)
+                              additive.attention_query_vector, p, seed, valid)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -358,10 +380,10 @@ def lstur_news(title, cat, sub, table, cat_table, conv, additive, p_drop, traini
 # ----------------------------------------------------------------------------------------------------------
 class _TextFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, cw, cb, Wa, ba, qv, p, seed):
+    def forward(ctx, ids, table, cw, cb, Wa, ba, qv, p, seed, valid=None):
         need_grad = any(ctx.needs_input_grad)
         out = torch.empty(ids.shape[0], NR_D, dtype=torch.float32, device=table.device)
-        st = text_fwd(ids, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr(), NR_D, None, 0, 'text')
+        st = text_fwd(ids, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr(), NR_D, None, 0, 'text', valid)
         if need_grad:
             ctx.save_for_backward(ids, table)
             ctx.st = st
@@ -379,15 +401,16 @@ class _TextFn(torch.autograd.Function):
         gt = text_bwd(ctx.st, g, NR_D, p, dx.data_ptr(), 'text')
         d_table = embed_scatter(ctx.sorted, ids.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[1] else None
         ctx.st = None
-        return (None, d_table, *gt, None, None)
+        return (None, d_table, *gt, None, None, None)
 
 
 def text_only(ids, table, conv, additive, p_drop, training):
     _require_cuda(table, "word_embedding.weight")
     p = float(p_drop) if training else 0.0
     seed = ops.new_seed() if p > 0 else 0
-    return _TextFn.apply(ids.contiguous(), table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
-                         additive.attention_query_vector, p, seed)
+    ids, valid = pad_text(ids, "text length")
+    return _TextFn.apply(ids, table, conv.weight, conv.bias, additive.linear.weight, additive.linear.bias,
+                         additive.attention_query_vector, p, seed, valid)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -89,8 +89,9 @@ def check_pack(be):
 
 
 # ---------------------------------------------------------------------------------------------------
-def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0):
-    """MHSA with the engine's rounding points (bf16 X, W, QKV, P; fp32 accumulate), float64 arithmetic between."""
+def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0, key_len=None):
+    """MHSA with the engine's rounding points (bf16 X, W, QKV, P; fp32 accumulate), float64 arithmetic between.  key_len [B]: the
+    `length` mask of multihead_self.py:60-70 (exp(scores) of keys >= length multiplied by 0 before the row sum)."""
     m = prefix + 'multihead_self_attention.'
     xq = bf16_round(x.astype(np.float32)).astype(np.float64)
     W = {n: bf16_round(params[m + n + '.weight']).astype(np.float64) for n in ('W_Q', 'W_K', 'W_V')}
@@ -104,6 +105,8 @@ def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0):
     q, k, v = proj('W_Q'), proj('W_K'), proj('W_V')
     s = (q @ np.swapaxes(k, -1, -2)) / np.sqrt(np.float32(dk)).astype(np.float64)
     e = np.exp(s)
+    if key_len is not None:
+        e = e * (np.arange(S)[None, :] < np.asarray(key_len)[:, None])[:, None, None, :]
     pr = e / (e.sum(-1, keepdims=True) + 1e-8)
     pr = bf16_round(pr.astype(np.float32)).astype(np.float64)
     ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, S, D)
@@ -112,8 +115,20 @@ def mhsa_quantized_oracle(x, params, prefix, mask2=None, scale=1.0):
     return ctx
 
 
-def run_mhsa(be, params, prefix, S, n_seq, ids=None, table=None, x=None, p_drop=0.0, seed=0, save=False):
+def run_mhsa(be, params, prefix, S, n_seq, ids=None, table=None, x=None, p_drop=0.0, seed=0, save=False, key_len=None):
     Wp, bp = pack_qkv(be, params, prefix)
+    if key_len is not None:
+        hl = be.dev(np.asarray(key_len, dtype=np.int32))
+        ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+        sp4 = (S + 3) // 4 * 4
+        sv = (be.empty((n_seq * S, NR_KP), np.uint16), be.empty((n_seq * S, NR_KP), np.uint16),
+              be.empty((n_seq, H, 20, sp4), np.uint16)) if save else (None, None, None)
+        hi, ht = (be.dev(ids.astype(np.int64)), be.dev(table)) if ids is not None else (None, None)
+        hx = be.dev(x.astype(np.float32)) if ids is None else None
+        ck(be, be.lib.nr_mhsa_fwd_len(be.ptr(hi), be.ptr(ht), table.shape[0] if ids is not None else 0, be.ptr(hx), be.ptr(Wp), be.ptr(bp),
+                                      be.ptr(ctx), be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), None, be.ptr(hl), n_seq, S, p_drop, seed, be.stream))
+        be.sync()
+        return (be.np(ctx), sv) if save else (be.np(ctx), ctx)
     ctx = be.poison((n_seq * S, NR_KP), np.uint16)
     sp4 = (S + 3) // 4 * 4
     sv = (be.empty((n_seq * S, NR_KP), np.uint16), be.empty((n_seq * S, NR_KP), np.uint16),
@@ -185,6 +200,22 @@ def check_mhsa_gather(be, n_seq=6, V=300, p_drop=0.0, seed=1234):
     return rel
 
 
+def check_mhsa_key_len(be, S=20, n_seq=7):
+    """nr_mhsa_fwd_len: per-sequence key lengths (the `length` argument of MultiHeadSelfAttention.forward), all queries computed."""
+    params = make_params(6)
+    rng = np.random.default_rng(17)
+    x = rng.normal(0, 0.7, size=(n_seq, S, NR_D)).astype(np.float32)
+    key_len = rng.integers(1, S + 1, size=n_seq)
+    key_len[0], key_len[-1] = S, 1
+    ctx_np, _ = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x, key_len=key_len)
+    ref = mhsa_quantized_oracle(x, params, 'user_encoder.', key_len=key_len)
+    assert_ctx_close(ctx_np, ref, f'mhsa key_len S={S}')
+    # a sequence truncated to its key length gives the same rows for the queries below it
+    L = int(key_len[1])
+    ref_t = mhsa_quantized_oracle(x[1:2, :L], params, 'user_encoder.')
+    np.testing.assert_allclose(ref[1, :L], ref_t[0], rtol=1e-12, atol=1e-12)
+
+
 def check_mhsa_dense(be, n_seq=3):
     S = 50
     params = make_params(6)
@@ -194,6 +225,31 @@ def check_mhsa_dense(be, n_seq=3):
     ctx_np, _ = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x)
     ref = mhsa_quantized_oracle(x, params, 'user_encoder.')
     return assert_ctx_close(ctx_np, ref, 'mhsa dense S=50')
+
+
+def check_additive_valid(be, S=20, n_seq=6, valid=13):
+    """nr_additive_fwd_v: pooling over the first `valid` tokens == the reference pooling of the truncated sequences; weights beyond are 0."""
+    params = make_params(8)
+    rng = np.random.default_rng(19)
+    ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
+    ctx[:, :NR_D] = rng.normal(0, 0.6, size=(n_seq * S, NR_D))
+    ctx_u = f32_to_bf16(ctx)
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    out = be.poison((n_seq, NR_D), np.float32)
+    aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd_v(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), NR_D, None, 0, be.ptr(aw),
+                                    n_seq, S, valid, be.stream))
+    be.sync()
+    a = 'news_encoder.additive_attention.'
+    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)[:, :valid]
+    ref, w, _ = onp.additive(x, bf16_round(params[a + 'linear.weight']).astype(np.float64), params[a + 'linear.bias'].astype(np.float64),
+                             params[a + 'attention_query_vector'].astype(np.float64))
+    got_w = be.np(aw)
+    np.testing.assert_allclose(got_w[:, :valid], w, rtol=2e-4, atol=2e-6)
+    assert not got_w[:, valid:].any()
+    np.testing.assert_allclose(be.np(out), ref, rtol=2e-4, atol=2e-5)
+    assert be.lib.nr_additive_fwd_v(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), NR_D, None, 0, be.ptr(aw),
+                                    n_seq, S, S + 1, be.stream) != 0
 
 
 def check_additive(be, S=20, n_seq=6):
@@ -270,12 +326,16 @@ def close_bf16(got, ref, what, rel=2.0 ** -6, floor=6e-3):
     return err.max() / scale
 
 
-def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77):
+def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
     from news_recommendation_amd._capi import NR_LDG
     params = make_params(12)
     rng = np.random.default_rng(13)
     x = rng.normal(0, 0.7, size=(n_seq, S, NR_D)).astype(np.float32)
-    ctx_np, sv = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x, p_drop=0.0, save=True)
+    key_len = None
+    if with_key_len:
+        key_len = rng.integers(1, S + 1, size=n_seq)
+        key_len[0] = S
+    ctx_np, sv = run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x, p_drop=0.0, save=True, key_len=key_len)
     qs, ks, vts = [be.np(h) for h in sv]
     dk = 20
     q = bf16_to_f32(qs[:, :NR_D]).astype(np.float64).reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
@@ -293,8 +353,13 @@ def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77):
     aw = rng.random(size=(n_seq, S)).astype(np.float32); aw /= aw.sum(1, keepdims=True)
     go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
     dqkv = be.empty((n_seq * S, NR_LDG), np.uint16)
-    ck(be, be.lib.nr_attn_bwd(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
-                              be.ptr(be.dev(go)), be.ptr(dqkv), n_seq, S, p_drop, seed, be.stream))
+    if key_len is None:
+        ck(be, be.lib.nr_attn_bwd(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
+                                  be.ptr(be.dev(go)), be.ptr(dqkv), n_seq, S, p_drop, seed, be.stream))
+    else:
+        ck(be, be.lib.nr_attn_bwd_len(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
+                                      be.ptr(be.dev(go)), be.ptr(dqkv), be.ptr(be.dev(np.asarray(key_len, dtype=np.int32))), n_seq, S, p_drop, seed,
+                                      be.stream))
     be.sync()
     out = be.np(dqkv)
     dC = bf16_to_f32(dg_u).astype(np.float64).reshape(n_seq, S, NR_D) + aw[:, :, None].astype(np.float64) * go[:, None, :]
@@ -304,6 +369,8 @@ def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77):
     dC = bf16_round(dC.astype(np.float32)).astype(np.float64)
     g = dC.reshape(n_seq, S, H, dk).transpose(0, 2, 1, 3)
     e = np.exp(q @ np.swapaxes(k, -1, -2) / np.sqrt(np.float32(dk)).astype(np.float64))
+    if key_len is not None:
+        e = e * (np.arange(S)[None, :] < np.asarray(key_len)[:, None])[:, None, None, :]
     attn = e / (e.sum(-1, keepdims=True) + 1e-8)
     dattn = g @ np.swapaxes(v, -1, -2)
     dv = np.swapaxes(attn, -1, -2) @ g

@@ -103,6 +103,31 @@ def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0
     return err.max() / np.abs(ref).max()
 
 
+def check_conv_fwd_valid(be, S=20, n_seq=6, V=300, valid=13):
+    """nr_conv3_fwd_v: texts of `valid` tokens zero-padded to S (padding ids are NOT zero here, to prove they are ignored): the first
+    `valid` outputs of every sequence equal the convolution of the truncated text (Conv2d zero padding right after its last token)."""
+    W, b = conv_params(2)
+    rng = np.random.default_rng(31)
+    table = rng.normal(0, 0.5, size=(V, NR_D)).astype(np.float32)
+    ids = rng.integers(1, V, size=(n_seq, S))
+    Wc, _, bc = pack_conv(be, W, b, False)
+    act = be.poison((n_seq * S, NR_KP), np.uint16)
+    xs = be.poison((seqpad_rows(n_seq, S), NR_KP), np.uint16)
+    ck(be, be.lib.nr_conv3_fwd_v(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
+                                 n_seq, S, valid, 0.0, 0, 0, be.stream))
+    be.sync()
+    xq = bf16_round(table[ids[:, :valid]]).astype(np.float64)
+    ref = np.maximum(conv_ref(xq, bf16_round(W).astype(np.float64), b.astype(np.float64)), 0.0)
+    got = bf16_to_f32(be.np(act)[:, :NR_D]).astype(np.float64).reshape(n_seq, S, NR_D)[:, :valid]
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -7 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all(), f'conv fwd valid={valid}: max err {err.max():.3g}'
+    # the saved token matrix holds zero vectors at the padded positions
+    xs_np = bf16_to_f32(be.np(xs))[1:].reshape(-1)[:n_seq * (S + 1) * NR_KP].reshape(n_seq, S + 1, NR_KP)[:, :S, :NR_D]
+    assert not xs_np[:, valid:].any() and np.array_equal(xs_np[:, :valid], xq.astype(np.float32))
+    assert be.lib.nr_conv3_fwd_v(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
+                                 n_seq, S, 0, 0.0, 0, 0, be.stream) != 0
+
+
 def check_conv_dgrad(be, S=20, n_seq=5):
     W, b = conv_params(5)
     rng = np.random.default_rng(6)

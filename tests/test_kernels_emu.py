@@ -19,6 +19,13 @@ def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=5, p_drop=0.2)
 def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=2)
 def test_mhsa_x_save(be): kc.check_mhsa_x_save(be)
 def test_mhsa_x_save_s50(be): kc.check_mhsa_x_save(be, S=50, n_seq=2, p_drop=0.0)
+def test_mhsa_key_len_s20(be): kc.check_mhsa_key_len(be, S=20, n_seq=7)
+def test_mhsa_key_len_s50(be): kc.check_mhsa_key_len(be, S=50, n_seq=3)
+def test_attn_bwd_key_len_s20(be): kc.check_attn_bwd(be, S=20, n_seq=5, with_key_len=True)
+def test_attn_bwd_key_len_s50(be): kc.check_attn_bwd(be, S=50, n_seq=2, with_key_len=True)
+def test_additive_valid_s20(be): kc.check_additive_valid(be, S=20, n_seq=6, valid=13)
+def test_additive_valid_s50(be): kc.check_additive_valid(be, S=50, n_seq=3, valid=31)
+def test_additive_valid_s4(be): kc.check_additive_valid(be, S=4, n_seq=23, valid=2)
 def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=6)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=3)
 def test_score_dot(be): kc.check_score_dot(be)
@@ -54,6 +61,8 @@ def test_pack_conv_small(be): kcc.check_pack_conv(be, D=60, Fn=48)
 def test_conv_fwd_s20(be): kcc.check_conv_fwd(be, S=20, n_seq=6)
 def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=5, p_drop=0.2, tok_offset=140)
 def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=3, p_drop=0.2)
+def test_conv_fwd_valid_s20(be): kcc.check_conv_fwd_valid(be, S=20, n_seq=6, valid=13)
+def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=3, valid=33)
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be)
@@ -89,7 +98,8 @@ def test_pool2_fwd_variant():
     import subprocess, sys, os
     env = dict(os.environ, NR_POOL2_FWD='1')
     code = ("from tests.backends import EmuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = EmuBackend(); "
-            "k.check_additive(be, S=20, n_seq=6); k.check_additive(be, S=20, n_seq=19); kc.check_additive_ex(be, S=20, n_seq=5)")
+            "k.check_additive(be, S=20, n_seq=6); k.check_additive(be, S=20, n_seq=19); kc.check_additive_ex(be, S=20, n_seq=5); "
+            "k.check_additive_valid(be, S=20, n_seq=5, valid=7)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
 

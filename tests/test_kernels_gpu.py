@@ -21,6 +21,13 @@ def test_mhsa_gather_dropout(be): kc.check_mhsa_gather(be, n_seq=515, V=5000, p_
 def test_mhsa_dense(be): kc.check_mhsa_dense(be, n_seq=131)
 def test_mhsa_x_save(be): kc.check_mhsa_x_save(be, n_seq=1027, V=5000)
 def test_mhsa_x_save_s50(be): kc.check_mhsa_x_save(be, S=50, n_seq=33, p_drop=0.0)
+def test_mhsa_key_len_s20(be): kc.check_mhsa_key_len(be, S=20, n_seq=1027)
+def test_mhsa_key_len_s50(be): kc.check_mhsa_key_len(be, S=50, n_seq=131)
+def test_attn_bwd_key_len_s20(be): kc.check_attn_bwd(be, S=20, n_seq=203, with_key_len=True)
+def test_attn_bwd_key_len_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37, with_key_len=True)
+def test_additive_valid_s20(be): kc.check_additive_valid(be, S=20, n_seq=1027, valid=13)
+def test_additive_valid_s50(be): kc.check_additive_valid(be, S=50, n_seq=131, valid=31)
+def test_additive_valid_s4(be): kc.check_additive_valid(be, S=4, n_seq=2047, valid=3)
 def test_additive_s20(be): kc.check_additive(be, S=20, n_seq=1027)
 def test_additive_s50(be): kc.check_additive(be, S=50, n_seq=131)
 def test_score_dot(be): kc.check_score_dot(be, B=513, C=3)
@@ -55,6 +62,8 @@ def test_pack_conv(be): kcc.check_pack_conv(be)
 def test_conv_fwd_s20(be): kcc.check_conv_fwd(be, S=20, n_seq=1027, V=5000)
 def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=515, V=5000, p_drop=0.2, tok_offset=140)
 def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=203, V=5000, p_drop=0.2)
+def test_conv_fwd_valid_s20(be): kcc.check_conv_fwd_valid(be, S=20, n_seq=515, valid=13)
+def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=131, valid=33)
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=515)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=131)
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be, S=20, n_seq=1027)
@@ -100,7 +109,8 @@ def test_pool2_fwd_variant():
     import sys
     env = dict(os.environ, NR_POOL2_FWD='1')
     code = ("from tests.backends import GpuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = GpuBackend(); "
-            "k.check_additive(be, S=20, n_seq=1027); k.check_additive(be, S=20, n_seq=3); kc.check_additive_ex(be, S=20, n_seq=131)")
+            "k.check_additive(be, S=20, n_seq=1027); k.check_additive(be, S=20, n_seq=3); kc.check_additive_ex(be, S=20, n_seq=131); "
+            "k.check_additive_valid(be, S=20, n_seq=515, valid=7)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
