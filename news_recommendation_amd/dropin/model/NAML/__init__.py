@@ -26,23 +26,24 @@ class NAML(torch.nn.Module):
         ne = self.news_encoder
         dev = self.user_encoder.additive_attention.linear.weight.device
         ops._require_cuda(self.user_encoder.additive_attention.linear.weight, "NAML parameters")
-        cand = {k: ops.stack_to_device([x[k] for x in candidate_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
-        click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
+        cand = {k: ops.stack_to_device([x[k] for x in candidate_news], dev, ne.table_rows(k), f"{k} id") for k in ne.attrs}
+        click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ne.attrs}
         return self.forward_ids(cand, click)
 
     def forward_ids(self, cand, click):
         """Same on stacked id tensors: dicts of int64 [B, C, ...] / [B, N, ...] (host or device resident)."""
-        dev = self.user_encoder.additive_attention.linear.weight.device
-        B, C = cand['category'].shape
-        N = click['category'].shape[1]
+        ne = self.news_encoder
+        k0 = ne.attrs[0]
+        B, C = cand[k0].shape[:2]
+        N = click[k0].shape[1]
 
         def flat(k):
             a, b = cand[k], click[k]
-            return self.news_encoder.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
-        vec, vec_b = self.news_encoder.encode(flat('title'), flat('abstract'), flat('category'), flat('subcategory'))
+            return ne.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
+        vec, vec_b = ne.encode_views({k: flat(k) for k in ne.attrs})
         candidate_news_vector = vec[:B * C].view(B, C, -1)
         clicked_news_vector = vec[B * C:].view(B, N, -1)
-        user_vector = self.user_encoder(clicked_news_vector, vec_b[B * C:])
+        user_vector = self.user_encoder(clicked_news_vector, None if vec_b is None else vec_b[B * C:])
         return self.click_predictor(candidate_news_vector, user_vector)
 
     def get_news_vector(self, news):

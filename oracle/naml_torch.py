@@ -90,19 +90,24 @@ class OracleNAMLNewsEncoder(nn.Module):
     View order (title, abstract, category, subcategory) is fixed here; the reference's order depends on set iteration
     (SURVEY 5.9 #12) and the final additive attention is permutation invariant."""
 
-    def __init__(self, num_words, d, num_categories, dcat, num_filters, window, qdim, p):
+    def __init__(self, num_words, d, num_categories, dcat, num_filters, window, qdim, p,
+                 attrs=('title', 'abstract', 'category', 'subcategory')):
+        """attrs = config.dataset_attributes['news']: the encoders that exist (:63-81); one view needs no final attention (:82-84)."""
         super().__init__()
         we = nn.Embedding(num_words, d, padding_idx=0)
-        self.text_encoders = nn.ModuleDict({n: OracleTextEncoder(we, d, num_filters, window, qdim, p) for n in ('title', 'abstract')})
+        self.text_encoders = nn.ModuleDict({n: OracleTextEncoder(we, d, num_filters, window, qdim, p) for n in ('title', 'abstract') if n in attrs})
         ce = nn.Embedding(num_categories, dcat, padding_idx=0)
-        self.element_encoders = nn.ModuleDict({n: OracleElementEncoder(ce, dcat, num_filters) for n in ('category', 'subcategory')})
-        self.final_attention = OracleAdditive(qdim, num_filters)
+        self.element_encoders = nn.ModuleDict({n: OracleElementEncoder(ce, dcat, num_filters) for n in ('category', 'subcategory') if n in attrs})
+        if len(self.text_encoders) + len(self.element_encoders) > 1:
+            self.final_attention = OracleAdditive(qdim, num_filters)
 
     def forward(self, news, keep=None):
         keep = keep or {}
         vecs = [enc(news[n], keep.get(n + '1'), keep.get(n + '2')) for n, enc in self.text_encoders.items()]
         vecs += [enc(news[n]) for n, enc in self.element_encoders.items()]
-        return self.final_attention(torch.stack(vecs, dim=1))                            # :108-114
+        if len(vecs) == 1:                                                               # :108-110
+            return vecs[0]
+        return self.final_attention(torch.stack(vecs, dim=1))                            # :111-114
 
 
 class OracleNAMLUserEncoder(nn.Module):
@@ -119,9 +124,10 @@ class OracleNAMLUserEncoder(nn.Module):
 class OracleNAML(nn.Module):
     """NAML, src/model/NAML/__init__.py:7-93."""
 
-    def __init__(self, num_words=70976, d=300, num_categories=275, dcat=100, num_filters=300, window=3, qdim=200, p_drop=0.2):
+    def __init__(self, num_words=70976, d=300, num_categories=275, dcat=100, num_filters=300, window=3, qdim=200, p_drop=0.2,
+                 attrs=('title', 'abstract', 'category', 'subcategory')):
         super().__init__()
-        self.news_encoder = OracleNAMLNewsEncoder(num_words, d, num_categories, dcat, num_filters, window, qdim, p_drop)
+        self.news_encoder = OracleNAMLNewsEncoder(num_words, d, num_categories, dcat, num_filters, window, qdim, p_drop, attrs)
         self.user_encoder = OracleNAMLUserEncoder(qdim, num_filters)
 
     def forward(self, candidate_news, clicked_news, keeps=None):
