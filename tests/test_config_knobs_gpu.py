@@ -97,7 +97,7 @@ def test_naml_view_subsets(attrs):
     """dataset_attributes['news'] subsets (src/model/NAML/news_encoder.py:63-84,100-114): same state_dict keys as the oracle built for
     the subset, logits and gradients vs that oracle; a single view bypasses the final attention."""
     from oracle.naml_torch import OracleNAML
-    from oracle.make_golden_naml_lstur import as_lists, synth_batch
+    from oracle.make_golden_naml_lstur import synth_batch
     from tests.test_naml_gpu import MIND, make_cfg
     from news_recommendation_amd.dropin.model.NAML import NAML
     c = dict(MIND, V=3000, B=5, seed=47, N=20, C=3)
@@ -105,6 +105,8 @@ def test_naml_view_subsets(attrs):
     cfg.dataset_attributes = {"news": list(attrs), "record": []}
     torch.manual_seed(47)
     ref = OracleNAML(c['V'], c['d'], c['ncat'], c['dcat'], c['F'], c['window'], c['Q'], 0.2, attrs=attrs).eval()
+    for te in ref.news_encoder.text_encoders.values():
+        te.CNN.q_operands = True            # conv operands rounded where the engine rounds them: same relu masks (tests/test_naml_gpu.py)
     m = NAML(cfg)
     assert set(m.state_dict()) == set(ref.state_dict())
     m.load_state_dict(ref.state_dict())
@@ -112,7 +114,8 @@ def test_naml_view_subsets(attrs):
     cand, click, _ = synth_batch(np.random.default_rng(47), c, True)
     cand = {k: v for k, v in cand.items() if k in attrs}
     click = {k: v for k, v in click.items() if k in attrs}
-    cl, hl = as_lists(cand, click)
+    lists = lambda d: [{k: torch.from_numpy(np.ascontiguousarray(v[:, j])) for k, v in d.items()} for j in range(next(iter(d.values())).shape[1])]
+    cl, hl = lists(cand), lists(click)
     lr = ref(cl, hl)
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(c['B'], dtype=torch.long)).backward()
     lg = m(cl, hl)
@@ -121,7 +124,7 @@ def test_naml_view_subsets(attrs):
     rg = {k: p.grad.numpy() for k, p in ref.named_parameters()}
     fl = grad_floor(rg)
     for k, p in m.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), rg[k], fl) < 8e-2, k       # conv relu flips at B = 5: looser than the fused-path tests
+        assert rel_err(p.grad.cpu().numpy(), rg[k], fl) < 6e-2, k
 
 
 def _ref_mhsa(x, mod, length):
