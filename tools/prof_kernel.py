@@ -23,18 +23,25 @@ nv = torch.empty(T, NR_D, device=dev); aw = torch.empty(T, 20, device=dev)
 ck = lambda rc: _capi.check(lib, rc)
 ck(lib.nr_pack_qkv(W[0].data_ptr(), bb[0].data_ptr(), W[1].data_ptr(), bb[1].data_ptr(), W[2].data_ptr(), bb[2].data_ptr(), Wp.data_ptr(), bp.data_ptr(), st()))
 ck(lib.nr_pack_additive(Wa.data_ptr(), ba.data_ptr(), qv.data_ptr(), 200, Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), st()))
-mh = lambda p, save: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(),
-                                        qs.data_ptr() if save else None, ks.data_ptr() if save else None, vts.data_ptr() if save else None, T, 20, p, 1, st()))
+xsv = torch.empty_like(ctx)
+# training form as the product launches it: Q / K / V^T saves AND the masked token matrix (x_save)
+mh = lambda p, save: ck(lib.nr_mhsa_fwd_ex(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(),
+                                           qs.data_ptr() if save else None, ks.data_ptr() if save else None, vts.data_ptr() if save else None,
+                                           xsv.data_ptr() if save else None, T, 20, p, 1, st()))
 mh(0.0, True)
 ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), aw.data_ptr(), T, 20, st()))
 gout = torch.randn(T, NR_D, generator=g).to(dev)
 dpre = torch.empty(T * 20, NR_QP, dtype=torch.int16, device=dev); dqp = torch.empty(lib.nr_additive_bwd_grid(T, 20), NR_QP, device=dev)
+WaT20 = torch.empty(NR_KP, 224, dtype=torch.int16, device=dev); dctx20 = torch.empty(T * 20, NR_KP, dtype=torch.int16, device=dev)
+ck(lib.nr_pack_additive_t(Wa.data_ptr(), 200, WaT20.data_ptr(), st()))
 dctx = torch.randn(T * 20, NR_D, generator=g).mul_(0.05).to(dev).to(torch.bfloat16)
 dqkv = torch.zeros(T * 20, NR_LDG, dtype=torch.int16, device=dev)
 fns = {
   'mhsa_infer': lambda: mh(0.0, False), 'mhsa_train': lambda: mh(0.2, True),
   'additive_fwd': lambda: ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), aw.data_ptr(), T, 20, st())),
-  'additive_bwd': lambda: ck(lib.nr_additive_bwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw.data_ptr(), gout.data_ptr(), dpre.data_ptr(), dqp.data_ptr(), T, 20, st())),
+  # as the product launches it: with the fused dctx = dpre @ Wa product (k_pool2.h by default)
+  'additive_bwd': lambda: ck(lib.nr_additive_bwd_ex(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw.data_ptr(), gout.data_ptr(), dpre.data_ptr(),
+                                                    dqp.data_ptr(), WaT20.data_ptr(), dctx20.data_ptr(), T, 20, st())),
   'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
 }
 if name.endswith('50'):          # abstract-shaped pooling: 27 k sequences of 50 ctx rows
