@@ -23,12 +23,17 @@
 
 namespace nr {
 
+// TPW titles per wave x NWAVE waves = 16 titles per workgroup in both instantiations: <4, 4> (one wave per SIMD, 5 token tiles, every LDS
+// weight fragment feeds 5 MFMAs) and <2, 8> (two waves per SIMD on 3 token tiles = 48 rows for 40 tokens: 17 % padding, but one wave's
+// loads / tanh / reductions overlap the other's MFMAs)
+template <int TPW_, int NWAVE_>
 struct Pool2Geom {
   static constexpr int S = 20;
-  static constexpr int TPW = 4;                  // titles per wave
-  static constexpr int NWAVE = 4;
+  static constexpr int TPW = TPW_;               // titles per wave
+  static constexpr int NWAVE = NWAVE_;
+  static constexpr int THREADS = NWAVE * 64;
   static constexpr int TOKW = S * TPW;           // 80 tokens per wave
-  static constexpr int MT = TOKW / 16;           // 5 token tiles
+  static constexpr int MT = (TOKW + 15) / 16;    // 5 (or 3) token tiles
   static constexpr int NTQ = QP / 16;            // 13 n-tiles of the query dim
   static constexpr int CH_NT = 5;                // n-tiles of Wa per chunk
   static constexpr int NCH = (NTQ + CH_NT - 1) / CH_NT;      // 3 chunks (5, 5, 3 n-tiles)
@@ -41,24 +46,25 @@ struct Pool2Geom {
   static constexpr int GROW = KP;                // floats per staged g_out row (zero padded beyond D)
   static constexpr int FWD_SMEM = 2 * CH_BYTES + NWAVE * WV_FLOATS * 4;
   static constexpr int BWD_SMEM = FWD_SMEM + NWAVE * TPW * GROW * 4 + NWAVE * QP * 4;
-  static_assert(CH_DT * KS2 * 1024 <= CH_BYTES && TOKW % 16 == 0, "geometry");
+  static_assert(CH_DT * KS2 * 1024 <= CH_BYTES && TPW * NWAVE == 16 && TOKW <= 128, "geometry");
 };
 
 // the wave's 80 ctx rows as B-operand fragments
-__device__ __forceinline__ void pool2_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t tok_total, u16x8 (&xf)[Pool2Geom::MT][KSTEPS]) {
+template <int MT, int TOKW>
+__device__ __forceinline__ void pool2_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t tok_total, u16x8 (&xf)[MT][KSTEPS]) {
   const int l = lane_id(), g = l >> 4, li = l & 15;
 #pragma unroll
-  for (int m = 0; m < Pool2Geom::MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int64_t tok = tok0 + m * 16 + li;
-    const bool live = tok < tok_total;
+    const bool live = tok < tok_total && m * 16 + li < TOKW;            // rows beyond the wave's tokens (48 rows for 40 tokens) are zero
     const u16* row = ctx + (live ? tok : 0) * KP + g * 8;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) xf[m][ks] = live ? *(const u16x8*)(row + ks * 32) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 }
 
-__global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(AdditiveParams p) {
-  using Gm = Pool2Geom;
+template <typename Gm>
+__global__ __launch_bounds__(Gm::THREADS) void pool2_fwd_kernel(AdditiveParams p) {
   constexpr int S = Gm::S, MT = Gm::MT;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
   };
   chunk_fetch(0, 0);
   u16x8 xf[MT][KSTEPS];
-  pool2_load_x(p.ctx, tok0, tok_total, xf);
+  pool2_load_x<MT, Gm::TOKW>(p.ctx, tok0, tok_total, xf);
   __syncthreads();
 
   // ---- scores: sum_n tanh(x . Wa[n] + ba[n]) * qv[n] -------------------------------------------------------------------------------
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const float s = sum_rows4(score[m]);    // over the four lane groups (the 16 query rows of every n-tile)
-    if (g == 0) sc[m * 16 + li] = s;
+    if (g == 0 && m * 16 + li < Gm::TOKW) sc[m * 16 + li] = s;
   }
   wave_barrier();
 
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
     if (t < Gm::TOKW) {
       const int base = (t / S) * S;
       float mx = -3.0e38f;
-#pragma unroll
+#pragma unroll 4
       for (int j = 0; j < S; ++j) mx = j < nvalid ? fmaxf(mx, sc[base + j]) : mx;
       float sum = 0.0f;
-#pragma unroll
+#pragma unroll 4
       for (int j = 0; j < S; ++j) sum += j < nvalid ? fast_exp(sc[base + j] - mx) : 0.0f;
       const float wt = t - base < nvalid ? fast_exp(sc[t] - mx) / sum : 0.0f;
       wl[t] = wt;
@@ -136,54 +142,62 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_fwd_kernel(Add
     }
   }
   wave_barrier();
+  NR_SCHED_BARRIER();
 
   // ---- weighted sum out[title][:] = sum_s w[s] x[s][:], straight from the fragment registers: title sq lives in token tiles
   //      (20 sq) / 16 and the next one; a lane adds its token's share (80 partial sums: 10 k-steps x 8 features), then the 16 lanes of a
   //      row are combined by RECURSIVE HALVING (reduce-scatter): at level b the lane keeps the half of its values that its lane-index
-  //      bit b selects and adds the partner's copy of that half -- 40 + 20 + 10 + 5 exchanges instead of the 4 x 80 of an all-reduce
-  //      butterfly (which made this phase half of the kernel's run time).  Lane li ends with values 5 li .. 5 li + 4. -------------------
+  //      bit b selects and adds the partner's copy of that half -- about 80 exchanges instead of the 4 x 80 of an all-reduce butterfly ----
   const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
 #pragma unroll
   for (int sq = 0; sq < Gm::TPW; ++sq) {
     const int m0 = (sq * S) / 16;
-    float v[KSTEPS * 8];
-#pragma unroll
-    for (int i = 0; i < KSTEPS * 8; ++i) v[i] = 0.0f;
+    float wm[2];
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm) {
-      const int m = m0 + dm;
-      const int t = m * 16 + li;
-      const float wm = (t >= sq * S && t < (sq + 1) * S) ? wl[t] : 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[ks * 8 + j] += wm * bf2f(xf[m][ks][j]);
+      const int t = (m0 + dm) * 16 + li;
+      wm[dm] = (t >= sq * S && t < (sq + 1) * S) ? wl[t] : 0.0f;
     }
-    float k1[40], k2[20], k3[10], k4[5];
+    // two halves of 5 k-steps (40 partial sums each) keep the live set small enough for two waves per SIMD: halving on lane bits 3, 2, 1
+    // (40 -> 20 -> 10 -> 5 values), then the pair of lanes that differ in bit 0 adds up and the even one stores
 #pragma unroll
-    for (int i = 0; i < 40; ++i) k1[i] = (b3 ? v[40 + i] : v[i]) + row_xchg<3>(b3 ? v[i] : v[40 + i]);
+    for (int h = 0; h < 2; ++h) {
+      float v[40];
 #pragma unroll
-    for (int i = 0; i < 20; ++i) k2[i] = (b2 ? k1[20 + i] : k1[i]) + row_xchg<2>(b2 ? k1[i] : k1[20 + i]);
+      for (int i = 0; i < 40; ++i) v[i] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) k3[i] = (b1 ? k2[10 + i] : k2[i]) + row_xchg<1>(b1 ? k2[i] : k2[10 + i]);
+      for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) k4[i] = (b0 ? k3[5 + i] : k3[i]) + row_xchg<0>(b0 ? k3[i] : k3[5 + i]);
-    if (seq0 + sq < p.n_seq) {
+        for (int ks = 0; ks < 5; ++ks)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int idx = 5 * li + i;                      // flat (k-step, feature-in-fragment) index of the value this lane ended up with
-        const int c = (idx >> 3) * 32 + g * 8 + (idx & 7);
-        if (p.out != nullptr && c < D) p.out[(seq0 + sq) * p.out_stride + c] = k4[i];
-        if (p.out_b != nullptr)                          // bf16 ctx-layout copy: cols < D data, col D = 1.0, rest of the K padding 0
-          p.out_b[(seq0 + sq) * p.out_b_stride + c] = c < D ? f2bf(k4[i]) : (c == D ? BF16_ONE : (u16)0);
+          for (int j = 0; j < 8; ++j) v[ks * 8 + j] += wm[dm] * bf2f(xf[m0 + dm][5 * h + ks][j]);
+      float k1[20], k2[10], k3[5];
+#pragma unroll
+      for (int i = 0; i < 20; ++i) k1[i] = (b3 ? v[20 + i] : v[i]) + row_xchg<3>(b3 ? v[i] : v[20 + i]);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) k2[i] = (b2 ? k1[10 + i] : k1[i]) + row_xchg<2>(b2 ? k1[i] : k1[10 + i]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) k3[i] = (b1 ? k2[5 + i] : k2[i]) + row_xchg<1>(b1 ? k2[i] : k2[5 + i]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) k3[i] += row_xchg<0>(k3[i]);
+      NR_SCHED_BARRIER();
+      if (!b0 && seq0 + sq < p.n_seq) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int idx = 5 * (li >> 1) + i;               // flat (k-step in the half, feature-in-fragment) index this lane pair ended up with
+          const int c = (5 * h + (idx >> 3)) * 32 + g * 8 + (idx & 7);
+          if (p.out != nullptr && c < D) p.out[(seq0 + sq) * p.out_stride + c] = k3[i];
+          if (p.out_b != nullptr)                          // bf16 ctx-layout copy: cols < D data, col D = 1.0, rest of the K padding 0
+            p.out_b[(seq0 + sq) * p.out_b_stride + c] = c < D ? f2bf(k3[i]) : (c == D ? BF16_ONE : (u16)0);
+        }
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(AdditiveBwdParams p) {
-  using Gm = Pool2Geom;
+template <typename Gm>
+__global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParams p) {
   constexpr int S = Gm::S, MT = Gm::MT;
   NR_SMEM_DECL(smem);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
   };
   chunk_fetch(0, 0);
   u16x8 xf[MT][KSTEPS];
-  pool2_load_x(p.ctx, tok0, tok_total, xf);
+  pool2_load_x<MT, Gm::TOKW>(p.ctx, tok0, tok_total, xf);
   // g_out rows and forward weights of this wave's titles -> wave-private LDS
   for (int i = l; i < Gm::TPW * (Gm::GROW / 4); i += 64) {
     const int sq = i / (Gm::GROW / 4), c = i - sq * (Gm::GROW / 4);
@@ -229,7 +243,8 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
   // ---- dw[tok] = g_out[title] . x[tok] --------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const float* go = gl + ((m * 16 + li) / S) * Gm::GROW + g * 8;
+    const int trow = m * 16 + li < Gm::TOKW ? m * 16 + li : Gm::TOKW - 1;          // rows past the wave's tokens (zero fragments) stay in range
+    const float* go = gl + (trow / S) * Gm::GROW + g * 8;
     float a = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
       a += g1[0] * bf2f(x[4]) + g1[1] * bf2f(x[5]) + g1[2] * bf2f(x[6]) + g1[3] * bf2f(x[7]);
     }
     a = sum_rows4(a);
-    if (g == 0) sc[m * 16 + li] = a;
+    if (g == 0 && m * 16 + li < Gm::TOKW) sc[m * 16 + li] = a;
   }
   wave_barrier();
   // ---- softmax backward: ds = w (dw - sum_s w dw) ---------------------------------------------------------------------------------------------
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
   wave_barrier();
   float ds[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) ds[m] = sc[m * 16 + li];
+  for (int m = 0; m < MT; ++m) ds[m] = m * 16 + li < Gm::TOKW ? sc[m * 16 + li] : 0.0f;
   __syncthreads();                          // Wa chunk 0 visible
 
   // ---- recompute t = tanh(x Wa^T + ba);  dpre = ds qv (1 - t^2) (kept packed in registers + stored);  dq += ds t ---------------------------
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
           const u16x4 pk = pack4(dp);
           dpk[nt0 + nt][m] = pk;
           const int64_t tok = tok0 + m * 16 + li;
-          if (tok < tok_total) *(u16x4*)(p.dpre + tok * QP + wrow) = pk;
+          if (tok < tok_total && m * 16 + li < Gm::TOKW) *(u16x4*)(p.dpre + tok * QP + wrow) = pk;
         }
         // dq partial of this wave: the tile's tokens live in the 16 lanes of a row -> DPP sum; the 4 waves are combined through LDS below
 #pragma unroll
@@ -344,13 +359,13 @@ __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void pool2_bwd_kernel(Add
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int64_t tok = tok0 + m * 16 + li;
-          if (tok < tok_total && col < D) *(u16x4*)(p.dctx + tok * KP + col) = pack4(acc[m]);
+          if (tok < tok_total && m * 16 + li < Gm::TOKW && col < D) *(u16x4*)(p.dctx + tok * KP + col) = pack4(acc[m]);
         }
       }
     }
     __syncthreads();                        // also orders the dqp stores above before the reduction below
   }
-  for (int n = tid; n < QP; n += 256) {
+  for (int n = tid; n < QP; n += Gm::THREADS) {
     float a = 0.0f;
 #pragma unroll
     for (int ww = 0; ww < Gm::NWAVE; ++ww) a += dqp[ww * QP + n];

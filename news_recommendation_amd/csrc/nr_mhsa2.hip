@@ -22,21 +22,33 @@ int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
   return 0;
 }
 
-// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup
-int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
-  using G = Pool2Geom;
-  const int per_wg = G::TPW * G::NWAVE;
-  if (set_max_dynamic_lds((const void*)pool2_fwd_kernel, G::FWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_fwd_kernel, (p.n_seq + per_wg - 1) / per_wg, 256, G::FWD_SMEM, stream, p);
+// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup.  NR_POOL2_GEOM=28: 8 waves x 2 titles (two waves per
+// SIMD), default 44: 4 waves x 4 titles (one wave per SIMD)
+static int pool2_geom() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NR_POOL2_GEOM"); v = e ? atoi(e) : 44; }
+  return v;
+}
+
+template <typename G>
+static int launch_pool2_fwd_t(const AdditiveParams& p, hipStream_t stream) {
+  if (set_max_dynamic_lds((const void*)pool2_fwd_kernel<G>, G::FWD_SMEM)) return -1;
+  NR_LAUNCH(pool2_fwd_kernel<G>, (p.n_seq + 15) / 16, G::THREADS, G::FWD_SMEM, stream, p);
+  return 0;
+}
+template <typename G>
+static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
+  if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G>, G::BWD_SMEM)) return -1;
+  NR_LAUNCH(pool2_bwd_kernel<G>, (p.n_seq + 15) / 16, G::THREADS, G::BWD_SMEM, stream, p);
   return 0;
 }
 
+int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
+  return pool2_geom() == 28 ? launch_pool2_fwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<4, 4>>(p, stream);
+}
+
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {
-  using G = Pool2Geom;
-  const int per_wg = G::TPW * G::NWAVE;
-  if (set_max_dynamic_lds((const void*)pool2_bwd_kernel, G::BWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_bwd_kernel, (p.n_seq + per_wg - 1) / per_wg, 256, G::BWD_SMEM, stream, p);
-  return 0;
+  return pool2_geom() == 28 ? launch_pool2_bwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<4, 4>>(p, stream);
 }
 
 }  // namespace nr
