@@ -22,12 +22,13 @@ int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
   return 0;
 }
 
-// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup.  NR_POOL2_GEOM=28: 8 waves x 2 titles (two waves per
-// SIMD), default 44: 4 waves x 4 titles (one wave per SIMD)
-static int pool2_geom() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NR_POOL2_GEOM"); v = e ? atoi(e) : 44; }
-  return v;
+// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup, as 8 waves x 2 titles (28: two waves per SIMD) or
+// 4 waves x 4 titles (44: one wave per SIMD).  Measured at B = 512, A/B on one box (gpurun_out/r02i): backward 368 us (28) vs 415 us (44);
+// forward 304 us (28) vs 271 us (44).  NR_POOL2_GEOM overrides both defaults.
+static int pool2_geom(int dflt) {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("NR_POOL2_GEOM"); v = e ? atoi(e) : -1; }
+  return v > 0 ? v : dflt;
 }
 
 template <typename G>
@@ -44,11 +45,11 @@ static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
 }
 
 int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
-  return pool2_geom() == 28 ? launch_pool2_fwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<4, 4>>(p, stream);
+  return pool2_geom(44) == 28 ? launch_pool2_fwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<4, 4>>(p, stream);
 }
 
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {
-  return pool2_geom() == 28 ? launch_pool2_bwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<4, 4>>(p, stream);
+  return pool2_geom(28) == 28 ? launch_pool2_bwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<4, 4>>(p, stream);
 }
 
 }  // namespace nr

@@ -116,12 +116,14 @@ def test_pool2_fwd_variant():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-def test_pool2_two_waves_per_simd_geometry():
-    """NR_POOL2_GEOM=28: the 8-wave x 2-title instantiation of csrc/k_pool2.h (48-row token tiles for 40 tokens), forward and backward."""
+@pytest.mark.parametrize('geom', ['28', '44'])
+def test_pool2_geometries(geom):
+    """Both instantiations of csrc/k_pool2.h, forward and backward: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
+    backward) and 4 waves x 4 titles (one wave per SIMD)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NR_POOL2_GEOM='28', NR_POOL2_FWD='1')
+    env = dict(os.environ, NR_POOL2_GEOM=geom, NR_POOL2_FWD='1')
     code = ("from tests.backends import GpuBackend as B; from tests import kernel_checks as k, kernel_checks_conv as kc; be = B(); "
             "k.check_additive(be, S=20, n_seq=1027); k.check_additive_valid(be, S=20, n_seq=5, valid=7); kc.check_additive_ex(be, S=20, n_seq=5); "
             "k.check_additive_bwd(be, S=20, n_seq=1027); k.check_additive_bwd(be, S=20, n_seq=17)")
