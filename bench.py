@@ -413,9 +413,12 @@ def main():
         per_call = ops.seq_launches.get(timed_name, 1)
         dom = (dom[0] * per_call, dom[1] / per_call, dom[2])
 
+    if world > 1:
+        # every rank leaves the process group here: what follows on rank 0 (roofline probes, scoring throughput) is local work, and a
+        # rank that kept the group open would wait in its destructor for peers that are still measuring
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
 
     T = B * (1 + cfg.negative_sampling_ratio + cfg.num_clicked_news_a_user)
@@ -467,23 +470,25 @@ def main():
                     "gathered rows to HBM (read_plus_write_GBs).  In NRMS training the gather is fused into nr_mhsa_fwd (rows go straight into "
                     "MFMA operand registers); this kernel is the north_star's stand-alone roofline probe"}
         # ---- the same training step through the real boundary: model(candidate_news, clicked_news) on CPU list-of-dicts ------------------
-        cpu_batches = [wl.as_dataloader_batch(b) for b in wl.batches(rank, 2, B, 'cpu')]
+        # (single-GPU runs only: a training step is a collective operation, and the other ranks have left by now)
+        if world == 1:
+            cpu_batches = [wl.as_dataloader_batch(b) for b in wl.batches(rank, 2, B, 'cpu')]
 
-        def step_dropin(i):
-            loss = crit(wl.forward_dropin(model, cpu_batches[i % len(cpu_batches)]), target)
-            loss.backward()
-            opt.step()
-        for i in range(3):
-            step_dropin(i)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(args.steps):
-            step_dropin(i)
-        torch.cuda.synchronize()
-        dtd = time.perf_counter() - ts
-        extras["value_dropin"] = {"value": B * args.steps / dtd, "unit": "impressions/s", "ms_per_step": dtd / args.steps * 1e3,
-                                  "what": "model(candidate_news, clicked_news) on the DataLoader's pinned CPU list-of-dicts "
-                                          "(train.py:166-203): host stacking + id range check + H2D copy inside the timed step"}
+            def step_dropin(i):
+                loss = crit(wl.forward_dropin(model, cpu_batches[i % len(cpu_batches)]), target)
+                loss.backward()
+                opt.step()
+            for i in range(3):
+                step_dropin(i)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(args.steps):
+                step_dropin(i)
+            torch.cuda.synchronize()
+            dtd = time.perf_counter() - ts
+            extras["value_dropin"] = {"value": B * args.steps / dtd, "unit": "impressions/s", "ms_per_step": dtd / args.steps * 1e3,
+                                      "what": "model(candidate_news, clicked_news) on the DataLoader's pinned CPU list-of-dicts "
+                                              "(train.py:166-203): host stacking + id range check + H2D copy inside the timed step"}
         # ---- forward-only (scoring) throughput on train-shaped batches, and eval-shaped scoring (phases A-C) ------------------------------
         model.eval()
         with torch.no_grad():
@@ -536,8 +541,6 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
