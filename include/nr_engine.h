@@ -137,6 +137,15 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
                        const float* g_out, uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx, int64_t n_seq, int S,
                        void* stream);
 
+/* Weight gradients of one encoder, from the form the two library GEMMs and nr_additive_bwd leave them in to the parameters' gradient
+ * buffers, in ONE launch: dW_parts f32[nc_w][3*NR_KP][NR_KP] = per-token-chunk partials of dqkv^T @ [X | 1] (row i*NR_KP + r = d W_i[r][:],
+ * column NR_D = d bias_i[r]; i = Q, K, V), dWa_parts f32[nc_a][NR_QP][NR_KP] likewise for the pooling linear, dq_part f32[nwg][NR_QP]
+ * (nr_additive_bwd).  Sums the partials in a fixed order and ACCUMULATES (+=) into gW*[NR_D][NR_D], gb*[NR_D], gWa[qdim][NR_D], gba[qdim],
+ * gq[qdim] -- what autograd's AccumulateGrad does for W_Q / W_K / W_V (multihead_self.py:35-37), additive.linear and
+ * attention_query_vector (additive.py:18-20) when loss.backward() runs (train.py:231), there as 2 + 9 + 1 separate kernels. */
+int nr_wgrad_unpack(const float* dW_parts, int nc_w, const float* dWa_parts, int nc_a, const float* dq_part, int64_t nwg, int qdim,
+                    float* gWq, float* gbq, float* gWk, float* gbk, float* gWv, float* gbv, float* gWa, float* gba, float* gq, void* stream);
+
 /* Token matrix for the weight-gradient GEMM dW = dqkv^T @ Xb: Xb bf16[n_tokens][NR_KP] = dropout1(table[ids]) (or
  * dense f32 rows), column D = 1.0 (bias gradient), rest 0. */
 int nr_gather_bf16(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, uint16_t* Xb,

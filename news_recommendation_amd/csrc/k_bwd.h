@@ -56,6 +56,7 @@ struct AttnBwdParams {
   int64_t n_seq;
   const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
+  int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
 };
 
 __device__ __forceinline__ u16x8 ld8(const u16* p) { return cat8(*(const u16x4*)p, *(const u16x4*)(p + 4)); }
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
 
   const int64_t n_pairs = p.n_seq * H;
   const int64_t stride = (int64_t)gridDim.x * WPB;
-  int64_t pair = (int64_t)blockIdx.x * WPB + w;
+  int64_t pair = (int64_t)(p.xcd_major ? xcd_major_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * WPB + w;
 
   AttnBwdRegs<Gm::IT, Gm::ITV> rg;
   auto load_regs = [&](int64_t pr) {

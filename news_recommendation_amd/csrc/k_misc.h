@@ -70,6 +70,62 @@ __global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __res
   }
 }
 
+// ---- weight gradients of one NRMS encoder: chunk partials -> the parameters' gradient buffers, one launch --------------------------
+// The projection / pooling weight gradients come out of two batched library GEMMs as per-token-chunk fp32 partials in the PACKED
+// operand geometry ([3*KP][KP] with the bias gradient in column D; [QP][KP] likewise), the query-vector gradient as one partial row
+// per pooling workgroup.  autograd would sum the chunks (2 reductions), slice 9 strided views and add each into its .grad (9 more
+// launches) plus the partial-row sum: 12 launches per encoder.  This kernel does all of it: one workgroup per output row sums the
+// chunks and ACCUMULATES into the nine destinations (what AccumulateGrad does); summation order is fixed, so it is deterministic.
+struct WgradUnpackParams {
+  const float* dW;       // [ncW][3*KP][KP]  chunk partials of dqkv^T @ [X | 1]
+  const float* dWa;      // [ncA][QP][KP]    chunk partials of dpre^T @ [ctx | 1]
+  const float* dq;       // [nwg][QP]        per-workgroup partials of d attention_query_vector
+  int ncW, ncA, qdim;
+  int64_t nwg;
+  float* gW[3];          // [D][D]   d W_Q / W_K / W_V .weight
+  float* gb[3];          // [D]      ... .bias
+  float* gWa;            // [qdim][D]
+  float* gba;            // [qdim]
+  float* gq;             // [qdim]
+};
+constexpr int WGU_THREADS = KP;          // one thread per packed column (D weights + the bias column)
+constexpr int WGU_DQ_PH = WGU_THREADS / 64;   // dq blocks: 64 entries x 5 row phases
+constexpr int WGU_SMEM = WGU_DQ_PH * 64 * 4;
+__device__ __host__ __forceinline__ int wgrad_unpack_grid(int qdim) { return 3 * D + qdim + (qdim + 63) / 64; }
+
+__global__ __launch_bounds__(WGU_THREADS) void wgrad_unpack_kernel(WgradUnpackParams p) {
+  NR_SMEM_DECL(smem);
+  float (*part)[64] = (float (*)[64])smem;          // [WGU_DQ_PH][64]
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b < 3 * D + p.qdim) {
+    const bool proj = b < 3 * D;
+    const int i = proj ? b / D : 0, r = proj ? b - i * D : b - 3 * D;
+    const float* src = proj ? p.dW + ((size_t)(i * KP + r)) * KP : p.dWa + (size_t)r * KP;
+    const size_t cs = proj ? (size_t)3 * KP * KP : (size_t)QP * KP;
+    const int nc = proj ? p.ncW : p.ncA;
+    if (t <= D) {
+      float a = 0.0f;
+      for (int c = 0; c < nc; ++c) a += src[c * cs + t];
+      float* dst = t < D ? (proj ? p.gW[i] : p.gWa) + (size_t)r * D + t : (proj ? p.gb[i] : p.gba) + r;
+      *dst += a;
+    }
+    return;
+  }
+  // query-vector gradient: this block owns 64 entries; 5 phases walk the partial rows, combined in a fixed order
+  const int j = (b - 3 * D - p.qdim) * 64 + (t & 63), ph = t >> 6;
+  float a = 0.0f;
+  if (j < p.qdim)
+    for (int64_t w = ph; w < p.nwg; w += WGU_DQ_PH) a += p.dq[w * QP + j];
+  part[ph][t & 63] = a;
+  __syncthreads();
+  if (ph == 0 && j < p.qdim) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < WGU_DQ_PH; ++k) s += part[k][t];
+    p.gq[j] += s;
+  }
+}
+
 // ---- K7: dot-product scorers -------------------------------------------------------------------------------
 // one wave per (b, c) pair; lanes stride the feature dim with float4 loads, shuffle-reduce.
 __device__ __forceinline__ float wave_sum(float v) {

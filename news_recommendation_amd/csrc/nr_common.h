@@ -100,6 +100,15 @@ __device__ __forceinline__ void unit_range(int ntiles, int MT, int w, int nw, in
 
 __device__ __forceinline__ int clamp_len(int v, int S) { return v < 0 ? 0 : (v > S ? S : v); }
 
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  A kernel whose NEIGHBOURING work items touch
+// the same cache lines (attn_bwd: the 15 heads of a token row are 40-byte pieces of one 600-byte row, read and written by 15 waves)
+// renumbers its workgroups XCD-major: the returned id is this workgroup's position when the grid is listed XCD by XCD, so consecutive
+// ids share an L2 -- the pieces of a line are then fetched once and merged into whole-line writes instead of once per XCD.
+__device__ __forceinline__ int xcd_major_block(int b, int nb) {
+  const int x = b & 7, q = nb >> 3, r = nb & 7;        // XCD x holds q + (x < r) workgroups
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 __device__ __forceinline__ u16x4 pack4(f32x4 v) {
   u16x4 o;
   o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);

@@ -110,6 +110,19 @@ int nr_pack_additive(const float* Wa, const float* ba, const float* qv, int qdim
   return check_launch("nr_pack_additive");
 }
 
+int nr_wgrad_unpack(const float* dW_parts, int nc_w, const float* dWa_parts, int nc_a, const float* dq_part, int64_t nwg, int qdim,
+                    float* gWq, float* gbq, float* gWk, float* gbk, float* gWv, float* gbv, float* gWa, float* gba, float* gq, void* stream) {
+  if (!dW_parts || !dWa_parts || !dq_part || !gWq || !gbq || !gWk || !gbk || !gWv || !gbv || !gWa || !gba || !gq)
+    return fail(NR_ERR_BADARG, "nr_wgrad_unpack: null pointer");
+  if (nc_w <= 0 || nc_a <= 0 || nwg < 0) return fail(NR_ERR_BADARG, "nr_wgrad_unpack: bad partial counts");
+  if (qdim <= 0 || qdim > NR_QP) return fail(NR_ERR_UNSUPPORTED, "nr_wgrad_unpack: query_vector_dim must be in [1,208]");
+  nr::WgradUnpackParams p;
+  p.dW = dW_parts; p.dWa = dWa_parts; p.dq = dq_part; p.ncW = nc_w; p.ncA = nc_a; p.qdim = qdim; p.nwg = nwg;
+  p.gW[0] = gWq; p.gW[1] = gWk; p.gW[2] = gWv; p.gb[0] = gbq; p.gb[1] = gbk; p.gb[2] = gbv; p.gWa = gWa; p.gba = gba; p.gq = gq;
+  NR_LAUNCH(nr::wgrad_unpack_kernel, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, nr::WGU_SMEM, (hipStream_t)stream, p);
+  return check_launch("nr_wgrad_unpack");
+}
+
 int nr_mhsa_fwd_len(const int64_t* ids, const float* table, int64_t num_rows, const float* x_dense, const uint16_t* Wp,
                     const float* bp, uint16_t* ctx, uint16_t* q_save, uint16_t* k_save, uint16_t* vt_save, uint16_t* x_save, const int32_t* key_len,
                     int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
@@ -262,6 +275,7 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
   nr::AttnBwdParams p;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
   p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed);
+  { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
   // grid (used by the tests to force many pairs per wave on small inputs).

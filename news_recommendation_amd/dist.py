@@ -40,7 +40,9 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # NR_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) -- how the N > 1 code path of bench.py and
+            # the optimiser's exchange are exercised on a single-GPU box (tools/gpu_two_ranks_one_gpu.sh); never a production setting
+            backend = os.environ.get('NR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -29,7 +29,7 @@ class LSTUR(torch.nn.Module):
     def _user_rows(self, user, masked):
         dev = self.user_embedding.weight.device
         ops.check_ids(user, self.user_embedding.weight.shape[0], "user id")
-        ids = user.to(dev, non_blocking=True)
+        ids = ops.to_device_async(user, dev)
         scale = None
         if masked:
             # F.dropout2d on the [1, B, D] user tensor (:74-77) = one Bernoulli draw per sample, survivors scaled by 1/(1-p)

@@ -68,23 +68,26 @@ class profile:
         return out
 
 
-_host_keepalive = collections.deque(maxlen=32)
 
 
 def to_device_async(t, device):
-    """Host -> device copy that does not drain the stream (``.to(device)`` without ``non_blocking`` ends in a stream synchronise).
-    The host tensor is kept referenced for a few more calls, well past the point where the copy engine has read it."""
-    _host_keepalive.append(t)
-    return t.to(device, non_blocking=True)
+    """Host -> device copy that does not drain the stream: the tensor is copied into a pinned staging buffer (rotating, reused only after
+    the copy engine has read it) and crosses PCIe asynchronously.  A pageable source is staged by the
+    runtime itself, and ``t.to(device)`` without ``non_blocking`` additionally ends in a stream synchronise."""
+    if t.is_cuda or torch.device(device).type == 'cpu':
+        return t
+    r = _pinned.stage([t.detach().contiguous()], device, dim=0)
+    return r[0][0]
 
 
 class _PinnedRing:
     """Host staging for the DataLoader's per-position tensors (train.py:166-203 hands the model 1+K+N dicts of [B, ...] CPU tensors per
     step): they are written into ONE pinned buffer and cross PCIe as a single asynchronous copy (4.3 MB per NRMS step) instead of 53
-    pageable ones, each of which would stall the stream.  Three buffers per (shape, dtype) rotate; a buffer is reused only after the copy
+    pageable ones, each of which would stall the stream.  Six buffers per (shape, dtype) rotate (two call sites may share a shape, and the
+    host may run a step ahead of the GPU); a buffer is reused only after the copy
     that read it has completed (event)."""
 
-    def __init__(self, depth=3):
+    def __init__(self, depth=6):
         self.depth, self.slots = depth, {}
 
     def stage(self, parts, device, dim=1):
@@ -348,23 +351,43 @@ def _wgrad_chunks(n, M, N):
     return best
 
 
-def _wgrad(a, b, name):
-    """a^T @ b for tall-skinny bf16 a [n, M], b [n, N] (n = tokens, up to ~1.4e6; M, N <= 2752) with fp32 result: a batched GEMM
-    over token chunks with fp32 partial products, summed in fp32."""
+def _wgrad_parts(a, b, name):
+    """a^T @ b for tall-skinny bf16 a [n, M], b [n, N] (n = tokens, up to ~1.4e6; M, N <= 2752) as fp32 partial products over token
+    chunks: f32 [nc, M, N] (a batched GEMM; nc = 1 when the shape needs no split).  The sum over dim 0 is the weight gradient."""
     n = a.shape[0]
     nc = _wgrad_chunks(n, a.shape[1], b.shape[1])
     if nc == 1:
-        return _mm_f32(a.t(), b, name)
+        return _mm_f32(a.t(), b, name).unsqueeze(0)
 
     def run():
         av, bv = a.view(nc, n // nc, a.shape[1]).transpose(1, 2), b.view(nc, n // nc, b.shape[1])
         if _HAS_OUT_DTYPE is not False:
             try:
-                return torch.bmm(av, bv, out_dtype=torch.float32).sum(dim=0)
+                return torch.bmm(av, bv, out_dtype=torch.float32)
             except (TypeError, RuntimeError):
                 pass
-        return torch.bmm(av, bv).float().sum(dim=0)
+        return torch.bmm(av, bv).float()
     return _timed(name, run)
+
+
+def _wgrad(a, b, name):
+    """a^T @ b with fp32 result (chunk partials summed in fp32)."""
+    parts = _wgrad_parts(a, b, name)
+    return parts[0] if parts.shape[0] == 1 else parts.sum(dim=0)
+
+
+def inplace_grads(params):
+    """The persistent gradient buffers of ``params`` when a trainer owns one for EVERY one of them (``_nr_inplace_grad``, see
+    grad_target), else None.  The encoder backward then accumulates its weight gradients there itself (nr_wgrad_unpack: one launch)
+    and hands autograd None for them, instead of 9 strided slices that AccumulateGrad adds one by one."""
+    out = []
+    for p in params:
+        g = getattr(p, 'grad', None)
+        if not (getattr(p, '_nr_inplace_grad', False) and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+                and g.shape == p.shape and g.device == p.device):
+            return None
+        out.append(g)
+    return out
 
 
 _ws = {}
@@ -580,6 +603,7 @@ class _EncoderFn(torch.autograd.Function):
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
             ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
+            ctx.wparams = (Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv)        # likewise: inplace_grads()
             ctx.sorted = sort_ids_async(ids_c, table.shape[0]) if gather and ctx.needs_input_grad[1] else None
         return out
 
@@ -598,11 +622,10 @@ class _EncoderFn(torch.autograd.Function):
         dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
         _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                                 _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
-        d_qv = dq_part.sum(dim=0)[:qdim]
         sw = side_wgrad(dev)
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        dWa_ext = sw.run(lambda: _wgrad(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))       # [QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))   # [nc, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
@@ -610,7 +633,7 @@ class _EncoderFn(torch.autograd.Function):
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)
-        dW_ext = sw.run(lambda: _wgrad(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))       # [960, KP]
+        dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))    # [nc, 960, KP]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
         dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
@@ -626,7 +649,17 @@ class _EncoderFn(torch.autograd.Function):
                 table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
-        sw.join(dWa_ext, dW_ext)
+        sw.join(dWa_parts, dW_parts)
+        # ---- the nine weight gradients.  A trainer with persistent gradient buffers: summed over the chunks and accumulated there in one
+        # launch; plain autograd: chunk sums, then slices of the packed geometry that AccumulateGrad adds into .grad one by one ----------
+        dst = inplace_grads(ctx.wparams) if all(ctx.needs_input_grad[3:12]) else None
+        if dst is not None:
+            _call('nr_wgrad_unpack', lib.nr_wgrad_unpack, _ptr(dW_parts), dW_parts.shape[0], _ptr(dWa_parts), dWa_parts.shape[0],
+                  _ptr(dq_part), nwg, qdim, *[_ptr(g) for g in dst], _stream())
+            return (None, d_table, d_x) + (None,) * 13
+        d_qv = dq_part.sum(dim=0)[:qdim]
+        dWa_ext = dWa_parts[0] if dWa_parts.shape[0] == 1 else dWa_parts.sum(dim=0)
+        dW_ext = dW_parts[0] if dW_parts.shape[0] == 1 else dW_parts.sum(dim=0)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]

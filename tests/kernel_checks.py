@@ -386,6 +386,31 @@ def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
     return rels
 
 
+def check_wgrad_unpack(be, nc_w=3, nc_a=2, nwg=11, qdim=200):
+    """nr_wgrad_unpack: chunk partials in the packed operand geometry -> accumulated (+=) into the nine parameter-shaped gradients."""
+    rng = np.random.default_rng(41)
+    dW = rng.normal(0, 1.0, size=(nc_w, 3 * NR_KP, NR_KP)).astype(np.float32)
+    dWa = rng.normal(0, 1.0, size=(nc_a, NR_QP, NR_KP)).astype(np.float32)
+    dq = rng.normal(0, 1.0, size=(nwg, NR_QP)).astype(np.float32)
+    shapes = [(NR_D, NR_D), (NR_D,)] * 3 + [(qdim, NR_D), (qdim,), (qdim,)]
+    init = [rng.normal(0, 1.0, size=sh).astype(np.float32) for sh in shapes]        # pre-existing gradient content: the kernel accumulates
+    dst = [be.dev(a) for a in init]
+    ck(be, be.lib.nr_wgrad_unpack(be.ptr(be.dev(dW)), nc_w, be.ptr(be.dev(dWa)), nc_a, be.ptr(be.dev(dq)), nwg, qdim,
+                                  *[be.ptr(d) for d in dst], be.stream))
+    be.sync()
+    sW, sWa, sq = dW.astype(np.float64).sum(0), dWa.astype(np.float64).sum(0), dq.astype(np.float64).sum(0)
+    ref = []
+    for i in range(3):
+        ref += [sW[i * NR_KP:i * NR_KP + NR_D, :NR_D], sW[i * NR_KP:i * NR_KP + NR_D, NR_D]]
+    ref += [sWa[:qdim, :NR_D], sWa[:qdim, NR_D], sq[:qdim]]
+    for k, (d, a, r) in enumerate(zip(dst, init, ref)):
+        np.testing.assert_allclose(be.np(d), a.astype(np.float64) + r, rtol=0, atol=2e-5 * max(nc_w, nc_a, nwg) ** 0.5, err_msg=f"wgrad_unpack destination {k}")
+    # argument checks
+    assert be.lib.nr_wgrad_unpack(None, nc_w, be.ptr(dst[0]), nc_a, be.ptr(dst[0]), nwg, qdim, *[be.ptr(d) for d in dst], be.stream) != 0
+    assert be.lib.nr_wgrad_unpack(be.ptr(dst[0]), 0, be.ptr(dst[0]), nc_a, be.ptr(dst[0]), nwg, qdim, *[be.ptr(d) for d in dst], be.stream) != 0
+    assert be.lib.nr_wgrad_unpack(be.ptr(dst[0]), 1, be.ptr(dst[0]), 1, be.ptr(dst[0]), nwg, NR_QP + 1, *[be.ptr(d) for d in dst], be.stream) != 0
+
+
 def check_additive_bwd(be, S=20, n_seq=6):
     params = make_params(14)
     rng = np.random.default_rng(15)

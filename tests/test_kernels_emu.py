@@ -37,6 +37,8 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=1)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=6)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=3)
+def test_wgrad_unpack(be): kc.check_wgrad_unpack(be)
+def test_wgrad_unpack_small_qdim(be): kc.check_wgrad_unpack(be, nc_w=1, nc_a=1, nwg=1, qdim=70)
 def test_gather_bf16(be): kc.check_gather_bf16(be)
 def test_scatter_add(be): kc.check_scatter_add(be)
 def test_score_bwd(be): kc.check_score_bwd(be)

@@ -39,6 +39,8 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
+def test_wgrad_unpack(be): kc.check_wgrad_unpack(be, nc_w=32, nc_a=64, nwg=1696)
+def test_wgrad_unpack_small_qdim(be): kc.check_wgrad_unpack(be, nc_w=1, nc_a=1, nwg=1, qdim=70)
 def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
 def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
 def test_score_bwd(be): kc.check_score_bwd(be, B=513)

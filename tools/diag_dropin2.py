@@ -2,7 +2,8 @@ import sys, time, torch, numpy as np, cProfile, pstats, io
 sys.path.insert(0, '/root/repo')
 import bench
 from news_recommendation_amd import ops
-cfg = bench.make_cfg('NRMS', 'small'); wl = bench.Workload('NRMS', cfg)
+M = sys.argv[1] if len(sys.argv) > 1 else 'NRMS'; SH = sys.argv[2] if len(sys.argv) > 2 else 'small'
+cfg = bench.make_cfg(M, SH, 0); wl = bench.Workload(M, cfg)
 dev = torch.device('cuda:0')
 model = wl.make_model().to(dev).train()
 opt = wl.make_optimizer(model)
