@@ -88,40 +88,66 @@ struct WgradUnpackParams {
   float* gba;            // [qdim]
   float* gq;             // [qdim]
 };
-constexpr int WGU_THREADS = KP;          // one thread per packed column (D weights + the bias column)
-constexpr int WGU_DQ_PH = WGU_THREADS / 64;   // dq blocks: 64 entries x 5 row phases
-constexpr int WGU_SMEM = WGU_DQ_PH * 64 * 4;
-__device__ __host__ __forceinline__ int wgrad_unpack_grid(int qdim) { return 3 * D + qdim + (qdim + 63) / 64; }
+constexpr int WGU_ROWS = 2;                      // output rows per workgroup: 80 lanes x 4 packed columns each
+constexpr int WGU_THREADS = WGU_ROWS * (KP / 4);
+constexpr int WGU_DQ_COLS = 16, WGU_DQ_PH = 32;  // dq kernel: 16 entries x 32 row phases per workgroup
+__device__ __host__ __forceinline__ int wgrad_unpack_grid(int qdim) { return (3 * D + qdim + WGU_ROWS - 1) / WGU_ROWS; }
 
+// VEC: all destinations are 16-byte aligned (float4 read-modify-write); otherwise element by element.
+template <bool VEC>
 __global__ __launch_bounds__(WGU_THREADS) void wgrad_unpack_kernel(WgradUnpackParams p) {
-  NR_SMEM_DECL(smem);
-  float (*part)[64] = (float (*)[64])smem;          // [WGU_DQ_PH][64]
-  const int b = blockIdx.x, t = threadIdx.x;
-  if (b < 3 * D + p.qdim) {
-    const bool proj = b < 3 * D;
-    const int i = proj ? b / D : 0, r = proj ? b - i * D : b - 3 * D;
-    const float* src = proj ? p.dW + ((size_t)(i * KP + r)) * KP : p.dWa + (size_t)r * KP;
-    const size_t cs = proj ? (size_t)3 * KP * KP : (size_t)QP * KP;
-    const int nc = proj ? p.ncW : p.ncA;
-    if (t <= D) {
-      float a = 0.0f;
-      for (int c = 0; c < nc; ++c) a += src[c * cs + t];
-      float* dst = t < D ? (proj ? p.gW[i] : p.gWa) + (size_t)r * D + t : (proj ? p.gb[i] : p.gba) + r;
-      *dst += a;
-    }
+  const int t = threadIdx.x, rr = t / (KP / 4), c4 = t - rr * (KP / 4);
+  const int b = blockIdx.x * WGU_ROWS + rr;                  // output row: [0, 3D) projections, [3D, 3D + qdim) pooling linear
+  if (b >= 3 * D + p.qdim || c4 > D / 4) return;             // columns > D are padding
+  const bool proj = b < 3 * D;
+  const int i = proj ? b / D : 0, r = proj ? b - i * D : b - 3 * D;
+  const float* src = (proj ? p.dW + ((size_t)(i * KP + r)) * KP : p.dWa + (size_t)r * KP) + c4 * 4;
+  const size_t cs = proj ? (size_t)3 * KP * KP : (size_t)QP * KP;
+  const int nc = proj ? p.ncW : p.ncA;
+  // four independent partial sums: up to 4 x 16 B per lane in flight per trip (fixed order -> deterministic)
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int c = 0;
+  for (; c + 4 <= nc; c += 4) {
+    a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
+    a1 = a1 + *(const f32x4*)(src + (size_t)(c + 1) * cs);
+    a2 = a2 + *(const f32x4*)(src + (size_t)(c + 2) * cs);
+    a3 = a3 + *(const f32x4*)(src + (size_t)(c + 3) * cs);
+  }
+  for (; c < nc; ++c) a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
+  const f32x4 a = (a0 + a1) + (a2 + a3);
+  if (c4 == D / 4) {                                         // packed column D: the bias gradient
+    float* dst = (proj ? p.gb[i] : p.gba) + r;
+    *dst += a[0];
     return;
   }
-  // query-vector gradient: this block owns 64 entries; 5 phases walk the partial rows, combined in a fixed order
-  const int j = (b - 3 * D - p.qdim) * 64 + (t & 63), ph = t >> 6;
-  float a = 0.0f;
-  if (j < p.qdim)
-    for (int64_t w = ph; w < p.nwg; w += WGU_DQ_PH) a += p.dq[w * QP + j];
-  part[ph][t & 63] = a;
+  float* dst = (proj ? p.gW[i] : p.gWa) + (size_t)r * D + c4 * 4;
+  if (VEC) {
+    *(f32x4*)dst = *(const f32x4*)dst + a;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] += a[k];
+  }
+}
+
+// d attention_query_vector: column sums of the per-workgroup partial rows, 16 columns per workgroup, 32 row phases combined through
+// LDS in a fixed order.
+__global__ __launch_bounds__(WGU_DQ_COLS * WGU_DQ_PH) void wgrad_dq_kernel(WgradUnpackParams p) {
+  NR_SMEM_DECL(smem);
+  float (*part)[WGU_DQ_COLS] = (float (*)[WGU_DQ_COLS])smem;          // [WGU_DQ_PH][WGU_DQ_COLS]
+  const int t = threadIdx.x, cj = t % WGU_DQ_COLS, ph = t / WGU_DQ_COLS;
+  const int j = blockIdx.x * WGU_DQ_COLS + cj;
+  float a0 = 0.0f, a1 = 0.0f;
+  if (j < p.qdim) {
+    int64_t w = ph;
+    for (; w + WGU_DQ_PH < p.nwg; w += 2 * WGU_DQ_PH) { a0 += p.dq[w * QP + j]; a1 += p.dq[(w + WGU_DQ_PH) * QP + j]; }
+    if (w < p.nwg) a0 += p.dq[w * QP + j];
+  }
+  part[ph][cj] = a0 + a1;
   __syncthreads();
   if (ph == 0 && j < p.qdim) {
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < WGU_DQ_PH; ++k) s += part[k][t];
+    for (int k = 0; k < WGU_DQ_PH; ++k) s += part[k][cj];
     p.gq[j] += s;
   }
 }

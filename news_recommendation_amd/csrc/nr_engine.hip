@@ -78,6 +78,44 @@ int launch_conv_t(nr::ConvParams& p, void* stream) {
   return NR_OK;
 }
 
+template <int KS_CT>
+static int launch_gru_fwd_persist(nr::GruFwdSeqParams& q, int T, hipStream_t stream) {
+  const int grid = nr::gru_grid(q.st.Hg / 16, (q.st.B + 127) / 128), smem = 3 * q.st.Hp * 16 * 2;
+  if (allow_smem(nr::gru_fwd_persist_kernel<KS_CT, 2>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot reserve LDS");
+  if (nr::kGridBarrier) {
+    q.sync = nr::grid_barrier_word(stream);
+    if (!q.sync) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot set up the grid barrier counter");
+    q.t0 = 0; q.t1 = T;
+    NR_LAUNCH2((nr::gru_fwd_persist_kernel<KS_CT, 2>), grid, 1, nr::WG, smem, stream, q);
+  } else {                                  // no grid barrier on this target (the emulator): the same kernel, one step per launch
+    q.sync = nullptr;
+    for (int t = 0; t < T; ++t) {
+      q.t0 = t; q.t1 = t + 1;
+      NR_LAUNCH2((nr::gru_fwd_persist_kernel<KS_CT, 2>), grid, 1, nr::WG, smem, stream, q);
+    }
+  }
+  return check_launch("nr_gru_fwd_seq");
+}
+
+template <int KS_CT>
+static int launch_gru_bwd_persist(nr::GruBwdSeqParams& q, hipStream_t stream) {
+  const int grid = nr::gru_grid(q.st.Hg / 16, (q.st.B + 127) / 128), smem = q.st.Kp * 16 * 2;
+  if (allow_smem(nr::gru_bwd_persist_kernel<KS_CT>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot reserve LDS");
+  if (nr::kGridBarrier) {
+    q.sync = nr::grid_barrier_word(stream);
+    if (!q.sync) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot set up the grid barrier counter");
+    q.i0 = 0; q.i1 = q.T + 1;
+    NR_LAUNCH2(nr::gru_bwd_persist_kernel<KS_CT>, grid, 1, nr::WG, smem, stream, q);
+  } else {
+    q.sync = nullptr;
+    for (int i = 0; i <= q.T; ++i) {
+      q.i0 = i; q.i1 = i + 1;
+      NR_LAUNCH2(nr::gru_bwd_persist_kernel<KS_CT>, grid, 1, nr::WG, smem, stream, q);
+    }
+  }
+  return check_launch("nr_gru_bwd_seq");
+}
+
 }  // namespace
 
 extern "C" {
@@ -119,7 +157,13 @@ int nr_wgrad_unpack(const float* dW_parts, int nc_w, const float* dWa_parts, int
   nr::WgradUnpackParams p;
   p.dW = dW_parts; p.dWa = dWa_parts; p.dq = dq_part; p.ncW = nc_w; p.ncA = nc_a; p.qdim = qdim; p.nwg = nwg;
   p.gW[0] = gWq; p.gW[1] = gWk; p.gW[2] = gWv; p.gb[0] = gbq; p.gb[1] = gbk; p.gb[2] = gbv; p.gWa = gWa; p.gba = gba; p.gq = gq;
-  NR_LAUNCH(nr::wgrad_unpack_kernel, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, nr::WGU_SMEM, (hipStream_t)stream, p);
+  const uintptr_t al = (uintptr_t)gWq | (uintptr_t)gWk | (uintptr_t)gWv | (uintptr_t)gWa | (uintptr_t)dW_parts | (uintptr_t)dWa_parts;
+  if ((al & 15) == 0) NR_LAUNCH(nr::wgrad_unpack_kernel<true>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, 0, (hipStream_t)stream, p);
+  else if ((((uintptr_t)dW_parts | (uintptr_t)dWa_parts) & 15) == 0)
+    NR_LAUNCH(nr::wgrad_unpack_kernel<false>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, 0, (hipStream_t)stream, p);
+  else return fail(NR_ERR_BADARG, "nr_wgrad_unpack: the partial-product buffers must be 16-byte aligned");
+  NR_LAUNCH(nr::wgrad_dq_kernel, (qdim + nr::WGU_DQ_COLS - 1) / nr::WGU_DQ_COLS, nr::WGU_DQ_COLS * nr::WGU_DQ_PH,
+            nr::WGU_DQ_COLS * nr::WGU_DQ_PH * 4, (hipStream_t)stream, p);
   return check_launch("nr_wgrad_unpack");
 }
 
@@ -586,6 +630,24 @@ int nr_tile_rows_bf16(const uint16_t* src, int n, int K, uint16_t* dst, void* st
   return check_launch("nr_tile_rows_bf16");
 }
 
+// GRU tuning knobs, read once.  NR_GRU_NB: sample tiles per wave in the forward step (default 2 from 256 samples up); NR_GRU_LDS=0:
+// register-only step kernels instead of the W_hh-tile-in-LDS ones (Hd = 900 / 450); NR_GRU_PERSIST=1: the persistent whole-sequence
+// kernels instead of one launch per step.  Off by default: measured on MI355X (LSTUR, B = 512, T = 50, A/B on one box, twice) the
+// persistent form is bit-identical but SLOWER, 6.43-6.52 vs 6.13-6.14 ms per training step: back-to-back step launches cost ~3-4 us of
+// gap each, the grid-wide barrier (write-through drain + 228 arrivals on one counter + polling) costs more than that.
+static int gru_nb_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_NB"); v = e ? atoi(e) : 0; } return v; }
+static int gru_lds_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_LDS"); v = e ? atoi(e) : 1; } return v; }
+static int gru_persist_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_PERSIST"); v = e ? atoi(e) : 0; } return v; }
+static int gru_cu_count() { static int v = -1; if (v < 0) v = nr::device_cu_count(); return v; }
+// the persistent kernels need the LDS-tile step form (two sample tiles per wave, Hd = 900 / 450) and every active workgroup resident at
+// once: one per CU
+static bool gru_persist_ok(int B, int Hd) {
+  const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
+  const int nb = gru_nb_knob() > 0 ? gru_nb_knob() : (B >= 256 ? 2 : 1);
+  return gru_persist_knob() == 1 && gru_lds_knob() == 1 && nb == 2 && (Hp == 29 * 32 || Hp == 15 * 32) && B > 0 &&
+         (Hg / 16) * ((B + 127) / 128) <= gru_cu_count();
+}
+
 int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_t,
                     uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t,
                     void* stream) {
@@ -595,13 +657,9 @@ int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, con
   nr::GruFwdParams p;
   p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_t = h_in_t; p.h_out_b = h_out_b; p.h_out_t = h_out_t; p.h_in_f = h_in_f;
   p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
-  // tuning knob NR_GRU_NB: sample tiles per wave in the forward step (default 2 from 256 samples up)
-  static int nbv = -1;
-  if (nbv < 0) { const char* e = getenv("NR_GRU_NB"); nbv = e ? atoi(e) : 0; }
-  const int nb = nbv > 0 ? nbv : (B >= 256 ? 2 : 1);
+  const int nb = gru_nb_knob() > 0 ? gru_nb_knob() : (B >= 256 ? 2 : 1);
   const int tiles = p.Hg / 16;
-  static int ldsv = -1;       // W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450): default since the round-1 driver run passed it on
-  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 1; }     // hardware; NR_GRU_LDS=0 selects the register-only kernels
+  const int ldsv = gru_lds_knob();      // W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450): the default
   if (ldsv == 1 && nb == 2 && (p.Hp == 29 * 32 || p.Hp == 15 * 32)) {
     const int grid = nr::gru_grid(tiles, (B + 127) / 128), smem = 3 * p.Hp * 16 * 2;
     if (p.Hp == 29 * 32) {
@@ -636,8 +694,7 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   p.g_last = g_last; p.dgh_next = dgh_next; p.carry_next = carry_next; p.WhhT = WhhT; p.gates = t >= 0 ? gates : nullptr; p.h_prev_b = h_prev_b;
   p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t = dgh_t; p.carry = carry; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32);
   p.Kp = ceil_to(3 * p.Hg, 32); p.t = t; p.first = first;
-  static int ldsv = -1;       // W_hh^T-tile-in-LDS variant (Hd = 900 / 450): default, NR_GRU_LDS=0 selects the register-only kernel
-  if (ldsv < 0) { const char* e = getenv("NR_GRU_LDS"); ldsv = e ? atoi(e) : 1; }
+  const int ldsv = gru_lds_knob();      // W_hh^T-tile-in-LDS variant (Hd = 900 / 450): default, NR_GRU_LDS=0 selects the register-only kernel
   if (ldsv == 1 && (p.Kp == 86 * 32 || p.Kp == 44 * 32)) {
     const int grid = nr::gru_grid(p.Hg / 16, (B + 127) / 128), smem = p.Kp * 16 * 2;
     if (p.Kp == 86 * 32) {
@@ -655,11 +712,32 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   return check_launch("nr_gru_bwd_step");
 }
 
+int nr_gru_seq_buffers(int B, int Hd, int T) { return (T > 0 && gru_persist_ok(B, Hd)) ? T + 1 : 2; }
+
+int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
+                     uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream);
+int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
+                     uint16_t* dgh, uint16_t* dgh_t2, int n_buf, float* carry2, int B, int N, int Hd, int T, void* stream);
+
 int nr_gru_fwd_seq(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2,
                    uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream) {
-  if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
+  return nr_gru_fwd_seq_n(gi, Whh, b_ih, b_hh, len, h_t2, 2, H_all, h_f2, gates, B, N, Hd, T, stream);
+}
+
+int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
+                     uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream) {
+  if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0 || n_buf < 2) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
   const size_t ht = (size_t)ceil_to(B, 16) * Hp, hf = (size_t)B * Hp;
+  if (T > 0 && n_buf >= T + 1 && gru_persist_ok(B, Hd)) {
+    if (!gi || !Whh || !b_ih || !b_hh || !len) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
+    nr::GruFwdSeqParams q;
+    q.st.gi = gi; q.st.Whh = Whh; q.st.b_ih = b_ih; q.st.b_hh = b_hh; q.st.len = len; q.st.h_in_t = nullptr; q.st.h_out_b = nullptr; q.st.h_out_t = nullptr;
+    q.st.h_in_f = nullptr; q.st.h_out_f = nullptr; q.st.gates = nullptr; q.st.B = B; q.st.N = N; q.st.Hd = Hd; q.st.Hg = Hg; q.st.Hp = Hp; q.st.t = 0;
+    q.h_t = h_t2; q.H_all = H_all; q.h_f2 = h_f2; q.gates_all = gates;
+    q.n_active = (unsigned)((Hg / 16) * ((B + 127) / 128));
+    return Hp == 29 * 32 ? launch_gru_fwd_persist<29>(q, T, (hipStream_t)stream) : launch_gru_fwd_persist<15>(q, T, (hipStream_t)stream);
+  }
   for (int t = 0; t < T; ++t) {
     const int rc = nr_gru_fwd_step(gi, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, H_all ? H_all + (size_t)(t + 1) * hf : nullptr,
                                    h_t2 + ((t + 1) & 1) * ht, h_f2 + (t & 1) * hf, h_f2 + ((t + 1) & 1) * hf,
@@ -671,10 +749,25 @@ int nr_gru_fwd_seq(const float* gi, const uint16_t* Whh, const float* b_ih, cons
 
 int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                    uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream) {
-  if (!g_last || !gates || !H_all || !dgi || !dgh || !dgh_t2 || !carry2 || T <= 0 || T > N || B < 0 || Hd <= 0)
+  return nr_gru_bwd_seq_n(g_last, WhhT, gates, H_all, len, dgi, dgh, dgh_t2, 2, carry2, B, N, Hd, T, stream);
+}
+
+int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
+                     uint16_t* dgh, uint16_t* dgh_t2, int n_buf, float* carry2, int B, int N, int Hd, int T, void* stream) {
+  if (!g_last || !gates || !H_all || !dgi || !dgh || !dgh_t2 || !carry2 || T <= 0 || T > N || B < 0 || Hd <= 0 || n_buf < 2)
     return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32), Kp = ceil_to(3 * Hg, 32);
   const size_t dt = (size_t)ceil_to(B, 16) * Kp, cf = (size_t)B * Hp, hb = (size_t)B * Hp, gb = (size_t)B * 4 * Hg, db = (size_t)B * Kp;
+  if (n_buf >= T + 1 && gru_persist_ok(B, Hd)) {
+    if (!WhhT || !len) return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
+    nr::GruBwdSeqParams q;
+    q.st.g_last = g_last; q.st.dgh_next = nullptr; q.st.carry_next = nullptr; q.st.WhhT = WhhT; q.st.gates = nullptr; q.st.h_prev_b = nullptr;
+    q.st.len = len; q.st.dgi = dgi; q.st.dgh = nullptr; q.st.dgh_t = nullptr; q.st.carry = nullptr; q.st.B = B; q.st.N = N; q.st.Hd = Hd; q.st.Hg = Hg;
+    q.st.Hp = Hp; q.st.Kp = Kp; q.st.t = 0; q.st.first = 0;
+    q.gates_all = gates; q.H_all = H_all; q.dgh_all = dgh; q.dgh_t = dgh_t2; q.carry2 = carry2; q.T = T;
+    q.n_active = (unsigned)((Hg / 16) * ((B + 127) / 128));
+    return Kp == 86 * 32 ? launch_gru_bwd_persist<86>(q, (hipStream_t)stream) : launch_gru_bwd_persist<44>(q, (hipStream_t)stream);
+  }
   int i = 0;
   for (int t = T - 1; t >= -1; --t, ++i) {
     const int first = i == 0;

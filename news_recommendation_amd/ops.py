@@ -376,10 +376,15 @@ def _wgrad(a, b, name):
     return parts[0] if parts.shape[0] == 1 else parts.sum(dim=0)
 
 
+_WGRAD_UNPACK = os.environ.get('NR_WGRAD_UNPACK', '1') == '1'       # A/B knob: 0 = hand the nine weight gradients to autograd
+
+
 def inplace_grads(params):
     """The persistent gradient buffers of ``params`` when a trainer owns one for EVERY one of them (``_nr_inplace_grad``, see
     grad_target), else None.  The encoder backward then accumulates its weight gradients there itself (nr_wgrad_unpack: one launch)
     and hands autograd None for them, instead of 9 strided slices that AccumulateGrad adds one by one."""
+    if not _WGRAD_UNPACK:
+        return None
     out = []
     for p in params:
         g = getattr(p, 'grad', None)

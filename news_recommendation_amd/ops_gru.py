@@ -98,11 +98,14 @@ class _GruFn(torch.autograd.Function):
             hf[0][:, :Hd].copy_(h0)
         _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf[0]), Hp, Hd, _ptr(H_all[0]), Hp, B, _stream())
         gates = torch.empty(T, B, 4, Hg, dtype=_BF16_AS_I16, device=dev) if need_grad else None
-        ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)               # step-to-step operand, tile order
+        # step-to-step operand, tile order: a ping-pong pair, or one buffer per step when the shape gets the persistent kernel (the rows /
+        # columns of padding are never written, so the zero fill of the cached workspace is done once)
+        nbuf = lib.nr_gru_seq_buffers(B, Hd, N)                      # sized for the longest history, so that the shape does not change with T
+        ht = _workspace('gru_h_t', (nbuf, _ceil(B, 16) * Hp), _BF16_AS_I16, dev, zero=True)
         _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(H_all[0]), B, Hp, _ptr(ht[0]), _stream())
         ops.seq_launches['nr_gru_fwd_seq'] = T
         if not ops.profiling('nr_gru_fwd_step'):        # one FFI crossing for the whole recurrence (per-step form: per-kernel profiling)
-            _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht),
+            _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq_n, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht), nbuf,
                   _ptr(H_all) if need_grad else None, _ptr(hf), _ptr(gates) if need_grad else None, B, N, Hd, T, _stream())
         else:
             for t in range(T):
@@ -128,12 +131,13 @@ class _GruFn(torch.autograd.Function):
             dgi.view(B, N, Kp)[:, T:].zero_()                                                # steps nobody reached
         dgh = _workspace('gru_dgh', (T, B, Kp), _BF16_AS_I16, dev, zero=True)
         carry = torch.empty(2, B, Hp, dtype=torch.float32, device=dev)
-        dght = _workspace('gru_dgh_t', (2, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)  # step-to-step operand, tile order
+        nbuf = lib.nr_gru_seq_buffers(B, Hd, N)
+        dght = _workspace('gru_dgh_t', (nbuf, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)   # step-to-step operand, tile order (see forward)
         per_step = ops.profiling('nr_gru_bwd_step')
         ops.seq_launches['nr_gru_bwd_seq'] = T + 1
         if not per_step:
-            _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
-                  _ptr(dght), _ptr(carry), B, N, Hd, T, _stream())
+            _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq_n, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
+                  _ptr(dght), nbuf, _ptr(carry), B, N, Hd, T, _stream())
         for i, t in enumerate(range(T - 1, -2, -1) if per_step else ()):
             first = 1 if i == 0 else 0
             _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dght[(i + 1) % 2]),

@@ -405,6 +405,18 @@ def check_wgrad_unpack(be, nc_w=3, nc_a=2, nwg=11, qdim=200):
     ref += [sWa[:qdim, :NR_D], sWa[:qdim, NR_D], sq[:qdim]]
     for k, (d, a, r) in enumerate(zip(dst, init, ref)):
         np.testing.assert_allclose(be.np(d), a.astype(np.float64) + r, rtol=0, atol=2e-5 * max(nc_w, nc_a, nwg) ** 0.5, err_msg=f"wgrad_unpack destination {k}")
+    # destinations that are only 4-byte aligned (parameters packed back to back in a flat buffer): the element-wise form
+    flat = be.dev(np.zeros(1 + sum(int(np.prod(sh)) for sh in shapes), dtype=np.float32))
+    offs, o = [], 1
+    for sh in shapes:
+        offs.append(o); o += int(np.prod(sh))
+    ck(be, be.lib.nr_wgrad_unpack(be.ptr(be.dev(dW)), nc_w, be.ptr(be.dev(dWa)), nc_a, be.ptr(be.dev(dq)), nwg, qdim,
+                                  *[be.ptr(flat) + 4 * o for o in offs], be.stream))
+    be.sync()
+    got = be.np(flat)
+    assert got[0] == 0
+    for k, (o, sh, r) in enumerate(zip(offs, shapes, ref)):
+        np.testing.assert_allclose(got[o:o + int(np.prod(sh))].reshape(sh), r, rtol=0, atol=2e-5 * max(nc_w, nc_a, nwg) ** 0.5, err_msg=f"wgrad_unpack (unaligned) destination {k}")
     # argument checks
     assert be.lib.nr_wgrad_unpack(None, nc_w, be.ptr(dst[0]), nc_a, be.ptr(dst[0]), nwg, qdim, *[be.ptr(d) for d in dst], be.stream) != 0
     assert be.lib.nr_wgrad_unpack(be.ptr(dst[0]), 0, be.ptr(dst[0]), nc_a, be.ptr(dst[0]), nwg, qdim, *[be.ptr(d) for d in dst], be.stream) != 0

@@ -91,6 +91,22 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     assert np.array_equal(be.np(hf2_d)[T % 2], be.np(hf[T % 2]))
     assert all(np.array_equal(be.np(Hs_d)[t], be.np(H_all[t])) for t in range(T + 1))
     assert all(np.array_equal(be.np(gs_d)[t], be.np(gates[t])) for t in range(T))
+    # ... and with one tile-order buffer per step (nr_gru_fwd_seq_n): the form that runs as ONE persistent launch when the shape allows it
+    nbuf = be.lib.nr_gru_seq_buffers(B, Hd, T)
+    assert nbuf in (2, T + 1)
+    htn = np.zeros((nbuf, B16, Hp), dtype=np.uint16)
+    htn_d = be.dev(htn)
+    ck(be, be.lib.nr_tile_rows_bf16(be.ptr(H_all[0]), B, Hp, be.ptr(htn_d), be.stream))
+    hfn_d = be.dev(hf2)
+    Hsn_d = be.dev(Hs)
+    gsn_d = be.poison((T, B, 4, Hg), np.uint16)
+    ck(be, be.lib.nr_gru_fwd_seq_n(be.ptr(h_gi), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(htn_d), nbuf, be.ptr(Hsn_d),
+                                   be.ptr(hfn_d), be.ptr(gsn_d), B, N, Hd, T, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(hfn_d)[T % 2], be.np(hf[T % 2]))
+    assert all(np.array_equal(be.np(Hsn_d)[t], be.np(H_all[t])) for t in range(T + 1))
+    assert all(np.array_equal(be.np(gsn_d)[t], be.np(gates[t])) for t in range(T))
+    assert np.array_equal(untile(be.np(htn_d)[T % nbuf if nbuf == 2 else T], B16, Hp)[:B], be.np(H_all[T]))
     h_last = be.np(hf[T % 2])[:, :Hd]
     # reference: the oracle recurrence in float64 on the same operands
     enc = OracleLSTURUserEncoder(Hd // 3 if Hd % 3 == 0 and I == Hd else 1, 'ini')
@@ -135,6 +151,13 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     be.sync()
     assert np.array_equal(be.np(carry2)[T % 2][:, :Hd], be.np(carry[T % 2])[:, :Hd]) and np.array_equal(be.np(dgi2), be.np(dgi))
     assert all(np.array_equal(be.np(dgh2)[t][:, :3 * Hg], be.np(dgh[t])[:, :3 * Hg]) for t in range(T))
+    dgi3 = be.dev(dgi0); dgh3 = be.dev(np.zeros((T, B, Kp), dtype=np.uint16))
+    dght3 = be.dev(np.zeros((nbuf, B16, Kp), dtype=np.uint16)); carry3 = be.poison((2, B, Hp), np.float32)
+    ck(be, be.lib.nr_gru_bwd_seq_n(be.ptr(hg), be.ptr(WhhT_p), be.ptr(gs_d), be.ptr(Hs_d), be.ptr(hlen), be.ptr(dgi3), be.ptr(dgh3), be.ptr(dght3),
+                                   nbuf, be.ptr(carry3), B, N, Hd, T, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(carry3)[T % 2][:, :Hd], be.np(carry[T % 2])[:, :Hd]) and np.array_equal(be.np(dgi3), be.np(dgi))
+    assert all(np.array_equal(be.np(dgh3)[t][:, :3 * Hg], be.np(dgh[t])[:, :3 * Hg]) for t in range(T))
     rel = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - b).max() / (np.abs(b).max() + 1e-30)
     assert rel(dh0, h0t.grad.numpy()) < 3e-2, rel(dh0, h0t.grad.numpy())
     dgi_np = bf16_to_f32(be.np(dgi)).reshape(B, N, Kp).astype(np.float64)

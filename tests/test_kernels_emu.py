@@ -87,8 +87,8 @@ def test_gru_two_batch_tiles(be): kcg.check_gru(be, B=19, N=2, Hd=48, I=40, seed
 def test_gru_lds_variant():
     """NR_GRU_LDS=1: the W_hh / W_hh^T tile staged in LDS and two sample tiles per wave (experimental knob) against the same oracle."""
     import subprocess, sys, os
-    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2')
-    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_gru as k; be = EmuBackend(); "
+    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2', NR_GRU_PERSIST='1')     # + the persistent kernels, one step per launch here
+    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_gru as k; be = EmuBackend(); assert be.lib.nr_gru_seq_buffers(37, 900, 3) == 4; "
             "k.check_gru(be, B=37, N=3, seed=4); k.check_gru(be, B=5, N=4, Hd=450, I=900, seed=5)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -90,6 +90,21 @@ def test_gru_lds_default_large_batch(be):
     kcg.check_gru(be, B=270, N=8, Hd=450, I=900, seed=4)
 
 
+def test_gru_persistent_full_grid():
+    """NR_GRU_PERSIST=1, B = 512: nr_gru_fwd_seq_n / nr_gru_bwd_seq_n run as ONE persistent launch each (57 unit tiles x 4 sample groups =
+    228 workgroups, one per CU, W_hh tile resident in LDS, grid-wide barrier between the steps) and must reproduce the per-step
+    launches bit for bit -- check_gru compares the two forms; a stale read across the barrier would show up there.  (Knobs are read
+    once per process, hence the subprocess.)"""
+    import subprocess, sys, os
+    env = dict(os.environ, NR_GRU_PERSIST='1')
+    code = ("from tests.backends import GpuBackend; from tests import kernel_checks_gru as k; be = GpuBackend(); "
+            "assert be.lib.nr_gru_seq_buffers(512, 900, 12) == 13 and be.lib.nr_gru_seq_buffers(100, 900, 12) == 2; "
+            "k.check_gru(be, B=512, N=12, Hd=900, I=900, seed=6); "
+            "k.check_gru(be, B=512, N=9, Hd=450, I=900, seed=7, lens=[1 + (7 * i) % 9 for i in range(512)])")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_gru_register_only_variant():
     """NR_GRU_LDS=0 (the round-1 default: operands straight from L2 into registers) stays selectable; knobs are read once per process,
     hence the subprocess."""
