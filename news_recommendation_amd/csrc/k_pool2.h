@@ -26,11 +26,14 @@ namespace nr {
 // TPW titles per wave x NWAVE waves = 16 titles per workgroup in both instantiations: <4, 4> (one wave per SIMD, 5 token tiles, every LDS
 // weight fragment feeds 5 MFMAs) and <2, 8> (two waves per SIMD on 3 token tiles = 48 rows for 40 tokens: 17 % padding, but one wave's
 // loads / tanh / reductions overlap the other's MFMAs)
-template <int TPW_, int NWAVE_>
+// <50, 1, 4> (backward only): one 50-token sequence (NAML abstracts, the NRMS click history) per wave on 4 token tiles, 4 sequences per
+// workgroup -- the LDS-tile kernel gives a whole workgroup ONE such sequence and re-reads Wa / Wa^T (266 KB) from L2 for it.
+template <int S_, int TPW_, int NWAVE_>
 struct Pool2Geom {
-  static constexpr int S = 20;
+  static constexpr int S = S_;
   static constexpr int TPW = TPW_;               // titles per wave
   static constexpr int NWAVE = NWAVE_;
+  static constexpr int PER_WG = TPW * NWAVE;     // sequences per workgroup
   static constexpr int THREADS = NWAVE * 64;
   static constexpr int TOKW = S * TPW;           // 80 tokens per wave
   static constexpr int MT = (TOKW + 15) / 16;    // 5 (or 3) token tiles
@@ -46,7 +49,7 @@ struct Pool2Geom {
   static constexpr int GROW = KP;                // floats per staged g_out row (zero padded beyond D)
   static constexpr int FWD_SMEM = 2 * CH_BYTES + NWAVE * WV_FLOATS * 4;
   static constexpr int BWD_SMEM = FWD_SMEM + NWAVE * TPW * GROW * 4 + NWAVE * QP * 4;
-  static_assert(CH_DT * KS2 * 1024 <= CH_BYTES && TPW * NWAVE == 16 && TOKW <= 128, "geometry");
+  static_assert(CH_DT * KS2 * 1024 <= CH_BYTES && TOKW <= 128, "geometry");
 };
 
 // the wave's 80 ctx rows as B-operand fragments

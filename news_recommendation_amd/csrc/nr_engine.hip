@@ -20,6 +20,7 @@ namespace nr {
 int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream);
 int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream);      // k_pool2.h, same translation unit
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream);
+int launch_pool2_bwd50(const AdditiveBwdParams& p, hipStream_t stream);
 }
 
 namespace {
@@ -65,6 +66,15 @@ int add_variant() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 4; }
   return v;
+}
+// 50-token sequences (NAML abstracts, click histories): the register-resident backward of k_pool2.h (<50, 1, 4>: 4 sequences per
+// workgroup) from 2048 sequences up -- measured on MI355X: 27,136 abstracts 1.31 -> 1.03 ms, but 512 histories 36 -> 45 us (128 workgroups
+// leave half of the CUs idle), so short batches keep the LDS-tile kernel (one sequence per workgroup).  NR_POOL2_S50=0: always the
+// LDS-tile kernel, 2: always the register-resident one.
+bool pool2_s50(int64_t n_seq) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NR_POOL2_S50"); v = e ? atoi(e) : 1; }
+  return add_variant() == 4 && (v == 2 || (v == 1 && n_seq >= 2048));
 }
 
 template <typename K>
@@ -343,7 +353,7 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
   if (S == 20) return add_variant() == 4 ? (n_seq + 15) / 16 : add_variant() == 1 ? (n_seq + 7) / 8 : add_variant() == 2 ? (n_seq + 1) / 2 : (n_seq + 3) / 4;
-  if (S == 50) return n_seq;
+  if (S == 50) return pool2_s50(n_seq) ? (n_seq + 3) / 4 : n_seq;
   if (S == 4) return (n_seq + 19) / 20;
   return -1;
 }
@@ -390,6 +400,8 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
     using G = nr::AddGeom<20, NSEQ>;
     if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
+  } else if (S == 50 && pool2_s50(n_seq)) {
+    if (nr::launch_pool2_bwd50(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
   } else if (S == 50) {
     constexpr int NSEQ = 1;
     using G = nr::AddGeom<50, NSEQ>;

@@ -34,22 +34,25 @@ static int pool2_geom(int dflt) {
 template <typename G>
 static int launch_pool2_fwd_t(const AdditiveParams& p, hipStream_t stream) {
   if (set_max_dynamic_lds((const void*)pool2_fwd_kernel<G>, G::FWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_fwd_kernel<G>, (p.n_seq + 15) / 16, G::THREADS, G::FWD_SMEM, stream, p);
+  NR_LAUNCH(pool2_fwd_kernel<G>, (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::FWD_SMEM, stream, p);
   return 0;
 }
 template <typename G>
 static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
   if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G>, G::BWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_bwd_kernel<G>, (p.n_seq + 15) / 16, G::THREADS, G::BWD_SMEM, stream, p);
+  NR_LAUNCH(pool2_bwd_kernel<G>, (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::BWD_SMEM, stream, p);
   return 0;
 }
 
 int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
-  return pool2_geom(44) == 28 ? launch_pool2_fwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<4, 4>>(p, stream);
+  return pool2_geom(44) == 28 ? launch_pool2_fwd_t<Pool2Geom<20, 2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<20, 4, 4>>(p, stream);
 }
 
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {
-  return pool2_geom(28) == 28 ? launch_pool2_bwd_t<Pool2Geom<2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<4, 4>>(p, stream);
+  return pool2_geom(28) == 28 ? launch_pool2_bwd_t<Pool2Geom<20, 2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<20, 4, 4>>(p, stream);
 }
+
+// 50-token sequences: 4 per workgroup (one per wave, one wave per SIMD)
+int launch_pool2_bwd50(const AdditiveBwdParams& p, hipStream_t stream) { return launch_pool2_bwd_t<Pool2Geom<50, 1, 4>>(p, stream); }
 
 }  // namespace nr

@@ -58,8 +58,9 @@ class LSTUR(torch.nn.Module):
             a, b = cand[k], click[k]
             return self.news_encoder.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
         vec = self.news_encoder.encode(flat('title'), flat('category'), flat('subcategory'))       # one kernel chain for all B*(C+N) news
-        candidate_news_vector = vec[:B * C].view(B, C, -1)
-        clicked_news_vector = vec[B * C:].view(B, N, -1)
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        candidate_news_vector = cand_rows.view(B, C, -1)
+        clicked_news_vector = click_rows.view(B, N, -1)
         user_row = self._user_rows(user, self.training)
         user_vector = self.user_encoder(user_row, clicked_news_length, clicked_news_vector)
         return self.click_predictor(candidate_news_vector, user_vector)

@@ -41,8 +41,9 @@ class NAML(torch.nn.Module):
             a, b = cand[k], click[k]
             return ne.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
         vec, vec_b = ne.encode_views({k: flat(k) for k in ne.attrs})
-        candidate_news_vector = vec[:B * C].view(B, C, -1)
-        clicked_news_vector = vec[B * C:].view(B, N, -1)
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        candidate_news_vector = cand_rows.view(B, C, -1)
+        clicked_news_vector = click_rows.view(B, N, -1)
         user_vector = self.user_encoder(clicked_news_vector, None if vec_b is None else vec_b[B * C:])
         return self.click_predictor(candidate_news_vector, user_vector)
 

@@ -41,8 +41,9 @@ class NRMS(torch.nn.Module):
         ops.check_ids(click, V, "title token id")
         ids = torch.cat([cand.reshape(B * C, L), click.reshape(B * N, L)], dim=0).to(dev, non_blocking=True)
         vec = self.news_encoder.encode_ids(ids)                               # [B*(C+N), D]
-        candidate_news_vector = vec[:B * C].view(B, C, -1)
-        clicked_news_vector = vec[B * C:].view(B, N, -1)
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        candidate_news_vector = cand_rows.view(B, C, -1)
+        clicked_news_vector = click_rows.view(B, N, -1)
         user_vector = self.user_encoder(clicked_news_vector)
         return self.click_predictor(candidate_news_vector, user_vector)
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.nr_version() >= 1 and lib.nr_supported_seq_len(20) == 1 and lib.nr_supported_seq_len(7) == 0
-    assert lib.nr_additive_bwd_grid(17, 20) == 2 and lib.nr_additive_bwd_grid(10, 50) == 10      # S = 20: 16 titles per workgroup (k_pool2.h)
+    assert lib.nr_additive_bwd_grid(17, 20) == 2 and lib.nr_additive_bwd_grid(10, 50) == 10 and lib.nr_additive_bwd_grid(4097, 50) == 1025      # k_pool2.h: 16 titles per workgroup; 4 fifty-token sequences from 2048 up
     # argument validation happens before any device work, so it can be exercised without a GPU
     assert lib.nr_gather_rows_f32(None, None, None, 5, 300, 10, None) == -2
     assert b'nr_gather_rows_f32' in lib.nr_last_error()

@@ -39,6 +39,20 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
+def test_additive_bwd_s50_register_resident(be): kc.check_additive_bwd(be, S=50, n_seq=2051)      # k_pool2.h <50, 1, 4> (the default from 2048 sequences up): 4 per workgroup, the last one partly filled
+
+
+def test_additive_bwd_s50_lds_tile_variant():
+    """NR_POOL2_S50=0: the LDS-tile backward for 50-token sequences (one sequence per workgroup), which the register-resident kernel of
+    csrc/k_pool2.h replaced as the default."""
+    import subprocess, sys, os
+    env = dict(os.environ, NR_POOL2_S50='0')
+    code = ("from tests.backends import GpuBackend; from tests import kernel_checks as k; be = GpuBackend(); "
+            "assert be.lib.nr_additive_bwd_grid(9, 50) == 9; k.check_additive_bwd(be, S=50, n_seq=131)")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_wgrad_unpack(be): kc.check_wgrad_unpack(be, nc_w=32, nc_a=64, nwg=1696)
 def test_wgrad_unpack_small_qdim(be): kc.check_wgrad_unpack(be, nc_w=1, nc_a=1, nwg=1, qdim=70)
 def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
