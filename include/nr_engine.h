@@ -198,6 +198,17 @@ int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int
 int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, const float* attn_w, const float* g_out, int64_t g_stride,
                     uint16_t* dy_pad, int64_t n_seq, int S, float p_drop, void* stream);
 
+/* Backward of the additive pooling over a conv text encoder's activations, through the activation stage, in one call: dpre / dq_part as
+ * nr_additive_bwd_ex, and dy_pad as nr_conv_act_bwd would produce it from dctx = dpre @ Wa (act is both the pooling's input ctx and the
+ * activation whose zeros are the relu / dropout mask; g_out f32 [n_seq][NR_D]).  With the register-resident pooling kernels (S = 20;
+ * S = 50 from 2048 sequences up) the product never reaches memory: the kernel's epilogue adds the direct term, masks, scales and stores
+ * the seqpad rows (one pass over the tokens less; the sum is rounded to bf16 once instead of twice).  Other shapes run the two kernels
+ * through dctx_scratch bf16 [n_seq*S][NR_KP].  Autograd of additive.py:35-52 composed with F.dropout(F.relu(conv)) (NAML / LSTUR
+ * news_encoder.py). */
+int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
+                        uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx_scratch, uint16_t* dy_pad, float p_drop,
+                        int64_t n_seq, int S, void* stream);
+
 /* nr_additive_fwd with strided outputs: out f32 rows of stride out_stride (may be NULL) and/or out_b, a bf16 copy in the
  * ctx layout (row i at out_b + i*out_b_stride: cols 0..D-1, col D = 1.0, rest 0) that can feed another pooling level
  * directly (NAML final_attention over the 4 views, news_encoder.py:108-114; NAML user encoder, user_encoder.py:18). */

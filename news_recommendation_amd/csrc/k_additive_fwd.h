@@ -57,6 +57,10 @@ struct AdditiveBwdParams {
   const u16* WaT;        // optional: bf16 [KP][QKP] = Wa^T (pack_additive_t) -> the kernel also emits dctx = dpre @ Wa
   u16* dctx;             // optional: bf16 [n_seq*S][KP] (columns < D written)
   int64_t n_seq;
+  // register-resident kernels (k_pool2.h) only, instead of dctx: the gradient of the conv + relu + dropout stage that produced ctx,
+  // dy_pad[seqpad row of tok] = (dpre @ Wa + attn_w (x) g_out) * [ctx != 0] * act_scale  (what conv_act_bwd_kernel computes from dctx)
+  u16* dy_pad;           // optional: bf16 seqpad rows [(tok + seq + 1)][KP] (columns < D written; separators / padding stay the caller's zeros)
+  float act_scale;       // 1 / (1 - p_drop)
 };
 
 template <int S, int NSEQ, int NW = 4>

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
   float* gl = (float*)(smem + Gm::FWD_SMEM) + w * Gm::TPW * Gm::GROW;      // [4][320] g_out rows of this wave's titles, zero padded
   float* dqp = (float*)(smem + Gm::FWD_SMEM + Gm::NWAVE * Gm::TPW * Gm::GROW * 4);     // [4][QP] per-wave dq partials
   const u16x4 Z4 = u16x4{0, 0, 0, 0};
-  const bool with_dctx = p.dctx != nullptr;        // the stand-alone AdditiveAttention backward stops at dpre / dq
+  const bool with_dctx = p.dctx != nullptr || p.dy_pad != nullptr;        // the stand-alone AdditiveAttention backward stops at dpre / dq
 
   // chunks 0..NCH-1: Wa (n-tiles 5c..), chunks NCH..NCH+NCH2-1: pair-permuted Wa^T (feature tiles 7c'..); both operands are in tile order
   auto chunk_fetch = [&](int c, int buf) {
@@ -361,8 +361,24 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
         const int col = (dt0 + dt) * 16 + 4 * g;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const int64_t tok = tok0 + m * 16 + li;
-          if (tok < tok_total && m * 16 + li < Gm::TOKW && col < D) *(u16x4*)(p.dctx + tok * KP + col) = pack4(acc[m]);
+          const int tl = m * 16 + li;
+          const int64_t tok = tok0 + tl;
+          if (tok < tok_total && tl < Gm::TOKW && col < D) {
+            if (p.dy_pad == nullptr) {
+              *(u16x4*)(p.dctx + tok * KP + col) = pack4(acc[m]);
+            } else {
+              // fused activation gradient (conv_act_bwd_kernel): direct term from the staged g_out row and forward weight, relu / dropout
+              // mask from the activation itself (ctx == 0 <=> dropped or relu-clipped), straight into the seqpad row
+              const int sq = tl / S;
+              const f32x4 go = *(const f32x4*)(gl + sq * Gm::GROW + col);
+              const float wt = wl[tl];
+              const u16x4 a = *(const u16x4*)(p.ctx + tok * KP + col);
+              f32x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = (a[r] & 0x7FFF) ? (acc[m][r] + wt * go[r]) * p.act_scale : 0.0f;
+              *(u16x4*)(p.dy_pad + (tok + seq0 + sq + 1) * KP + col) = pack4(o);
+            }
+          }
         }
       }
     }

@@ -382,7 +382,7 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   if (n_seq == 0) return NR_OK;
   nr::AdditiveBwdParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
-  p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq;
+  p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq; p.dy_pad = nullptr; p.act_scale = 1.0f;
   if (S == 20 && add_variant() == 4) {
     if (nr::launch_pool2_bwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
   } else if (S == 20 && add_variant() == 1) {
@@ -558,6 +558,29 @@ int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, con
   NR_LAUNCH(nr::conv_act_bwd_kernel, grid_for(n_seq * S * (NR_D / 4), 256, 8192), 256, 0, (hipStream_t)stream, act, dact_gemm, ldc, attn_w,
             g_out, g_stride, dy_pad, n_seq, S, 1.0f / (1.0f - p_drop));
   return check_launch("nr_conv_act_bwd");
+}
+
+int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
+                        uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx_scratch, uint16_t* dy_pad, float p_drop,
+                        int64_t n_seq, int S, void* stream) {
+  if (!act || !Wap || !bap || !qvp || !attn_w || !g_out || !dpre || !dq_part || !WaT || !dctx_scratch || !dy_pad || n_seq < 0)
+    return fail(NR_ERR_BADARG, "nr_additive_bwd_act: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_act: dropout probability out of range");
+  if (n_seq == 0) return NR_OK;
+  static int fuse = -1;       // NR_POOL_ACT_FUSE=0: always the two-kernel form (A/B knob)
+  if (fuse < 0) { const char* e = getenv("NR_POOL_ACT_FUSE"); fuse = e ? atoi(e) : 1; }
+  const bool reg = (S == 20 && add_variant() == 4) || (S == 50 && pool2_s50(n_seq));
+  if (fuse == 1 && reg) {
+    nr::AdditiveBwdParams p;
+    p.ctx = act; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre; p.dq_part = dq_part; p.WaT = WaT;
+    p.dctx = nullptr; p.n_seq = n_seq; p.dy_pad = dy_pad; p.act_scale = 1.0f / (1.0f - p_drop);
+    if (S == 20 ? nr::launch_pool2_bwd(p, (hipStream_t)stream) : nr::launch_pool2_bwd50(p, (hipStream_t)stream))
+      return fail(NR_ERR_LAUNCH, "nr_additive_bwd_act: cannot reserve LDS");
+    return check_launch("nr_additive_bwd_act");
+  }
+  const int rc = nr_additive_bwd_ex(act, Wap, bap, qvp, attn_w, g_out, dpre, dq_part, WaT, dctx_scratch, n_seq, S, stream);
+  if (rc) return rc;
+  return nr_conv_act_bwd(act, dctx_scratch, NR_KP, attn_w, g_out, NR_D, dy_pad, n_seq, S, p_drop, stream);
 }
 
 int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const float* g_out, float* dx, int64_t n_seq, int S,

@@ -91,10 +91,13 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None, dy=None, p_drop=0.0):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
     Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.  With ``sw`` (ops.side_wgrad) the
-    weight-gradient GEMM runs on the side stream and the CALLER joins it (before the shared dpre workspace is written again)."""
+    weight-gradient GEMM runs on the side stream and the CALLER joins it (before the shared dpre workspace is written again).
+    With ``dy`` (seqpad buffer of a conv text encoder whose activations ctx_b are) the gradient goes on through the relu / dropout stage
+    into dy in the same call (nr_additive_bwd_act: fused into the pooling kernel's epilogue where the register-resident kernels run);
+    dgemm is then only scratch."""
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
@@ -102,8 +105,12 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None):
     dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
     dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
     dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
-    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_ex, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
-          _ptr(dq_part), _ptr(WaT), _ptr(dgemm), n_seq, S, _stream())
+    if dy is None:
+        _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_ex, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
+              _ptr(dq_part), _ptr(WaT), _ptr(dgemm), n_seq, S, _stream())
+    else:
+        _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_act, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
+              _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
     dpre_b, ctx_bb = _bf16(dpre), _bf16(ctx_b)
     if sw is not None:
@@ -124,11 +131,12 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     # side stream: they overlap with the activation backward and the data-gradient conv, and are joined before this function returns
     sw = ops.side_wgrad(dev)
     sw.pending = []
-    d_Wa, d_ba, d_qv, dgemm = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, sw)
+    if g_stride != NR_D:
+        raise ValueError("text_bwd: the pooled-vector gradient must be contiguous [n_seq, D]")
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
-    _call(f'nr_conv_act_bwd[{tag}]', lib.nr_conv_act_bwd, _ptr(st.act), _ptr(dgemm), NR_KP, _ptr(st.aw), _ptr(g), g_stride, _ptr(dy),
-          n_seq, S, p, _stream())
+    # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
+    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, sw, dy=dy, p_drop=p)
     dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
     xs_b = _bf16(st.xstore)
 

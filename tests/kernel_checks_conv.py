@@ -216,6 +216,51 @@ def check_additive_ex(be, S=4, n_seq=23, out_stride=900, col0=600):
     assert (ob[:, 1, NR_D] == 0x3F80).all() and not ob[:, 1, NR_D + 1:].any()
 
 
+def check_additive_bwd_act(be, S=20, n_seq=7, p_drop=0.2):
+    """nr_additive_bwd_act == nr_additive_bwd_ex followed by nr_conv_act_bwd (to bf16 rounding: the fused epilogue rounds the sum once, the
+    two-kernel form rounds dctx and the result), on activations with exact zeros (relu / dropout) and against the float64 formula."""
+    W, b, q = additive_params(21)
+    rng = np.random.default_rng(22)
+    act = np.maximum(rng.normal(0, 0.6, size=(n_seq * S, NR_D)), 0)                 # ~half of the entries are exact zeros
+    act[rng.random(size=act.shape) < 0.2] = 0
+    ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
+    ctx[:, :NR_D] = act
+    ctx[:, NR_D] = 1.0
+    ctx_u = f32_to_bf16(ctx)
+    Wap, bap, qvp = pack_add(be, W, b, q)
+    hctx = be.dev(ctx_u)
+    out = be.poison((n_seq, NR_D), np.float32); aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw), n_seq, S, be.stream))
+    go = rng.normal(size=(n_seq, NR_D)).astype(np.float32)
+    hgo = be.dev(go)
+    nwg = be.lib.nr_additive_bwd_grid(n_seq, S)
+    WaT = be.poison((NR_KP, 224), np.uint16)
+    ck(be, be.lib.nr_pack_additive_t(be.ptr(be.dev(W)), W.shape[0], be.ptr(WaT), be.stream))
+    # two kernels
+    dpre1 = be.empty((n_seq * S, NR_QP), np.uint16); dqp1 = be.poison((nwg, NR_QP), np.float32)
+    dctx1 = be.empty((n_seq * S, NR_KP), np.uint16); dy1 = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16)
+    ck(be, be.lib.nr_additive_bwd_ex(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo), be.ptr(dpre1), be.ptr(dqp1),
+                                     be.ptr(WaT), be.ptr(dctx1), n_seq, S, be.stream))
+    ck(be, be.lib.nr_conv_act_bwd(be.ptr(hctx), be.ptr(dctx1), NR_KP, be.ptr(aw), be.ptr(hgo), NR_D, be.ptr(dy1), n_seq, S, p_drop, be.stream))
+    # one call
+    dpre2 = be.empty((n_seq * S, NR_QP), np.uint16); dqp2 = be.poison((nwg, NR_QP), np.float32)
+    scratch = be.empty((n_seq * S, NR_KP), np.uint16); dy2 = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16)
+    ck(be, be.lib.nr_additive_bwd_act(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo), be.ptr(dpre2), be.ptr(dqp2),
+                                      be.ptr(WaT), be.ptr(scratch), be.ptr(dy2), p_drop, n_seq, S, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(dpre1), be.np(dpre2)) and np.array_equal(be.np(dqp1), be.np(dqp2))
+    # float64 reference from the kernel's own dpre (bit-level operands) and forward weights
+    dref = bf16_to_f32(be.np(dpre2)).astype(np.float64)[:, :W.shape[0]] @ bf16_round(W).astype(np.float64)
+    full = (dref.reshape(n_seq, S, NR_D) + be.np(aw).astype(np.float64)[:, :, None] * go.astype(np.float64)[:, None, :]) / (1.0 - p_drop)
+    full = np.where(bf16_to_f32(ctx_u[:, :NR_D]).reshape(n_seq, S, NR_D) != 0, full, 0.0)
+    want = np.zeros((n_seq * S, NR_KP)); want[:, :NR_D] = full.reshape(-1, NR_D)
+    want = to_seqpad(want, n_seq, S)
+    for name, dy in (('two kernels', dy1), ('one call', dy2)):
+        got = bf16_to_f32(be.np(dy)).astype(np.float64)
+        assert not got[want == 0].any(), f'{name}: masked / separator / padding positions must be exact zeros'
+        close_bf16(got, want, f'additive_bwd_act {name} S={S}', rel=2.0 ** -6, floor=2e-3)
+
+
 def check_additive_bwd_s4(be, n_seq=45):
     S = 4
     W, b, q = additive_params(10)

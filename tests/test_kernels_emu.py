@@ -90,6 +90,19 @@ def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=3, val
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be)
+def test_additive_bwd_act_fused_s20(be): kcc.check_additive_bwd_act(be, S=20, n_seq=7); kcc.check_additive_bwd_act(be, S=20, n_seq=17)
+def test_additive_bwd_act_two_kernels_s50(be): kcc.check_additive_bwd_act(be, S=50, n_seq=3)       # below 2048 sequences: LDS-tile kernel + conv_act_bwd
+
+
+def test_additive_bwd_act_fused_s50():
+    import subprocess, sys, os
+    env = dict(os.environ, NR_POOL2_S50='2')        # the register-resident kernel for 50-token sequences regardless of the batch size
+    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_conv as k; be = EmuBackend(); "
+            "k.check_additive_bwd_act(be, S=50, n_seq=6); k.check_additive_bwd_act(be, S=50, n_seq=3)")
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_additive_ex_s4(be): kcc.check_additive_ex(be, S=4, n_seq=23)
 def test_additive_ex_s20(be): kcc.check_additive_ex(be, S=20, n_seq=5)
 def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be)

@@ -83,6 +83,9 @@ def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=131, v
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=515)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=131)
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be, S=20, n_seq=1027)
+def test_additive_bwd_act_fused_s20(be): kcc.check_additive_bwd_act(be, S=20, n_seq=1027)
+def test_additive_bwd_act_fused_s50(be): kcc.check_additive_bwd_act(be, S=50, n_seq=2051)
+def test_additive_bwd_act_two_kernels_s50(be): kcc.check_additive_bwd_act(be, S=50, n_seq=131)
 def test_additive_ex_s4(be): kcc.check_additive_ex(be, S=4, n_seq=2047)
 def test_additive_ex_s50(be): kcc.check_additive_ex(be, S=50, n_seq=131)
 def test_additive_bwd_s4(be): kcc.check_additive_bwd_s4(be, n_seq=2047)
