@@ -100,14 +100,17 @@ class _PinnedRing:
         key = (tuple(shape), p0.dtype)
         ring = self.slots.get(key)
         if ring is None:
-            ring = self.slots[key] = {'i': 0, 'bufs': [None] * self.depth, 'evs': [None] * self.depth}
+            # all buffers of a shape are pinned when it is first seen (page-locking costs milliseconds per buffer: done lazily, the first
+            # `depth` training steps would each pay for it)
+            ring = self.slots[key] = {'i': 0, 'bufs': [torch.empty(shape, dtype=p0.dtype).pin_memory() for _ in range(self.depth)],
+                                      'evs': [None] * self.depth}
             if len(self.slots) > 16:                                  # varying batch shapes: forget the oldest shape
                 self.slots.pop(next(iter(self.slots)))
+        else:
+            self.slots[key] = self.slots.pop(key)                     # most recently used last: the shape forgotten above is the stalest
         i = ring['i']
         ring['i'] = (i + 1) % self.depth
-        if ring['bufs'][i] is None:
-            ring['bufs'][i] = torch.empty(shape, dtype=p0.dtype).pin_memory()
-        elif ring['evs'][i] is not None:
+        if ring['evs'][i] is not None:
             ring['evs'][i].synchronize()
         buf = ring['bufs'][i]
         # numpy does the interleave on the calling thread: torch's CPU stack / reductions wake the whole intra-op pool, which costs

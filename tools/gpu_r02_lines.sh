@@ -1,11 +1,9 @@
 #!/bin/bash
-# Round-2 measurement pass: parity tests, smoke, bench lines (all workloads), rocprofv3 kernel stats, PMC traffic of the dominant kernels.
+# bench lines only (all workloads), after tools/gpu_r02_final.sh has produced the profiles
 export TMPDIR=/tmp
-TAG=${1:-r02final}
+TAG=${1:-r02lines}
 O=gpurun_out/$TAG
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 q() { python - "$1" <<'PY'
 import json, sys
 try:
@@ -28,18 +26,3 @@ timeout 900 python bench.py --shape large > $O/bench_line_NRMS_large.json 2> $O/
 timeout 1200 python bench.py --model LSTUR --shape large > $O/bench_line_LSTUR_large.json 2> $O/bench_line_LSTUR_large.err; q $O/bench_line_LSTUR_large.json
 timeout 900 python bench.py --model NAML > $O/bench_line_NAML_small.json 2> $O/bench_line_NAML_small.err; q $O/bench_line_NAML_small.json
 timeout 900 python bench.py --model LSTUR > $O/bench_line_LSTUR_small.json 2> $O/bench_line_LSTUR_small.err; q $O/bench_line_LSTUR_small.json
-for W in "NRMS small" "NRMS large" "LSTUR large" "NAML small"; do
-  set -- $W
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$1_$2 -o bench -- python bench.py --model $1 --shape $2 --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extras > $O/under_rocprof_$1_$2.log 2>&1
-  DB=$(find $O/prof_$1_$2 -name "*.db" | head -1)
-  [ -n "$DB" ] && python tools/rocpd_summary.py $DB $O/kernel_stats_$1_$2.csv > /dev/null && python tools/rocpd_gaps.py $DB > $O/gaps_$1_$2.txt 2>&1
-  rm -rf $O/prof_$1_$2
-done
-head -12 $O/kernel_stats_NRMS_small.csv | cut -c1-200
-for K in mhsa_train attn_bwd additive_bwd; do
-  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${K}_fetch -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_fetch.log 2>&1
-  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${K}_write -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_write.log 2>&1
-done
-python tools/pmc_traffic.py $O | tee $O/pmc_traffic.txt
-rm -rf $O/pmc_*_fetch $O/pmc_*_write
-bash tools/gpu_two_ranks_one_gpu.sh > $O/two_ranks.log 2>&1; grep "^rc\[" $O/two_ranks.log; cp gpurun_out/two_ranks_NRMS.log gpurun_out/two_ranks_LSTUR.log $O/ 2>/dev/null
