@@ -109,8 +109,21 @@ __device__ __forceinline__ uint64_t ballot(bool pred) { return __ballot(pred); }
 template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }   // streaming store: not re-read soon
 
+// > 64 KiB of dynamic LDS needs an opt-in per kernel function.  The attribute sticks, so the runtime call is made once per (kernel, size,
+// device) and remembered: the GRU sweep alone issues ~100 such launches per training step.
 inline int set_max_dynamic_lds(const void* kernel, int bytes) {
-  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+  struct Seen { const void* k; int bytes, dev; };
+  static Seen seen[256];
+  static int n_seen = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int i = 0; i < n_seen; ++i)
+    if (seen[i].k == kernel && seen[i].dev == dev && seen[i].bytes >= bytes) return 0;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+  if (n_seen < 256) seen[n_seen++] = Seen{kernel, bytes, dev};
+  return 0;
 }
 
 __device__ __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
