@@ -141,3 +141,29 @@ def test_grad_target_and_profile_switches():
         assert not ops.profiling('nr_gru_bwd_step') and ops.profiling('nr_gru_bwd_seq')
     t = ops.to_device_async(torch.arange(3), 'cpu')
     assert t.tolist() == [0, 1, 2]
+
+
+def test_split_rows_and_inplace_grads():
+    """ops.split_rows == slicing (values and gradients, also when one part is unused); ops.inplace_grads hands out the trainer's gradient
+    views only when EVERY parameter has one."""
+    import torch
+    from news_recommendation_amd import ops, dist as nrdist
+    x = torch.randn(7, 3, requires_grad=True)
+    a, b = ops.split_rows(x, 3)
+    assert torch.equal(a, x[:3]) and torch.equal(b, x[3:])
+    (a.sum() * 2 + (b * b).sum()).backward()
+    y = x.detach().clone().requires_grad_(True)
+    (y[:3].sum() * 2 + (y[3:] * y[3:]).sum()).backward()
+    assert torch.equal(x.grad, y.grad)
+    x.grad = None
+    a, b = ops.split_rows(x, 3)
+    a.sum().backward()                                  # the unused part contributes zeros
+    assert torch.equal(x.grad[:3], torch.ones(3, 3)) and not x.grad[3:].any()
+    p, q, r = (torch.nn.Parameter(torch.zeros(4, 2)) for _ in range(3))
+    assert ops.inplace_grads((p, q)) is None            # plain autograd
+    fgb = nrdist.FlatGradBuffer([p, q])
+    g = ops.inplace_grads((p, q))
+    assert g is not None and g[0].data_ptr() == fgb.flat.data_ptr() and g[1].shape == q.shape
+    assert ops.inplace_grads((p, q, r)) is None         # r is not the trainer's
+    q.grad = None
+    assert ops.inplace_grads((p, q)) is None            # zero_grad(set_to_none=True) dropped a view
