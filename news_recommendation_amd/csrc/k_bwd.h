@@ -191,6 +191,10 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) ident[t][j] = (8 * g + j == 16 * t + li) ? ONE : (u16)0;
+  // identity on the CL k-slots: a packed CL tile used as an A operand carries row a = 4g + r in k-slot (g, r), i.e. k = 8g + r
+  u16x8 identc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) identc[j] = (j < 4 && 4 * g + j == li) ? ONE : (u16)0;
 
   while (pair < n_pairs) {
     const int64_t seq = pair / H;
@@ -281,31 +285,33 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         for (int r = 0; r < 4; ++r) ds[r] = pT[kt][r] * (dPT[kt][r] - dot) * inv_sqrt_dk;
         dsT[kt][qt] = pack4(ds);
       }
-      // ---- normal pass for the same query tile: P, dS with rows = queries 4g+r (row stats fetched from lane 4g+r) --
-      float rden_r[4], dot_r[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        rden_r[r] = shfl(rden, 4 * g + r);
-        dot_r[r] = shfl(dot, 4 * g + r);
-      }
+      // ---- the same tiles with rows = queries, CL(P) and CL(dS), for the dK / dV products: TRANSPOSED BY THE MATRIX CORE from the packed
+      // transposed tiles (A = the packed CL(X^T) tile read as "X with k = key", B = identity on the CL k-slots: one MFMA per tile, exact
+      // for bf16 inputs) instead of recomputed in the other orientation -- that second pass cost 16 more v_exp_f32 and ~160 more vector
+      // instructions per pair plus 8 cross-lane fetches of the row statistics (A/B on one MI355X: 963 / 973 -> 894 / 949 us per launch).  Padded queries are columns here: they are zeroed first
+      // (they must not reach the contractions over q; padded keys are already exact zeros).
+      const bool qok = qt * 16 + li < S;
 #pragma unroll
       for (int kt = 0; kt < Gm::QT; ++kt) {
-        f32x4 sN = mfma_16x16x32_bf16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // S[q][key]
-        // dP[q][key] = sum_dv dC[q][dv] V[key][dv]:  A = CL(dC)^T-style operand is not needed: contract over dv with
-        // A = dC AL in the permuted slot order, B = V operand of the key tile (same slot order)
-        f32x4 dPN = mfma_16x16x32_bf16(cperm[qt], va[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-        f32x4 pv, dv4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = qt * 16 + 4 * g + r < S;          // padded query rows; padded keys are already exact zeros
-          float e = fast_exp2(fminf(sN[r] * c2, clamp2)) * rden_r[r];
-          e = ok ? e : 0.0f;
-          pv[r] = e;
-          dv4[r] = e * (dPN[r] - dot_r[r]) * inv_sqrt_dk;
-        }
-        pN[qt][kt] = pack4(pv);
-        dsN[qt][kt] = pack4(dv4);
+        pN[kt][qt] = qok ? pack4(pT[kt]) : Z4;       // still CL(P^T) [key tile][query tile] here, transposed in place below
+        if (!qok) dsT[kt][qt] = Z4;
       }
+      NR_SCHED_BARRIER();
+    }
+    {
+      u16x4 tp[Gm::QT][Gm::QT];
+#pragma unroll
+      for (int qt = 0; qt < Gm::QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < Gm::QT; ++kt) {
+          tp[qt][kt] = pack4(mfma_16x16x32_bf16(cat8(pN[kt][qt], Z4), identc, f32x4{0.f, 0.f, 0.f, 0.f}));
+          dsN[qt][kt] = pack4(mfma_16x16x32_bf16(cat8(dsT[kt][qt], Z4), identc, f32x4{0.f, 0.f, 0.f, 0.f}));
+        }
+#pragma unroll
+      for (int qt = 0; qt < Gm::QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < Gm::QT; ++kt) pN[qt][kt] = tp[qt][kt];
+      NR_SCHED_BARRIER();
     }
 
     // ---- output products: every A/B operand below is a packed CL tile already in registers --------------------------
