@@ -199,9 +199,13 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_fwd_kernel(AdditiveParams p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-template <typename Gm>
-__global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParams p) {
+// DBG = true: a second instantiation with phase switches for timing decompositions (NR_POOL_DEBUG -> dbgv; tools/prof_kernel.py):
+// 1 no ctx loads, 2 no dw / softmax-backward phase, 4 no projection MFMAs, 8 no tanh / dpre / dq arithmetic, 16 no dctx product,
+// 32 no global stores.  In the production instantiation `dbg` is the constant 0 and every switch folds away.
+template <typename Gm, bool DBG = false>
+__global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParams p, int dbgv) {
   constexpr int S = Gm::S, MT = Gm::MT;
+  const int dbg = DBG ? dbgv : 0;
   NR_SMEM_DECL(smem);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int64_t seq0 = ((int64_t)blockIdx.x * Gm::NWAVE + w) * Gm::TPW;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
   };
   chunk_fetch(0, 0);
   u16x8 xf[MT][KSTEPS];
-  pool2_load_x<MT, Gm::TOKW>(p.ctx, tok0, tok_total, xf);
+  pool2_load_x<MT, Gm::TOKW>(p.ctx, tok0, (dbg & 1) ? 0 : tok_total, xf);
   // g_out rows and forward weights of this wave's titles -> wave-private LDS
   for (int i = l; i < Gm::TPW * (Gm::GROW / 4); i += 64) {
     const int sq = i / (Gm::GROW / 4), c = i - sq * (Gm::GROW / 4);
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
 
   // ---- dw[tok] = g_out[title] . x[tok] --------------------------------------------------------------------------------------------------
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = (dbg & 2) ? MT : 0; m < MT; ++m) {
     const int trow = m * 16 + li < Gm::TOKW ? m * 16 + li : Gm::TOKW - 1;          // rows past the wave's tokens (zero fragments) stay in range
     const float* go = gl + (trow / S) * Gm::GROW + g * 8;
     float a = 0.0f;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
         const u16* wp = Wc + (nt * KSTEPS) * 512 + l * 8;
         u16x8 a = *(const u16x8*)wp;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+        for (int ks = (dbg & 4) ? KSTEPS : 0; ks < KSTEPS; ++ks) {
           const u16x8 an = ks + 1 < KSTEPS ? *(const u16x8*)(wp + (ks + 1) * 512) : a;
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, xf[m][ks], acc[m]);
@@ -318,14 +322,14 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
           f32x4 dp;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float t = fast_tanh(acc[m][r]);
-            dp[r] = ds[m] * q4[r] * (1.0f - t * t);
-            dq4[r] += ds[m] * t;
+            const float t = (dbg & 8) ? acc[m][r] : fast_tanh(acc[m][r]);
+            dp[r] = (dbg & 8) ? t : ds[m] * q4[r] * (1.0f - t * t);
+            dq4[r] += (dbg & 8) ? 0.0f : ds[m] * t;
           }
           const u16x4 pk = pack4(dp);
           dpk[nt0 + nt][m] = pk;
           const int64_t tok = tok0 + m * 16 + li;
-          if (tok < tok_total && m * 16 + li < Gm::TOKW) *(u16x4*)(p.dpre + tok * QP + wrow) = pk;
+          if (tok < tok_total && m * 16 + li < Gm::TOKW && !(dbg & 32)) *(u16x4*)(p.dpre + tok * QP + wrow) = pk;
         }
         // dq partial of this wave: the tile's tokens live in the 16 lanes of a row -> DPP sum; the 4 waves are combined through LDS below
 #pragma unroll
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
 
   // ---- dctx[tok][:] = dpre[tok][:] @ Wa  (transposed product: A = Wa^T rows of a feature tile, B = the packed dpre registers) -----------
   if (!with_dctx) __syncthreads();          // orders the dqp stores before the reduction below
-  for (int c2 = 0; c2 < (with_dctx ? Gm::NCH2 : 0); ++c2) {
+  for (int c2 = 0; c2 < ((with_dctx && !(dbg & 16)) ? Gm::NCH2 : 0); ++c2) {
     const int c = Gm::NCH + c2;
     if (c2 + 1 < Gm::NCH2) chunk_fetch(c + 1, (c + 1) & 1);
     const int dt0 = c2 * Gm::CH_DT;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
         const u16* wp = Wc + (dt * Gm::KS2) * 512 + l * 8;
 #pragma unroll
         for (int ks = 0; ks < Gm::KS2; ++ks) {
-          const u16x8 a = *(const u16x8*)(wp + ks * 512);
+          const u16x8 a = *(const u16x8*)(wp + ks * 512);      // (an explicit one-ahead prefetch of this fragment measures the same: A/B r02v)
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, cat8(dpk[2 * ks][m], dpk[2 * ks + 1][m]), acc[m]);
         }
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(Gm::THREADS) void pool2_bwd_kernel(AdditiveBwdParam
         for (int m = 0; m < MT; ++m) {
           const int tl = m * 16 + li;
           const int64_t tok = tok0 + tl;
-          if (tok < tok_total && tl < Gm::TOKW && col < D) {
+          if (tok < tok_total && tl < Gm::TOKW && col < D && !(dbg & 32)) {
             if (p.dy_pad == nullptr) {
               *(u16x4*)(p.dctx + tok * KP + col) = pack4(acc[m]);
             } else {

@@ -39,8 +39,14 @@ static int launch_pool2_fwd_t(const AdditiveParams& p, hipStream_t stream) {
 }
 template <typename G>
 static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
-  if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G>, G::BWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_bwd_kernel<G>, (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::BWD_SMEM, stream, p);
+  const char* d = getenv("NR_POOL_DEBUG");         // profiling: phase switches of pool2_bwd_kernel (re-read per call)
+  if (d != nullptr && atoi(d) != 0) {
+    if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G, true>, G::BWD_SMEM)) return -1;
+    NR_LAUNCH((pool2_bwd_kernel<G, true>), (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::BWD_SMEM, stream, p, atoi(d));
+    return 0;
+  }
+  if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G, false>, G::BWD_SMEM)) return -1;
+  NR_LAUNCH((pool2_bwd_kernel<G, false>), (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::BWD_SMEM, stream, p, 0);
   return 0;
 }
 
