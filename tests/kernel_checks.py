@@ -312,6 +312,15 @@ def check_bad_args(be):
     ctx = be.empty((4 * 33, NR_KP), np.uint16); x = be.empty((4, 33, NR_D), np.float32)
     rc = be.lib.nr_mhsa_fwd(None, None, 0, be.ptr(x), be.ptr(Wp), be.ptr(bp), be.ptr(ctx), None, None, None, 4, 33, 0.0, 0, be.stream)
     assert rc == -1 and be.lib.nr_supported_seq_len(33) == 0 and be.lib.nr_supported_seq_len(20) == 1
+    # the entry points added in round 2 follow the same convention: non-zero return code, text in nr_last_error(), nothing launched
+    a = be.empty((64,), np.float32)
+    pa = be.ptr(a)
+    assert be.lib.nr_additive_bwd_act(pa, pa, pa, pa, pa, pa, pa, pa, pa, pa, None, 0.2, 4, 20, be.stream) != 0 and b'nr_additive_bwd_act' in be.lib.nr_last_error()
+    assert be.lib.nr_additive_bwd_act(pa, pa, pa, pa, pa, pa, pa, pa, pa, pa, pa, 1.0, 4, 20, be.stream) != 0      # p_drop out of range
+    assert be.lib.nr_gru_fwd_seq_n(pa, pa, pa, pa, pa, pa, 1, None, pa, None, 4, 3, 48, 2, be.stream) != 0 and b'nr_gru_fwd_seq' in be.lib.nr_last_error()
+    assert be.lib.nr_gru_bwd_seq_n(pa, pa, pa, pa, pa, pa, pa, pa, 1, pa, 4, 3, 48, 2, be.stream) != 0
+    assert be.lib.nr_gru_seq_buffers(4, 48, 3) == 2 and be.lib.nr_gru_seq_buffers(512, 900, 0) == 2
+    assert be.lib.nr_sort_ids(None, 0, 0, None, None, None, 0, be.stream) != 0 if hasattr(be.lib, 'nr_sort_ids') else True
 
 
 # ---------------------------------------------------------------------------------------------------
