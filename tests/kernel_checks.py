@@ -432,7 +432,10 @@ def check_wgrad_unpack(be, nc_w=3, nc_a=2, nwg=11, qdim=200):
     assert be.lib.nr_wgrad_unpack(be.ptr(dst[0]), 1, be.ptr(dst[0]), 1, be.ptr(dst[0]), nwg, NR_QP + 1, *[be.ptr(d) for d in dst], be.stream) != 0
 
 
-def check_additive_bwd(be, S=20, n_seq=6):
+def check_additive_bwd(be, S=20, n_seq=6, valid=None):
+    """valid < S: sequences zero-padded to the instantiated length (config knobs num_words_title / num_words_abstract /
+    num_clicked_news_a_user below 20 / 50): the forward pools the first `valid` positions (nr_additive_fwd_v), the backward sees zero
+    attention weights beyond them and must produce exact zeros there and the truncated sequences' gradients before."""
     params = make_params(14)
     rng = np.random.default_rng(15)
     ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
@@ -443,7 +446,12 @@ def check_additive_bwd(be, S=20, n_seq=6):
     hctx = be.dev(ctx_u)
     out = be.poison((n_seq, NR_D), np.float32)
     aw = be.poison((n_seq, S), np.float32)
-    ck(be, be.lib.nr_additive_fwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw), n_seq, S, be.stream))
+    if valid is None:
+        ck(be, be.lib.nr_additive_fwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw), n_seq, S, be.stream))
+    else:
+        ck(be, be.lib.nr_additive_fwd_v(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), NR_D, None, 0, be.ptr(aw), n_seq, S, valid,
+                                        be.stream))
+    V_ = S if valid is None else valid
     go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
     nwg = be.lib.nr_additive_bwd_grid(n_seq, S)
     dpre = be.empty((n_seq * S, NR_QP), np.uint16)
@@ -472,7 +480,7 @@ def check_additive_bwd(be, S=20, n_seq=6):
     be.sync()
     assert np.array_equal(be.np(dpre), be.np(dpre2)) and np.array_equal(be.np(dqp), be.np(dqp2))
     a = 'news_encoder.additive_attention.'
-    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)
+    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)[:, :V_]
     W = bf16_round(params[a + 'linear.weight']).astype(np.float64)
     b = params[a + 'linear.bias'].astype(np.float64); qv = params[a + 'attention_query_vector'].astype(np.float64)
     _, w, temp = onp.additive(x, W, b, qv)
@@ -481,7 +489,9 @@ def check_additive_bwd(be, S=20, n_seq=6):
     ds = w * (dw - (w * dw).sum(1, keepdims=True))
     dpre_ref = ds[:, :, None] * qv[None, None, :] * (1 - temp * temp)
     dq_ref = np.einsum('bs,bsq->q', ds, temp)
-    got = bf16_to_f32(be.np(dpre))
+    got = bf16_to_f32(be.np(dpre)).reshape(n_seq, S, NR_QP)
+    assert not got[:, V_:].any() and not bf16_to_f32(be.np(dctx)).reshape(n_seq, S, NR_KP)[:, V_:, :NR_D].any(), 'padded positions must get exact zeros'
+    got = got[:, :V_].reshape(-1, NR_QP)
     close_bf16(got[:, :200], dpre_ref.reshape(-1, 200), 'additive_bwd dpre', rel=2.0 ** -7, floor=2e-3)
     assert not got[:, 200:].any()
     dq = be.np(dqp).astype(np.float64).sum(0)

@@ -37,13 +37,15 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=1)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=6)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=3)
+def test_additive_bwd_valid_length(be): kc.check_additive_bwd(be, S=20, n_seq=6, valid=13); kc.check_additive_bwd(be, S=50, n_seq=3, valid=37)
 def test_additive_bwd_s50_register_resident():
     """k_pool2.h <50, 1, 4> (4 fifty-token sequences per workgroup; the default from 2048 sequences up, forced here with NR_POOL2_S50=2):
     full, partly filled and single workgroups."""
     import subprocess, sys, os
     env = dict(os.environ, NR_POOL2_S50='2')
     code = ("from tests.backends import EmuBackend; from tests import kernel_checks as k; be = EmuBackend(); "
-            "assert be.lib.nr_additive_bwd_grid(9, 50) == 3; k.check_additive_bwd(be, S=50, n_seq=6); k.check_additive_bwd(be, S=50, n_seq=3)")
+            "assert be.lib.nr_additive_bwd_grid(9, 50) == 3; k.check_additive_bwd(be, S=50, n_seq=6); k.check_additive_bwd(be, S=50, n_seq=3); "
+            "k.check_additive_bwd(be, S=50, n_seq=5, valid=37)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
 

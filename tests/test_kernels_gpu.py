@@ -39,6 +39,7 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
+def test_additive_bwd_valid_length(be): kc.check_additive_bwd(be, S=20, n_seq=1027, valid=13); kc.check_additive_bwd(be, S=50, n_seq=131, valid=37); kc.check_additive_bwd(be, S=50, n_seq=2051, valid=41)
 def test_additive_bwd_s50_register_resident(be): kc.check_additive_bwd(be, S=50, n_seq=2051)      # k_pool2.h <50, 1, 4> (the default from 2048 sequences up): 4 per workgroup, the last one partly filled
 
 
