@@ -357,12 +357,15 @@ def _mm(a, b, name='gemm'):
     return _timed(name, lambda: torch.mm(a, b))
 
 
+_WGRAD_NC = int(os.environ.get('NR_WGRAD_NC', '0'))        # A/B knob: upper bound of the chunk count (0 = the measured rule below)
+
+
 def _wgrad_chunks(n, M, N):
     """Number of token chunks for a^T @ b ([n, M]^T x [n, N]): hipBLASLt does not split K for this tall-skinny shape, so the token
     dim is cut into nc independent products.  Measured on MI355X (n = 542,720): the best nc puts ~300 output tiles of ~192 x 256
     in flight -- M=960,N=320: nc=32 (422 us vs 727 us at nc=256); M=208,N=320: nc=64 (154 us vs 210 us)."""
     tiles = ((M + 191) // 192) * ((N + 255) // 256)
-    want = max(1, 320 // tiles)
+    want = _WGRAD_NC if _WGRAD_NC > 0 else max(1, 320 // tiles)
     best = 1
     for c in (2, 4, 8, 16, 32, 64, 128, 256):
         if n % c == 0 and n // c >= 512 and c <= want:
