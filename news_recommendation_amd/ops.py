@@ -68,12 +68,10 @@ class profile:
         return out
 
 
-
-
 def to_device_async(t, device):
     """Host -> device copy that does not drain the stream: the tensor is copied into a pinned staging buffer (rotating, reused only after
-    the copy engine has read it) and crosses PCIe asynchronously.  A pageable source is staged by the
-    runtime itself, and ``t.to(device)`` without ``non_blocking`` additionally ends in a stream synchronise."""
+    the copy engine has read it) and crosses PCIe asynchronously on the copy stream.  A pageable source is staged by the runtime itself, and
+    ``t.to(device)`` without ``non_blocking`` additionally ends in a stream synchronise."""
     if t.is_cuda or torch.device(device).type == 'cpu':
         return t
     r = _pinned.stage([t.detach().contiguous()], device, dim=0)
