@@ -161,6 +161,7 @@ class Workload:
         pool20 = T * 2 * 20 * 300 * 200
         return {
             'nr_mhsa_fwd[S=20]': mhsa20, 'nr_news_fwd[S=20]': mhsa20 + pool20,
+            'nr_qkv_proj_fwd[S=20]': T * 2 * 20 * 300 * 900, 'nr_attn_fwd[S=20]': T * 2 * 2 * 15 * 20 * 20 * 20,
             'nr_mhsa_fwd[S=50]': B * (2 * 50 * 300 * 900 + 2 * 2 * 15 * 50 * 50 * 20),
             'nr_attn_bwd[S=20]': T * 15 * 6 * 2 * 20 * 20 * 20,
             'nr_attn_bwd[S=50]': B * 15 * 6 * 2 * 50 * 50 * 20,

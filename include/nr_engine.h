@@ -120,6 +120,31 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
                     const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
                     uint64_t seed, void* stream);
 
+/* ---- training form of the news-encoder front end as a gather-fused projection GEMM + a stand-alone attention kernel -----------------
+ * (csrc/k_proj.h).  nr_mhsa_fwd's register-resident kernel remains the inference form; in training everything it keeps in registers has
+ * to be written for the backward anyway.
+ *
+ * Saved-activation layout "head-major": qkv bf16[n_seq][15][3][400] -- per (sequence, head) the 20 x 20 blocks Q [token][d], K [token][d]
+ * and V^T [d][token] back to back (2,400 contiguous bytes), NR_QKV_HM_SEQ elements per sequence. */
+#define NR_QKV_HM_SEQ (NR_HEADS * 3 * 20 * NR_DK)
+#define NR_K16 19       /* k-steps of 16 over D (304 columns) in the tile32-ordered projection operand */
+/* Pack the three nn.Linear(D,D) of MultiHeadSelfAttention (multihead_self.py:36-38) for nr_qkv_proj_fwd: Wp32 bf16[3*NR_NP][304] in
+ * "tile32 order" -- 32 x 16 blocks (row tile, k-step) of the 64 lanes' 16-byte v_mfma_f32_32x32x16_bf16 fragments back to back: element
+ * (r, k) at ((r/32)*19 + k/16)*512 + (((k%16)/8)*32 + r%32)*8 + k%8 -- and bp f32[3*NR_NP] (as nr_pack_qkv). */
+int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                  uint16_t* Wp32, float* bp, void* stream);
+/* x = F.dropout(table[ids]) (src/model/NRMS/news_encoder.py:38-40), then Q, K, V = x W^T + b (multihead_self.py:53-55), S = 20.
+ * ids int64[n_seq*S]; qkv: head-major (above); x_save (optional) bf16[n_seq*S][NR_KP]: the dropout-masked token matrix, column D = 1.0,
+ * other padding 0 -- the operand of the weight-gradient GEMM dW = dqkv^T @ [X | 1]. */
+int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wp32, const float* bp, uint16_t* qkv,
+                    uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+/* ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) from a head-major qkv buffer;
+ * ctx as nr_mhsa_fwd writes it (second dropout of news_encoder.py:43-45 applied when p_drop > 0, column D = 1.0). */
+int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+/* nr_attn_bwd_len reading the head-major saves of nr_qkv_proj_fwd (S = 20). */
+int nr_attn_bwd_hm(const uint16_t* qkv, const uint16_t* dctx_gemm, int ldc, const float* attn_w, const float* g_out, uint16_t* dqkv,
+                   const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+
 /* Backward of AdditiveAttention (additive.py:35-52) up to the pre-activation: dpre bf16[n_seq*S][NR_QP] and
  * per-workgroup partial sums of the query-vector gradient dq_part f32[nr_additive_bwd_grid()][NR_QP]
  * (sum over rows = d attention_query_vector).  The caller finishes with two plain GEMMs:
@@ -350,6 +375,9 @@ int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, in
 /* Hardware probe: runs one v_mfma_f32_16x16x32_bf16 on A[16][32], B[32][16] (bf16 bits, row-major)
  * and writes D f32[16][16]; used by the GPU tests to pin the fragment-layout assumptions. */
 int nr_probe_mfma(const uint16_t* A, const uint16_t* B, float* D, void* stream);
+/* Test hook: LDS transpose read (ds_read_b64_tr_b16) of a 4096-entry LDS ramp lds[i] = i; lane l reads at byte offset offs[l] (int32[64],
+ * 8-byte aligned, < 8184) and stores its four elements to out u16[64][4]. */
+int nr_probe_tr16(const int32_t* offs, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,10 @@ SIGNATURES = {
     'nr_mhsa_fwd_ex': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_mhsa_fwd_len': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_attn_bwd_len': ([_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_pack_qkv32': ([_P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    'nr_qkv_proj_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_attn_fwd': ([_P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_attn_bwd_hm': ([_P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_fwd_v': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_bwd_grid': ([c_int64, c_int], c_int64),
@@ -72,11 +76,14 @@ SIGNATURES = {
     'nr_sort_ids': ([_P, c_int64, c_int64, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
+    'nr_probe_tr16': ([_P, _P, _P], c_int),
 }
 
 # layout constants mirrored from include/nr_engine.h
 NR_D, NR_KP, NR_HEADS, NR_DK, NR_NP, NR_QP = 300, 320, 15, 20, 320, 208
 NR_LDG = 3 * NR_KP
+NR_QKV_HM_SEQ = NR_HEADS * 3 * 20 * NR_DK      # elements per sequence of the head-major Q | K | V^T saves
+NR_K16 = 19
 
 LIB_NAME = 'libnr_engine.so'
 _lib = None

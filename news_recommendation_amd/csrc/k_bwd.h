@@ -57,6 +57,8 @@ struct AttnBwdParams {
   const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
   int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
+  int hm;                // 1: q_save is the head-major [n_seq][H][3][S*DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V^T of a pair
+                         // are 2,400 contiguous bytes (k_save / vt_save unused)
 };
 
 __device__ __forceinline__ u16x8 ld8(const u16* p) { return cat8(*(const u16x4*)p, *(const u16x4*)(p + 4)); }
@@ -102,8 +104,10 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const int64_t tok0 = seq * S;
     // (wave-uniform 64-bit base) + (32-bit lane offset that does not depend on the pair): the per-lane 64-bit multiply-adds of
     // `(tok0 + r) * KP` were a quarter-rate instruction per address
-    const u16* qb = p.q_save + tok0 * KP + hd * DK;
-    const u16* kb = p.k_save + tok0 * KP + hd * DK;
+    // head-major saves: row r of the pair's Q block at + r * DK, K one block further -- same piece index i, a different row stride
+    const int rs = p.hm ? DK : KP;
+    const u16* qb = p.hm ? p.q_save + pr * (3 * S * DK) : p.q_save + tok0 * KP + hd * DK;
+    const u16* kb = p.hm ? qb + S * DK : p.k_save + tok0 * KP + hd * DK;
     const u16* gb = p.dctx_gemm + tok0 * p.ldc + hd * DK;
     const float* gob = p.g_out + seq * D + hd * DK;
     const float* wb = p.attn_w + tok0;
@@ -112,14 +116,14 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       const int i = it * 64 + l;
       if (i < S * Gm::PCS) {
         const int r = i / Gm::PCS, c = (i - r * Gm::PCS) * 4;
-        rg.q[it] = *(const u16x4*)(qb + (r * KP + c));
-        rg.k[it] = *(const u16x4*)(kb + (r * KP + c));
+        rg.q[it] = *(const u16x4*)(qb + (r * rs + c));
+        rg.k[it] = *(const u16x4*)(kb + (r * rs + c));
         rg.dg[it] = *(const u16x4*)(gb + (r * p.ldc + c));
         rg.go[it] = *(const f32x4*)(gob + c);
         rg.wt[it] = wb[r];
       }
     }
-    const u16* vblk = p.vt_save + (seq * H + hd) * DK * Gm::SP4;
+    const u16* vblk = p.hm ? qb + 2 * S * DK : p.vt_save + (seq * H + hd) * DK * Gm::SP4;
 #pragma unroll
     for (int it = 0; it < Gm::ITV; ++it) {
       const int i = it * 64 + l;

@@ -233,4 +233,17 @@ __global__ __launch_bounds__(64) void probe_mfma_kernel(const u16* __restrict__ 
   for (int r = 0; r < 4; ++r) Dm[(g * 4 + r) * 16 + i] = c[r];
 }
 
+// ---- LDS transpose-read probe (ds_read_b64_tr_b16): LDS holds lds[i] = i (u16, 4096 entries); lane l reads the piece at byte offset
+// offs[l] (8-byte aligned) and stores the four elements it receives: the parity tests hold the result to the semantics documented at
+// lds_tr16_b64 (nr_prims.h), which the weight-gradient kernel's operand loads rely on ------------------------------------------------
+__global__ __launch_bounds__(64) void probe_tr16_kernel(const int32_t* __restrict__ offs, u16* __restrict__ out) {
+  NR_SMEM_DECL(smem);
+  u16* lds = (u16*)smem;
+  const int l = lane_id();
+  for (int i = l; i < 4096; i += 64) lds[i] = (u16)i;
+  __syncthreads();
+  const u16x4 v = lds_tr16_b64(lds + (offs[l] >> 1));
+  *(u16x4*)(out + l * 4) = v;
+}
+
 }  // namespace nr

@@ -4,6 +4,7 @@
 #include "k_mhsa_fwd.h"
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
+#include "k_proj.h"
 #include "k_conv.h"
 #include "k_naml.h"
 #include "k_gru.h"
@@ -319,16 +320,18 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
   return nr_attn_bwd_len(q_save, k_save, vt_save, dctx_gemm, ldc, attn_w, g_out, dqkv, nullptr, n_seq, S, p_drop, seed, stream);
 }
 
-int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
-                    const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
-                    uint64_t seed, void* stream) {
-  if (!q_save || !k_save || !vt_save || !dctx_gemm || !attn_w || !g_out || !dqkv || n_seq < 0 || ldc < NR_D || (ldc & 3))
+static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, int hm, const uint16_t* dctx_gemm, int ldc,
+                           const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                           uint64_t seed, void* stream) {
+  if (!q_save || (!hm && (!k_save || !vt_save)) || !dctx_gemm || !attn_w || !g_out || !dqkv || n_seq < 0 || ldc < NR_D || (ldc & 3))
     return fail(NR_ERR_BADARG, "nr_attn_bwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_bwd: dropout probability out of range");
+  if (hm && S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd_hm: the head-major layout is instantiated for 20-token sequences");
   if (n_seq == 0) return NR_OK;
   nr::AttnBwdParams p;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
-  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed);
+  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm;
+  // head-major saves: a pair's operands are contiguous, nothing is shared between the heads of a token row except the dqkv row that is written
   { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
@@ -349,6 +352,54 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
     return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd: sequence length not instantiated (20, 50)");
   }
   return check_launch("nr_attn_bwd");
+}
+
+int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, const uint16_t* dctx_gemm, int ldc,
+                    const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                    uint64_t seed, void* stream) {
+  return attn_bwd_launch(q_save, k_save, vt_save, 0, dctx_gemm, ldc, attn_w, g_out, dqkv, key_len, n_seq, S, p_drop, seed, stream);
+}
+
+int nr_attn_bwd_hm(const uint16_t* qkv, const uint16_t* dctx_gemm, int ldc, const float* attn_w, const float* g_out, uint16_t* dqkv,
+                   const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+  return attn_bwd_launch(qkv, nullptr, nullptr, 1, dctx_gemm, ldc, attn_w, g_out, dqkv, key_len, n_seq, S, p_drop, seed, stream);
+}
+
+int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                  uint16_t* Wp32, float* bp, void* stream) {
+  if (!Wq || !bq || !Wk || !bk || !Wv || !bv || !Wp32 || !bp) return fail(NR_ERR_BADARG, "nr_pack_qkv32: null pointer");
+  NR_LAUNCH(nr::pack_qkv32_kernel, 256, 256, 0, (hipStream_t)stream, Wq, bq, Wk, bk, Wv, bv, Wp32, bp);
+  return check_launch("nr_pack_qkv32");
+}
+
+int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wp32, const float* bp, uint16_t* qkv,
+                    uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+  if (!ids || !table || num_rows <= 0 || !Wp32 || !bp || !qkv || n_seq < 0) return fail(NR_ERR_BADARG, "nr_qkv_proj_fwd: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_qkv_proj_fwd: dropout probability out of range");
+  if (S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_qkv_proj_fwd: instantiated for 20-token sequences");
+  if (n_seq == 0) return NR_OK;
+  nr::ProjParams p;
+  p.ids = ids; p.table = table; p.num_rows = num_rows; p.Wp32 = Wp32; p.bp = bp; p.qkv = qkv; p.x_save = x_save; p.n_tok = n_seq * S;
+  p.dc = make_drop(p_drop, seed);
+  using G = nr::ProjGeom;
+  const int64_t grid = (p.n_tok + G::TOK_WG - 1) / G::TOK_WG;
+  static int ksplit = -1;                           // A/B knob NR_PROJ_KSPLIT: 1 = one accumulator chain per chunk, 2 (default) = two
+  if (ksplit < 0) { const char* e = getenv("NR_PROJ_KSPLIT"); ksplit = e ? atoi(e) : 2; }
+  if (ksplit == 1) NR_LAUNCH(nr::qkv_proj_kernel<1>, grid, 256, G::SMEM, (hipStream_t)stream, p);
+  else NR_LAUNCH(nr::qkv_proj_kernel<2>, grid, 256, G::SMEM, (hipStream_t)stream, p);
+  return check_launch("nr_qkv_proj_fwd");
+}
+
+int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+  if (!qkv || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_attn_fwd: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_fwd: dropout probability out of range");
+  if (S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_attn_fwd: instantiated for 20-token sequences");
+  if (n_seq == 0) return NR_OK;
+  nr::AttnFwdParams p;
+  p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  using G = nr::AttnFwdGeom;
+  NR_LAUNCH(nr::attn_fwd_kernel, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
+  return check_launch("nr_attn_fwd");
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
@@ -932,6 +983,12 @@ int nr_probe_mfma(const uint16_t* A, const uint16_t* B, float* D, void* stream) 
   if (!A || !B || !D) return fail(NR_ERR_BADARG, "nr_probe_mfma: null pointer");
   NR_LAUNCH(nr::probe_mfma_kernel, 1, 64, 0, (hipStream_t)stream, A, B, D);
   return check_launch("nr_probe_mfma");
+}
+
+int nr_probe_tr16(const int32_t* offs, uint16_t* out, void* stream) {
+  if (!offs || !out) return fail(NR_ERR_BADARG, "nr_probe_tr16: null pointer");
+  NR_LAUNCH(nr::probe_tr16_kernel, 1, 64, 8192, (hipStream_t)stream, offs, out);
+  return check_launch("nr_probe_tr16");
 }
 
 }  // extern "C"

@@ -32,6 +32,7 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -45,6 +46,22 @@ __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_
 
 __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// v_mfma_f32_32x32x16_bf16: A[32][16], B[16][32]; lane l holds A[i = l & 31][k = 8 (l >> 5) + j], B[k = 8 (l >> 5) + j][n = l & 31], j = 0..7;
+// C/D (16 fp32): col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) -- four quads of 4 consecutive rows per lane.
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: LDS transpose read.  Every lane passes the 8-byte-aligned LDS address of a piece of 4 consecutive 16-bit elements;
+// inside each group of 16 lanes the 16 pieces P_0 .. P_15 form a 4 x 16 matrix M[r][4 q + e] = P_{4 r + q}[e], and lane i of the group
+// receives its COLUMN i: element j = M[j][i] = P_{4 j + i / 4}[i % 4].  With P_{4 r + q} = &T[k0 + r][n0 + 4 q] of a row-major tile T this
+// hands lane i the four k-consecutive values T[k0 .. k0 + 3][n0 + i]: half of an MFMA operand fragment whose contraction index runs along
+// the ROWS of T, without a transposed copy.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u16x4 lds_tr16_b64(const u16* piece) {
+  return __builtin_bit_cast(u16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)piece));
 }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

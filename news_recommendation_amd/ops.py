@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import _capi
-from ._capi import NR_D, NR_KP, NR_NP, NR_QP, NR_HEADS, NR_DK, NR_LDG
+from ._capi import NR_D, NR_KP, NR_NP, NR_QP, NR_HEADS, NR_DK, NR_LDG, NR_QKV_HM_SEQ, NR_K16
 
 _BF16_AS_I16 = torch.int16   # bf16 buffers crossing the C-ABI are raw 16-bit words
 
@@ -306,6 +306,18 @@ def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
     return _packed('qkv', (Wq, bq, Wk, bk, Wv, bv), build)
 
 
+def pack_qkv32(Wq, bq, Wk, bk, Wv, bv):
+    """The projection operand of nr_qkv_proj_fwd: bf16 [3*NP][304] in tile32 order (include/nr_engine.h) + the packed bias vector."""
+    def build():
+        dev = Wq.device
+        Wp32 = torch.empty(3 * NR_NP * NR_K16 * 16, dtype=_BF16_AS_I16, device=dev)
+        bp = torch.empty(3 * NR_NP, dtype=torch.float32, device=dev)
+        args = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
+        _call('nr_pack_qkv32', _lib().nr_pack_qkv32, *[_ptr(a) for a in args], _ptr(Wp32), _ptr(bp), _stream())
+        return Wp32, bp
+    return _packed('qkv32', (Wq, bq, Wk, bk, Wv, bv), build)
+
+
 def pack_additive(Wa, ba, qv):
     def build():
         dev = Wa.device
@@ -414,6 +426,10 @@ def inplace_grads(params):
         out.append(g)
     return out
 
+
+# NR_FWD_SPLIT: 1 (default) = title encoders that need gradients run nr_qkv_proj_fwd + nr_attn_fwd (csrc/k_proj.h) instead of the
+# register-resident nr_mhsa_fwd kernel; 2 = inference too; 0 = never (A/B)
+_FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
 
 _ws = {}
 _side = {}
@@ -595,20 +611,36 @@ class _EncoderFn(torch.autograd.Function):
         valid = S if valid is None else int(valid)
         key_len = uniform_lengths(n_seq, valid, dev) if valid < S else None
         need_grad = any(ctx.needs_input_grad)
-        Wp, bp = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
+        # training form of the title encoder: gather-fused projection GEMM + stand-alone attention kernel on head-major saves (csrc/k_proj.h);
+        # the register-resident kernel stays the inference form (_FWD_SPLIT = 2 uses the split form there too)
+        split = gather and S == 20 and (_FWD_SPLIT == 2 or (_FWD_SPLIT == 1 and need_grad))
+        Wp, bp = (None, None) if split else pack_qkv(Wq, bq, Wk, bk, Wv, bv)
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
         WaT = pack_additive_t(Wa) if need_grad else None
         WpT = pack_qkv_t(Wq, bq, Wk, bk, Wv, bv) if need_grad else None
-        if need_grad:
+        if split:
+            qs = torch.empty(n_seq * NR_QKV_HM_SEQ, dtype=_BF16_AS_I16, device=dev)      # head-major Q | K | V^T
+            ks = vts = None
+            xb = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev) if need_grad else None
+        elif need_grad:
             qs = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             ks = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
             vts = torch.empty(n_seq, NR_HEADS, NR_DK, sp4, dtype=_BF16_AS_I16, device=dev)
             xb = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)       # masked bf16 tokens for dW = dqkv^T @ X (written by the kernel)
         else:
             qs = ks = vts = xb = None
-        if gather:
+        if split:
+            ids_c = ids.contiguous()
+            tab = table.detach()
+            assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
+            Wp32, bp32 = pack_qkv32(Wq, bq, Wk, bk, Wv, bv)
+            _call(f'nr_qkv_proj_fwd[S={S}]', lib.nr_qkv_proj_fwd, _ptr(ids_c), _ptr(tab), tab.shape[0], _ptr(Wp32), _ptr(bp32), _ptr(qs), _ptr(xb),
+                  n_seq, S, p_drop, seed, _stream())
+            _call(f'nr_attn_fwd[S={S}]', lib.nr_attn_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
+            xd = None
+        elif gather:
             ids_c = ids.contiguous()
             tab = table.detach()
             assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
@@ -626,7 +658,7 @@ class _EncoderFn(torch.autograd.Function):
               n_seq, S, valid, _stream())
         if need_grad:
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len)
-            ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather)
+            ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather, split)
             ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
             ctx.wparams = (Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv)        # likewise: inplace_grads()
             ctx.sorted = sort_ids_async(ids_c, table.shape[0]) if gather and ctx.needs_input_grad[1] else None
@@ -636,7 +668,7 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, g_out):
         lib = _lib()
         ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT, key_len = ctx.saved_tensors
-        S, p_drop, seed, n_seq, qdim, gather = ctx.meta
+        S, p_drop, seed, n_seq, qdim, gather, split = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
@@ -653,8 +685,12 @@ class _EncoderFn(torch.autograd.Function):
         dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))   # [nc, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
-        _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
-                            _ptr(key_len), n_seq, S, p_drop, seed, _stream())
+        if split:
+            _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_hm, _ptr(qs), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv), _ptr(key_len),
+                  n_seq, S, p_drop, seed, _stream())
+        else:
+            _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
+                  _ptr(key_len), n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)

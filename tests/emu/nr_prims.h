@@ -127,6 +127,7 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
@@ -162,6 +163,50 @@ __forceinline__ f32x4 mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
   }
   nr_emu::wave_sync();
   return d;
+}
+
+// v_mfma_f32_32x32x16_bf16 (cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = 8 (l >> 5) + j], B[k][n = l & 31];
+// C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)
+__forceinline__ f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  memcpy(&ws.stage[l][0], &a, 16);
+  memcpy(&ws.stage[l][4], &b, 16);
+  nr_emu::wave_sync();
+  f32x16 d = c;
+  const int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h) {
+      u16 av[8], bv[8];
+      memcpy(av, &ws.stage[h * 32 + row][0], 16);
+      memcpy(bv, &ws.stage[h * 32 + col][4], 16);
+      for (int j = 0; j < 8; ++j) acc += bf2f(av[j]) * bf2f(bv[j]);
+    }
+    d[r] = acc;
+  }
+  nr_emu::wave_sync();
+  return d;
+}
+
+// ds_read_b64_tr_b16 (see csrc/nr_prims.h): in each group of 16 lanes, lane i gets element j = P_{4 j + i / 4}[i % 4] of the 16 pieces P
+__forceinline__ u16x4 lds_tr16_b64(const u16* piece) {
+  nr_emu::BlockState* blk = nr_emu::g_blk;
+  const int l = lane_id();
+  nr_emu::WaveState& ws = blk->waves[blk->cur / 64];
+  memcpy(&ws.stage[l][0], piece, 8);
+  nr_emu::wave_sync();
+  u16x4 o;
+  const int grp = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; ++j) {
+    u16 pc[4];
+    memcpy(pc, &ws.stage[grp + 4 * j + i / 4][0], 8);
+    o[j] = pc[i % 4];
+  }
+  nr_emu::wave_sync();
+  return o;
 }
 
 __forceinline__ float shfl_xor(float v, int mask) {

@@ -31,6 +31,26 @@ def check_probe_mfma(be):
     np.testing.assert_allclose(be.np(d), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-5, atol=1e-5)
 
 
+def check_probe_tr16(be):
+    """ds_read_b64_tr_b16 (lds_tr16_b64): in each group of 16 lanes, lane i receives element j = P_{4 j + i // 4}[i % 4] of the group's 16
+    four-element pieces -- with the canonical row-major 4 x 16 block addresses, and with arbitrary 8-byte-aligned per-lane addresses."""
+    rng = np.random.default_rng(31)
+    canon = np.array([(64 * (l >> 4) + 4 * (l & 15)) * 2 + 512 for l in range(64)], dtype=np.int32)
+    strided = np.array([((l >> 4) * 8 + (l & 15) // 4) * 272 + ((l & 15) % 4) * 8 + 64 for l in range(64)], dtype=np.int32)   # rows of a [tok][136] tile
+    rand = (rng.integers(0, 1000, size=64) * 8).astype(np.int32)
+    for offs in (canon, strided, rand):
+        out = be.poison((64, 4), np.uint16)
+        ck(be, be.lib.nr_probe_tr16(be.ptr(be.dev(offs)), be.ptr(out), be.stream))
+        be.sync()
+        got = be.np(out)
+        ref = np.zeros((64, 4), dtype=np.uint16)
+        for l in range(64):
+            grp, i = l & ~15, l & 15
+            for j in range(4):
+                ref[l, j] = offs[grp + 4 * j + i // 4] // 2 + i % 4
+        assert np.array_equal(got, ref), f'ds_read_b64_tr_b16 semantics differ from the model:\n{got[:16]}\nexpected\n{ref[:16]}'
+
+
 def check_gather(be, n_tokens=1000, V=777):
     rng = np.random.default_rng(2)
     table = rng.normal(size=(V, NR_D)).astype(np.float32)

@@ -1,0 +1,179 @@
+"""Backend-agnostic parity checks of the split training forward (csrc/k_proj.h): nr_pack_qkv32, nr_qkv_proj_fwd, nr_attn_fwd and
+nr_attn_bwd_hm against the numpy oracle and against the register-resident kernels they replace in training."""
+import numpy as np
+
+from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_HEADS, NR_LDG, NR_QKV_HM_SEQ, NR_K16
+from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
+from tests import kernel_checks as kc
+
+H = NR_HEADS
+DK = 20
+S = 20
+
+
+def untile32(a):
+    """tile32 order (include/nr_engine.h) -> row-major [3*NP][304]."""
+    return np.asarray(a).reshape(3 * NR_NP // 32, NR_K16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(3 * NR_NP, NR_K16 * 16)
+
+
+def pack_qkv32(be, params, prefix):
+    m = prefix + 'multihead_self_attention.'
+    Wp32 = be.poison((3 * NR_NP * NR_K16 * 16,), np.uint16)
+    bp = be.poison((3 * NR_NP,), np.float32)
+    hs = [be.dev(params[m + n]) for n in ('W_Q.weight', 'W_Q.bias', 'W_K.weight', 'W_K.bias', 'W_V.weight', 'W_V.bias')]
+    kc.ck(be, be.lib.nr_pack_qkv32(*[be.ptr(h) for h in hs], be.ptr(Wp32), be.ptr(bp), be.stream))
+    return Wp32, bp
+
+
+def check_pack32(be):
+    params = kc.make_params(3)
+    Wp32, bp = pack_qkv32(be, params, 'news_encoder.')
+    be.sync()
+    W = untile32(be.np(Wp32))
+    m = 'news_encoder.multihead_self_attention.'
+    for i, n in enumerate(('W_Q', 'W_K', 'W_V')):
+        blk = W[i * NR_NP:(i + 1) * NR_NP]
+        assert np.array_equal(blk[:NR_D, :NR_D], f32_to_bf16(params[m + n + '.weight']))
+        assert not blk[NR_D:].any() and not blk[:, NR_D:].any()
+        assert np.array_equal(be.np(bp)[i * NR_NP:i * NR_NP + NR_D], params[m + n + '.bias'])
+        assert not be.np(bp)[i * NR_NP + NR_D:(i + 1) * NR_NP].any()
+
+
+def hm_split(qkv_u16, n_seq):
+    """head-major buffer -> float64 Q, K, V as [n_seq, H, S, dk]."""
+    a = bf16_to_f32(np.asarray(qkv_u16).reshape(n_seq, H, 3, S * DK)).astype(np.float64)
+    q = a[:, :, 0].reshape(n_seq, H, S, DK)
+    k = a[:, :, 1].reshape(n_seq, H, S, DK)
+    v = a[:, :, 2].reshape(n_seq, H, DK, S).transpose(0, 1, 3, 2)
+    return q, k, v
+
+
+def hm_from_rowmajor(qs, ks, vts, n_seq):
+    """q_save / k_save [n_seq*S][KP], vt_save [n_seq][H][20][S] (nr_mhsa_fwd) -> head-major uint16 buffer."""
+    out = np.zeros((n_seq, H, 3, S * DK), dtype=np.uint16)
+    q = np.asarray(qs)[:, :NR_D].reshape(n_seq, S, H, DK).transpose(0, 2, 1, 3)
+    k = np.asarray(ks)[:, :NR_D].reshape(n_seq, S, H, DK).transpose(0, 2, 1, 3)
+    out[:, :, 0] = q.reshape(n_seq, H, S * DK)
+    out[:, :, 1] = k.reshape(n_seq, H, S * DK)
+    out[:, :, 2] = np.asarray(vts)[:, :, :, :S].reshape(n_seq, H, DK * S)
+    return out.reshape(-1)
+
+
+def run_proj(be, params, ids, table, p_drop=0.0, seed=0, x_save=True):
+    n_seq = ids.shape[0]
+    Wp32, bp = pack_qkv32(be, params, 'news_encoder.')
+    qkv = be.poison((n_seq * NR_QKV_HM_SEQ,), np.uint16)
+    xs = be.poison((n_seq * S, NR_KP), np.uint16) if x_save else None
+    kc.ck(be, be.lib.nr_qkv_proj_fwd(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), table.shape[0], be.ptr(Wp32), be.ptr(bp),
+                                     be.ptr(qkv), be.ptr(xs), n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    return qkv, xs
+
+
+def check_qkv_proj(be, n_seq=13, V=300, p_drop=0.0, seed=4321):
+    """Q, K, V^T of nr_qkv_proj_fwd == bf16(bf16(dropout(table[ids])) @ bf16(W)^T + b); x_save == nr_gather_bf16."""
+    params = kc.make_params(4, V)
+    rng = np.random.default_rng(21)
+    ids = rng.integers(1, V, size=(n_seq, S))
+    ids[:, 13:] = 0
+    ids[1] = 0
+    table = params['news_encoder.word_embedding.weight']
+    qkv, xs = run_proj(be, params, ids, table, p_drop, seed)
+    x = table[ids].astype(np.float64)
+    if p_drop > 0:
+        m1 = kc.export_mask(be, n_seq * S * NR_D, p_drop, seed, 1).reshape(n_seq, S, NR_D)
+        x = x * m1 * np.float32(1.0 / (1.0 - p_drop))
+    xq = bf16_round(x.astype(np.float32))
+    got_x = be.np(xs)
+    assert np.array_equal(bf16_to_f32(got_x[:, :NR_D]), xq.reshape(-1, NR_D)), 'x_save differs from the masked bf16 token matrix'
+    assert (got_x[:, NR_D] == 0x3F80).all() and not got_x[:, NR_D + 1:].any(), 'x_save K padding wrong'
+    q, k, v = hm_split(be.np(qkv), n_seq)
+    m = 'news_encoder.multihead_self_attention.'
+    rels = []
+    for name, t in (('W_Q', q), ('W_K', k), ('W_V', v)):
+        ref = xq.astype(np.float64) @ bf16_round(params[m + name + '.weight']).astype(np.float64).T + params[m + name + '.bias']
+        ref = ref.reshape(n_seq, S, H, DK).transpose(0, 2, 1, 3)
+        rels.append(kc.close_bf16(t, ref, 'proj ' + name, rel=2.0 ** -7, floor=1e-3))
+    return rels
+
+
+def check_proj_attn(be, n_seq=9, V=300, p_drop=0.0, seed=99, with_key_len=False):
+    """nr_qkv_proj_fwd + nr_attn_fwd == the quantised MHSA oracle (the check nr_mhsa_fwd's gather form passes), ctx padding included."""
+    params = kc.make_params(4, V)
+    rng = np.random.default_rng(22)
+    ids = rng.integers(1, V, size=(n_seq, S))
+    ids[:, 15:] = 0
+    ids[2] = 0
+    table = params['news_encoder.word_embedding.weight']
+    key_len = None
+    if with_key_len:
+        key_len = rng.integers(1, S + 1, size=n_seq)
+        key_len[0], key_len[-1] = S, 1
+    qkv, _ = run_proj(be, params, ids, table, p_drop, seed, x_save=False)
+    ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    hl = be.dev(np.asarray(key_len, dtype=np.int32)) if key_len is not None else None
+    kc.ck(be, be.lib.nr_attn_fwd(be.ptr(qkv), be.ptr(ctx), be.ptr(hl), n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    x = table[ids].astype(np.float64)
+    mask2, scale = None, 1.0
+    if p_drop > 0:
+        scale = np.float32(1.0 / (1.0 - p_drop))
+        m1 = kc.export_mask(be, n_seq * S * NR_D, p_drop, seed, 1).reshape(n_seq, S, NR_D)
+        mask2 = kc.export_mask(be, n_seq * S * NR_D, p_drop, seed, 2).reshape(n_seq, S, NR_D)
+        x = x * m1 * scale
+    ref = kc.mhsa_quantized_oracle(x, params, 'news_encoder.', mask2, scale, key_len=key_len)
+    return kc.assert_ctx_close(be.np(ctx), ref, f'proj + attn_fwd p={p_drop} key_len={with_key_len}')
+
+
+def check_attn_fwd_matches_fused(be, n_seq=6, V=300):
+    """Same saved Q / K / V^T -> nr_attn_fwd's ctx == nr_mhsa_fwd's ctx bit for bit (same formulas on the same bf16 operands)."""
+    params = kc.make_params(4, V)
+    rng = np.random.default_rng(23)
+    ids = rng.integers(0, V, size=(n_seq, S))
+    table = params['news_encoder.word_embedding.weight']
+    ctx_ref, sv = kc.run_mhsa(be, params, 'news_encoder.', S, n_seq, ids=ids, table=table, save=True)
+    qkv = hm_from_rowmajor(be.np(sv[0]), be.np(sv[1]), be.np(sv[2]), n_seq)
+    ctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    kc.ck(be, be.lib.nr_attn_fwd(be.ptr(be.dev(qkv)), be.ptr(ctx), None, n_seq, S, 0.0, 0, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(ctx), ctx_ref), 'attn_fwd differs from the fused kernel on identical operands'
+
+
+def check_attn_bwd_hm(be, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
+    """nr_attn_bwd_hm on the head-major saves == nr_attn_bwd_len on the row-major saves of the same values, bit for bit."""
+    params = kc.make_params(12)
+    rng = np.random.default_rng(13)
+    x = rng.normal(0, 0.7, size=(n_seq, S, NR_D)).astype(np.float32)
+    key_len = None
+    if with_key_len:
+        key_len = rng.integers(1, S + 1, size=n_seq)
+        key_len[0] = S
+    _, sv = kc.run_mhsa(be, params, 'user_encoder.', S, n_seq, x=x, save=True, key_len=key_len)
+    dg_u = f32_to_bf16(rng.normal(0, 0.05, size=(n_seq * S, NR_D)).astype(np.float32))
+    aw = rng.random(size=(n_seq, S)).astype(np.float32)
+    aw /= aw.sum(1, keepdims=True)
+    go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
+    hl = be.dev(np.asarray(key_len, dtype=np.int32)) if key_len is not None else None
+    ref = be.empty((n_seq * S, NR_LDG), np.uint16)
+    kc.ck(be, be.lib.nr_attn_bwd_len(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)), be.ptr(be.dev(go)),
+                                     be.ptr(ref), be.ptr(hl), n_seq, S, p_drop, seed, be.stream))
+    qkv = hm_from_rowmajor(be.np(sv[0]), be.np(sv[1]), be.np(sv[2]), n_seq)
+    got = be.empty((n_seq * S, NR_LDG), np.uint16)
+    kc.ck(be, be.lib.nr_attn_bwd_hm(be.ptr(be.dev(qkv)), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)), be.ptr(be.dev(go)), be.ptr(got), be.ptr(hl),
+                                    n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(got), be.np(ref))
+    assert be.np(ref).any()
+
+
+def check_proj_bad_args(be):
+    a = be.empty((64,), np.float32)
+    pa = be.ptr(a)
+    assert be.lib.nr_qkv_proj_fwd(None, pa, 10, pa, pa, pa, None, 1, 20, 0.0, 0, be.stream) != 0 and b'nr_qkv_proj_fwd' in be.lib.nr_last_error()
+    assert be.lib.nr_qkv_proj_fwd(pa, pa, 10, pa, pa, pa, None, 1, 50, 0.0, 0, be.stream) == -1
+    assert be.lib.nr_qkv_proj_fwd(pa, pa, 10, pa, pa, pa, None, 1, 20, 1.0, 0, be.stream) != 0
+    assert be.lib.nr_attn_fwd(None, pa, None, 1, 20, 0.0, 0, be.stream) != 0 and b'nr_attn_fwd' in be.lib.nr_last_error()
+    assert be.lib.nr_attn_fwd(pa, pa, None, 1, 50, 0.0, 0, be.stream) == -1
+    assert be.lib.nr_attn_bwd_hm(pa, pa, NR_D, pa, pa, pa, None, 1, 50, 0.0, 0, be.stream) == -1
+    assert be.lib.nr_attn_bwd_hm(None, pa, NR_D, pa, pa, pa, None, 1, 20, 0.0, 0, be.stream) != 0
+    assert be.lib.nr_qkv_proj_fwd(pa, pa, 10, pa, pa, pa, None, 0, 20, 0.0, 0, be.stream) == 0          # empty batch: nothing launched

@@ -12,6 +12,7 @@ def be():
 
 
 def test_probe_mfma(be): kc.check_probe_mfma(be)
+def test_probe_tr16(be): kc.check_probe_tr16(be)
 def test_gather(be): kc.check_gather(be, n_tokens=300)
 def test_pack(be): kc.check_pack(be)
 def test_mhsa_gather(be): kc.check_mhsa_gather(be, n_seq=6)

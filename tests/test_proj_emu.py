@@ -1,0 +1,28 @@
+"""Split training forward (csrc/k_proj.h) on the CPU wave emulator: the same kernel sources, checked against the numpy oracle and against
+the register-resident kernels.  The -m gpu twin is tests/test_proj_gpu.py."""
+import pytest
+from tests import kernel_checks_proj as kp
+from tests.backends import EmuBackend
+
+
+@pytest.fixture(scope='module')
+def be():
+    return EmuBackend()
+
+
+def test_pack32(be): kp.check_pack32(be)
+def test_qkv_proj(be): kp.check_qkv_proj(be, n_seq=13)          # 260 tokens: two full workgroups + a partly filled one
+def test_qkv_proj_dropout(be): kp.check_qkv_proj(be, n_seq=7, p_drop=0.2)
+def test_qkv_proj_single_accumulator():
+    import subprocess, sys, os
+    env = dict(os.environ, NR_PROJ_KSPLIT='1')
+    code = "from tests.backends import EmuBackend; from tests import kernel_checks_proj as k; k.check_qkv_proj(EmuBackend(), n_seq=5)"
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+def test_proj_attn(be): kp.check_proj_attn(be, n_seq=9)
+def test_proj_attn_dropout(be): kp.check_proj_attn(be, n_seq=6, p_drop=0.2)
+def test_proj_attn_key_len(be): kp.check_proj_attn(be, n_seq=7, with_key_len=True)
+def test_attn_fwd_matches_fused(be): kp.check_attn_fwd_matches_fused(be, n_seq=6)
+def test_attn_bwd_hm(be): kp.check_attn_bwd_hm(be, n_seq=5)
+def test_attn_bwd_hm_dropout_key_len(be): kp.check_attn_bwd_hm(be, n_seq=4, p_drop=0.2, with_key_len=True)
+def test_proj_bad_args(be): kp.check_proj_bad_args(be)

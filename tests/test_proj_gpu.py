@@ -1,0 +1,107 @@
+"""Split training forward (csrc/k_proj.h) on the real library (cuda:0): the checks of tests/test_proj_emu.py at MI355X-filling sizes, and the
+autograd path of ops._EncoderFn with the split form against the register-resident form."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from tests.backends import GpuBackend
+    return GpuBackend()
+
+
+def test_pack32(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_pack32(be)
+
+
+def test_qkv_proj(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_qkv_proj(be, n_seq=13)
+    kp.check_qkv_proj(be, n_seq=1999, V=5000)            # 312 full workgroups + a partly filled one
+
+
+def test_qkv_proj_dropout(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_qkv_proj(be, n_seq=257, V=900, p_drop=0.2)
+
+
+def test_proj_attn(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_proj_attn(be, n_seq=9)
+    kp.check_proj_attn(be, n_seq=1031, V=3000)
+    kp.check_proj_attn(be, n_seq=130, p_drop=0.2)
+    kp.check_proj_attn(be, n_seq=67, with_key_len=True)
+
+
+def test_attn_fwd_matches_fused(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_attn_fwd_matches_fused(be, n_seq=403, V=2000)
+
+
+def test_attn_bwd_hm(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_attn_bwd_hm(be, n_seq=5)
+    kp.check_attn_bwd_hm(be, n_seq=700, p_drop=0.2, with_key_len=True)
+
+
+def test_proj_bad_args(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_proj_bad_args(be)
+
+
+def test_qkv_proj_single_accumulator():
+    env = dict(os.environ, NR_PROJ_KSPLIT='1')
+    code = "from tests.backends import GpuBackend; from tests import kernel_checks_proj as k; k.check_qkv_proj(GpuBackend(), n_seq=300, V=2000)"
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def _encoder_run(split, seed=3):
+    """loss + every gradient of one title-encoder call through ops.encode_titles in a child process (NR_FWD_SPLIT is read at import)."""
+    code = f'''
+import torch, numpy as np, sys
+from news_recommendation_amd import ops
+from news_recommendation_amd.dropin.model.NRMS.news_encoder import NewsEncoder
+from news_recommendation_amd.default_config import NRMSConfig
+torch.manual_seed({seed})
+cfg = NRMSConfig
+cfg.num_words = 3000
+enc = NewsEncoder(cfg, None).to("cuda:0")
+g = torch.Generator().manual_seed(5)
+ids = torch.randint(0, 3000, (530, 20), generator=g).to("cuda:0")
+ids[:, 14:] = 0
+enc.eval()
+out = enc({{"title": ids}})
+w = torch.randn(out.shape, generator=g).to("cuda:0")
+(out * w).sum().backward()
+res = {{"out": out.detach().cpu().numpy()}}
+for n, p_ in enc.named_parameters():
+    res[n] = p_.grad.detach().cpu().numpy()
+np.savez(sys.argv[1], **res)
+'''
+    import tempfile
+    path = tempfile.mktemp(suffix='.npz')
+    env = dict(os.environ, NR_FWD_SPLIT='1' if split else '0')
+    r = subprocess.run([sys.executable, '-c', code, path], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = dict(np.load(path))
+    os.unlink(path)
+    return d
+
+
+def test_encoder_autograd_split_vs_fused():
+    """The title encoder's output and every parameter gradient with the split training forward == the register-resident form, to the
+    accumulation-order noise of the projection (bf16 rounding of Q / K / V flips a last bit here and there): 1e-2 of each tensor's scale."""
+    a, b = _encoder_run(True), _encoder_run(False)
+    assert set(a) == set(b)
+    for k in a:
+        scale = np.abs(b[k]).max() + 1e-30
+        err = np.abs(a[k] - b[k]).max()
+        assert err <= 1e-2 * scale, f'{k}: max diff {err:.3g} on scale {scale:.3g}'
