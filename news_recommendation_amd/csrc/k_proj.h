@@ -75,16 +75,19 @@ struct ProjParams {
   u16* x_save;             // optional [n_tok][KP]: the dropout-masked bf16 token matrix (col D = 1.0) for the weight-gradient GEMM
   int64_t n_tok;           // multiple of 20
   DropCfg dc;              // dropout site 1
+  int debug;               // profiling only (NR_PROJ_DEBUG, DBG instantiation): 1 skip the table loads, 2 skip the MFMAs, 4 skip the Q / K / V^T
+                           // stores, 8 skip the x_save stores, 16 skip the weight-chunk copies
 };
 
 #ifndef NR_PROJ_OCC
 #define NR_PROJ_OCC 3      // waves per SIMD the register allocation must allow
 #endif
 // KSPLIT = 2: even / odd k-steps accumulate into two independent accumulators (no MFMA waits on the previous one's result)
-template <int KSPLIT>
+template <int KSPLIT, bool DBG>
 __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p) {
   using Gm = ProjGeom;
   constexpr int S = Gm::S;
+  const int dbg = DBG ? p.debug : 0;
   NR_SMEM_DECL(smem);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
   const int64_t tile_tok0 = ((int64_t)blockIdx.x * Gm::NWAVE + w) * Gm::TOKW;
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   auto chunk_fetch = [&](int c, int buf) {
     const u16* src = p.Wp32 + (size_t)c * K16 * 512 + l * 8;
     unsigned char* dst = smem + buf * Gm::CH_BYTES;
+    if (dbg & 16) return;
     for (int blk = w; blk < K16; blk += Gm::NWAVE) NR_GLDS16(src + blk * 512, dst + blk * 1024);
   };
   chunk_fetch(0, 0);
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
       const int ks = kb + j;
       if (ks < K16) {
         const int c = ks * 16 + h * 8;                  // c + 3 < D for every (ks, h); c + 4 .. c + 7 leave the row at (18, 1)
-        lo[j] = live ? *(const f32x4*)(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        hi[j] = (live && c + 4 < D) ? *(const f32x4*)(row + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        lo[j] = (live && !(dbg & 1)) ? *(const f32x4*)(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        hi[j] = (live && c + 4 < D && !(dbg & 1)) ? *(const f32x4*)(row + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
           if (c + 4 < D) b = b * drop_mul4(p.dc, 1u, (uint64_t)tok * D4 + (c >> 2) + 1);
         }
         xf[ks] = cat8(pack4(a), pack4(b));
-        if (p.x_save != nullptr && live) {
+        if (p.x_save != nullptr && live && !(dbg & 8)) {
           u16x8 o = xf[ks];
           if (ks == D / 16 && h == (D % 16) / 8) o[D % 8] = BF16_ONE;      // column D = 1.0: the weight-gradient GEMM then also yields the bias gradient
           *(u16x8*)(p.x_save + tok * KP + c) = o;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
       for (int r = 0; r < 16; ++r) acc[KSPLIT - 1][r] = 0.0f;
     }
 #pragma unroll
-    for (int ks = 0; ks < K16; ++ks) {
+    for (int ks = (dbg & 2) ? K16 : 0; ks < K16; ++ks) {
       const u16x8 wf = *(const u16x8*)(wp + ks * 512);
       f32x16& a = acc[ks % KSPLIT];
       a = which < 2 ? mfma_32x32x16_bf16(wf, xf[ks], a) : mfma_32x32x16_bf16(xf[ks], wf, a);
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] += acc[KSPLIT - 1][r];
     }
-    if (which < 2) {
+    if (dbg & 4) {
+    } else if (which < 2) {
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -225,6 +230,7 @@ struct AttnFwdParams {
   const int32_t* key_len;  // optional [n_seq]: keys >= key_len[seq] get zero weight (MultiHeadSelfAttention's `length`); null: 20
   int64_t n_seq;
   DropCfg dc;              // dropout site 2
+  int debug;               // profiling only (NR_ATTNF_DEBUG, DBG instantiation): 1 skip the operand loads, 2 skip the exp / normalisation, 4 skip the ctx stores
 };
 
 struct AttnFwdGeom {
@@ -239,9 +245,11 @@ struct AttnFwdRaw {
   u16x4 klo[2], khi[2], qlo[2], qhi[2], vlo[2], vhi[2];
 };
 
+template <bool DBG>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
   using Gm = AttnFwdGeom;
   constexpr int S = Gm::S;
+  const int dbg = DBG ? p.debug : 0;
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int64_t seq0 = (int64_t)blockIdx.x * Gm::TPB;
   const int nseq_blk = (int)((p.n_seq - seq0) < Gm::TPB ? (p.n_seq - seq0) : Gm::TPB);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int rw = 16 * t + li;
-      const bool rok = rw < S;
+      const bool rok = rw < S && !(dbg & 1);
       const u16* q_ = base + rw * DK + 8 * g;
       r.qlo[t] = (rok && g < 3) ? *(const u16x4*)q_ : Z4;
       r.qhi[t] = (rok && g < 2) ? *(const u16x4*)(q_ + 4) : Z4;
@@ -302,13 +310,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
 #pragma unroll
       for (int ki = 0; ki < 2; ++ki) {
         e[ki] = mfma_16x16x32_bf16(kf[ki], qf[qj], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (!(dbg & 2)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e[ki][r] = fast_exp2(fminf(e[ki][r] * c2, clamp2));
-          sum += e[ki][r];
+          for (int r = 0; r < 4; ++r) {
+            e[ki][r] = fast_exp2(fminf(e[ki][r] * c2, clamp2));
+            sum += e[ki][r];
+          }
         }
       }
-      sum = sum_rows4(sum);
+      if (!(dbg & 2)) sum = sum_rows4(sum);
       const float rden = fast_rcp(sum + 1e-8f);      // exp / (sum + 1e-8): multihead_self.py:16-20 verbatim
       pt[0][qj] = pack4(e[0] * rden);
       pt[1][qj] = pack4(e[1] * rden);
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
       for (int qj = 0; qj < 2; ++qj) {
         f32x4 acc = mfma_16x16x32_bf16(va, cat8(pt[0][qj], pt[1][qj]), f32x4{0.f, 0.f, 0.f, 0.f});
         const int tokl = 16 * qj + li, dv = 16 * t + 4 * g;
-        if (tokl < S && dv < DK) {
+        if (tokl < S && dv < DK && !(dbg & 4)) {
           const int64_t tok = seq * S + tokl;
           const int col = hd * DK + dv;
           if (p.dc.enabled) acc = acc * drop_mul4(p.dc, 2u, (uint64_t)tok * D4 + (col >> 2));

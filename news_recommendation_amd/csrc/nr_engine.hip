@@ -380,13 +380,17 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
   if (n_seq == 0) return NR_OK;
   nr::ProjParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.Wp32 = Wp32; p.bp = bp; p.qkv = qkv; p.x_save = x_save; p.n_tok = n_seq * S;
-  p.dc = make_drop(p_drop, seed);
+  p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::ProjGeom;
   const int64_t grid = (p.n_tok + G::TOK_WG - 1) / G::TOK_WG;
   static int ksplit = -1;                           // A/B knob NR_PROJ_KSPLIT: 1 = one accumulator chain per chunk, 2 (default) = two
   if (ksplit < 0) { const char* e = getenv("NR_PROJ_KSPLIT"); ksplit = e ? atoi(e) : 2; }
-  if (ksplit == 1) NR_LAUNCH(nr::qkv_proj_kernel<1>, grid, 256, G::SMEM, (hipStream_t)stream, p);
-  else NR_LAUNCH(nr::qkv_proj_kernel<2>, grid, 256, G::SMEM, (hipStream_t)stream, p);
+  const char* d = getenv("NR_PROJ_DEBUG");          // profiling: phase switches (ProjParams::debug), re-read per call
+  if (d != nullptr && atoi(d) != 0) {
+    p.debug = atoi(d);
+    NR_LAUNCH((nr::qkv_proj_kernel<2, true>), grid, 256, G::SMEM, (hipStream_t)stream, p);
+  } else if (ksplit == 1) NR_LAUNCH((nr::qkv_proj_kernel<1, false>), grid, 256, G::SMEM, (hipStream_t)stream, p);
+  else NR_LAUNCH((nr::qkv_proj_kernel<2, false>), grid, 256, G::SMEM, (hipStream_t)stream, p);
   return check_launch("nr_qkv_proj_fwd");
 }
 
@@ -396,9 +400,13 @@ int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int6
   if (S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_attn_fwd: instantiated for 20-token sequences");
   if (n_seq == 0) return NR_OK;
   nr::AttnFwdParams p;
-  p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed);
+  p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::AttnFwdGeom;
-  NR_LAUNCH(nr::attn_fwd_kernel, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
+  const char* d = getenv("NR_ATTNF_DEBUG");         // profiling: phase switches (AttnFwdParams::debug), re-read per call
+  if (d != nullptr && atoi(d) != 0) {
+    p.debug = atoi(d);
+    NR_LAUNCH(nr::attn_fwd_kernel<true>, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
+  } else NR_LAUNCH(nr::attn_fwd_kernel<false>, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
   return check_launch("nr_attn_fwd");
 }
 

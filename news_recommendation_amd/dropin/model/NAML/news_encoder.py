@@ -72,7 +72,9 @@ class NewsEncoder(torch.nn.Module):
         self.element_encoders = nn.ModuleDict({
             name: ElementEncoder(category_embedding, config.category_embedding_dim, config.num_filters)
             for name in ('category', 'subcategory') if name in attrs})
-        if len(self.attrs) > 1:                                              # news_encoder.py:82-84
+        # the reference counts EVERY listed attribute here, title_entities / abstract_entities included (news_encoder.py:82): the module (its
+        # state_dict keys and its share of the init RNG stream) exists for ['title', 'title_entities'] although forward pools a single view
+        if len(config.dataset_attributes['news']) > 1:
             self.final_attention = AdditiveAttention(config.query_vector_dim, config.num_filters)
 
     def _device(self):

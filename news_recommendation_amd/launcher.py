@@ -29,18 +29,10 @@ def install_shims():
         numpy.Inf = numpy.inf
     # torch >= 2.6 defaults torch.load(weights_only=True); the reference's checkpoints (train.py:268-275) carry a numpy scalar
     # ('early_stop_value') and are loaded with a bare torch.load(path) (train.py:149, evaluate.py:287), which that default rejects.
-    # The reference was written for the old default: restore it for ITS OWN checkpoint files.
-    import functools
+    # weights_only stays on for every load of the process: only the numpy scalar / dtype types that value needs are allow-listed.
     import torch
-    if not getattr(torch.load, '_nr_shim', False):
-        orig = torch.load
-
-        @functools.wraps(orig)
-        def load(*a, **k):
-            k.setdefault('weights_only', False)
-            return orig(*a, **k)
-        load._nr_shim = True
-        torch.load = load
+    from news_recommendation_amd.train_fast import checkpoint_safe_globals
+    torch.serialization.add_safe_globals(checkpoint_safe_globals())
     try:
         import torch.utils.tensorboard  # noqa: F401
     except Exception:

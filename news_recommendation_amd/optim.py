@@ -22,6 +22,9 @@ What the reference does per step: ``optimizer.zero_grad()``, ``loss.backward()``
 There is no CPU implementation: the update runs in the HIP library (``_capi.load()``).  ``lib=`` lets the GPU-less unit tests inject
 a host build of the same kernel sources that the test suite owns (test infrastructure; the product never loads it).
 """
+import math
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -34,6 +37,10 @@ _ALIGN = 64                        # flat regions start on 256-byte boundaries
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 class AdamSchedule:
@@ -68,10 +75,12 @@ class AdamSchedule:
 
 
 class _Region:
-    __slots__ = ('name', 'lo', 'hi', 'work')
+    """[lo, hi): the parameters; [hi, end): zero padding so that a table region divides into `world` equal, 256-byte aligned shards."""
+    __slots__ = ('name', 'lo', 'hi', 'end', 'work')
 
-    def __init__(self, name, lo, hi):
+    def __init__(self, name, lo, hi, end=None):
         self.name, self.lo, self.hi, self.work = name, lo, hi, None
+        self.end = hi if end is None else end
 
 
 class _SparseTable:
@@ -83,7 +92,12 @@ class EngineAdam:
     row-sparse tables.  Drop-in for the ``optimizer`` object of src/train.py: ``zero_grad()``, ``step()``, ``state_dict()``,
     ``load_state_dict()``, ``param_groups``."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, row_sparse=(), overlap=True, lib=None, stream_fn=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, row_sparse=(), overlap=True, lib=None, stream_fn=None,
+                 table_rs=None, force_dist=False):
+        """table_rs (default: env NR_TABLE_RS=1): the table buckets are exchanged as reduce-scatter -> Adam on this rank's 1/world shard ->
+        all-gather of the updated parameters instead of all-reduce -> Adam on the whole table (same bytes on the wire, 1/world of the
+        update pass per GPU).  force_dist: take the multi-rank code path even in a world of one (the RCCL path can then be
+        exercised on a single GPU: collectives over one rank are identities)."""
         if isinstance(model, torch.nn.Module):
             named = list(model.named_parameters())
             self._module = model
@@ -105,7 +119,11 @@ class EngineAdam:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("EngineAdam: all parameters must be fp32 on one device")
         self.t = 0
-        self._uniform_rows = {}
+        self._row_cap = {}
+        self.table_rs = (os.environ.get('NR_TABLE_RS', '0') == '1') if table_rs is None else bool(table_rs)
+        self.force_dist = bool(force_dist)
+        self.skip_comm = os.environ.get('NR_SKIP_COMM', '0') == '1'      # measurement only: every collective skipped (ranks drift apart)
+        self.comm_bytes = {}                                             # bucket name -> payload bytes per step (bench.py reports them)
         self.sched = AdamSchedule(self.lr, self.betas, dev)
 
         sparse_names = [n for n in self.names if any(n == s or n.endswith(s) for s in row_sparse)]
@@ -119,11 +137,13 @@ class EngineAdam:
             self.slices[n] = (off, off + p.numel())
             off += p.numel()
         self.regions = [_Region('small', 0, off)] if off else []
+        shard_mult = _ALIGN * math.lcm(8, _world())        # a table region splits into `world` equal shards on 256-byte boundaries
         for n, p in tables:
             off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
             self.slices[n] = (off, off + p.numel())
-            self.regions.append(_Region(n, off, off + p.numel()))
-            off += p.numel()
+            end = off + (p.numel() + shard_mult - 1) // shard_mult * shard_mult
+            self.regions.append(_Region(n, off, off + p.numel(), end))
+            off = end
         total = (off + _ALIGN - 1) // _ALIGN * _ALIGN
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -168,12 +188,30 @@ class EngineAdam:
     def _make_ready(self, region):
         def ready():
             """The table's gradient is complete (its scatter is enqueued on the current stream): start the bucket's all-reduce now."""
-            if _world() > 1 and self.overlap:
+            if self._dist_on() and self.overlap and not self.skip_comm:
                 if region.work is not None:
                     raise RuntimeError(f"EngineAdam(overlap=True): the gradient of {region.name} was completed twice in one step; "
                                        "use overlap=False when a table is scattered by more than one backward call per step")
-                region.work = dist.all_reduce(self.flat_g[region.lo:region.hi], op=dist.ReduceOp.SUM, async_op=True)
+                region.work = self._start_table_exchange(region)
         return ready
+
+    def _dist_on(self):
+        return _world() > 1 or (self.force_dist and dist.is_available() and dist.is_initialized())
+
+    def _shard(self, region):
+        """(lo, hi) of this rank's shard of a table region (table_rs)."""
+        sh = (region.end - region.lo) // _world()
+        lo = region.lo + _rank() * sh
+        return lo, lo + sh
+
+    def _start_table_exchange(self, region):
+        """The table bucket's gradient exchange, asynchronous on the process group's stream (RCCL's own stream on GPUs)."""
+        if self.table_rs:
+            lo, hi = self._shard(region)
+            self.comm_bytes[region.name] = (region.end - region.lo) * 4
+            return dist.reduce_scatter_tensor(self.flat_g[lo:hi], self.flat_g[region.lo:region.end], op=dist.ReduceOp.SUM, async_op=True)
+        self.comm_bytes[region.name] = (region.hi - region.lo) * 4
+        return dist.all_reduce(self.flat_g[region.lo:region.hi], op=dist.ReduceOp.SUM, async_op=True)
 
     def _make_sink(self, st):
         def sink(ids, rows):
@@ -228,24 +266,38 @@ class EngineAdam:
         ops.invalidate_packed()                  # the kernels below rewrite parameter memory behind torch's version counters
         world = _world()
         scale = 1.0 / world
-        if world == 1:
+        if not self._dist_on() or self.skip_comm:
             if self.regions:
-                self._adam(0, self.regions[-1].hi, 1.0)                       # one launch over [small | tables]
+                self._adam(0, self.regions[-1].end, 1.0)                      # one launch over [small | tables]
         else:
-            works = []
             for r in self.regions:                                           # tables first (already in flight when overlapped), small last
                 if r.name != 'small' and r.work is None:
-                    r.work = dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True)
+                    r.work = self._start_table_exchange(r)
             gathered = [self._exchange_rows(st) for st in self.sparse]
             for r in self.regions:
                 if r.name == 'small':
+                    self.comm_bytes['small'] = (r.hi - r.lo) * 4
                     r.work = dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True)
+            param_gathers = []
             for r in sorted(self.regions, key=lambda r: r.name != 'small'):   # small bucket is the short message: update it while the table flies
                 r.work.wait()
                 r.work = None
-                self._adam(r.lo, r.hi, scale)
+                if self.table_rs and r.name != 'small':
+                    # Adam on this rank's shard only (it also clears the shard's gradient); the other shards of the gradient buffer still
+                    # hold this rank's local gradients and are cleared here; then every rank collects the updated parameters
+                    lo, hi = self._shard(r)
+                    self._adam(lo, hi, scale)
+                    if lo > r.lo:
+                        self.flat_g[r.lo:lo].zero_()
+                    if hi < r.end:
+                        self.flat_g[hi:r.end].zero_()
+                    param_gathers.append(dist.all_gather_into_tensor(self.flat_p[r.lo:r.end], self.flat_p[lo:hi], async_op=True))
+                else:
+                    self._adam(r.lo, r.end, scale)
             for st, (ids, rows) in zip(self.sparse, gathered):
                 self._row_step(st, ids, rows, scale)
+            for w in param_gathers:                                           # the next forward reads the whole table
+                w.wait()
             return
         for st in self.sparse:
             if st.pending:
@@ -265,35 +317,41 @@ class EngineAdam:
             ids = torch.zeros(0, dtype=torch.int64, device=self.device)
             rows = torch.zeros(0, d, dtype=torch.float32, device=self.device)
         st.pending.clear()
-        # Every rank normally contributes the same number of rows (fixed per-GPU batch, DataLoader(drop_last=True), src/train.py:118-124).
-        # That is verified with one tiny all-gather (a host round trip) the first time and whenever the local count changes; steady-state
-        # steps then exchange ids and rows without any host synchronisation.  Unequal counts take the padded path every step.
-        if self._uniform_rows.get(st.name) != ids.numel():
-            n = torch.tensor([ids.numel()], dtype=torch.int64, device=self.device)
+        # The protocol must not depend on rank-local state (a rank that picked another collective than its peers would hang or corrupt the
+        # exchange): every rank, every step, all-gathers exactly `cap` (id, row) pairs, padded with id 0 -- the padding row of
+        # nn.Embedding(padding_idx=0), which the update skips.  `cap` is agreed once, at the first exchange of the table (one all-gather of
+        # the local counts: the only host round trip), as the largest per-rank count -- the fixed per-GPU batch of
+        # DataLoader(drop_last=True) (src/train.py:118-124); a shorter batch is padded, a longer one is an error on the rank that sees it.
+        n_local = ids.numel()
+        cap = self._row_cap.get(st.name)
+        if cap is None:
+            n = torch.tensor([n_local], dtype=torch.int64, device=self.device)
             counts = [torch.zeros_like(n) for _ in range(world)]
             dist.all_gather(counts, n)
-            counts = [int(c.item()) for c in counts]
-            if all(c == counts[0] for c in counts):
-                self._uniform_rows[st.name] = counts[0]
-            else:
-                self._uniform_rows.pop(st.name, None)
-                nmax = max(counts)
-                pid = torch.zeros(nmax, dtype=torch.int64, device=self.device)       # id 0 = the padding row: skipped by the update
-                prow = torch.zeros(nmax, d, dtype=torch.float32, device=self.device)
-                pid[:ids.numel()] = ids
-                prow[:ids.numel()] = rows
-                gid = [torch.empty_like(pid) for _ in range(world)]
-                grow = [torch.empty_like(prow) for _ in range(world)]
-                dist.all_gather(gid, pid)
-                dist.all_gather(grow, prow)
-                return torch.cat([g[:c] for g, c in zip(gid, counts)]), torch.cat([g[:c] for g, c in zip(grow, counts)])
-        if ids.numel() == 0:
+            cap = self._row_cap[st.name] = max(int(c.item()) for c in counts)
+        if n_local > cap:
+            raise RuntimeError(f"EngineAdam: {n_local} gradient rows for {st.name} on rank {_rank()}, but the ranks agreed on at most {cap} per "
+                               "step at the first exchange; keep the per-rank batch fixed or call set_row_capacity() on every rank")
+        if cap == 0:
             return ids, rows
-        gid = torch.empty(world * ids.numel(), dtype=torch.int64, device=self.device)
-        grow = torch.empty(world * ids.numel(), d, dtype=torch.float32, device=self.device)
+        if n_local < cap:
+            pid = torch.zeros(cap, dtype=torch.int64, device=self.device)
+            prow = torch.zeros(cap, d, dtype=torch.float32, device=self.device)
+            pid[:n_local] = ids
+            prow[:n_local] = rows
+            ids, rows = pid, prow
+        self.comm_bytes[st.name] = world * cap * (8 + 4 * d)
+        gid = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+        grow = torch.empty(world * cap, d, dtype=torch.float32, device=self.device)
         dist.all_gather_into_tensor(gid, ids.contiguous())
         dist.all_gather_into_tensor(grow, rows)
         return gid, grow
+
+    def set_row_capacity(self, cap, name=None):
+        """Fix the per-rank, per-step capacity of the touched-row exchange (call with the same value on every rank, e.g. the largest batch)."""
+        for st in self.sparse:
+            if name is None or st.name == name:
+                self._row_cap[st.name] = int(cap)
 
     def _row_step(self, st, ids, rows, scale):
         if ids.numel() == 0:
@@ -329,8 +387,19 @@ class EngineAdam:
         st = next(s for s in self.sparse if s.name == n)
         return st.m, st.v
 
+    def _gather_moment_shards(self):
+        """table_rs: every rank maintains the Adam moments of its own shard only; collect the others' before the moments are read as a whole."""
+        if not (self.table_rs and self._dist_on()) or self.skip_comm:
+            return
+        for r in self.regions:
+            if r.name != 'small':
+                lo, hi = self._shard(r)
+                for buf in (self.flat_m, self.flat_v):
+                    dist.all_gather_into_tensor(buf[r.lo:r.end], buf[lo:hi].clone())
+
     def state_dict(self):
         self.flush()
+        self._gather_moment_shards()
         state = {}
         if self.t > 0:
             for i in range(len(self.params)):

@@ -35,6 +35,23 @@ class EarlyStopping:
         return self.counter >= self.patience, False
 
 
+def checkpoint_safe_globals():
+    """The numpy types a checkpoint of the reference's format needs beside tensors: its 'early_stop_value' is a numpy scalar
+    (train.py:268-275), which torch >= 2.6's default weights_only=True unpickler rejects unless these are allow-listed."""
+    try:
+        from numpy._core import multiarray as _ma
+    except ImportError:                      # numpy < 2
+        from numpy.core import multiarray as _ma
+    return [_ma.scalar, np.dtype] + [type(np.dtype(t)) for t in (np.float64, np.float32, np.float16, np.int64, np.int32, np.bool_)]
+
+
+def load_checkpoint(path, device):
+    """A checkpoint of this run directory, written by this trainer or by the reference's train.py (the launcher path): weights_only stays
+    on, with checkpoint_safe_globals() allowed."""
+    with torch.serialization.safe_globals(checkpoint_safe_globals()):
+        return torch.load(path, map_location=device, weights_only=True)
+
+
 def latest_checkpoint(directory):
     """src/train.py:54-64."""
     if not os.path.exists(directory):
@@ -92,7 +109,7 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
     path = latest_checkpoint(ckdir)
     if path is not None:
         log(f"Load saved parameters in {path}")
-        ck = torch.load(path, map_location=device)
+        ck = load_checkpoint(path, device)
         early_stopping(ck['early_stop_value'])
         step = ck['step']
         model.load_state_dict(ck['model_state_dict'])

@@ -137,13 +137,17 @@ class _ToyRec(torch.nn.Module):
         return self.lin(w + u)
 
 
-def _toy_batches(rank, steps):
+def _toy_batches(rank, steps, ragged=False):
+    """ragged: rank 1's batches 1 and 2 are shorter (3 and 1 samples instead of 5): fewer gradient rows than its peer in those steps."""
     g = torch.Generator().manual_seed(50 + rank)
-    return [(torch.randint(0, 60, (5, 4), generator=g), torch.randint(0, 30, (5,), generator=g), torch.randint(0, 3, (5,), generator=g))
-            for _ in range(steps)]
+    out = []
+    for i in range(steps):
+        n = (3 if i == 1 else 1) if (ragged and rank == 1 and i in (1, 2)) else 5
+        out.append((torch.randint(0, 60, (n, 4), generator=g), torch.randint(0, 30, (n,), generator=g), torch.randint(0, 3, (n,), generator=g)))
+    return out
 
 
-def _engine_worker(rank, world, port, overlap, q):
+def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     from news_recommendation_amd import dist as nrdist, optim
@@ -153,13 +157,28 @@ def _engine_worker(rank, world, port, overlap, q):
     torch.manual_seed(100 + rank)
     model = _ToyRec()
     nrdist.broadcast_parameters(model)
-    opt = optim.EngineAdam(model, lr=1e-2, row_sparse=('user_embedding.weight',), overlap=overlap, lib=EmuBackend().lib, stream_fn=lambda: None)
+    opt = optim.EngineAdam(model, lr=1e-2, row_sparse=('user_embedding.weight',), overlap=overlap, lib=EmuBackend().lib, stream_fn=lambda: None,
+                           table_rs=table_rs)
     assert [r.name for r in opt.regions] == ['small', 'word_embedding.weight']
-    for words, users, y in _toy_batches(rank, 4):
+    assert (opt.regions[1].end - opt.regions[1].lo) % (world * 64) == 0 and opt.regions[1].hi - opt.regions[1].lo == 480
+    for words, users, y in _toy_batches(rank, 4, ragged):
         torch.nn.functional.cross_entropy(model(words, users), y).backward()
         opt.step()
         assert not opt.flat_g.any()
+    assert opt.comm_bytes['small'] > 0 and opt.comm_bytes['word_embedding.weight'] >= 480 * 4 and opt.comm_bytes['user_embedding.weight'] == world * 5 * (8 + 32)
     sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    osd = opt.state_dict()                      # (collective under table_rs: the moment shards are gathered)
+    for i, st in osd['state'].items():
+        sd[f'opt/{i}/exp_avg'] = st['exp_avg'].numpy().copy()
+        sd[f'opt/{i}/exp_avg_sq'] = st['exp_avg_sq'].numpy().copy()
+    if ragged and rank == 1:
+        # a batch LONGER than the capacity the ranks agreed on at the first exchange is an error on the rank that sees it, raised before
+        # any collective is entered (its peers are not left in a mismatched collective by this rank picking another protocol)
+        st = opt.sparse[0]
+        st.pending.append((torch.arange(1, 8), torch.ones(7, 8)))
+        with pytest.raises(RuntimeError, match='agreed on at most 5'):
+            opt._exchange_rows(st)
+        st.pending.clear()
     q.put((rank, sd))
     dist.barrier()
     dist.destroy_process_group()
@@ -191,15 +210,56 @@ def test_engine_adam_world2_equals_single_process_mean_gradient(overlap):
     import numpy as np
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), f"replicas diverged in {k}"
-    # single-process reference: same initial weights (rank 0's init), dense torch Adam on the mean loss of both shards
+    _assert_equals_single_process(res[0])
+
+
+def _assert_equals_single_process(got, ragged=False):
+    """single-process reference: same initial weights (rank 0's init), dense torch Adam on the mean loss of both shards"""
+    import numpy as np
     torch.manual_seed(100)
     ref = _ToyRec()
     opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
-    b0, b1 = _toy_batches(0, 4), _toy_batches(1, 4)
+    b0, b1 = _toy_batches(0, 4, ragged), _toy_batches(1, 4, ragged)
     for (w0, u0, y0), (w1, u1, y1) in zip(b0, b1):
         opt.zero_grad()
         loss = 0.5 * (torch.nn.functional.cross_entropy(ref(w0, u0), y0) + torch.nn.functional.cross_entropy(ref(w1, u1), y1))
         loss.backward()
         opt.step()
     for k, v in ref.state_dict().items():
-        np.testing.assert_allclose(res[0][k], v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(got[k], v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+def _run_world2(overlap, table_rs=False, ragged=False):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, overlap, q, table_rs, ragged)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_engine_adam_table_reduce_scatter_equals_allreduce():
+    """table_rs: reduce-scatter -> Adam on the rank's shard -> all-gather of the updated table leaves the replicas bit-identical to each
+    other AND to the all-reduce form, parameters and (gathered) Adam moments alike (same bytes on the wire, 1/world of the
+    update pass per GPU)."""
+    import numpy as np
+    rs, ar = _run_world2(True, table_rs=True), _run_world2(True, table_rs=False)
+    assert any(k.startswith('opt/') for k in rs[0])
+    for k in ar[0]:
+        assert np.array_equal(rs[0][k], rs[1][k]), f"replicas diverged in {k}"
+        assert np.array_equal(rs[0][k], ar[0][k]), f"reduce-scatter form differs from the all-reduce form in {k}"
+
+
+def test_engine_adam_unequal_row_counts_keep_one_protocol():
+    """A rank with a shorter batch pads its (row id, gradient row) message to the agreed capacity (id 0 = the padding row, skipped by the
+    update) instead of switching collectives on its own: replicas stay identical and equal to the single-process mean-of-means update."""
+    import numpy as np
+    res = _run_world2(True, ragged=True)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), f"replicas diverged in {k}"
+    _assert_equals_single_process(res[0], ragged=True)
