@@ -124,13 +124,14 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
  * (csrc/k_proj.h).  nr_mhsa_fwd's register-resident kernel remains the inference form; in training everything it keeps in registers has
  * to be written for the backward anyway.
  *
- * Saved-activation layout "head-major": qkv bf16[n_seq][15][3][400] -- per (sequence, head) the 20 x 20 blocks Q [token][d], K [token][d]
- * and V^T [d][token] back to back (2,400 contiguous bytes), NR_QKV_HM_SEQ elements per sequence. */
+ * Saved-activation layout "head-major": qkv bf16[n_seq][15][3][20][20] -- per (sequence, head) the blocks Q, K, V, each [token][d]
+ * row-major, back to back (2,400 contiguous bytes), NR_QKV_HM_SEQ elements per sequence. */
 #define NR_QKV_HM_SEQ (NR_HEADS * 3 * 20 * NR_DK)
 #define NR_K16 19       /* k-steps of 16 over D (304 columns) in the tile32-ordered projection operand */
 /* Pack the three nn.Linear(D,D) of MultiHeadSelfAttention (multihead_self.py:36-38) for nr_qkv_proj_fwd: Wp32 bf16[3*NR_NP][304] in
  * "tile32 order" -- 32 x 16 blocks (row tile, k-step) of the 64 lanes' 16-byte v_mfma_f32_32x32x16_bf16 fragments back to back: element
- * (r, k) at ((r/32)*19 + k/16)*512 + (((k%16)/8)*32 + r%32)*8 + k%8 -- and bp f32[3*NR_NP] (as nr_pack_qkv). */
+ * (r, k) at ((r/32)*19 + k/16)*512 + (((k%16)/8)*32 + r%32)*8 + k%8 -- with the rows of each projection in PACKED order: row c holds
+ * output feature 60*(c/64) + c%64 when c%64 < 60 (groups of 3 heads), zeros otherwise; bp f32[3*NR_NP] in the same row order. */
 int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                   uint16_t* Wp32, float* bp, void* stream);
 /* x = F.dropout(table[ids]) (src/model/NRMS/news_encoder.py:38-40), then Q, K, V = x W^T + b (multihead_self.py:53-55), S = 20.

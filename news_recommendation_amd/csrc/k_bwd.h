@@ -57,8 +57,8 @@ struct AttnBwdParams {
   const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
   int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
-  int hm;                // 1: q_save is the head-major [n_seq][H][3][S*DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V^T of a pair
-                         // are 2,400 contiguous bytes (k_save / vt_save unused)
+  int hm;                // 1: q_save is the head-major [n_seq][H][3][S][DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V of a pair, each
+                         // [token][d] row-major, are 2,400 contiguous bytes (k_save / vt_save unused)
 };
 
 __device__ __forceinline__ u16x8 ld8(const u16* p) { return cat8(*(const u16x4*)p, *(const u16x4*)(p + 4)); }
@@ -123,11 +123,20 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         rg.wt[it] = wb[r];
       }
     }
-    const u16* vblk = p.hm ? qb + 2 * S * DK : p.vt_save + (seq * H + hd) * DK * Gm::SP4;
+    if (p.hm) {                        // V [token][d] like Q and K: the same piece index
+      const u16* vb = qb + 2 * S * DK;
 #pragma unroll
-    for (int it = 0; it < Gm::ITV; ++it) {
-      const int i = it * 64 + l;
-      if (i < DK * Gm::VP) rg.v[it] = *(const u16x4*)(vblk + i * 4);     // block is dense: [dv][SP4]
+      for (int it = 0; it < Gm::IT && it < Gm::ITV; ++it) {
+        const int i = it * 64 + l;
+        if (i < S * Gm::PCS) rg.v[it] = *(const u16x4*)(vb + i * 4);
+      }
+    } else {
+      const u16* vblk = p.vt_save + (seq * H + hd) * DK * Gm::SP4;
+#pragma unroll
+      for (int it = 0; it < Gm::ITV; ++it) {
+        const int i = it * 64 + l;
+        if (i < DK * Gm::VP) rg.v[it] = *(const u16x4*)(vblk + i * 4);     // block is dense: [dv][SP4]
+      }
     }
   };
   // registers -> wave-private LDS, all 8-B row-major stores; dC assembled with its direct term and dropout
@@ -149,8 +158,10 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
           dc4 = dc4 * drop_mul4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
         }
         *(u16x4*)(dCm + r * Gm::DS + c) = pack4(dc4);
+        if (p.hm && it < Gm::ITV) *(u16x4*)(Vt + r * Gm::DS + c) = rg.v[it];        // row-major V [token][DS] in the V^T region
       }
     }
+    if (p.hm) return;
 #pragma unroll
     for (int it = 0; it < Gm::ITV; ++it) {
       const int i = it * 64 + l;
@@ -229,8 +240,19 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         ccl[t][dt] = pack4(mfma_16x16x32_bf16(cf, ident[dt], f32x4{0.f, 0.f, 0.f, 0.f}));
       }
     }
-    // V as an A operand "V[key][k = dv]" per key tile: CL(Vt)[dv][key] tiles for dv tiles 0,1 -> slots j<4 / j>=4
+    // V as an A operand "V[key][k = dv]" per key tile, k-slots in the CL-compatible order of cperm (j < 4: dv = 4 g + j, j >= 4: dv = 16 + 4 g + j - 4).
+    // Row-major V (head-major saves): a plain fragment read.  dv-major V^T blocks (vt_save): CL(Vt)[dv][key] tiles for dv tiles 0, 1 built on
+    // the matrix core.
     u16x8 va[Gm::QT];
+    if (p.hm) {
+#pragma unroll
+      for (int kt = 0; kt < Gm::QT; ++kt) {
+        int row = kt * 16 + li;
+        row = row < S ? row : S - 1;           // clamped duplicates: these keys carry exact-zero probabilities
+        const u16* v_ = Vt + row * Gm::DS;
+        va[kt] = cat8(*(const u16x4*)(v_ + 4 * g), (16 + 4 * g < DK) ? *(const u16x4*)(v_ + 16 + 4 * g) : Z4);
+      }
+    } else
 #pragma unroll
     for (int kt = 0; kt < Gm::QT; ++kt) {
       u16x4 part[Gm::DTL];

@@ -402,11 +402,12 @@ int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int6
   nr::AttnFwdParams p;
   p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::AttnFwdGeom;
+  const int64_t grid = (n_seq + G::WPB - 1) / G::WPB;
   const char* d = getenv("NR_ATTNF_DEBUG");         // profiling: phase switches (AttnFwdParams::debug), re-read per call
   if (d != nullptr && atoi(d) != 0) {
     p.debug = atoi(d);
-    NR_LAUNCH(nr::attn_fwd_kernel<true>, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
-  } else NR_LAUNCH(nr::attn_fwd_kernel<false>, (n_seq + G::TPB - 1) / G::TPB, G::WPB * 64, 0, (hipStream_t)stream, p);
+    NR_LAUNCH(nr::attn_fwd_kernel<true>, grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  } else NR_LAUNCH(nr::attn_fwd_kernel<false>, grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
   return check_launch("nr_attn_fwd");
 }
 

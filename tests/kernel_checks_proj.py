@@ -25,18 +25,28 @@ def pack_qkv32(be, params, prefix):
     return Wp32, bp
 
 
+def packed_rows():
+    """packed row c of a projection -> output feature: 64-row groups of 3 heads (60 features) + 4 zero rows (csrc/k_proj.h)."""
+    c = np.arange(NR_NP)
+    feat = 60 * (c // 64) + c % 64
+    return np.where(c % 64 < 60, feat, -1)
+
+
 def check_pack32(be):
     params = kc.make_params(3)
     Wp32, bp = pack_qkv32(be, params, 'news_encoder.')
     be.sync()
     W = untile32(be.np(Wp32))
     m = 'news_encoder.multihead_self_attention.'
+    feat = packed_rows()
+    real = feat >= 0
+    assert sorted(feat[real].tolist()) == list(range(NR_D))
     for i, n in enumerate(('W_Q', 'W_K', 'W_V')):
         blk = W[i * NR_NP:(i + 1) * NR_NP]
-        assert np.array_equal(blk[:NR_D, :NR_D], f32_to_bf16(params[m + n + '.weight']))
-        assert not blk[NR_D:].any() and not blk[:, NR_D:].any()
-        assert np.array_equal(be.np(bp)[i * NR_NP:i * NR_NP + NR_D], params[m + n + '.bias'])
-        assert not be.np(bp)[i * NR_NP + NR_D:(i + 1) * NR_NP].any()
+        assert np.array_equal(blk[real][:, :NR_D], f32_to_bf16(params[m + n + '.weight'])[feat[real]])
+        assert not blk[~real].any() and not blk[:, NR_D:].any()
+        b = be.np(bp)[i * NR_NP:(i + 1) * NR_NP]
+        assert np.array_equal(b[real], params[m + n + '.bias'][feat[real]]) and not b[~real].any()
 
 
 def hm_split(qkv_u16, n_seq):
@@ -44,7 +54,7 @@ def hm_split(qkv_u16, n_seq):
     a = bf16_to_f32(np.asarray(qkv_u16).reshape(n_seq, H, 3, S * DK)).astype(np.float64)
     q = a[:, :, 0].reshape(n_seq, H, S, DK)
     k = a[:, :, 1].reshape(n_seq, H, S, DK)
-    v = a[:, :, 2].reshape(n_seq, H, DK, S).transpose(0, 1, 3, 2)
+    v = a[:, :, 2].reshape(n_seq, H, S, DK)
     return q, k, v
 
 
@@ -55,7 +65,7 @@ def hm_from_rowmajor(qs, ks, vts, n_seq):
     k = np.asarray(ks)[:, :NR_D].reshape(n_seq, S, H, DK).transpose(0, 2, 1, 3)
     out[:, :, 0] = q.reshape(n_seq, H, S * DK)
     out[:, :, 1] = k.reshape(n_seq, H, S * DK)
-    out[:, :, 2] = np.asarray(vts)[:, :, :, :S].reshape(n_seq, H, DK * S)
+    out[:, :, 2] = np.asarray(vts)[:, :, :, :S].transpose(0, 1, 3, 2).reshape(n_seq, H, S * DK)        # [dv][token] -> [token][dv]
     return out.reshape(-1)
 
 
@@ -71,7 +81,7 @@ def run_proj(be, params, ids, table, p_drop=0.0, seed=0, x_save=True):
 
 
 def check_qkv_proj(be, n_seq=13, V=300, p_drop=0.0, seed=4321):
-    """Q, K, V^T of nr_qkv_proj_fwd == bf16(bf16(dropout(table[ids])) @ bf16(W)^T + b); x_save == nr_gather_bf16."""
+    """Q, K, V of nr_qkv_proj_fwd == bf16(bf16(dropout(table[ids])) @ bf16(W)^T + b); x_save == nr_gather_bf16."""
     params = kc.make_params(4, V)
     rng = np.random.default_rng(21)
     ids = rng.integers(1, V, size=(n_seq, S))
@@ -126,7 +136,9 @@ def check_proj_attn(be, n_seq=9, V=300, p_drop=0.0, seed=99, with_key_len=False)
 
 
 def check_attn_fwd_matches_fused(be, n_seq=6, V=300):
-    """Same saved Q / K / V^T -> nr_attn_fwd's ctx == nr_mhsa_fwd's ctx bit for bit (same formulas on the same bf16 operands)."""
+    """Same saved Q / K / V^T -> nr_attn_fwd's ctx == nr_mhsa_fwd's ctx: same formulas on the same bf16 operands.  Bit for bit on the emulator;
+    on the matrix core the two kernels feed a head's 20 features through different k-slots (the fused kernel shares 16-row tiles between
+    neighbouring heads), so fp32 sums may round differently and flip the last bf16 bit of P or ctx: held to 2 bf16 ulps there."""
     params = kc.make_params(4, V)
     rng = np.random.default_rng(23)
     ids = rng.integers(0, V, size=(n_seq, S))
@@ -136,7 +148,15 @@ def check_attn_fwd_matches_fused(be, n_seq=6, V=300):
     ctx = be.poison((n_seq * S, NR_KP), np.uint16)
     kc.ck(be, be.lib.nr_attn_fwd(be.ptr(be.dev(qkv)), be.ptr(ctx), None, n_seq, S, 0.0, 0, be.stream))
     be.sync()
-    assert np.array_equal(be.np(ctx), ctx_ref), 'attn_fwd differs from the fused kernel on identical operands'
+    got = be.np(ctx)
+    if be.name == 'emu':
+        assert np.array_equal(got, ctx_ref), 'attn_fwd differs from the fused kernel on identical operands'
+    else:
+        assert np.array_equal(got[:, NR_D:], ctx_ref[:, NR_D:])
+        a, b = bf16_to_f32(got[:, :NR_D]).astype(np.float64), bf16_to_f32(ctx_ref[:, :NR_D]).astype(np.float64)
+        bad = np.abs(a - b) > 2.0 ** -7 * np.abs(b) + 1e-3 * np.abs(b).max()
+        assert not bad.any(), f'{bad.sum()} / {bad.size} ctx elements differ from the fused kernel by more than 2 bf16 ulps'
+        assert (got[:, :NR_D] == ctx_ref[:, :NR_D]).mean() > 0.9
 
 
 def check_attn_bwd_hm(be, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):

@@ -87,3 +87,24 @@ def test_fast_trainer_trains_validates_checkpoints_and_resumes(tmp_path, model_n
         assert any('Load saved parameters' in l for l in lines) and r2['steps'] == 2
     finally:
         os.chdir(cwd)
+
+
+def test_load_checkpoint_accepts_reference_format_with_weights_only(tmp_path):
+    """train.py:264-277 saves 'early_stop_value' as a numpy scalar; torch >= 2.6's default weights_only=True rejects it.  The trainer's
+    loader (and the launcher's process-wide allow-list) admit exactly the numpy scalar / dtype types, nothing else."""
+    import numpy as np
+    from news_recommendation_amd import train_fast
+    path = str(tmp_path / 'ckpt-7.pth')
+    torch.save({'model_state_dict': {'w': torch.arange(4.0)}, 'optimizer_state_dict': {'state': {}, 'param_groups': []}, 'step': 7,
+                'early_stop_value': -np.float64(0.61)}, path)
+    with pytest.raises(Exception):
+        torch.load(path, map_location='cpu', weights_only=True)
+    ck = train_fast.load_checkpoint(path, 'cpu')
+    assert ck['step'] == 7 and float(ck['early_stop_value']) == -0.61 and torch.equal(ck['model_state_dict']['w'], torch.arange(4.0))
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    torch.save({'x': Evil()}, path)
+    with pytest.raises(Exception):
+        train_fast.load_checkpoint(path, 'cpu')
