@@ -313,6 +313,75 @@ def score_eval(wl, model, device, n_impr_cap=100000):
             "what": "phases A+B+C of src/evaluate.py:185-272 (batched driver), host index arrays -> four metric means; best of 3 runs"}
 
 
+def comm_probe(opt, step, barrier, world, k, ms_step, device):
+    """N > 1 only, every rank: (1) the same training step with every collective skipped (EngineAdam.skip_comm) -> exposed_comm_ms = step time -
+    that; (2) each bucket's collective on its own, HIP-event timed on the group's stream order: payload bytes, algorithmic GB/s and bus GB/s
+    (x 2 (n - 1) / n for all-reduce, x (n - 1) / n for reduce-scatter / all-gather: the per-link load a ring puts on xGMI)."""
+    import torch.distributed as dist
+    res = {}
+    opt.skip_comm = True
+    for i in range(2):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(k):
+        step(i)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    opt.skip_comm = False
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    res["ms_per_step_without_comm"] = float(t.item()) / k * 1e3
+    res["exposed_comm_ms"] = ms_step - res["ms_per_step_without_comm"]
+    opt.discard_grads()
+
+    def timed(fn, reps=5):
+        fn()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tt = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    rank = dist.get_rank()
+    buckets = {}
+    for r in opt.regions:
+        if opt.table_rs and r.name != 'small':
+            sh = (r.end - r.lo) // world
+            shard = opt.flat_g[r.lo + rank * sh:r.lo + (rank + 1) * sh]
+            full = opt.flat_g[r.lo:r.end]
+
+            def fn(shard=shard, full=full):
+                dist.reduce_scatter_tensor(shard, full)
+                dist.all_gather_into_tensor(full, shard)
+            nbytes, factor, kind = (r.end - r.lo) * 4, 2.0 * (world - 1) / world, "reduce_scatter+all_gather"
+        else:
+            buf = opt.flat_g[r.lo:r.hi]
+
+            def fn(buf=buf):
+                dist.all_reduce(buf)
+            nbytes, factor, kind = (r.hi - r.lo) * 4, 2.0 * (world - 1) / world, "all_reduce"
+        ms = timed(fn)
+        buckets[r.name] = {"collective": kind, "bytes": nbytes, "ms": ms, "alg_GBs": nbytes / ms / 1e6, "bus_GBs": nbytes * factor / ms / 1e6}
+    for st in opt.sparse:
+        cap = opt._row_cap.get(st.name, 0)
+        if cap:
+            d = st.param.shape[1]
+            rows = torch.zeros(cap, d, device=device)
+            out = torch.empty(world * cap, d, device=device)
+            ms = timed(lambda: dist.all_gather_into_tensor(out, rows))
+            nbytes = world * cap * d * 4
+            buckets[st.name] = {"collective": "all_gather (touched rows)", "bytes": nbytes, "ms": ms, "alg_GBs": nbytes / ms / 1e6,
+                                "bus_GBs": nbytes * (world - 1) / world / ms / 1e6}
+    opt.flat_g.zero_()
+    res["buckets"] = buckets
+    return res
+
+
 def gather_point(lib, table, ids, device):
     st = torch.cuda.current_stream().cuda_stream
     gout = torch.empty(ids.numel(), 300, device=device)
@@ -418,6 +487,10 @@ def main():
         per_call = ops.seq_launches.get(timed_name, 1)
         dom = (dom[0] * per_call, dom[1] / per_call, dom[2])
 
+    comm = None
+    if world > 1:
+        # ---- how much of the step is EXPOSED gradient exchange, and what the buckets achieve on the wire (all ranks, still in the group) ----
+        comm = comm_probe(opt, step, barrier, world, min(args.steps, 10), dt / args.steps * 1e3, device)
     if world > 1:
         # every rank leaves the process group here: what follows on rank 0 (roofline probes, scoring throughput) is local work, and a
         # rank that kept the group open would wait in its destructor for peers that are still measuring
@@ -527,10 +600,15 @@ def main():
         "roofline": roofline,
         "loss": float(loss.item()),
         "grad_exchange": {"dense_allreduce_bytes": opt.dense_nbytes, "buckets": [[r.name, (r.hi - r.lo) * 4] for r in opt.regions],
-                          "row_sparse_tables": [[s.name, list(s.param.shape), f"{B} (id, row) pairs per rank and step"] for s in opt.sparse]},
+                          "row_sparse_tables": [[s.name, list(s.param.shape), f"{B} (id, row) pairs per rank and step"] for s in opt.sparse],
+                          "table_bucket_form": "reduce_scatter + sharded Adam + all_gather" if opt.table_rs else "all_reduce + Adam",
+                          "bytes_per_step": dict(opt.comm_bytes)},
         "kernel_breakdown_us_per_step": {k: round(v[2] / NPROF, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])},
     }
     out.update(extras)
+    if comm is not None:
+        out["exposed_comm_ms"] = comm.pop("exposed_comm_ms")
+        out["comm"] = comm
     if world == 1 and not args.no_parity:
         states = {"trained": model}
         m0 = wl.make_model().to(device)

@@ -110,6 +110,56 @@ def narrow_visibility(env):
     env['HIP_VISIBLE_DEVICES'] = str(lr)
 
 
+def shard_workdir(workdir, rank, world):
+    """Data parallelism for the UNCHANGED train.py: the reference builds its DataLoader from ./data/train/behaviors_parsed.tsv
+    with shuffle=True and no DistributedSampler (train.py:113-124), so every rank gets its OWN working directory whose behaviors_parsed.tsv
+    holds that rank's 1/world of the rows (row i goes to rank i % world; every shard is cut to floor(n / world) rows, because the step count
+    derives from len(dataset) (train.py:166) and a rank with one more step would wait forever in the gradient exchange).  Everything else
+    of ./data is shared through symlinks; ./checkpoint is rank 0's (all ranks resume from the same file); returns the directory."""
+    workdir = os.path.abspath(workdir)
+    if world <= 1:
+        return workdir
+    dst = os.path.join(workdir, f'.dp_rank{rank}_of_{world}')
+    src_train = os.path.join(workdir, 'data', 'train')
+    os.makedirs(os.path.join(dst, 'data', 'train'), exist_ok=True)
+
+    def link(src, name):
+        if not os.path.lexists(name):
+            os.symlink(src, name)
+    for entry in os.listdir(os.path.join(workdir, 'data')):
+        if entry != 'train':
+            link(os.path.join(workdir, 'data', entry), os.path.join(dst, 'data', entry))
+    for entry in os.listdir(src_train):
+        if entry != 'behaviors_parsed.tsv':
+            link(os.path.join(src_train, entry), os.path.join(dst, 'data', 'train', entry))
+    for d in ('checkpoint', 'runs'):
+        os.makedirs(os.path.join(workdir, d), exist_ok=True)
+        link(os.path.join(workdir, d), os.path.join(dst, d))
+    with open(os.path.join(src_train, 'behaviors_parsed.tsv')) as f:
+        header = f.readline()
+        rows = f.readlines()
+    per_rank = len(rows) // world
+    tmp = os.path.join(dst, 'data', 'train', f'.behaviors_parsed.tsv.{os.getpid()}')
+    with open(tmp, 'w') as f:
+        f.write(header)
+        f.writelines(rows[rank:per_rank * world:world])
+    os.replace(tmp, os.path.join(dst, 'data', 'train', 'behaviors_parsed.tsv'))
+    return dst
+
+
+def rank0_only_checkpoints(rank):
+    """Every rank runs train.py's validation + checkpoint logic on identical weights (train.py:247-277); only rank 0's torch.save reaches
+    the shared ./checkpoint directory -- N concurrent writers of one path would tear the file."""
+    if rank == 0:
+        return
+    import torch
+    if not getattr(torch.save, '_nr_rank_gate', False):
+        def save(*a, **k):
+            return None
+        save._nr_rank_gate = True
+        torch.save = save
+
+
 def apply_overrides(model_name, overrides):
     """``--set knob=value``: override attributes of the reference's config class IN MEMORY (src/config.py is the knob surface; its sizes
     -- num_words, num_users, ... -- are meant to be hand-edited after preprocessing, README.md:62; the file itself stays untouched).
@@ -136,6 +186,10 @@ def run(script, reference_src, workdir, model_name='NRMS', fast_eval=False, over
             sys.path.remove(p)
         sys.path.insert(0, p)
     install_shims()
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if script == 'train' and world > 1:
+        workdir = shard_workdir(workdir, rank, world)
+        rank0_only_checkpoints(rank)
     os.chdir(workdir)
     apply_overrides(model_name, overrides)
     _patch_dp(model_name)

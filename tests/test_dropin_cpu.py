@@ -167,3 +167,47 @@ def test_split_rows_and_inplace_grads():
     assert ops.inplace_grads((p, q, r)) is None         # r is not the trainer's
     q.grad = None
     assert ops.inplace_grads((p, q)) is None            # zero_grad(set_to_none=True) dropped a view
+
+
+def _shard_worker(rank, world, root, q):
+    """One launcher rank up to (not including) the reference's train.py: per-rank working directory + checkpoint gate."""
+    import torch
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from news_recommendation_amd import launcher
+    d = launcher.shard_workdir(root, rank, world)
+    launcher.rank0_only_checkpoints(rank)
+    os.chdir(d)
+    with open('data/train/behaviors_parsed.tsv') as f:
+        lines = f.read().splitlines()
+    os.makedirs('checkpoint/NRMS', exist_ok=True)
+    torch.save({'rank': rank}, f'./checkpoint/NRMS/ckpt-{10 + rank}.pth')          # what train.py:264-277 does on every rank
+    q.put((rank, d, lines, sorted(os.listdir('data/train')), os.path.islink('data/val'), os.path.realpath('checkpoint')))
+
+
+def test_launcher_shards_training_rows_per_rank_and_gates_checkpoints(tmp_path):
+    """SURVEY 8 e2 for the unchanged train.py: two ranks, each its own working directory with HALF of behaviors_parsed.tsv (equal counts,
+    disjoint, header kept), the rest of ./data shared by symlinks, one shared ./checkpoint that only rank 0 writes."""
+    import multiprocessing as mp
+    from news_recommendation_amd import synth
+    root = str(tmp_path)
+    synth.write_reference_dataset(root, n_news=60, n_train=101, n_val_impr=8, num_words=200)
+    with open(os.path.join(root, 'data', 'train', 'behaviors_parsed.tsv')) as f:
+        full = f.read().splitlines()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (d0, l0, files0, val0, ck0), (d1, l1, files1, val1, ck1) = res[0], res[1]
+    assert d0 != d1 and l0[0] == l1[0] == full[0]
+    n = (len(full) - 1) // 2
+    assert len(l0) - 1 == len(l1) - 1 == n == 50
+    assert l0[1:] == full[1:][0:2 * n:2] and l1[1:] == full[1:][1:2 * n:2]
+    assert not set(l0[1:]) & set(l1[1:]) or len(set(full[1:])) < len(full) - 1
+    assert files0 == files1 and 'news_parsed.tsv' in files0 and val0 and val1
+    assert ck0 == ck1 == os.path.realpath(os.path.join(root, 'checkpoint'))
+    assert os.listdir(os.path.join(root, 'checkpoint', 'NRMS')) == ['ckpt-10.pth']          # rank 1's torch.save was gated

@@ -1,0 +1,89 @@
+"""The RCCL code path of EngineAdam on the one GPU a test box has: a process group of ONE rank over backend 'nccl' (= RCCL on ROCm) with
+the optimiser forced onto its multi-rank branch (force_dist) -- the table bucket's collective started from inside the backward on RCCL's
+stream, the small bucket, the touched-row all-gather, and the reduce-scatter / sharded-Adam / all-gather form.  Collectives over one rank
+are identities, so the parameters after a few training steps must equal the single-process fast path BIT FOR BIT; what the test exercises
+is the stream ordering between the engine's kernels (current stream) and RCCL's internal stream, and the allocator hand-off of the
+buffers the collectives touch (net-new vs src/train.py:227-233, which has no distributed code)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys, numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+mode, model_name, out = sys.argv[2], sys.argv[3], sys.argv[4]
+from bench import Workload, make_cfg
+from news_recommendation_amd import optim
+optim.TABLE_MIN_NUMEL = 1 << 18                   # the reduced word table below is still "the table bucket"
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+if mode != 'local':
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{sys.argv[5]}', rank=0, world_size=1)
+cfg = make_cfg(model_name, 'small', vocab=5000)
+cfg.num_news, cfg.num_users = 3000, 700
+wl = Workload(model_name, cfg)
+model = wl.make_model(seed=11).to(dev).train()
+opt = optim.EngineAdam(model, lr=1e-3, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else (),
+                       force_dist=(mode != 'local'), table_rs=(mode == 'rs'))
+assert opt._dist_on() == (mode != 'local')
+assert any(r.name != 'small' for r in opt.regions)
+batches = wl.batches(0, 3, 64, dev)
+target = torch.zeros(64, dtype=torch.long, device=dev)
+crit = torch.nn.CrossEntropyLoss()
+torch.manual_seed(123)                            # dropout seeds are drawn from torch's CPU generator: same masks in every mode
+losses = []
+for i in range(4):
+    loss = crit(wl.forward(model, batches[i % 3]), target)
+    loss.backward()
+    opt.step()
+    losses.append(float(loss.item()))
+    assert not opt.flat_g.any()
+if mode != 'local':
+    assert opt.comm_bytes and all(v > 0 for v in opt.comm_bytes.values()), opt.comm_bytes
+sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+osd = opt.state_dict()
+for i, st in osd['state'].items():
+    sd[f'opt/{i}/exp_avg'] = st['exp_avg'].cpu().numpy()
+    sd[f'opt/{i}/exp_avg_sq'] = st['exp_avg_sq'].cpu().numpy()
+sd['losses'] = np.array(losses)
+np.savez(out, **sd)
+if mode != 'local':
+    dist.destroy_process_group()
+print('ok', mode, model_name, losses)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(mode, model_name, tmp_path):
+    out = str(tmp_path / f'{mode}_{model_name}.npz')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-c', CHILD, ROOT, mode, model_name, out, str(_free_port())], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize('model_name', ['NRMS', 'LSTUR'])
+def test_engine_adam_over_rccl_world1_equals_local_path(tmp_path, model_name):
+    local = _run('local', model_name, tmp_path)
+    assert np.isfinite(local['losses']).all()
+    for mode in ('ar', 'rs'):                      # all-reduce form, reduce-scatter + sharded Adam + all-gather form
+        got = _run(mode, model_name, tmp_path)
+        assert set(got) == set(local)
+        for k in local:
+            assert np.array_equal(got[k], local[k]), f'{model_name} / {mode}: {k} differs from the single-process path'
