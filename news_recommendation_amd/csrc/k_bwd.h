@@ -42,6 +42,11 @@ struct AttnBwdGeom {
   static constexpr int IT = (S * PCS + 63) / 64;    // row-piece iterations per lane
   static constexpr int VP = SP4 / 4;                // 8-B pieces per dv row of the saved V block
   static constexpr int ITV = (DK * VP + 63) / 64;
+  // TILE form (one workgroup per sequence): the sequence's dqkv rows are assembled in LDS and leave as one contiguous run
+  static constexpr int TROW = 3 * KP * 2 + 16;      // bytes per staged dqkv row (1,920 + 16: rows shift by 4 banks, 16-byte aligned)
+  static constexpr int TILE_BYTES = S * TROW;
+  static constexpr int SMEM_TILE = SMEM + TILE_BYTES;
+  static constexpr int WO_IT = (S * (3 * KP / 8) + WPB * 64 - 1) / (WPB * 64);    // 16-byte pieces per thread of the row write-out
 };
 
 struct AttnBwdParams {
@@ -57,6 +62,7 @@ struct AttnBwdParams {
   const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
   int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
+  int debug;             // profiling only (NR_ATTNB_DEBUG, DBG instantiation): 1 skip the global loads, 4 skip the dqkv stores
   int hm;                // 1: q_save is the head-major [n_seq][H][3][S][DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V of a pair, each
                          // [token][d] row-major, are 2,400 contiguous bytes (k_save / vt_save unused)
 };
@@ -82,9 +88,15 @@ struct AttnBwdRegs {
 #ifndef NR_ATTN_OCC
 #define NR_ATTN_OCC 1      // minimum workgroups per CU the register allocation must allow (tuning knob)
 #endif
-template <int S, int WPB>
+// TILE = true (H % WPB == 0): one workgroup per sequence at a time, wave w takes heads w, w + WPB, ...; the pairs' outputs go to an LDS tile
+// [S][3 KP] and the sequence's rows are written as ONE contiguous run of S x 1,920 bytes.  The plain form stores every output tile as
+// 8-byte pieces of 16 different 1,920-byte rows -- 12 such instructions per pair -- and, like the first version of the split forward
+// kernels (k_proj.h), spends more time issuing those stores than computing.
+template <int S, int WPB, bool DBG = false, bool TILE = false>
 __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwdParams p) {
   using Gm = AttnBwdGeom<S, WPB>;
+  static_assert(!TILE || H % WPB == 0, "TILE form: every wave takes the same number of heads");
+  const int dbg = DBG ? p.debug : 0;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   u16* base = (u16*)(smem + w * Gm::WAVE_BYTES);
@@ -92,13 +104,23 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
   u16* Km = Qm + Gm::TD_ELEMS;
   u16* dCm = Km + Gm::TD_ELEMS;
   u16* Vt = dCm + Gm::TD_ELEMS;
+  unsigned char* const tile = smem + Gm::SMEM;        // TILE form only
 
   const int64_t n_pairs = p.n_seq * H;
   const int64_t stride = (int64_t)gridDim.x * WPB;
-  int64_t pair = (int64_t)(p.xcd_major ? xcd_major_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * WPB + w;
+  int64_t pair = TILE ? (int64_t)blockIdx.x * H + w
+                      : (int64_t)(p.xcd_major ? xcd_major_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * WPB + w;
+  if (TILE) {             // K padding of the staged rows (cols D .. KP - 1 of the three blocks) is zero and never overwritten
+    constexpr int PADQ = (KP - D) / 4;
+    for (int i = threadIdx.x; i < S * 3 * PADQ; i += WPB * 64) {
+      const int r = i / (3 * PADQ), c = i - r * (3 * PADQ);
+      *(u16x4*)(tile + r * Gm::TROW + ((c / PADQ) * KP + D + (c % PADQ) * 4) * 2) = u16x4{0, 0, 0, 0};
+    }
+  }
 
   AttnBwdRegs<Gm::IT, Gm::ITV> rg;
   auto load_regs = [&](int64_t pr) {
+    if (dbg & 1) return;
     const int64_t seq = pr / H;
     const int hd = (int)(pr - seq * H);
     const int64_t tok0 = seq * S;
@@ -217,7 +239,8 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const int64_t tok0 = seq * S;
     const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
     store_lds(pair);
-    const int64_t next = pair + stride;
+    // TILE: the wave's next head of this sequence, then its first head of the workgroup's next sequence
+    const int64_t next = !TILE ? pair + stride : (hd + WPB < H ? pair + WPB : (seq + gridDim.x) * H + w);
     if (next < n_pairs) load_regs(next);          // prefetch the next pair while this one is computed
     wave_barrier();
 
@@ -360,7 +383,14 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         }
         // A operand rows: i = li -> d = dt*16 + li; output CL: rows d = dt*16 + 4g + r, col = token ot*16 + li
         const int tok = ot * 16 + li;
-        if (d0 < DK && tok < S) {
+        if (TILE) {
+          if (d0 < DK && tok < S) {
+            u16* dst = (u16*)(tile + tok * Gm::TROW) + hd * DK + d0;
+            *(u16x4*)dst = pack4(aq);
+            *(u16x4*)(dst + KP) = pack4(ak);
+            *(u16x4*)(dst + 2 * KP) = pack4(av);
+          }
+        } else if (d0 < DK && tok < S && !(dbg & 4)) {
           u16* dst = (p.dqkv + tok0 * LDG + hd * DK) + (tok * LDG + d0);
           *(u16x4*)dst = pack4(aq);
           *(u16x4*)(dst + KP) = pack4(ak);
@@ -369,6 +399,19 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       }
     }
     wave_barrier();        // all LDS reads of this pair done before the next pair's stores
+    if (TILE && hd + WPB >= H) {                 // the sequence is complete in every wave after this barrier: S x 1,920 contiguous bytes leave
+      __syncthreads();
+      if (!(dbg & 4)) {
+        u16* dst = p.dqkv + tok0 * LDG;
+#pragma unroll
+        for (int i = 0; i < Gm::WO_IT; ++i) {
+          const int idx = threadIdx.x + i * WPB * 64;
+          const int r = idx / (LDG / 8), pc = idx - r * (LDG / 8);
+          if (idx < S * (LDG / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + r * Gm::TROW + pc * 16);
+        }
+      }
+      __syncthreads();
+    }
     pair = next;
   }
 }

@@ -5,7 +5,7 @@
 //                     [tokens x 304] x [304 x 960] on v_mfma_f32_32x32x16_bf16: a wave owns 32 tokens whose operand fragments stay in
 //                     registers (76 VGPRs) for all 30 column chunks; the weights stream through LDS in 32-column chunks
 //                     (global_load_lds_dwordx4, fragment-major "tile32 order", shared by the four waves, double buffered).
-//   attn_fwd_kernel   ScaledDotProductAttention (multihead_self.py:15-23) per (title, head) from the saved Q, K, V: one wave per title,
+//   attn_fwd_kernel   ScaledDotProductAttention (multihead_self.py:15-23) per (title, head) from the saved Q, K, V: two waves per title,
 //                     writes the ctx rows (second dropout of news_encoder.py:43-45 applied) the pooling kernels read.
 //
 // Both kernels move every byte to and from global memory as whole cache lines.  The first version of this file loaded the table rows
@@ -13,7 +13,7 @@
 // instruction: its phase decomposition (profiles/r03b_split_forward_phases.txt) put 483 of the projection kernel's 710 us on those stores,
 // 177 us on the loads and only 103 us on the MFMAs; 322 of the attention kernel's 406 us were loads and stores.  Now:
 //   * table rows are read as contiguous float4 pieces (a wave instruction = 1 KiB of one row), masked / rounded, written to a wave-private
-//     LDS tile [8 rows][320] -- from which the x_save rows leave as one contiguous 5 KiB run and the lanes pick up their operand fragments;
+//     LDS tile [4 rows][320] -- from which the x_save rows leave as one contiguous 2.5 KiB run and the lanes pick up their operand fragments;
 //   * the projection accumulators of a 64-column group (= 3 heads + 4 padding columns: the packed weight rows are ordered that way) are
 //     staged in the same wave-private tile as [head][token][20] and leave as contiguous runs of the head-major layout below;
 //   * the attention kernel fetches a pair's 2,400 operand bytes as 16-byte pieces, assembles the title's ctx rows [20][320] in LDS and
@@ -72,16 +72,17 @@ struct ProjGeom {
   static constexpr int TOKW = 32;                    // tokens per wave: one 32-row MFMA tile
   static constexpr int TOK_WG = NWAVE * TOKW;        // 128
   static constexpr int CH_BYTES = K16 * 1024;        // 19,456 B: one 32-column chunk of W = 19 fragment blocks
-  static constexpr int RP = 8;                       // token rows per gather pass
-  static constexpr int NPASS = TOKW / RP;            // 4
+  static constexpr int RP = 4;                       // token rows per gather pass
+  static constexpr int NPASS = TOKW / RP;            // 8
   static constexpr int XROW = 656;                   // bytes per staged token row: 320 bf16 + 16 (rows shift by 4 banks, 16-byte aligned)
-  static constexpr int STAGE_BYTES = RP * XROW;      // 5,248 B per wave; the projection epilogue reuses it as [3 heads][32 tokens][20] = 3,840 B
-  static constexpr int SMEM = 2 * CH_BYTES + NWAVE * STAGE_BYTES;   // 59,904 B: two workgroups per CU
+  static constexpr int STAGE_BYTES = PG_HEADS * TOKW * DK * 2;      // 3,840 B per wave: the projection epilogue's [3 heads][32 tokens][20]; the gather
+                                                     // passes use the first RP * XROW = 2,624 B
+  static constexpr int SMEM = 2 * CH_BYTES + NWAVE * STAGE_BYTES;   // 54,272 B: three workgroups per CU (163,840 B)
   static constexpr int NCHUNK = 3 * NT32;            // 30
   static constexpr int QPR = D / 4;                  // 75 float4 quads per table row
   static constexpr int LD_IT = (RP * QPR + 63) / 64; // 10 row pieces per lane and pass
   static constexpr int WO_IT = (PG_HEADS * TOKW * (DK / 4) + 63) / 64;   // 8 eight-byte pieces per lane and column group
-  static_assert(STAGE_BYTES >= PG_HEADS * TOKW * DK * 2, "epilogue staging fits the gather tile");
+  static_assert(STAGE_BYTES >= RP * XROW && 3 * SMEM <= 163840, "the gather tile fits the epilogue staging; three workgroups per CU");
 };
 
 struct ProjParams {
@@ -99,7 +100,7 @@ struct ProjParams {
 };
 
 #ifndef NR_PROJ_OCC
-#define NR_PROJ_OCC 2      // waves per SIMD the register allocation must allow
+#define NR_PROJ_OCC 3      // waves per SIMD the register allocation must allow
 #endif
 // KSPLIT = 2: even / odd k-steps accumulate into two independent accumulators (no MFMA waits on the previous one's result)
 template <int KSPLIT, bool DBG>
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   };
   chunk_fetch(0, 0);
 
-  // ---- gather: 4 passes of 8 token rows.  Row pieces (float4 = one dropout quad) are read lane-linear along the rows, masked, rounded and
-  // written to the wave's LDS tile; the tile leaves as 8 x 640 contiguous bytes of x_save, and the 16 lanes that own these 8 tokens take
+  // ---- gather: 8 passes of 4 token rows.  Row pieces (float4 = one dropout quad) are read lane-linear along the rows, masked, rounded and
+  // written to the wave's LDS tile; the tile leaves as 4 x 640 contiguous bytes of x_save, and the 8 lanes that own these 4 tokens take
   // their 19 operand fragments (features 16 ks + 8 h .. + 7 of token li) from it -----------------------------------------------------------
   u16x8 xf[K16];
   int myrow = 0;                                                  // table row of token li (lanes li and li + 32 hold the same)
@@ -159,16 +160,17 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
     }
     wave_barrier();
     if (p.x_save != nullptr && !(dbg & 8)) {
-      u16* dst = p.x_save + (tile_tok0 + ps * Gm::RP) * KP;       // the pass's 8 rows are 5,120 contiguous bytes
+      u16* dst = p.x_save + (tile_tok0 + ps * Gm::RP) * KP;       // the pass's rows are RP x 640 contiguous bytes
 #pragma unroll
-      for (int i = 0; i < Gm::RP * (KP / 8) / 64; ++i) {
+      for (int i = 0; i < (Gm::RP * (KP / 8) + 63) / 64; ++i) {
         const int idx = l + 64 * i;
         const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
-        if (tile_tok0 + ps * Gm::RP + r < p.n_tok) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(stage + r * Gm::XROW + pc * 16);
+        if (idx < Gm::RP * (KP / 8) && tile_tok0 + ps * Gm::RP + r < p.n_tok)
+          *(u16x8*)(dst + idx * 8) = *(const u16x8*)(stage + r * Gm::XROW + pc * 16);
       }
     }
-    if ((li >> 3) == ps) {
-      const unsigned char* src = stage + (li & 7) * Gm::XROW + h * 16;
+    if (li / Gm::RP == ps) {
+      const unsigned char* src = stage + (li % Gm::RP) * Gm::XROW + h * 16;
 #pragma unroll
       for (int ks = 0; ks < K16; ++ks) xf[ks] = *(const u16x8*)(src + ks * 32);
     }
@@ -195,18 +197,16 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   auto run_chunk = [&](int which, int j, int s, int c) {
     if (c + 1 < Gm::NCHUNK) chunk_fetch(c + 1, (c + 1) & 1);
     const u16* wp = (const u16*)(smem + (c & 1) * Gm::CH_BYTES) + l * 8;
+    // the bias is requested now and added after the MFMAs: as the accumulators' initial value its L2 round trip sat in front of every chunk
     const float* bsrc = p.bp + which * NP + j * PG_COLS + s * 32 + 4 * h;
+    f32x4 b4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4*)(bsrc + 8 * q);
     f32x16 acc[KSPLIT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = *(const f32x4*)(bsrc + 8 * q);
+    for (int k = 0; k < KSPLIT; ++k)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[0][4 * q + e] = b4[e];
-    }
-    if (KSPLIT > 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[KSPLIT - 1][r] = 0.0f;
-    }
+      for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
 #pragma unroll
     for (int ks = (dbg & 2) ? K16 : 0; ks < K16; ++ks) {
       const u16x8 wf = *(const u16x8*)(wp + ks * 512);
@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
       const int r = s * 32 + 8 * q + 4 * h;                     // column inside the group: head r / 20, feature r % 20 (a quad never straddles heads)
       if (r < PG_HEADS * DK) {
         const int hh = r / DK, d = r - hh * DK;
-        *(u16x4*)(stage + ((hh * Gm::TOKW + li) * DK + d) * 2) = pack4(f32x4{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]});
+        *(u16x4*)(stage + ((hh * Gm::TOKW + li) * DK + d) * 2) =
+            pack4(f32x4{acc[0][4 * q] + b4[q][0], acc[0][4 * q + 1] + b4[q][1], acc[0][4 * q + 2] + b4[q][2], acc[0][4 * q + 3] + b4[q][3]});
       }
     }
     if (s == 1) {
@@ -256,34 +257,39 @@ struct AttnFwdParams {
 
 struct AttnFwdGeom {
   static constexpr int S = 20;
-  static constexpr int WPB = 4;                       // waves per workgroup, one title each
+  static constexpr int WPB = 8;                       // waves per workgroup: two per title (heads 0 .. 7 and 8 .. 14)
+  static constexpr int TPB = WPB / 2;                 // titles per workgroup
+  static constexpr int HSPLIT = 8;
   static constexpr int CROW = 656;                    // bytes per staged ctx row (320 bf16 + 16)
-  static constexpr int TILE_BYTES = S * CROW;         // 13,120 B
-  static constexpr int OPER_BYTES = HM_PAIR * 2;      // 2,400 B: Q, K, V of one pair
-  static constexpr int WAVE_BYTES = TILE_BYTES + OPER_BYTES;     // 15,520 B (16-byte multiple)
-  static constexpr int SMEM = WPB * WAVE_BYTES;       // 62,080 B: two workgroups per CU
+  static constexpr int TILE_BYTES = S * CROW;         // 13,120 B per title
+  static constexpr int OPER_BYTES = HM_PAIR * 2;      // 2,400 B per wave: Q, K, V of one pair
+  static constexpr int SMEM = TPB * TILE_BYTES + WPB * OPER_BYTES;   // 71,680 B: two workgroups per CU = 4 waves per SIMD
   static constexpr int OP_IT = (OPER_BYTES / 16 + 63) / 64;      // 3 sixteen-byte pieces per lane and pair
-  static constexpr int WO_IT = (S * (KP / 8) + 63) / 64;         // 13 sixteen-byte pieces per lane and title
+  static constexpr int WO_ROWS = S / 2;               // rows each of the title's two waves writes out
+  static constexpr int WO_IT = (WO_ROWS * (KP / 8) + 63) / 64;   // 7 sixteen-byte pieces per lane
 };
 
 template <bool DBG>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
+__global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwdParams p) {
   using Gm = AttnFwdGeom;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
-  const int64_t seq = (int64_t)blockIdx.x * Gm::WPB + w;
-  if (seq >= p.n_seq) return;                                     // no workgroup barrier below: waves are independent
-  unsigned char* const tile = smem + w * Gm::WAVE_BYTES;          // ctx rows of the title
-  unsigned char* const oper = tile + Gm::TILE_BYTES;              // operands of the current pair
+  const int half = w & 1;                                         // this wave's share of the title's heads
+  const int64_t seq = (int64_t)blockIdx.x * Gm::TPB + (w >> 1);
+  if (seq >= p.n_seq) return;                                     // (both waves of a title leave together; exited waves do not hold up the barrier)
+  unsigned char* const tile = smem + (w >> 1) * Gm::TILE_BYTES;   // ctx rows of the title, shared by its two waves (disjoint columns)
+  unsigned char* const oper = smem + Gm::TPB * Gm::TILE_BYTES + w * Gm::OPER_BYTES;      // operands of this wave's current pair
   const u16x4 Z4 = u16x4{0, 0, 0, 0};
+  const int hd0 = half * Gm::HSPLIT, hd1 = half ? H : Gm::HSPLIT;
 
   // K padding of the staged ctx rows: col D = 1.0 (bias-gradient column), cols D + 1 .. KP - 1 = 0
-  for (int i = l; i < S * 5; i += 64) {
-    const int r = i / 5, cq = i - r * 5;
-    *(u16x4*)(tile + r * Gm::CROW + (D + cq * 4) * 2) = u16x4{(u16)(cq == 0 ? BF16_ONE : 0), 0, 0, 0};
-  }
+  if (half == 0)
+    for (int i = l; i < S * 5; i += 64) {
+      const int r = i / 5, cq = i - r * 5;
+      *(u16x4*)(tile + r * Gm::CROW + (D + cq * 4) * 2) = u16x4{(u16)(cq == 0 ? BF16_ONE : 0), 0, 0, 0};
+    }
   const u16* const qkv_seq = p.qkv + seq * (H * HM_PAIR);
   u16x8 nxt[Gm::OP_IT];
   auto fetch = [&](int hd) {
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
       nxt[i] = (idx < Gm::OPER_BYTES / 16 && !(dbg & 1)) ? *(const u16x8*)(qkv_seq + hd * HM_PAIR + idx * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   };
-  fetch(0);
+  fetch(hd0);
 
   const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
   const float c2 = LOG2E / sqrtf((float)DK), clamp2 = EXP_CLAMP * LOG2E;
@@ -309,11 +315,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
   //   (q = 1, k = 0 for a live key, -29952 for a padded one: exp2 of it underflows to exactly 0, no select per element);
   //   the packed P^T tiles are the B operand of ctx^T = V^T P^T with k-slot (g, j < 4) = key 4 g + j and (g, j >= 4) = key 16 + 4 g + j - 4:
   //   exactly the slots of the two packed CL(V) tiles (rows = keys) used as the A operand.
-  for (int hd = 0; hd < H; ++hd) {
+  for (int hd = hd0; hd < hd1; ++hd) {
 #pragma unroll
     for (int i = 0; i < Gm::OP_IT; ++i)
       if (l + 64 * i < Gm::OPER_BYTES / 16) *(u16x8*)(oper + (l + 64 * i) * 16) = nxt[i];
-    if (hd + 1 < H) fetch(hd + 1);
+    if (hd + 1 < hd1) fetch(hd + 1);
     wave_barrier();
     u16x8 kf[2], qf[2], vf[2];
 #pragma unroll
@@ -370,14 +376,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdParams p) {
       }
     }
   }
-  wave_barrier();
+  __syncthreads();                                   // both waves of the title have written their heads' columns
   if (!(dbg & 4)) {
-    u16* dst = p.ctx + seq * S * KP;                 // the title's 20 rows are 12,800 contiguous bytes
+    u16* dst = p.ctx + (seq * S + half * Gm::WO_ROWS) * KP;       // this wave's 10 rows are 6,400 contiguous bytes
 #pragma unroll
     for (int i = 0; i < Gm::WO_IT; ++i) {
       const int idx = l + 64 * i;
       const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
-      if (idx < S * (KP / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + r * Gm::CROW + pc * 16);
+      if (idx < Gm::WO_ROWS * (KP / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + (half * Gm::WO_ROWS + r) * Gm::CROW + pc * 16);
     }
   }
 }

@@ -330,7 +330,7 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   if (n_seq == 0) return NR_OK;
   nr::AttnBwdParams p;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
-  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm;
+  p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm; p.debug = 0;
   // head-major saves: a pair's operands are contiguous, nothing is shared between the heads of a token row except the dqkv row that is written
   { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
   const int64_t pairs = n_seq * NR_HEADS;
@@ -341,6 +341,29 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   if (S == 20) {
     constexpr int WPB = 4;
     using G = nr::AttnBwdGeom<20, WPB>;
+    static int tilev = -1;                          // A/B knob NR_ATTN_TILE: 1 (default) = one workgroup per sequence, dqkv rows staged in LDS
+    if (tilev < 0) { const char* e = getenv("NR_ATTN_TILE"); tilev = e ? atoi(e) : 1; }
+    const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches (AttnBwdParams::debug), re-read per call
+    if (tilev) {
+      constexpr int TW = 5;                         // 15 heads = 3 rounds of 5 waves
+      using GT = nr::AttnBwdGeom<20, TW>;
+      const int grid = (int)(n_seq < (capdiv > 0 ? capdiv : 256 * 8) ? n_seq : (capdiv > 0 ? capdiv : 256 * 8));
+      if (d != nullptr && atoi(d) != 0) {
+        p.debug = atoi(d);
+        if (allow_smem(nr::attn_bwd_kernel<20, TW, true, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+        NR_LAUNCH((nr::attn_bwd_kernel<20, TW, true, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
+      } else {
+        if (allow_smem(nr::attn_bwd_kernel<20, TW, false, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+        NR_LAUNCH((nr::attn_bwd_kernel<20, TW, false, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
+      }
+      return check_launch("nr_attn_bwd");
+    }
+    if (d != nullptr && atoi(d) != 0) {
+      p.debug = atoi(d);
+      if (allow_smem(nr::attn_bwd_kernel<20, WPB, true>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+      NR_LAUNCH((nr::attn_bwd_kernel<20, WPB, true>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 24), WPB * 64, G::SMEM, (hipStream_t)stream, p);
+      return check_launch("nr_attn_bwd");
+    }
     if (allow_smem(nr::attn_bwd_kernel<20, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
     NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 24), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 50) {
@@ -402,7 +425,8 @@ int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int6
   nr::AttnFwdParams p;
   p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::AttnFwdGeom;
-  const int64_t grid = (n_seq + G::WPB - 1) / G::WPB;
+  const int64_t grid = (n_seq + G::TPB - 1) / G::TPB;
+  if (allow_smem(nr::attn_fwd_kernel<false>, G::SMEM) || allow_smem(nr::attn_fwd_kernel<true>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_fwd: cannot reserve LDS");
   const char* d = getenv("NR_ATTNF_DEBUG");         // profiling: phase switches (AttnFwdParams::debug), re-read per call
   if (d != nullptr && atoi(d) != 0) {
     p.debug = atoi(d);

@@ -101,7 +101,10 @@ def test_encoder_autograd_split_vs_fused():
     accumulation-order noise of the projection (bf16 rounding of Q / K / V flips a last bit here and there): 1e-2 of each tensor's scale."""
     a, b = _encoder_run(True), _encoder_run(False)
     assert set(a) == set(b)
+    # absolute floor for gradients that are analytically ~0 (W_K.bias: a per-query constant shift of the scores cancels in exp / (sum + 1e-8)):
+    # 2e-2 of the largest bias gradient, as in tests/test_model_gpu.py
+    floor = 2e-2 * max(np.abs(v).max() for k, v in b.items() if k.endswith('bias'))
     for k in a:
         scale = np.abs(b[k]).max() + 1e-30
         err = np.abs(a[k] - b[k]).max()
-        assert err <= 1e-2 * scale, f'{k}: max diff {err:.3g} on scale {scale:.3g}'
+        assert err <= 1e-2 * scale + (floor if k.endswith('bias') else 0.0), f'{k}: max diff {err:.3g} on scale {scale:.3g}'
