@@ -421,6 +421,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='issue the step kernel by kernel (default on 1 GPU for NRMS / NAML: one HIP graph of forward + backward + Adam, replayed)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -466,18 +468,54 @@ def main():
     hand = {k: v for k, v in prof.items() if k.startswith('nr_') and not k.startswith(('nr_pack', 'nr_sort', 'nr_adam', 'nr_row_adam'))}
     dominant = max(hand, key=lambda k: hand[k][2]) if hand else 'nr_mhsa_fwd[S=20]'
 
+    # ---- single GPU, dense models: the step as ONE HIP graph (news_recommendation_amd/graph.py); the per-kernel HIP-event pass that the
+    # roofline needs then runs as an eager pass of the same K steps AFTER the timed region (events cannot bracket nodes of a replayed graph)
+    use_graph = world == 1 and args.model != 'LSTUR' and not args.no_graph
+    sg = None
+    if use_graph:
+        from news_recommendation_amd.graph import StepGraph
+        flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs]
+
+        def step_fn(*xs):
+            n = len(wl.attrs)
+            cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:]))
+            l_ = crit(model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click), target)
+            l_.backward()
+            opt.step()
+            return l_
+        sg = StepGraph(step_fn, flat(batches[0]), opt, warmup=1)
+        for i in range(2):
+            sg(*flat(batches[i % len(batches)]))
+
     barrier()
     t0 = time.perf_counter()
     # the GRU steps are issued as one C call per recurrence in the timed region (per-step launches from Python make the LSTUR step
     # host-bound): the event pair then brackets T (+1) launches and the per-launch average is total / launches
     SEQ = {'nr_gru_fwd_step': 'nr_gru_fwd_seq', 'nr_gru_bwd_step': 'nr_gru_bwd_seq'}
     timed_name = SEQ.get(dominant, dominant)
-    with ops.profile(only={timed_name}) as rec2:
+    if sg is not None:
         for i in range(args.steps):
-            loss = step(i)
+            loss = sg(*flat(batches[i % len(batches)]))
+        rec2 = None
+    else:
+        with ops.profile(only={timed_name}) as rec2:
+            for i in range(args.steps):
+                loss = step(i)
     t_enq = time.perf_counter() - t0       # host time to ENQUEUE the timed steps (launch-bound if it approaches dt)
     barrier()
     dt = time.perf_counter() - t0
+    eager_ms = None
+    if sg is not None:
+        # the same K steps kernel by kernel (same counter protocol), HIP events around the dominant kernel: the roofline's duration
+        loss_graph = float(loss.item())
+        barrier()
+        t1 = time.perf_counter()
+        with ops.profile(only={timed_name}) as rec2:
+            for i in range(args.steps):
+                loss = sg.eager_step(*flat(batches[i % len(batches)]))
+        barrier()
+        eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        sg.close()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -598,6 +636,9 @@ def main():
                    "num_clicked": 50, "d": 300, "heads": 15, "vocab": cfg.num_words, "num_news": cfg.num_news, "num_users": cfg.num_users,
                    "dropout": cfg.dropout_probability, "parallelism": f"dp{world}"},
         "roofline": roofline,
+        "step_issue": ("one HIP graph per step (forward + backward + Adam), replayed; roofline durations from an eager pass of the same "
+                       f"{args.steps} steps after the timed region" if sg is not None else "kernel by kernel"),
+        "ms_per_step_eager": eager_ms,
         "loss": float(loss.item()),
         "grad_exchange": {"dense_allreduce_bytes": opt.dense_nbytes, "buckets": [[r.name, (r.hi - r.lo) * 4] for r in opt.regions],
                           "row_sparse_tables": [[s.name, list(s.param.shape), f"{B} (id, row) pairs per rank and step"] for s in opt.sparse],

@@ -375,6 +375,14 @@ int nr_dropout_mask(float* mask, int64_t n_elem, float p_drop, uint64_t seed, in
 
 /* Hardware probe: runs one v_mfma_f32_16x16x32_bf16 on A[16][32], B[32][16] (bf16 bits, row-major)
  * and writes D f32[16][16]; used by the GPU tests to pin the fragment-layout assumptions. */
+/* ---- device-resident step counter: what lets ONE captured HIP graph of a training step (forward + backward + Adam; the reference's
+ * train.py:183-233 loop body) be replayed for every step.  Seeds and the optimiser's step index are by-value arguments, frozen into the
+ * graph's kernel nodes at capture; with a counter attached, every dropout kernel folds *ctr into its key (a new mask per replay) and
+ * nr_adam_flat takes its step index from *ctr.  The graph's first node is nr_step_counter_add(ctr, 1).  nr_dropout_mask follows the same
+ * rule, so masks stay reproducible by the tests.  ctr: uint32 in device memory, owned by the caller; NULL detaches (the default). */
+int nr_set_step_counter(const uint32_t* ctr);
+int nr_step_counter_add(uint32_t* ctr, uint32_t inc, void* stream);
+
 int nr_probe_mfma(const uint16_t* A, const uint16_t* B, float* D, void* stream);
 /* Test hook: LDS transpose read (ds_read_b64_tr_b16) of a 4096-entry LDS ramp lds[i] = i; lane l reads at byte offset offs[l] (int32[64],
  * 8-byte aligned, < 8184) and stores its four elements to out u16[64][4]. */

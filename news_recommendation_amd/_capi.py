@@ -75,6 +75,8 @@ SIGNATURES = {
     'nr_sort_ids_workspace': ([c_int64, c_int64], c_int64),
     'nr_sort_ids': ([_P, c_int64, c_int64, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
+    'nr_set_step_counter': ([_P], c_int),
+    'nr_step_counter_add': ([_P, ctypes.c_uint32, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
     'nr_probe_tr16': ([_P, _P, _P], c_int),
 }

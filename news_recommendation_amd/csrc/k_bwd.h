@@ -45,7 +45,9 @@ struct AttnBwdGeom {
   // TILE form (one workgroup per sequence): the sequence's dqkv rows are assembled in LDS and leave as one contiguous run
   static constexpr int TROW = 3 * KP * 2 + 16;      // bytes per staged dqkv row (1,920 + 16: rows shift by 4 banks, 16-byte aligned)
   static constexpr int TILE_BYTES = S * TROW;
-  static constexpr int SMEM_TILE = SMEM + TILE_BYTES;
+  static constexpr int DCT_BYTES = S * KP * 2;      // the sequence's dctx_gemm rows [S][KP], copied global -> LDS one sequence ahead
+  static constexpr int SMEM_TILE = SMEM + TILE_BYTES + DCT_BYTES;
+  static constexpr int ROUNDS = (H + WPB - 1) / WPB;
   static constexpr int WO_IT = (S * (3 * KP / 8) + WPB * 64 - 1) / (WPB * 64);    // 16-byte pieces per thread of the row write-out
 };
 
@@ -88,15 +90,17 @@ struct AttnBwdRegs {
 #ifndef NR_ATTN_OCC
 #define NR_ATTN_OCC 1      // minimum workgroups per CU the register allocation must allow (tuning knob)
 #endif
-// TILE = true (H % WPB == 0): one workgroup per sequence at a time, wave w takes heads w, w + WPB, ...; the pairs' outputs go to an LDS tile
-// [S][3 KP] and the sequence's rows are written as ONE contiguous run of S x 1,920 bytes.  The plain form stores every output tile as
-// 8-byte pieces of 16 different 1,920-byte rows -- 12 such instructions per pair -- and, like the first version of the split forward
-// kernels (k_proj.h), spends more time issuing those stores than computing.
+// TILE = true: one workgroup per sequence at a time, wave w takes heads w, w + WPB, ... (ROUNDS rounds; a wave without a head in the last
+// round only keeps the barriers); the pairs' outputs go to an LDS tile [S][3 KP] and the sequence's rows are written as ONE contiguous
+// run of S x 1,920 bytes; the sequence's dctx_gemm rows arrive the same way, as one contiguous 12.8 KB global -> LDS copy issued a
+// sequence ahead (when ldc == KP).  The plain form stores every output tile as 8-byte pieces of 16 different 1,920-byte rows -- 12 such
+// instructions per pair -- and fetches dctx as 40-byte pieces of 20 rows; its phase decomposition (profiles/r03d_attn_bwd_phases.txt:
+// 940 us, 598 without the loads, 596 without the stores, 462 without both) shows it issuing memory instructions for half of its time.
 template <int S, int WPB, bool DBG = false, bool TILE = false>
 __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwdParams p) {
   using Gm = AttnBwdGeom<S, WPB>;
-  static_assert(!TILE || H % WPB == 0, "TILE form: every wave takes the same number of heads");
   const int dbg = DBG ? p.debug : 0;
+  p.dc = drop_resolve(p.dc);
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   u16* base = (u16*)(smem + w * Gm::WAVE_BYTES);
@@ -105,6 +109,14 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
   u16* dCm = Km + Gm::TD_ELEMS;
   u16* Vt = dCm + Gm::TD_ELEMS;
   unsigned char* const tile = smem + Gm::SMEM;        // TILE form only
+  unsigned char* const dctile = tile + Gm::TILE_BYTES;
+  // dctx rows through LDS: needs whole 16-byte pieces of contiguous rows
+  const bool staged = TILE && p.ldc == KP && (((uintptr_t)p.dctx_gemm) & 15) == 0;
+  auto stage_dctx = [&](int64_t sq) {                 // async copy of sequence sq's S x KP block; visible after the next workgroup barrier
+    const u16* src = p.dctx_gemm + sq * S * KP;
+    for (int b = w; b * 64 < S * KP / 8; b += WPB)
+      if (b * 64 + l < S * KP / 8 && !(dbg & 1)) NR_GLDS16(src + (b * 64 + l) * 8, dctile + b * 1024);
+  };
 
   const int64_t n_pairs = p.n_seq * H;
   const int64_t stride = (int64_t)gridDim.x * WPB;
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         const int r = i / Gm::PCS, c = (i - r * Gm::PCS) * 4;
         rg.q[it] = *(const u16x4*)(qb + (r * rs + c));
         rg.k[it] = *(const u16x4*)(kb + (r * rs + c));
-        rg.dg[it] = *(const u16x4*)(gb + (r * p.ldc + c));
+        if (!staged) rg.dg[it] = *(const u16x4*)(gb + (r * p.ldc + c));
         rg.go[it] = *(const f32x4*)(gob + c);
         rg.wt[it] = wb[r];
       }
@@ -174,8 +186,9 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         *(u16x4*)(Qm + r * Gm::DS + c) = rg.q[it];
         *(u16x4*)(Km + r * Gm::DS + c) = rg.k[it];
         f32x4 dc4;
+        const u16x4 dg = staged ? *(const u16x4*)(dctile + (r * KP + hd * DK + c) * 2) : rg.dg[it];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dc4[j] = bf2f(rg.dg[it][j]) + rg.wt[it] * rg.go[it][j];
+        for (int j = 0; j < 4; ++j) dc4[j] = bf2f(dg[j]) + rg.wt[it] * rg.go[it][j];
         if (p.dc.enabled) {
           dc4 = dc4 * drop_mul4(p.dc, 2u, (uint64_t)(tok0 + r) * D4 + ((hd * DK + c) >> 2));
         }
@@ -233,14 +246,28 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
 #pragma unroll
   for (int j = 0; j < 8; ++j) identc[j] = (j < 4 && 4 * g + j == li) ? ONE : (u16)0;
 
-  while (pair < n_pairs) {
-    const int64_t seq = pair / H;
+  // TILE iteration state: (sequence, round); every wave of the workgroup runs the same iterations and meets the same barriers
+  int64_t seq_t = blockIdx.x;
+  int rnd = 0;
+  if (TILE) {
+    if (staged && seq_t < p.n_seq) stage_dctx(seq_t);
+    __syncthreads();
+  }
+  while (TILE ? seq_t < p.n_seq : pair < n_pairs) {
+    const bool act = !TILE || w + rnd * WPB < H;
+    if (TILE) pair = seq_t * H + w + rnd * WPB;
+    const int64_t seq = TILE ? seq_t : pair / H;
     const int hd = (int)(pair - seq * H);
     const int64_t tok0 = seq * S;
     const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
-    store_lds(pair);
+    if (act) store_lds(pair);
+    if (TILE && staged && rnd == Gm::ROUNDS - 1) {          // every wave has taken its last pieces of this sequence's dctx rows
+      __syncthreads();
+      if (seq_t + gridDim.x < p.n_seq) stage_dctx(seq_t + gridDim.x);
+    }
     // TILE: the wave's next head of this sequence, then its first head of the workgroup's next sequence
     const int64_t next = !TILE ? pair + stride : (hd + WPB < H ? pair + WPB : (seq + gridDim.x) * H + w);
+    if (act) {
     if (next < n_pairs) load_regs(next);          // prefetch the next pair while this one is computed
     wave_barrier();
 
@@ -399,7 +426,8 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       }
     }
     wave_barrier();        // all LDS reads of this pair done before the next pair's stores
-    if (TILE && hd + WPB >= H) {                 // the sequence is complete in every wave after this barrier: S x 1,920 contiguous bytes leave
+    }                      // act
+    if (TILE && rnd == Gm::ROUNDS - 1) {         // the sequence is complete in every wave after this barrier: S x 1,920 contiguous bytes leave
       __syncthreads();
       if (!(dbg & 4)) {
         u16* dst = p.dqkv + tok0 * LDG;
@@ -412,7 +440,11 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       }
       __syncthreads();
     }
-    pair = next;
+    if (TILE) {
+      if (++rnd == Gm::ROUNDS) { rnd = 0; seq_t += gridDim.x; }
+    } else {
+      pair = next;
+    }
   }
 }
 
@@ -602,6 +634,8 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
 __global__ __launch_bounds__(256) void gather_bf16_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                           int64_t num_rows, const float* __restrict__ x_dense,
                                                           u16* __restrict__ Xb, int64_t n_tokens, DropCfg dc) {
+  dc = drop_resolve(dc);
+  dc = drop_resolve(dc);
   constexpr int PC = KP / 4;   // 80 quads per row
   const int64_t total = n_tokens * PC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -666,6 +700,7 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t
                                                                    const int64_t* __restrict__ perm, const SRC* __restrict__ dx,
                                                                    int64_t ldx, float* __restrict__ grad_table, int64_t num_rows,
                                                                    int64_t n_tokens, DropCfg dc, int pad_row) {
+  dc = drop_resolve(dc);
   const int l = lane_id();
   const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave_id()) * SC_CH;
   if (s0 >= n_tokens) return;

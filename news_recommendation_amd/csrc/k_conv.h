@@ -54,6 +54,7 @@ struct ConvParams {
 
 template <int S, int NSEQ, int NW>
 __global__ __launch_bounds__(NW * 64) void conv3_kernel(ConvParams p) {
+  p.dc = drop_resolve(p.dc);
   using Gm = ConvGeom<S, NSEQ>;
   constexpr int WG = NW * 64;          // shadows nr::WG: this kernel runs with 4 or 8 waves
   NR_SMEM_DECL(smem);

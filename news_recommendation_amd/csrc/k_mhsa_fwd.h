@@ -161,6 +161,7 @@ __device__ __forceinline__ void stage_tokens(const MhsaParams& p, u16* Xs, int* 
 
 template <int S, int NSEQ, int NW, int GS>
 __global__ __launch_bounds__(NW * 64, NW / 2) void mhsa_fwd_kernel(MhsaParams p) {
+  p.dc = drop_resolve(p.dc);
   using Gm = MhsaGeom<S, NSEQ, NW>;
   constexpr int WG = NW * 64;
   NR_SMEM_DECL(smem);

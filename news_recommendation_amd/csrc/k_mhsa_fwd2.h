@@ -43,6 +43,7 @@ template <bool DBG>
 __global__ __launch_bounds__(256) NR_ONE_WAVE_PER_SIMD void mhsa_fwd2_kernel(MhsaParams p) {
   using Gm = Mhsa2Geom;
   const int dbg = DBG ? p.debug : 0;
+  p.dc = drop_resolve(p.dc);
   constexpr int S = Gm::S, MT = Gm::MT;
   NR_SMEM_DECL(smem);
   auto wl = [&](int buf) -> u16* { return (u16*)(smem + buf * Gm::CH_BYTES); };

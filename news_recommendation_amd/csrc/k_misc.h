@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void score_csr_kernel(const float* __restrict_
 
 // ---- dropout mask export (verification of the fused kernels' RNG) -------------------------------------------
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, int64_t n_elem, DropCfg dc, int site) {
+  dc = drop_resolve(dc);
   int64_t nquad = (n_elem + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
     uint32_t m = drop_keep4(dc, (uint32_t)site, (uint64_t)q);

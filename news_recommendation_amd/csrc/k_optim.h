@@ -22,6 +22,8 @@
 namespace nr {
 
 struct AdamCfg {
+  const uint32_t* t_dev; // optional device-resident step counter (nr_set_step_counter): the dense kernel then takes its step index from it
+                        // instead of its by-value argument, so that a step captured into a HIP graph advances at every replay
   const float* sched;   // [2 * (max_step + 1)]
   float om_b1;          // 1 - beta1
   float b2, om_b2;      // beta2, 1 - beta2
@@ -49,9 +51,14 @@ __device__ __forceinline__ void adam_elem_idle(float& p, float& m, float& v, flo
   p = p - step_size * (m / denom);
 }
 
+__global__ __launch_bounds__(64) void step_counter_add_kernel(uint32_t* ctr, uint32_t inc) {
+  if (threadIdx.x == 0) *ctr += inc;
+}
+
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, AdamCfg c, int64_t step, float grad_scale,
                                                         int zero_grad) {
+  if (c.t_dev != nullptr) step = (int64_t)*c.t_dev;
   const float step_size = c.sched[2 * step], bc2_sqrt = c.sched[2 * step + 1];
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

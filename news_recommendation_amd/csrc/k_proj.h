@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   using Gm = ProjGeom;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
+  p.dc = drop_resolve(p.dc);
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
   const int64_t tile_tok0 = ((int64_t)blockIdx.x * Gm::NWAVE + w) * Gm::TOKW;
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
   using Gm = AttnFwdGeom;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
+  p.dc = drop_resolve(p.dc);
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int half = w & 1;                                         // this wave's share of the title's heads

@@ -43,7 +43,19 @@ struct DropCfg {
   uint32_t thresh;     // drop iff rand16 < thresh  (thresh = p * 2^16)
   float scale;         // 1/(1-p)
   int enabled;
+  const uint32_t* ctr; // optional device-resident step counter (nr_set_step_counter): folded into the key by drop_resolve(), so that a
+                       // training step captured ONCE into a HIP graph (seed baked into the kernel nodes) draws new masks at every replay
 };
+
+// The kernels call this once, on their by-value parameter copy, before any mask is drawn.
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg dc) {
+  if (dc.ctr != nullptr) {
+    const uint32_t c = *dc.ctr;
+    dc.k0 ^= c * 0x9E3779B1u;
+    dc.k1 += c * 0x85EBCA77u;
+  }
+  return dc;
+}
 
 // the two 32-bit words of a quad: r0 = lowbias32 of (counter ^ key ^ site), r1 = one more multiply-xorshift of (r0 ^ key')
 __device__ __forceinline__ void drop_words(const DropCfg& dc, uint32_t site, uint64_t quad, uint32_t& r0, uint32_t& r1) {

@@ -42,8 +42,12 @@ int check_launch(const char* what) {
   return NR_OK;
 }
 
+// device-resident step counter of the process (nr_set_step_counter); null: seeds and step indices are taken by value as given
+const uint32_t* g_step_ctr = nullptr;
+
 nr::DropCfg make_drop(float p, uint64_t seed) {
   nr::DropCfg dc;
+  dc.ctr = g_step_ctr;
   dc.enabled = p > 0.0f ? 1 : 0;
   dc.k0 = (uint32_t)seed;
   dc.k1 = (uint32_t)(seed >> 32);
@@ -345,7 +349,7 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
     if (tilev < 0) { const char* e = getenv("NR_ATTN_TILE"); tilev = e ? atoi(e) : 1; }
     const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches (AttnBwdParams::debug), re-read per call
     if (tilev) {
-      constexpr int TW = 5;                         // 15 heads = 3 rounds of 5 waves
+      constexpr int TW = 4;                         // 15 heads = 4 rounds of 4 waves (the last round: 3): two workgroups per CU at 2 waves per SIMD
       using GT = nr::AttnBwdGeom<20, TW>;
       const int grid = (int)(n_seq < (capdiv > 0 ? capdiv : 256 * 8) ? n_seq : (capdiv > 0 ? capdiv : 256 * 8));
       if (d != nullptr && atoi(d) != 0) {
@@ -909,6 +913,7 @@ int nr_impression_metrics(const float* scores, const int32_t* labels, const int6
 // ---- optimiser (src/train.py:127-128,227-233) ------------------------------------------------------------------------------------
 static nr::AdamCfg make_adam(const float* sched, double beta1, double beta2, double eps) {
   nr::AdamCfg c;
+  c.t_dev = nullptr;
   c.sched = sched; c.om_b1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.om_b2 = (float)(1.0 - beta2); c.eps = (float)eps;
   return c;
 }
@@ -919,9 +924,21 @@ int nr_adam_flat(float* p, float* g, float* m, float* v, int64_t n, const float*
   if (!p || !g || !m || !v || !sched || n < 0 || step < 1 || bad_betas(beta1, beta2, eps)) return fail(NR_ERR_BADARG, "nr_adam_flat: bad argument");
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(NR_ERR_BADARG, "nr_adam_flat: buffers must be 16-byte aligned");
   if (n == 0) return NR_OK;
-  NR_LAUNCH(nr::adam_flat_kernel, grid_for((n + 3) / 4, 256, 256 * 16), 256, 0, (hipStream_t)stream, p, g, m, v, n,
-            make_adam(sched, beta1, beta2, eps), step, grad_scale, zero_grad);
+  nr::AdamCfg cfg = make_adam(sched, beta1, beta2, eps);
+  cfg.t_dev = g_step_ctr;                  // with a device step counter attached, the kernel reads the step index from it
+  NR_LAUNCH(nr::adam_flat_kernel, grid_for((n + 3) / 4, 256, 256 * 16), 256, 0, (hipStream_t)stream, p, g, m, v, n, cfg, step, grad_scale, zero_grad);
   return check_launch("nr_adam_flat");
+}
+
+int nr_set_step_counter(const uint32_t* ctr) {
+  g_step_ctr = ctr;
+  return NR_OK;
+}
+
+int nr_step_counter_add(uint32_t* ctr, uint32_t inc, void* stream) {
+  if (!ctr) return fail(NR_ERR_BADARG, "nr_step_counter_add: null pointer");
+  NR_LAUNCH(nr::step_counter_add_kernel, 1, 64, 0, (hipStream_t)stream, ctr, inc);
+  return check_launch("nr_step_counter_add");
 }
 
 int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,

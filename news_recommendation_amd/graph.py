@@ -1,0 +1,82 @@
+"""One HIP graph for the whole training step (forward + backward + fused Adam) -- the loop body of src/train.py:183-233.
+
+At B = 512 the NRMS step is ~60 kernel launches of 5 - 900 us each; issued one by one they leave ~0.3 ms of idle gaps per step on the
+GPU and cost 1.2 - 1.4 ms of host time per step.  Captured once and replayed, the step costs one launch.
+
+What has to be true for a captured step to remain a TRAINING step when replayed:
+  * new dropout masks every step      -> the kernels fold a device-resident step counter into their keys (nr_set_step_counter,
+                                         csrc/nr_common.h drop_resolve); the seeds frozen into the graph are only a base;
+  * Adam's bias-correction step index -> nr_adam_flat reads it from the same counter (csrc/k_optim.h);
+  * inputs                            -> copied into static device buffers before each replay;
+  * no host round trips, no allocation outside the graph's pool -- true of the engine's step by construction (ids resident in HBM,
+    gradients accumulate into the optimiser's flat buffers, the token-id sort runs on a forked side stream that joins before the scatter).
+The counter is bumped by the graph's first node, so replay k uses counter value t0 + k: exactly what the eager loop below (`eager_step`)
+does with one nr_step_counter_add launch per step -- which is how the tests hold replays to the eager path bit for bit.
+
+Scope: single process (world = 1), dense parameters (NRMS, NAML).  Data-parallel steps keep their RCCL calls outside any graph
+(collectives are the natural graph boundaries); LSTUR's step depends on host-side history lengths and is not captured.
+"""
+import torch
+
+from . import _capi, ops
+
+
+class StepGraph:
+    """``g = StepGraph(step_fn, example_inputs, optimizer)``; ``loss = g(*inputs)`` runs one training step.
+
+    step_fn(*inputs) must run forward, ``loss.backward()`` and ``optimizer.step()`` and return the (device) loss tensor; `optimizer` is
+    an ``optim.EngineAdam`` without row-sparse tables.  ``max_steps`` sizes the optimiser's per-step scalar table once (its address is
+    frozen into the graph)."""
+
+    def __init__(self, step_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20):
+        if optimizer.sparse:
+            raise NotImplementedError("StepGraph: row-sparse tables (LSTUR) update from host-side row lists; not capturable")
+        if optimizer._dist_on():
+            raise NotImplementedError("StepGraph: data-parallel steps are not captured (the collectives are graph boundaries)")
+        self.lib = _capi.load()
+        self.opt = optimizer
+        self.step_fn = step_fn
+        dev = optimizer.device
+        self.static = [torch.empty_like(x) for x in example_inputs]
+        for s, x in zip(self.static, example_inputs):
+            s.copy_(x)
+        optimizer.sched.ensure(optimizer.t + max_steps)
+        self.max_t = optimizer.t + max_steps
+        # the device counter mirrors optimizer.t: both are bumped at the START of a step
+        self.ctr = torch.full((1,), optimizer.t, dtype=torch.int32, device=dev)
+        _capi.check(self.lib, self.lib.nr_set_step_counter(self.ctr.data_ptr()))
+        # warm-up on a side stream (lazy initialisation, LDS opt-ins, packed-operand caches, workspace growth) -- these are real steps
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.eager_step(*self.static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        ops.invalidate_packed()                 # the captured step must contain its own packing launches
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
+            self.loss = step_fn(*self.static)
+        # the capture ran the Python side of one step (optimizer.t advanced) without executing a kernel: take it back
+        self.opt.t -= 1
+
+    def eager_step(self, *inputs):
+        """The same step without the graph, on the same counter protocol (used for warm-up and as the reference in tests)."""
+        _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
+        return self.step_fn(*inputs)
+
+    def __call__(self, *inputs):
+        if self.opt.t + 1 > self.max_t:
+            raise RuntimeError("StepGraph: max_steps exhausted (the optimiser's step table is sized at capture)")
+        for s, x in zip(self.static, inputs):
+            if s.data_ptr() != x.data_ptr():
+                s.copy_(x, non_blocking=True)
+        self.graph.replay()
+        self.opt.t += 1
+        ops.invalidate_packed()                 # parameters changed behind torch's version counters (as after an eager optimizer.step())
+        return self.loss
+
+    def close(self):
+        """Detach the counter: later launches of this process take seeds / step indices by value again."""
+        _capi.check(self.lib, self.lib.nr_set_step_counter(None))

@@ -355,7 +355,8 @@ def close_bf16(got, ref, what, rel=2.0 ** -6, floor=6e-3):
     return err.max() / scale
 
 
-def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
+def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False, ldc=NR_D):
+    """ldc: row stride of the dctx_gemm input (NR_KP = the training layout, which the S = 20 kernel copies through LDS)."""
     from news_recommendation_amd._capi import NR_LDG
     params = make_params(12)
     rng = np.random.default_rng(13)
@@ -379,14 +380,16 @@ def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
         close_bf16(t, ref, 'saved ' + name, rel=2.0 ** -7, floor=1e-3)
     dg = rng.normal(0, 0.05, size=(n_seq * S, NR_D)).astype(np.float32)
     dg_u = f32_to_bf16(dg)
+    dg_in = np.full((n_seq * S, ldc), 0x7FC0, dtype=np.uint16)          # padding columns hold NaN: they must never be read as data
+    dg_in[:, :NR_D] = dg_u
     aw = rng.random(size=(n_seq, S)).astype(np.float32); aw /= aw.sum(1, keepdims=True)
     go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
     dqkv = be.empty((n_seq * S, NR_LDG), np.uint16)
     if key_len is None:
-        ck(be, be.lib.nr_attn_bwd(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
+        ck(be, be.lib.nr_attn_bwd(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_in)), ldc, be.ptr(be.dev(aw)),
                                   be.ptr(be.dev(go)), be.ptr(dqkv), n_seq, S, p_drop, seed, be.stream))
     else:
-        ck(be, be.lib.nr_attn_bwd_len(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_u)), NR_D, be.ptr(be.dev(aw)),
+        ck(be, be.lib.nr_attn_bwd_len(be.ptr(sv[0]), be.ptr(sv[1]), be.ptr(sv[2]), be.ptr(be.dev(dg_in)), ldc, be.ptr(be.dev(aw)),
                                       be.ptr(be.dev(go)), be.ptr(dqkv), be.ptr(be.dev(np.asarray(key_len, dtype=np.int32))), n_seq, S, p_drop, seed,
                                       be.stream))
     be.sync()

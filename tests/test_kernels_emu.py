@@ -34,6 +34,7 @@ def test_score_csr(be): kc.check_score_csr(be)
 def test_impression_metrics(be): kc.check_impression_metrics(be)
 def test_bad_args(be): kc.check_bad_args(be)
 def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=3)
+def test_attn_bwd_s20_dctx_through_lds(be): kc.check_attn_bwd(be, S=20, n_seq=7, p_drop=0.2, ldc=320); kc.check_attn_bwd(be, S=20, n_seq=3, with_key_len=True, ldc=320)
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0.2)
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=1)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=6)

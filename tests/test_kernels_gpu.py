@@ -36,6 +36,7 @@ def test_score_csr(be): kc.check_score_csr(be, n_news=5000, n_users=300, n_impr=
 def test_impression_metrics(be): kc.check_impression_metrics(be, n_impr=3001)
 def test_bad_args(be): kc.check_bad_args(be)
 def test_attn_bwd_s20(be): kc.check_attn_bwd(be, S=20, n_seq=203)
+def test_attn_bwd_s20_dctx_through_lds(be): kc.check_attn_bwd(be, S=20, n_seq=2500, p_drop=0.2, ldc=320); kc.check_attn_bwd(be, S=20, n_seq=203, with_key_len=True, ldc=320)
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=0.2)
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)

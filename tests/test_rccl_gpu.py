@@ -1,9 +1,12 @@
 """The RCCL code path of EngineAdam on the one GPU a test box has: a process group of ONE rank over backend 'nccl' (= RCCL on ROCm) with
 the optimiser forced onto its multi-rank branch (force_dist) -- the table bucket's collective started from inside the backward on RCCL's
 stream, the small bucket, the touched-row all-gather, and the reduce-scatter / sharded-Adam / all-gather form.  Collectives over one rank
-are identities, so the parameters after a few training steps must equal the single-process fast path BIT FOR BIT; what the test exercises
-is the stream ordering between the engine's kernels (current stream) and RCCL's internal stream, and the allocator hand-off of the
-buffers the collectives touch (net-new vs src/train.py:227-233, which has no distributed code)."""
+are identities, so the parameters after a few training steps must equal the single-process fast path up to the run-to-run noise of the
+embedding scatter (rows that span several chunks of the sorted token list are combined with fp32 atomics: the summation order, hence the
+last bit, varies between two runs of the SAME path -- measured here with a second single-process run).  What the test exercises is the
+stream ordering between the engine's kernels (current stream) and RCCL's internal stream, and the allocator hand-off of the buffers the
+collectives touch (net-new vs src/train.py:227-233, which has no distributed code): a collective that ran before its input was complete,
+or an update that ran before the collective, shows up as a difference of the order of the update itself (1e-3), not of the last bit."""
 import os
 import socket
 import subprocess
@@ -81,9 +84,13 @@ def _run(mode, model_name, tmp_path):
 @pytest.mark.parametrize('model_name', ['NRMS', 'LSTUR'])
 def test_engine_adam_over_rccl_world1_equals_local_path(tmp_path, model_name):
     local = _run('local', model_name, tmp_path)
+    again = _run('local', model_name, tmp_path)
     assert np.isfinite(local['losses']).all()
+    noise = max(float(np.abs(again[k].astype(np.float64) - local[k]).max()) for k in local)
+    tol = max(4 * noise, 2e-6)                     # parameters move by ~1e-3 per step (lr): a mis-ordered exchange is 3 orders above this
     for mode in ('ar', 'rs'):                      # all-reduce form, reduce-scatter + sharded Adam + all-gather form
         got = _run(mode, model_name, tmp_path)
         assert set(got) == set(local)
         for k in local:
-            assert np.array_equal(got[k], local[k]), f'{model_name} / {mode}: {k} differs from the single-process path'
+            err = float(np.abs(got[k].astype(np.float64) - local[k]).max())
+            assert err <= tol, f'{model_name} / {mode}: {k} differs from the single-process path by {err:.3g} (run-to-run noise {noise:.3g})'
