@@ -153,6 +153,16 @@ class Workload:
             return model(mb['user'], mb['clicked_news_length'].clone(), mb['candidate_news'], mb['clicked_news'])
         return model(mb['candidate_news'], mb['clicked_news'])      # train.py:202-203
 
+    def hbm_bytes(self, B):
+        """Algorithmic HBM bytes per launch of the kernels that are bandwidth / instruction bound, not dense contractions (the
+        attention core is reported against HBM, never against the MFMA peak): bf16 saves read + bf16 results written."""
+        tok = B * 53 * 20
+        return {
+            'nr_attn_fwd[S=20]': tok * (3 * 300 * 2 + 300 * 2),                      # Q, K, V in; ctx out
+            'nr_attn_bwd[S=20]': tok * (3 * 300 * 2 + 300 * 2 + 3 * 300 * 2),        # Q, K, V, dctx in; dQ, dK, dV out
+            'nr_embed_scatter_sorted[S=20]': tok * (300 * 2 + 16),                   # dX rows + (id, position) in; table rows reduced in registers
+        }
+
     def flops(self, B):
         """Algorithmic FLOPs per launch of the kernels we know how to price (SURVEY 8 d6 / DESIGN.md)."""
         T = B * 53
@@ -539,7 +549,12 @@ def main():
 
     T = B * (1 + cfg.negative_sampling_ratio + cfg.num_clicked_news_a_user)
     flops = wl.flops(B)
-    if dominant in flops:
+    hbm = wl.hbm_bytes(B)
+    if dominant in hbm:
+        ach = hbm[dominant] / (dom[1] * 1e-6) / 1e9
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": dom[1], "launches": dom[0], "bytes_per_launch": hbm[dominant]}
+    elif dominant in flops:
         ach = flops[dominant] / (dom[1] * 1e-6) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / MFMA_BF16_PEAK_TF, "traffic": None, "avg_us": dom[1], "launches": dom[0],

@@ -8,7 +8,10 @@
 //   AUC   = sum_{pos i} ( #{neg j : s_j < s_i} + 0.5 #{neg j : s_j == s_i} ) / (P * N)          (Mann-Whitney = trapezoidal ROC area)
 //   MRR   = sum_{pos i} 1 / (rank_i + 1) / P
 //   nDCG@k = sum_{pos i, rank_i < k} 1 / log2(rank_i + 2)  /  sum_{r < min(P, k)} 1 / log2(r + 2)
-//   Impressions with a single label class give four NaNs (the reference's ValueError path), skipped by the caller's nanmean.
+//   Single-class impressions follow what src/evaluate.py:160-168 does with the scikit-learn it runs on today (1.7.2, observed by running
+//   the reference here): roc_auc_score returns NaN with a warning instead of raising, so an ALL-POSITIVE impression keeps its MRR and nDCG
+//   (AUC = NaN only) and an all-negative one is 0 / 0 = NaN in all four; the caller's nanmean skips NaNs column by column.  (Under
+//   scikit-learn < 1.? roc_auc_score raised ValueError and the reference dropped all four values of both kinds.)
 #pragma once
 #include "nr_common.h"
 #include "k_misc.h"
@@ -48,8 +51,8 @@ __global__ __launch_bounds__(256) void impression_metrics_kernel(const float* __
   auc = wave_sum(auc); mrr = wave_sum(mrr); d5 = wave_sum(d5); d10 = wave_sum(d10);
   if (l == 0) {
     float* o = out + imp * 4;
-    if (npos == 0.f || nneg == 0.f) {
-      const float nan = __builtin_nanf("");
+    const float nan = __builtin_nanf("");
+    if (npos == 0.f) {
       o[0] = o[1] = o[2] = o[3] = nan;
     } else {
       float b5 = 0.f, b10 = 0.f;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void impression_metrics_kernel(const float* __
         if (r < 5) b5 += g;
         b10 += g;
       }
-      o[0] = auc / (npos * nneg); o[1] = mrr / npos; o[2] = d5 / b5; o[3] = d10 / b10;
+      o[0] = nneg == 0.f ? nan : auc / (npos * nneg); o[1] = mrr / npos; o[2] = d5 / b5; o[3] = d10 / b10;
     }
   }
 }

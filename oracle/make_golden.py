@@ -104,8 +104,11 @@ def run_metrics():
         n = int(rng.integers(2, 40))
         y = rng.integers(0, 2, size=n)
         if i % 7 == 0:
-            y[:] = 0
-        y[0], y[-1] = (1, 0) if i % 7 else (y[0], y[-1])
+            y[:] = 0                                              # all-negative impression: 0 / 0 -> four NaNs
+        elif i % 7 == 3:
+            y[:] = 1                                              # all-positive: roc_auc_score is undefined; what the reference returns then depends
+        else:                                                     # on its scikit-learn (1.7.2 here: NaN AUC + a warning, MRR / nDCG kept)
+            y[0], y[-1] = 1, 0
         s = rng.normal(size=n).round(1 if i % 3 == 0 else 6)      # rounded => ties
         ys.append(y.astype(np.int64)); ss.append(s)
         import warnings

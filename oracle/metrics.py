@@ -54,11 +54,12 @@ def auc_score(y_true, y_score):
 
 
 def single_impression_metrics(y_true, y_score):
-    """src/evaluate.py:160-168 -> [auc, mrr, ndcg5, ndcg10]; an impression with a
-    single label class yields four NaNs (the reference relies on ValueError; see
-    SURVEY.md 5.9 #11 -- synthetic impressions here always carry both classes)."""
+    """src/evaluate.py:160-168 -> [auc, mrr, ndcg5, ndcg10].  Single-class impressions as the reference treats them on the
+    scikit-learn it runs with here (1.7.2; tests/test_evaluate_fast.py holds this to the imported reference): roc_auc_score returns
+    NaN (a warning, no ValueError), so an all-positive impression keeps MRR / nDCG and an all-negative one is 0 / 0 = NaN in all four
+    (SURVEY.md 5.9 #11)."""
     y_true = np.asarray(y_true)
-    if y_true.sum() == 0 or y_true.sum() == len(y_true):
+    if y_true.sum() == 0:
         return [np.nan] * 4
     return [auc_score(y_true, y_score), mrr_score(y_true, y_score),
             ndcg_score(y_true, y_score, 5), ndcg_score(y_true, y_score, 10)]

@@ -653,10 +653,13 @@ def check_impression_metrics(be, n_impr=40, seed=5):
     got = be.np(out)
     for i in range(n_impr):
         ref = om.single_impression_metrics(ys[i], ss[i].astype(np.float64))
-        if np.isnan(ref[0]):
-            assert np.isnan(got[i]).all(), i
+        if np.isnan(ref[1]):                                          # all-negative impression: 0 / 0 in all four (src/evaluate.py:38,31)
+            assert np.isnan(got[i]).all() and not ys[i].any(), i
             continue
-        assert abs(got[i][0] - ref[0]) < 1e-5, (i, got[i], ref)       # AUC: tie handling is exact (average ranks)
+        if np.isnan(ref[0]):                                          # all-positive: AUC undefined (NaN), MRR / nDCG are those of a perfect ranking
+            assert np.isnan(got[i][0]) and ys[i].all(), i
+        else:
+            assert abs(got[i][0] - ref[0]) < 1e-5, (i, got[i], ref)   # AUC: tie handling is exact (average ranks)
         if len(np.unique(ss[i])) == len(ss[i]):                      # MRR / nDCG depend on the tie ORDER of argsort; exact without ties
             np.testing.assert_allclose(got[i][1:], ref[1:], rtol=2e-5, atol=2e-6, err_msg=str(i))
     return got

@@ -142,3 +142,40 @@ def test_fast_evaluate_equals_reference_style_loop(tmp_path, model_name):
     # same vectors, same scorer arithmetic (fp32 dot products), fp32 vs fp64 metric accumulation
     np.testing.assert_allclose(np.asarray(fast), slow, rtol=2e-4, atol=2e-5)
     assert all(np.isfinite(fast)) and all(np.isfinite(fast7)) and 0.0 <= fast[0] <= 1.0
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+def test_single_class_impressions_follow_the_reference_as_it_runs_here():
+    """src/evaluate.py:160-168 wraps roc_auc_score in `except ValueError`; what a single-class impression yields therefore depends on the
+    scikit-learn the reference runs on.  With the one installed beside it here (1.7.2) roc_auc_score returns NaN + a warning, so an
+    all-positive impression contributes its MRR / nDCG (AUC = NaN only) and an all-negative one contributes nothing.  The oracle
+    (oracle/metrics.py), hence the device kernel held to it (kernel_checks.check_impression_metrics), follow THAT observed behaviour."""
+    code = r'''
+import sys, types, warnings, json
+import numpy as np
+sys.dont_write_bytecode = True
+sys.path.insert(0, sys.argv[1])
+import os
+os.environ['MODEL_NAME'] = 'NRMS'
+sys.modules.setdefault('torch.utils.tensorboard', types.ModuleType('torch.utils.tensorboard'))
+import evaluate as ref_eval
+warnings.simplefilter('ignore')
+cases = {'all_pos': ([1, 1, 1, 1], [0.3, 0.2, 0.9, 0.1]), 'all_neg': ([0, 0, 0], [0.3, 0.2, 0.9]), 'one_pos': ([1], [0.5]),
+         'mixed': ([1, 0, 0, 1], [0.3, 0.2, 0.9, 0.1])}
+print(json.dumps({k: [None if np.isnan(x) else float(x) for x in ref_eval.calculate_single_user_metric(v)] for k, v in cases.items()}))
+'''
+    import json
+    p = subprocess.run([sys.executable, '-c', code, REF], capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert p.returncode == 0, p.stderr[-2000:]
+    ref = json.loads(p.stdout.strip().splitlines()[-1])
+    from oracle import metrics as om
+    cases = {'all_pos': ([1, 1, 1, 1], [0.3, 0.2, 0.9, 0.1]), 'all_neg': ([0, 0, 0], [0.3, 0.2, 0.9]), 'one_pos': ([1], [0.5]),
+             'mixed': ([1, 0, 0, 1], [0.3, 0.2, 0.9, 0.1])}
+    for k, (y, s) in cases.items():
+        got = om.single_impression_metrics(np.array(y), np.array(s, dtype=np.float64))
+        want = [np.nan if x is None else x for x in ref[k]]
+        np.testing.assert_allclose(got, want, rtol=1e-12, equal_nan=True, err_msg=k)
+    assert ref['all_pos'][0] is None and ref['all_pos'][1] is not None and ref['all_neg'] == [None] * 4
+    # and the dataset-level mean skips NaNs column by column (src/evaluate.py:270-272)
+    m = om.evaluate_impressions([np.array(c[0]) for c in cases.values()], [np.array(c[1], dtype=np.float64) for c in cases.values()])
+    assert np.isclose(m[0], ref['mixed'][0]) and np.isclose(m[1], np.mean([ref[k][1] for k in ('all_pos', 'one_pos', 'mixed')]))

@@ -1,5 +1,7 @@
-"""HIP graph of the training step (news_recommendation_amd/graph.py): replays == the eager loop on the same device step counter, bit for
-bit -- new dropout masks and the right Adam step index at every replay -- for NRMS and NAML."""
+"""HIP graph of the training step (news_recommendation_amd/graph.py): replays == the eager loop on the same device step counter -- new
+dropout masks and the right Adam step index at every replay -- for NRMS and NAML.  "Equal" up to the run-to-run noise of the embedding
+scatter's fp32 atomics (measured with a second eager run): a replay that reused a mask or a step index would be off by the size of an
+update (1e-3), not by last bits."""
 import os
 import subprocess
 import sys
@@ -81,7 +83,11 @@ def _run(mode, model_name, tmp_path):
 @pytest.mark.parametrize('model_name', ['NRMS', 'NAML'])
 def test_step_graph_replays_equal_eager_steps(tmp_path, model_name):
     eager, graph = _run('eager', model_name, tmp_path), _run('graph', model_name, tmp_path)
+    again = _run('eager', model_name, tmp_path)
     assert np.isfinite(eager['losses']).all() and len(set(np.round(eager['losses'], 6))) > 1
     assert set(eager) == set(graph)
+    noise = max(float(np.abs(again[k].astype(np.float64) - eager[k]).max()) for k in eager)
+    tol = max(4 * noise, 2e-6)
     for k in eager:
-        assert np.array_equal(eager[k], graph[k]), f'{model_name}: {k} differs between graph replays and eager steps'
+        err = float(np.abs(eager[k].astype(np.float64) - graph[k]).max())
+        assert err <= tol, f'{model_name}: {k} differs between graph replays and eager steps by {err:.3g} (run-to-run noise {noise:.3g})'
