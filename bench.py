@@ -675,6 +675,20 @@ def main():
         states["pretrained_table"] = wl.make_model(seed=1, pretrained=pre).to(device)
         out["parity"] = parity_eval(wl, states, device)
         del states, m0
+        # the other two model families of the hot path, initial weights, n = 1,000 impressions (BASELINE configs[0] size), in the SAME line
+        # the driver records (the full three-state tables of all models: bench.py --model NAML / LSTUR)
+        others = {}
+        for other in ('NRMS', 'NAML', 'LSTUR'):
+            if other == args.model:
+                continue
+            wo = Workload(other, make_cfg(other, shape, args.vocab))
+            mo = wo.make_model(seed=0).to(device)
+            pe = parity_eval(wo, {"init": mo}, device, n_news=2000, n_impr=1000)
+            others[other] = {"abs_diff_auc_n1000": pe["worst_abs_diff_auc_n1000"], "abs_diff_ndcg10_n1000": pe["worst_abs_diff_ndcg10_n1000"],
+                             "rms_logit_err": pe["states"]["init"]["rms_logit_err"], "logit_scale": pe["states"]["init"]["logit_scale"],
+                             "within_tolerance": pe["within_tolerance"]}
+            del mo, wo
+        out["parity_models"] = others
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, shape, args.vocab)
     else:

@@ -8,7 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 out = sys.argv[1]
-tags = {'mhsa_train': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2'), 'attn_bwd': ('nr_attn_bwd[S=20]', 'attn_bwd'), 'additive_bwd': ('nr_additive_bwd[S=20]', 'pool2_bwd')}
+tags = {'proj_train': ('nr_qkv_proj_fwd[S=20]', 'qkv_proj'), 'attn_fwd': ('nr_attn_fwd[S=20]', 'attn_fwd_kernel'), 'attn_bwd_hm': ('nr_attn_bwd[S=20]', 'attn_bwd'),
+        'additive_bwd': ('nr_additive_bwd[S=20]', 'pool2_bwd'), 'mhsa_infer': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2')}
+SRC = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r03_pmc_traffic.txt'
 
 
 def avg(d, sub, counter):
@@ -26,7 +28,7 @@ for tag, (name, sub) in tags.items():
     if f is None or w is None:
         print('missing', tag, f, w)
         continue
-    res[name] = {"fetch_kib_raw": f, "write_kib_raw": w, "bytes": int((2 * f + w) * 1024), "source": f"profiles/r02_pmc_traffic.txt",
+    res[name] = {"fetch_kib_raw": f, "write_kib_raw": w, "bytes": int((2 * f + w) * 1024), "source": SRC,
                  "source_hash": bench.kernel_source_hash(), "workload": "NRMS/small/B512"}
     print(f"{name}: FETCH_SIZE {f:.0f} KiB (x2 = {2 * f / 1e6:.3f} GB), WRITE_SIZE {w:.0f} KiB ({w * 1024 / 1e9:.3f} GB), total {(2 * f + w) * 1024 / 1e9:.3f} GB per launch")
 json.dump(res, open(os.path.join(ROOT, 'gpurun_out', os.path.basename(out.rstrip('/')), 'traffic.json'), 'w'), indent=1)
