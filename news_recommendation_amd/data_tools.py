@@ -16,8 +16,11 @@ What is pinned and what is not (tests/test_data_tools_cpu.py):
   * ``tokenize`` restates the published Penn-Treebank rules behind ``nltk.tokenize.word_tokenize`` (NLTK 3.x, unpinned in the
     reference's requirements.txt:5, not installed here).  NLTK first splits sentences with the Punkt model (a trained artefact that
     cannot be restated); here a sentence ends at ``.``, ``?`` or ``!`` followed by whitespace unless the token is a known abbreviation.
-    Token parity with NLTK is therefore UNPINNED; vocabularies built by this module are self-consistent (train / val / test use the
-    same function) but may differ from ones built with NLTK on titles containing unusual punctuation.
+    The Treebank word rules are PINNED against NLTK's own published known-answer vectors (13 doctest examples of
+    nltk/test/tokenize.doctest and the word_tokenize / TreebankWordTokenizer docstrings, tests/golden/data_tools/nltk_doctest_vectors.json,
+    tests/test_data_tools_cpu.py); the sentence split remains a restated heuristic, so vocabularies built by this module are
+    self-consistent (train / val / test use the same function) but may differ from ones built with NLTK on texts whose sentence
+    boundaries Punkt places differently (abbreviations it has learnt, ellipses).
 """
 import argparse
 import csv

@@ -77,3 +77,16 @@ def test_tokenize_treebank_rules():
     assert t('mr. smith went to the u.s. in 2019') == ['mr.', 'smith', 'went', 'to', 'the', 'u.s.', 'in', '2019']
     assert t('') == [] and t('   ') == []
     assert t('(really) -- cannot') == ['(', 'really', ')', '--', 'can', 'not']
+
+
+def test_tokenizer_reproduces_nltk_published_doctest_vectors():
+    """f4: the dependency-free tokeniser against NLTK's OWN published known-answer vectors (tokenize.doctest 'Tokenizing some test strings',
+    the word_tokenize / TreebankWordTokenizer docstrings; provenance in the fixture): contractions, currency, percent, times, quotes,
+    brackets, 'cannot', commas inside and after numbers, sentence-final periods of a multi-sentence text."""
+    import json
+    from news_recommendation_amd.data_tools import tokenize
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data_tools', 'nltk_doctest_vectors.json')) as f:
+        vec = json.load(f)
+    assert len(vec['word_tokenize']) >= 13
+    for text, want in vec['word_tokenize']:
+        assert tokenize(text) == want, text
