@@ -139,6 +139,12 @@ int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float
  * other padding 0 -- the operand of the weight-gradient GEMM dW = dqkv^T @ [X | 1]. */
 int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wp32, const float* bp, uint16_t* qkv,
                     uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+/* Input gradient of the three projections as a hand-written GEMM (autograd of multihead_self.py:53-55 w.r.t. its input, triggered at
+ * src/train.py:231): dX bf16[n_tok][NR_KP] = dqkv bf16[n_tok][NR_LDG] @ [Wq; Wk; Wv] (rows = the NR_LDG columns of dqkv, padding rows zero;
+ * columns >= D of dX come out as exact zeros).  WdX: the weights packed by nr_pack_qkv_dx, bf16[60][10][64][8]: block (k-step ks, column
+ * tile nt) = the 64 lanes' v_mfma_f32_32x32x16_bf16 fragments, lane l: Wall[16 ks + 8 (l >> 5) + j][32 nt + (l & 31)], j = 0..7. */
+int nr_pack_qkv_dx(const float* Wq, const float* Wk, const float* Wv, uint16_t* WdX, void* stream);
+int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t n_tok, void* stream);
 /* ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) from a head-major qkv buffer;
  * ctx as nr_mhsa_fwd writes it (second dropout of news_encoder.py:43-45 applied when p_drop > 0, column D = 1.0). */
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);

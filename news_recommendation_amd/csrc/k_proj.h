@@ -390,4 +390,120 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Input gradient of the three projections as a hand-written GEMM: dX[tok][n] = sum_k dqkv[tok][k] Wall[k][n], k = (which, feature) over the
+// 960 columns of the dQ | dK | dV rows, n < 320 (autograd of multihead_self.py:53-55 w.r.t. its input; the reference leaves it to
+// torch.autograd, src/train.py:231).  Accumulator-stationary: a wave owns 32 tokens x all 320 output columns (10 v_mfma_f32_32x32x16_bf16
+// tiles = 160 VGPRs); the contraction runs in 30 chunks of 32 columns: the token rows' 64-byte pieces and the 20 weight fragments of a
+// chunk are copied global -> LDS directly (global_load_lds_dwordx4, double buffered, one barrier per chunk); the token pieces are placed
+// with a 4-row XOR swizzle of their 16-byte slots so that the fragment reads are bank-conflict free; the result leaves through LDS as whole
+// 640-byte rows.
+constexpr int DXK = 3 * KP;                 // 960 contraction columns
+struct DxGeom {
+  static constexpr int NWAVE = 4;
+  static constexpr int TOKW = 32;
+  static constexpr int TOK_WG = NWAVE * TOKW;          // 128
+  static constexpr int KC = 2;                         // k-steps of 16 per chunk (32 columns = 64 bytes of a token row)
+  static constexpr int NCH = DXK / (16 * KC);          // 30
+  static constexpr int A_BYTES = TOK_WG * KC * 32;     // 8,192 B: 128 rows x 64 B
+  static constexpr int W_BYTES = KC * NT32 * 1024;     // 20,480 B: 20 fragments
+  static constexpr int BUF_BYTES = A_BYTES + W_BYTES;  // 28,672 B
+  static constexpr int OROW = 656;                     // bytes per staged output row
+  static constexpr int OUT_BYTES = NWAVE * 16 * OROW;  // 41,984 B: 16 rows per wave at a time
+  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 B (>= OUT_BYTES): two workgroups per CU
+  static_assert(SMEM >= OUT_BYTES, "epilogue staging fits the chunk buffers");
+};
+
+// packed operand of dx_gemm_kernel: WdX bf16 [60 k-steps][10 n-tiles][64 lanes][8]: lane l of block (ks, nt) holds
+// Wall[k = 16 ks + 8 (l >> 5) + j][n = 32 nt + (l & 31)], j = 0..7, Wall[which * KP + f][n] = W_which[f][n] (zero for f, n >= D)
+__global__ __launch_bounds__(256) void pack_qkv_dx_kernel(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                          u16* __restrict__ WdX) {
+  const int total = DXK * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i / KP, n = i - k * KP;
+    const int which = k / KP, f = k - which * KP;
+    const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
+    const float v = (f < D && n < D) ? W[f * D + n] : 0.0f;
+    const int ks = k >> 4, h = (k & 15) >> 3, j = k & 7, nt = n >> 5;
+    WdX[((size_t)(ks * NT32 + nt) * 64 + h * 32 + (n & 31)) * 8 + j] = f2bf(v);
+  }
+}
+
+struct DxParams {
+  const u16* dqkv;       // [n_tok][960] bf16 (padding columns zero)
+  const u16* WdX;        // packed (pack_qkv_dx_kernel)
+  u16* dX;               // [n_tok][KP] bf16: columns >= D come out as exact zeros
+  int64_t n_tok;
+};
+
+__global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
+  using Gm = DxGeom;
+  NR_SMEM_DECL(smem);
+  const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
+  const int64_t wg_tok0 = (int64_t)blockIdx.x * Gm::TOK_WG;
+  const int64_t tile_tok0 = wg_tok0 + w * Gm::TOKW;
+
+  // chunk c -> buffer b: this wave copies its own 32 token rows (2 instructions: 16 rows x 4 slots each) and 5 of the 20 weight fragments.
+  // Slot s of row r holds the row's 16-byte piece s ^ ((r >> 2) & 3).
+  auto fetch = [&](int c, int b) {
+    unsigned char* abuf = smem + b * Gm::BUF_BYTES;
+    unsigned char* wbuf = abuf + Gm::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = w * Gm::TOKW + i * 16 + (l >> 2), s = l & 3;
+      int64_t tok = wg_tok0 + r;
+      tok = tok < p.n_tok ? tok : p.n_tok - 1;                       // rows past the end repeat the last row (never stored)
+      const u16* src = p.dqkv + tok * DXK + c * (16 * Gm::KC) + ((s ^ ((r >> 2) & 3)) * 8);
+      NR_GLDS16(src, abuf + (w * Gm::TOKW + i * 16) * 64);
+    }
+    const u16* wsrc = p.WdX + (size_t)c * Gm::KC * NT32 * 512 + l * 8;
+    for (int f = w; f < Gm::KC * NT32; f += Gm::NWAVE) NR_GLDS16(wsrc + f * 512, wbuf + f * 1024);
+  };
+  fetch(0, 0);
+  f32x16 acc[NT32];
+#pragma unroll
+  for (int nt = 0; nt < NT32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+  __syncthreads();
+  const int arow = w * Gm::TOKW + li;
+  for (int c = 0; c < Gm::NCH; ++c) {
+    if (c + 1 < Gm::NCH) fetch(c + 1, (c + 1) & 1);
+    const unsigned char* abuf = smem + (c & 1) * Gm::BUF_BYTES;
+    const unsigned char* wbuf = abuf + Gm::A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < Gm::KC; ++ks) {
+      const u16x8 af = *(const u16x8*)(abuf + arow * 64 + (((ks * 2 + h) ^ ((arow >> 2) & 3)) * 16));
+#pragma unroll
+      for (int nt = 0; nt < NT32; ++nt) {
+        const u16x8 wf = *(const u16x8*)(wbuf + (ks * NT32 + nt) * 1024 + l * 16);
+        acc[nt] = mfma_32x32x16_bf16(wf, af, acc[nt]);               // C[n][token]: the lane holds 4 x 4 consecutive columns of ITS token's row
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: 16 token rows per wave at a time through LDS, each batch leaves as 16 x 640 contiguous bytes ---------------------------
+  unsigned char* ost = smem + w * 16 * Gm::OROW;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((li >> 4) == half) {
+      unsigned char* row = ost + (li & 15) * Gm::OROW;
+#pragma unroll
+      for (int nt = 0; nt < NT32; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(u16x4*)(row + (nt * 32 + 8 * q + 4 * h) * 2) = pack4(f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]});
+    }
+    wave_barrier();
+    const int64_t t0 = tile_tok0 + half * 16;
+#pragma unroll
+    for (int i = 0; i < 16 * (KP / 8) / 64; ++i) {
+      const int idx = l + 64 * i;
+      const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
+      if (t0 + r < p.n_tok) *(u16x8*)(p.dX + t0 * KP + idx * 8) = *(const u16x8*)(ost + r * Gm::OROW + pc * 16);
+    }
+    wave_barrier();
+  }
+}
+
 }  // namespace nr

@@ -421,6 +421,23 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
   return check_launch("nr_qkv_proj_fwd");
 }
 
+int nr_pack_qkv_dx(const float* Wq, const float* Wk, const float* Wv, uint16_t* WdX, void* stream) {
+  if (!Wq || !Wk || !Wv || !WdX) return fail(NR_ERR_BADARG, "nr_pack_qkv_dx: null pointer");
+  NR_LAUNCH(nr::pack_qkv_dx_kernel, 256, 256, 0, (hipStream_t)stream, Wq, Wk, Wv, WdX);
+  return check_launch("nr_pack_qkv_dx");
+}
+
+int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t n_tok, void* stream) {
+  if (!dqkv || !WdX || !dX || n_tok < 0) return fail(NR_ERR_BADARG, "nr_dx_gemm: bad argument");
+  if ((((uintptr_t)dqkv | (uintptr_t)WdX | (uintptr_t)dX) & 15) != 0) return fail(NR_ERR_BADARG, "nr_dx_gemm: buffers must be 16-byte aligned");
+  if (n_tok == 0) return NR_OK;
+  nr::DxParams p;
+  p.dqkv = dqkv; p.WdX = WdX; p.dX = dX; p.n_tok = n_tok;
+  using G = nr::DxGeom;
+  NR_LAUNCH(nr::dx_gemm_kernel, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
+  return check_launch("nr_dx_gemm");
+}
+
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
   if (!qkv || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_attn_fwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_fwd: dropout probability out of range");

@@ -318,6 +318,16 @@ def pack_qkv32(Wq, bq, Wk, bk, Wv, bv):
     return _packed('qkv32', (Wq, bq, Wk, bk, Wv, bv), build)
 
 
+def pack_qkv_dx(Wq, Wk, Wv):
+    """[Wq; Wk; Wv] as the fragment-ordered operand of nr_dx_gemm (include/nr_engine.h)."""
+    def build():
+        WdX = torch.empty(60 * 10 * 64 * 8, dtype=_BF16_AS_I16, device=Wq.device)
+        args = [_f32c(t) for t in (Wq, Wk, Wv)]
+        _call('nr_pack_qkv_dx', _lib().nr_pack_qkv_dx, *[_ptr(a) for a in args], _ptr(WdX), _stream())
+        return WdX
+    return _packed('qkv_dx', (Wq, Wk, Wv), build)
+
+
 def pack_additive(Wa, ba, qv):
     def build():
         dev = Wa.device
@@ -430,6 +440,10 @@ def inplace_grads(params):
 # NR_FWD_SPLIT: 1 (default) = title encoders that need gradients run nr_qkv_proj_fwd + nr_attn_fwd (csrc/k_proj.h) instead of the
 # register-resident nr_mhsa_fwd kernel; 2 = inference too; 0 = never (A/B)
 _FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
+
+# NR_DX_GEMM: 1 = the input gradient dX = dqkv @ [Wq; Wk; Wv] runs in the hand-written kernel (nr_dx_gemm, csrc/k_proj.h); 0 (default) = in
+# hipBLASLt through torch: measured side by side in profiles/r03_ab_switches.txt -- the library call stays where it is the faster one
+_DX_GEMM = int(os.environ.get('NR_DX_GEMM', '0'))
 
 _ws = {}
 _side = {}
@@ -619,7 +633,9 @@ class _EncoderFn(torch.autograd.Function):
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
         WaT = pack_additive_t(Wa) if need_grad else None
-        WpT = pack_qkv_t(Wq, bq, Wk, bk, Wv, bv) if need_grad else None
+        WpT = None
+        if need_grad:
+            WpT = pack_qkv_dx(Wq, Wk, Wv) if _DX_GEMM else pack_qkv_t(Wq, bq, Wk, bk, Wv, bv)
         if split:
             qs = torch.empty(n_seq * NR_QKV_HM_SEQ, dtype=_BF16_AS_I16, device=dev)      # head-major Q | K | V^T
             ks = vts = None
@@ -697,7 +713,11 @@ class _EncoderFn(torch.autograd.Function):
         dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))    # [nc, 960, KP]
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
-        dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
+        if _DX_GEMM:
+            dX = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
+            _call(f'nr_dx_gemm[S={S}]', lib.nr_dx_gemm, _ptr(dqkv), _ptr(WpT), _ptr(dX), ntok, _stream())
+        else:
+            dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:

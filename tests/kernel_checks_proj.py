@@ -186,6 +186,29 @@ def check_attn_bwd_hm(be, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
     assert be.np(ref).any()
 
 
+def check_dx_gemm(be, n_tok=300, seed=31):
+    """nr_dx_gemm == bf16(dqkv) @ bf16([Wq; Wk; Wv]) with fp32 accumulation, rounded to bf16; padding columns exact zeros."""
+    params = kc.make_params(9)
+    rng = np.random.default_rng(seed)
+    m = 'news_encoder.multihead_self_attention.'
+    Ws = [params[m + n + '.weight'] for n in ('W_Q', 'W_K', 'W_V')]
+    WdX = be.poison((60 * 10 * 64 * 8,), np.uint16)
+    kc.ck(be, be.lib.nr_pack_qkv_dx(*[be.ptr(be.dev(W)) for W in Ws], be.ptr(WdX), be.stream))
+    dq = np.zeros((n_tok, NR_LDG), dtype=np.float32)
+    for i in range(3):
+        dq[:, i * NR_KP:i * NR_KP + NR_D] = rng.normal(0, 0.3, size=(n_tok, NR_D))
+    dq_u = f32_to_bf16(dq)
+    dX = be.poison((n_tok, NR_KP), np.uint16)
+    kc.ck(be, be.lib.nr_dx_gemm(be.ptr(be.dev(dq_u)), be.ptr(WdX), be.ptr(dX), n_tok, be.stream))
+    be.sync()
+    got = be.np(dX)
+    ref = sum(bf16_to_f32(dq_u[:, i * NR_KP:i * NR_KP + NR_D]).astype(np.float64) @ bf16_round(Ws[i]).astype(np.float64) for i in range(3))
+    kc.close_bf16(bf16_to_f32(got[:, :NR_D]), ref, 'dx_gemm', rel=2.0 ** -7, floor=1e-3)
+    assert not got[:, NR_D:].any(), 'padding columns of dX must be exact zeros'
+    assert be.lib.nr_dx_gemm(None, be.ptr(WdX), be.ptr(dX), n_tok, be.stream) != 0 and b'nr_dx_gemm' in be.lib.nr_last_error()
+    assert be.lib.nr_dx_gemm(be.ptr(dX), be.ptr(WdX), be.ptr(dX), 0, be.stream) == 0
+
+
 def check_proj_bad_args(be):
     a = be.empty((64,), np.float32)
     pa = be.ptr(a)

@@ -51,6 +51,12 @@ def test_attn_bwd_hm(be):
     kp.check_attn_bwd_hm(be, n_seq=700, p_drop=0.2, with_key_len=True)
 
 
+def test_dx_gemm(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_dx_gemm(be, n_tok=300)
+    kp.check_dx_gemm(be, n_tok=20000 + 77, seed=32)
+
+
 def test_proj_bad_args(be):
     from tests import kernel_checks_proj as kp
     kp.check_proj_bad_args(be)

@@ -37,6 +37,17 @@ dctx = torch.randn(ntok, NR_KP, generator=g).mul_(0.05).to(torch.bfloat16).to(de
 aw = torch.full((T, 20), 0.05, device=dev); go = torch.randn(T, NR_D, generator=g).to(dev)
 dqkv = torch.zeros(ntok, NR_LDG, dtype=torch.int16, device=dev)
 p = 0.2
+WdX = torch.empty(60 * 10 * 64 * 8, dtype=torch.int16, device=dev)
+ck(lib.nr_pack_qkv_dx(W[0].data_ptr(), W[1].data_ptr(), W[2].data_ptr(), WdX.data_ptr(), st()))
+Wall = torch.zeros(NR_LDG, NR_KP, device=dev)
+for i in range(3):
+    Wall[i * NR_KP:i * NR_KP + 300, :300] = W[i]
+WpT = Wall.to(torch.bfloat16).t().contiguous()                       # [KP, 960]: the operand form ops.pack_qkv_t hands to hipBLASLt
+dqkv_r = torch.zeros(ntok, NR_LDG, device=dev)
+for i in range(3):
+    dqkv_r[:, i * NR_KP:i * NR_KP + 300] = torch.randn(ntok, 300, device=dev) * 0.1
+dqkv_b = dqkv_r.to(torch.bfloat16); del dqkv_r
+dX_hand = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
 kern = {
   'pack_qkv32': lambda: ck(lib.nr_pack_qkv32(*wargs, Wp32.data_ptr(), bp32.data_ptr(), st())),
   'proj_train(x_save,drop)': lambda: ck(lib.nr_qkv_proj_fwd(ids.data_ptr(), table.data_ptr(), V, Wp32.data_ptr(), bp32.data_ptr(), qkv.data_ptr(), xs.data_ptr(), T, 20, p, 1, st())),
@@ -47,6 +58,8 @@ kern = {
   'mhsa_fwd2_train(drop)': lambda: ck(lib.nr_mhsa_fwd_len(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), xs.data_ptr(), None, T, 20, p, 1, st())),
   'mhsa_fwd2_infer': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), None, None, None, T, 20, 0.0, 0, st())),
   'attn_bwd_rowmajor': lambda: ck(lib.nr_attn_bwd_len(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_KP, aw.data_ptr(), go.data_ptr(), dqkv.data_ptr(), None, T, 20, p, 1, st())),
+  'dX_gemm_hand': lambda: ck(lib.nr_dx_gemm(dqkv_b.data_ptr(), WdX.data_ptr(), dX_hand.data_ptr(), ntok, st())),
+  'dX_gemm_hipblaslt': lambda: torch.nn.functional.linear(dqkv_b, WpT),
   'attn_bwd_hm': lambda: ck(lib.nr_attn_bwd_hm(qkv.data_ptr(), dctx.data_ptr(), NR_KP, aw.data_ptr(), go.data_ptr(), dqkv.data_ptr(), None, T, 20, p, 1, st())),
 }
 only = os.environ.get('KB_ONLY')
@@ -63,6 +76,11 @@ for name, fn in kern.items():
     e1.record(); torch.cuda.synchronize()
     res[name] = e0.elapsed_time(e1) / n * 1e3
     print(f'{name:28s} {res[name]:10.1f} us', flush=True)
+if 'dX_gemm_hand' in res and 'dX_gemm_hipblaslt' in res:
+    ref = torch.nn.functional.linear(dqkv_b, WpT).float()
+    err = (dX_hand.float() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'dX hand vs hipBLASLt: max rel diff {err:.3g}; TFLOP/s (algorithmic 2*900*300 per token): hand {ntok * 2 * 900 * 300 / res["dX_gemm_hand"] / 1e6:.0f}, '
+          f'hipBLASLt {ntok * 2 * 900 * 300 / res["dX_gemm_hipblaslt"] / 1e6:.0f}')
 flop_proj = ntok * 2 * 300 * 900
 out = {'B': B, 'us': res, 'env': {k: v for k, v in os.environ.items() if k.startswith('NR_')}}
 for k in res:
