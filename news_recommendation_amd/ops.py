@@ -441,9 +441,10 @@ def inplace_grads(params):
 # register-resident nr_mhsa_fwd kernel; 2 = inference too; 0 = never (A/B)
 _FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
 
-# NR_DX_GEMM: 1 = the input gradient dX = dqkv @ [Wq; Wk; Wv] runs in the hand-written kernel (nr_dx_gemm, csrc/k_proj.h); 0 (default) = in
-# hipBLASLt through torch: measured side by side in profiles/r03_ab_switches.txt -- the library call stays where it is the faster one
-_DX_GEMM = int(os.environ.get('NR_DX_GEMM', '0'))
+# NR_DX_GEMM: 1 (default) = the input gradient dX = dqkv @ [Wq; Wk; Wv] runs in the hand-written kernel (nr_dx_gemm, csrc/k_proj.h); 0 = in
+# hipBLASLt through torch.  Measured side by side on one MI355X (profiles/r03_ab_switches.txt): 365 vs 462 us inside the NRMS step at B = 512,
+# bit-identical results
+_DX_GEMM = int(os.environ.get('NR_DX_GEMM', '1'))
 
 _ws = {}
 _side = {}
