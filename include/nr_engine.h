@@ -145,6 +145,13 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
  * tile nt) = the 64 lanes' v_mfma_f32_32x32x16_bf16 fragments, lane l: Wall[16 ks + 8 (l >> 5) + j][32 nt + (l & 31)], j = 0..7. */
 int nr_pack_qkv_dx(const float* Wq, const float* Wk, const float* Wv, uint16_t* WdX, void* stream);
 int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t n_tok, void* stream);
+/* Weight (and bias) gradients of a linear layer as a hand-written split-K "TN" GEMM (autograd of multihead_self.py:53-55 / additive.py:35
+ * w.r.t. weight and bias; src/train.py:231): out f32[P][M][NR_KP], out[p][m][n] = sum over the tokens of partition p of G[tok][m] * X[tok][n];
+ * the sum over p is the gradient (nr_wgrad_unpack reduces the partitions in a fixed order).  G bf16[n_tok][ldg] (dqkv with M = NR_LDG, dpre
+ * with M = NR_QP), X bf16[n_tok][NR_KP] (column D = 1.0: row D of the result is the bias gradient), zeros: 16 zero bytes in device memory.
+ * P: a multiple of 8; nr_tn_gemm_parts(M, n_tok) gives the library's choice (enough workgroups for two per CU). */
+int nr_tn_gemm_parts(int M, int64_t n_tok);
+int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream);
 /* ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) from a head-major qkv buffer;
  * ctx as nr_mhsa_fwd writes it (second dropout of news_encoder.py:43-45 applied when p_drop > 0, column D = 1.0). */
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);

@@ -506,4 +506,116 @@ __global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradients as a hand-written "TN" GEMM with split K: out[part][m][n] = sum over the partition's tokens of G[tok][m] X[tok][n]
+// (autograd of the nn.Linear layers w.r.t. weight and bias -- multihead_self.py:53-55 with G = dqkv [tok][960], X = the masked token matrix
+// [tok][320] whose column D is 1.0 (bias gradient); additive.py:35 with G = dpre [tok][208], X = ctx).  Both operands are token-major, i.e. the
+// contraction index runs along the ROWS of both: the MFMA fragments (8 consecutive tokens of one column per lane) are taken from row-major
+// LDS tiles with the transposing LDS read ds_read_b64_tr_b16 (lds_tr16_b64) -- no transposed copy of either operand exists anywhere.
+//   workgroup = a 128-row slab of the output (one 32-row tile per wave) x all 320 columns (160 accumulator VGPRs per wave) x one partition
+//   of the tokens, walked in chunks of 32 tokens; G [32][128] and X [32][320] of a chunk arrive by LDS-DMA (double buffered, one barrier per
+//   chunk) with their 16-byte slots XOR-swizzled per row so that the four token rows a transposing read touches sit in different banks;
+//   the slabs of one partition run on one XCD (block id -> (xcd, slab, partition)), so that X comes from HBM once.
+// The fp32 partials [P][M][320] are what nr_wgrad_unpack reduces in a fixed order (deterministic, no atomics).
+struct TnGeom {
+  static constexpr int NWAVE = 4;
+  static constexpr int BM = NWAVE * 32;                // 128 output rows per workgroup
+  static constexpr int TC = 32;                        // tokens per chunk (2 k-steps of 16)
+  static constexpr int G_BYTES = TC * BM * 2;          // 8,192
+  static constexpr int X_BYTES = TC * KP * 2;          // 20,480
+  static constexpr int BUF_BYTES = G_BYTES + X_BYTES;
+  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 B: two workgroups per CU
+};
+
+struct TnParams {
+  const u16* G;          // [n_tok][ldg] bf16
+  int ldg;               // row stride of G in elements (multiple of 8)
+  int M;                 // output rows = columns of G used (<= ldg)
+  const u16* X;          // [n_tok][KP] bf16
+  const u16* zeros;      // >= 16 zero bytes: what lanes beyond a partition's tokens / G's columns copy
+  float* out;            // [P][M][KP] fp32 partial products
+  int64_t n_tok;
+  int P;                 // token partitions (multiple of 8)
+  int nslab;             // ceil(M / 128)
+  int64_t tok_per_part;  // multiple of 32
+};
+
+__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(TnParams p) {
+  using Gm = TnGeom;
+  NR_SMEM_DECL(smem);
+  const int l = lane_id(), w = wave_id(), h = l >> 5;
+  // block id -> (xcd, slab, partition): ids that differ by a multiple of 8 share an XCD (round-robin dispatch); the slabs of a partition get
+  // consecutive such ids, run side by side on that XCD and find each other's X chunks in its L2
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slab = j % p.nslab, part = (j / p.nslab) * 8 + xcd;
+  const int64_t t_begin = (int64_t)part * p.tok_per_part;
+  int64_t t_end = t_begin + p.tok_per_part;
+  t_end = t_end < p.n_tok ? t_end : p.n_tok;
+  const int nchunk = t_end > t_begin ? (int)((t_end - t_begin + Gm::TC - 1) / Gm::TC) : 0;
+
+  auto fetch = [&](int c, int b) {
+    unsigned char* gbuf = smem + b * Gm::BUF_BYTES;
+    unsigned char* xbuf = gbuf + Gm::G_BYTES;
+    const int64_t tok0 = t_begin + (int64_t)c * Gm::TC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                              // G: 32 rows x 16 slots; this wave copies rows 8 w + 4 i .. + 3
+      const int r = w * 8 + i * 4 + (l >> 4), s = l & 15;
+      const int col = slab * Gm::BM + ((s ^ (4 * (r & 3))) * 8);
+      const u16* src = (tok0 + r < t_end && col < p.ldg) ? p.G + (tok0 + r) * p.ldg + col : p.zeros;
+      NR_GLDS16(src, gbuf + (w * 8 + i * 4) * 256);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {                              // X: 32 rows x 40 slots = 20 blocks of 64 slots; this wave copies blocks 5 w .. 5 w + 4
+      const int gs = (w * 5 + i) * 64 + l;
+      const int r = gs / 40, s = gs - r * 40;
+      const u16* src = tok0 + r < t_end ? p.X + (tok0 + r) * KP + ((s ^ (4 * ((r >> 1) & 1))) * 8) : p.zeros;
+      NR_GLDS16(src, xbuf + (w * 5 + i) * 1024);
+    }
+  };
+  f32x16 acc[NT32];
+#pragma unroll
+  for (int nt = 0; nt < NT32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+  if (nchunk > 0) fetch(0, 0);
+  __syncthreads();
+  // per-lane geometry of the transposing reads: the lane supplies the piece (row k0 + (l & 15) / 4, columns n0 + 4 (l & 3) .. + 3) of the
+  // 4 x 16 block its 16-lane group transposes, and receives column n0 + (l & 15), rows k0 .. k0 + 3
+  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) fetch(c + 1, (c + 1) & 1);
+    const unsigned char* gbuf = smem + (c & 1) * Gm::BUF_BYTES;
+    const unsigned char* xbuf = gbuf + Gm::G_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u16x4 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * w + pcol;
+        a[t] = lds_tr16_b64((const u16*)(gbuf + (row * 16 + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
+      }
+      const u16x8 af = cat8(a[0], a[1]);
+#pragma unroll
+      for (int nt = 0; nt < NT32; ++nt) {
+        u16x4 b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * nt + pcol;
+          b[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
+        }
+        acc[nt] = mfma_32x32x16_bf16(af, cat8(b[0], b[1]), acc[nt]);       // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
+      }
+    }
+    __syncthreads();
+  }
+  float* obase = p.out + ((size_t)part * p.M + slab * Gm::BM + 32 * w) * KP + (l & 31);
+#pragma unroll
+  for (int nt = 0; nt < NT32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (slab * Gm::BM + 32 * w + m < p.M) obase[(size_t)m * KP + nt * 32] = acc[nt][r];
+    }
+}
+
 }  // namespace nr

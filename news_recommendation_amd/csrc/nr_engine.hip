@@ -438,6 +438,30 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
   return check_launch("nr_dx_gemm");
 }
 
+int nr_tn_gemm_parts(int M, int64_t n_tok) {
+  if (M <= 0 || n_tok < 0) return -1;
+  // enough workgroups for two per CU (one per CU for narrow outputs, whose partials would otherwise outweigh the operands): partitions x
+  // slabs ~ 512 / 256, partitions a multiple of 8, at least one 32-token chunk each when possible
+  const int nslab = (M + nr::TnGeom::BM - 1) / nr::TnGeom::BM;
+  int P = ((nslab >= 4 ? 512 : 256) + nslab - 1) / nslab;
+  P = (P + 7) / 8 * 8;
+  const int64_t maxp = (n_tok + 31) / 32;
+  while (P > 8 && P > maxp) P -= 8;
+  return P;
+}
+
+int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream) {
+  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || n_tok < 0 || P <= 0 || (P & 7))
+    return fail(NR_ERR_BADARG, "nr_tn_gemm: bad argument");
+  if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)zeros) & 15) != 0) return fail(NR_ERR_BADARG, "nr_tn_gemm: operands must be 16-byte aligned");
+  nr::TnParams p;
+  p.G = G; p.ldg = ldg; p.M = M; p.X = X; p.zeros = zeros; p.out = out; p.n_tok = n_tok; p.P = P;
+  p.nslab = (M + nr::TnGeom::BM - 1) / nr::TnGeom::BM;
+  p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32;
+  NR_LAUNCH(nr::tn_gemm_kernel, (int64_t)P * p.nslab, 256, nr::TnGeom::SMEM, (hipStream_t)stream, p);
+  return check_launch("nr_tn_gemm");
+}
+
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
   if (!qkv || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_attn_fwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_fwd: dropout probability out of range");

@@ -412,6 +412,25 @@ def _wgrad_parts(a, b, name):
     return _timed(name, run)
 
 
+# NR_WGRAD_GEMM: 1 (default) = the weight-gradient products dqkv^T @ [X | 1] and dpre^T @ [ctx | 1] of the NRMS encoders run in the hand-written
+# split-K kernel nr_tn_gemm (csrc/k_proj.h: transposing LDS reads, no transposed operand copies); 0 = chunked hipBLASLt batched GEMMs
+_WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '1'))
+_zeros16 = {}
+
+
+def _wgrad_parts_hand(G, M, X, name):
+    """G^T @ X for bf16 (int16-typed) G [n, ldg >= M], X [n, KP]: fp32 partial products [P, M, KP] over P token partitions."""
+    lib = _lib()
+    n, ldg = G.shape
+    P = lib.nr_tn_gemm_parts(M, n)
+    out = torch.empty(P, M, NR_KP, dtype=torch.float32, device=G.device)
+    z = _zeros16.get(G.device)
+    if z is None:
+        z = _zeros16[G.device] = torch.zeros(64, dtype=_BF16_AS_I16, device=G.device)
+    _call(name, lib.nr_tn_gemm, _ptr(G), ldg, M, _ptr(X), _ptr(z), _ptr(out), n, P, _stream())
+    return out
+
+
 def _wgrad(a, b, name):
     """a^T @ b with fp32 result (chunk partials summed in fp32)."""
     parts = _wgrad_parts(a, b, name)
@@ -699,7 +718,10 @@ class _EncoderFn(torch.autograd.Function):
         sw = side_wgrad(dev)
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))   # [nc, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        if _WGRAD_GEMM:
+            dWa_parts = _wgrad_parts_hand(dpre, NR_QP, cbuf, f'nr_tn_gemm_dWa[S={S}]')    # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        else:
+            dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         if split:
@@ -711,7 +733,10 @@ class _EncoderFn(torch.autograd.Function):
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)
-        dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))    # [nc, 960, KP]
+        if _WGRAD_GEMM:
+            dW_parts = _wgrad_parts_hand(dqkv, NR_LDG, Xb, f'nr_tn_gemm_dWqkv[S={S}]')     # [P, 960, KP]
+        else:
+            dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
         if _DX_GEMM:

@@ -2,7 +2,7 @@
 nr_attn_bwd_hm against the numpy oracle and against the register-resident kernels they replace in training."""
 import numpy as np
 
-from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_HEADS, NR_LDG, NR_QKV_HM_SEQ, NR_K16
+from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_QP, NR_HEADS, NR_LDG, NR_QKV_HM_SEQ, NR_K16
 from tests.backends import bf16_to_f32, f32_to_bf16, bf16_round
 from tests import kernel_checks as kc
 
@@ -207,6 +207,35 @@ def check_dx_gemm(be, n_tok=300, seed=31):
     assert not got[:, NR_D:].any(), 'padding columns of dX must be exact zeros'
     assert be.lib.nr_dx_gemm(None, be.ptr(WdX), be.ptr(dX), n_tok, be.stream) != 0 and b'nr_dx_gemm' in be.lib.nr_last_error()
     assert be.lib.nr_dx_gemm(be.ptr(dX), be.ptr(WdX), be.ptr(dX), 0, be.stream) == 0
+
+
+def check_tn_gemm(be, n_tok=300, M=NR_LDG, ldg=None, seed=41, P=None):
+    """nr_tn_gemm: sum over the partitions of out[p] == G^T X (bf16 operands, fp32 accumulation); every partition is written (empty ones
+    as zeros); rows >= M untouched."""
+    ldg = M if ldg is None else ldg
+    rng = np.random.default_rng(seed)
+    G = f32_to_bf16(rng.normal(0, 0.5, size=(n_tok, ldg)).astype(np.float32))
+    X = f32_to_bf16(rng.normal(0, 0.5, size=(n_tok, NR_KP)).astype(np.float32))
+    X[:, NR_D] = 0x3F80
+    P = be.lib.nr_tn_gemm_parts(M, n_tok) if P is None else P
+    assert P > 0 and P % 8 == 0
+    out = be.poison((P, M, NR_KP), np.float32)
+    zeros = be.empty((64,), np.uint16)
+    kc.ck(be, be.lib.nr_tn_gemm(be.ptr(be.dev(G)), ldg, M, be.ptr(be.dev(X)), be.ptr(zeros), be.ptr(out), n_tok, P, be.stream))
+    be.sync()
+    got = be.np(out).astype(np.float64)
+    assert np.isfinite(got).all()
+    ref = bf16_to_f32(G[:, :M]).astype(np.float64).T @ bf16_to_f32(X).astype(np.float64)
+    np.testing.assert_allclose(got.sum(0), ref, rtol=0, atol=2e-4 * np.sqrt(n_tok) * 0.25 + 1e-5)
+    # partition p covers tokens [p * tpp, (p + 1) * tpp): check one partition on its own
+    tpp = ((n_tok + P - 1) // P + 31) // 32 * 32
+    lo, hi = 0, min(tpp, n_tok)
+    ref0 = bf16_to_f32(G[lo:hi, :M]).astype(np.float64).T @ bf16_to_f32(X[lo:hi]).astype(np.float64)
+    np.testing.assert_allclose(got[0], ref0, rtol=0, atol=1e-4 * np.sqrt(hi - lo) + 1e-5)
+    if (P - 1) * tpp >= n_tok:
+        assert not got[P - 1].any(), 'an empty partition must be written as zeros'
+    assert be.lib.nr_tn_gemm(None, ldg, M, be.ptr(zeros), be.ptr(zeros), be.ptr(out), n_tok, P, be.stream) != 0 and b'nr_tn_gemm' in be.lib.nr_last_error()
+    assert be.lib.nr_tn_gemm(be.ptr(zeros), ldg, M, be.ptr(zeros), be.ptr(zeros), be.ptr(out), n_tok, 12, be.stream) != 0      # P not a multiple of 8
 
 
 def check_proj_bad_args(be):

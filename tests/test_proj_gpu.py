@@ -57,6 +57,14 @@ def test_dx_gemm(be):
     kp.check_dx_gemm(be, n_tok=20000 + 77, seed=32)
 
 
+def test_tn_gemm(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_tn_gemm(be, n_tok=300, M=960, P=8)
+    kp.check_tn_gemm(be, n_tok=77, M=208, P=8)
+    kp.check_tn_gemm(be, n_tok=40000 + 60, M=960, seed=42)          # the library's partition count: 64 partitions x 8 slabs
+    kp.check_tn_gemm(be, n_tok=40000 + 60, M=208, seed=43)
+
+
 def test_proj_bad_args(be):
     from tests import kernel_checks_proj as kp
     kp.check_proj_bad_args(be)
