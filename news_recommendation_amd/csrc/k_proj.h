@@ -81,7 +81,8 @@ struct ProjGeom {
   static constexpr int NCHUNK = 3 * NT32;            // 30
   static constexpr int QPR = D / 4;                  // 75 float4 quads per table row
   static constexpr int LD_IT = (RP * QPR + 63) / 64; // 10 row pieces per lane and pass
-  static constexpr int WO_IT = (PG_HEADS * TOKW * (DK / 4) + 63) / 64;   // 8 eight-byte pieces per lane and column group
+  static constexpr int WO_PC = TOKW * DK * 2 / 16;   // 80 sixteen-byte pieces per head of a column group
+  static constexpr int WO_IT = (PG_HEADS * WO_PC + 63) / 64;            // 4 sixteen-byte pieces per lane and column group
   static_assert(STAGE_BYTES >= RP * XROW && 3 * SMEM <= 163840, "the gather tile fits the epilogue staging; three workgroups per CU");
 };
 
@@ -179,17 +180,19 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   }
   __syncthreads();
 
-  // write-out geometry of a column group (fixed per lane): piece idx = l + 64 i of [3 heads][32 tokens][5 quads]
+  // write-out geometry of a column group (fixed per lane): 16-byte piece idx = l + 64 i of [3 heads][32 tokens x 40 B].  A wave's 32 tokens
+  // start at an even position of their title (32 k mod 20 is even) and title fragments hold an even number of tokens, so every fragment
+  // starts on a 16-byte boundary of its head-major block and is a whole number of pieces: a piece may span two token rows, never two titles
   int wo_off[Gm::WO_IT];           // element offset inside qkv relative to the wave's first title, -1: nothing to write
   const int64_t seq_base = tile_tok0 / S;
 #pragma unroll
   for (int i = 0; i < Gm::WO_IT; ++i) {
     const int idx = l + 64 * i;
-    const int hh = idx / (Gm::TOKW * 5), pc = idx - hh * (Gm::TOKW * 5);
-    const int t = pc / 5, dq = pc - t * 5;
+    const int hh = idx / Gm::WO_PC, pc = idx - hh * Gm::WO_PC;
+    const int t = (2 * pc) / 5, e = 8 * pc - DK * t;            // first token the piece touches, element offset inside its row
     const int64_t tok = tile_tok0 + t;
     const int sq = (int)(tok / S - seq_base), tis = (int)(tok % S);
-    wo_off[i] = (idx < PG_HEADS * Gm::TOKW * 5 && tok < p.n_tok) ? (sq * H + hh) * HM_PAIR + tis * DK + dq * 4 : -1;
+    wo_off[i] = (idx < PG_HEADS * Gm::WO_PC && tok < p.n_tok) ? (sq * H + hh) * HM_PAIR + tis * DK + e : -1;
   }
   u16* const qkv_wave = p.qkv + seq_base * (H * HM_PAIR);
 
@@ -208,11 +211,18 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
     for (int k = 0; k < KSPLIT; ++k)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+    // weight fragments are requested PF k-steps ahead of their MFMA (the compiler's own schedule: two reads, wait, two MFMAs); the bias
+    // request above is pinned in front of them (left alone, the scheduler sank it to the end of the chain and waited for it there)
+    constexpr int PF = KSPLIT > 1 ? 4 : 6;
+    u16x8 wf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) wf[i] = *(const u16x8*)(wp + i * 512);
+    NR_SCHED_BARRIER();
 #pragma unroll
     for (int ks = (dbg & 2) ? K16 : 0; ks < K16; ++ks) {
-      const u16x8 wf = *(const u16x8*)(wp + ks * 512);
       f32x16& a = acc[ks % KSPLIT];
-      a = mfma_32x32x16_bf16(wf, xf[ks], a);
+      a = mfma_32x32x16_bf16(wf[ks % PF], xf[ks], a);
+      if (ks + PF < K16) wf[ks % PF] = *(const u16x8*)(wp + (ks + PF) * 512);
     }
     if (KSPLIT > 1) {
 #pragma unroll
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
         u16* dst = qkv_wave + (j * PG_HEADS * 3 + which) * HM_BLK;
 #pragma unroll
         for (int i = 0; i < Gm::WO_IT; ++i)
-          if (wo_off[i] >= 0) *(u16x4*)(dst + wo_off[i]) = *(const u16x4*)(stage + (l + 64 * i) * 8);
+          if (wo_off[i] >= 0) *(u16x8*)(dst + wo_off[i]) = *(const u16x8*)(stage + (l + 64 * i) * 16);
       }
     }
     __syncthreads();       // drains the in-flight global->LDS copies of chunk c + 1; everybody is done reading chunk c's buffer (and its staging tile)
@@ -471,14 +481,23 @@ __global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
     if (c + 1 < Gm::NCH) fetch(c + 1, (c + 1) & 1);
     const unsigned char* abuf = smem + (c & 1) * Gm::BUF_BYTES;
     const unsigned char* wbuf = abuf + Gm::A_BYTES;
+    // all ten weight fragments of a k-step are requested before its first MFMA and refilled for the next k-step as they are consumed
+    // (the compiler's own schedule was "two reads, wait, two MFMAs": an LDS round trip exposed every 64 MFMA cycles)
+    u16x8 wf[NT32];
+#pragma unroll
+    for (int nt = 0; nt < NT32; ++nt) wf[nt] = *(const u16x8*)(wbuf + nt * 1024 + l * 16);
+    u16x8 af = *(const u16x8*)(abuf + arow * 64 + ((h ^ ((arow >> 2) & 3)) * 16));
+    NR_SCHED_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < Gm::KC; ++ks) {
-      const u16x8 af = *(const u16x8*)(abuf + arow * 64 + (((ks * 2 + h) ^ ((arow >> 2) & 3)) * 16));
+      u16x8 afn = af;
+      if (ks + 1 < Gm::KC) afn = *(const u16x8*)(abuf + arow * 64 + ((((ks + 1) * 2 + h) ^ ((arow >> 2) & 3)) * 16));
 #pragma unroll
       for (int nt = 0; nt < NT32; ++nt) {
-        const u16x8 wf = *(const u16x8*)(wbuf + (ks * NT32 + nt) * 1024 + l * 16);
-        acc[nt] = mfma_32x32x16_bf16(wf, af, acc[nt]);               // C[n][token]: the lane holds 4 x 4 consecutive columns of ITS token's row
+        acc[nt] = mfma_32x32x16_bf16(wf[nt], af, acc[nt]);           // C[n][token]: the lane holds 4 x 4 consecutive columns of ITS token's row
+        if (ks + 1 < Gm::KC) wf[nt] = *(const u16x8*)(wbuf + ((ks + 1) * NT32 + nt) * 1024 + l * 16);
       }
+      af = afn;
     }
     __syncthreads();
   }
@@ -586,25 +605,36 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(TnParams p) {
     if (c + 1 < nchunk) fetch(c + 1, (c + 1) & 1);
     const unsigned char* gbuf = smem + (c & 1) * Gm::BUF_BYTES;
     const unsigned char* xbuf = gbuf + Gm::G_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    auto read_a = [&](int ks) -> u16x8 {
       u16x4 a[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * w + pcol;
         a[t] = lds_tr16_b64((const u16*)(gbuf + (row * 16 + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
       }
-      const u16x8 af = cat8(a[0], a[1]);
+      return cat8(a[0], a[1]);
+    };
+    auto read_b = [&](int ks, int nt) -> u16x8 {
+      u16x4 b[2];
 #pragma unroll
-      for (int nt = 0; nt < NT32; ++nt) {
-        u16x4 b[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * nt + pcol;
-          b[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
-        }
-        acc[nt] = mfma_32x32x16_bf16(af, cat8(b[0], b[1]), acc[nt]);       // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * nt + pcol;
+        b[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
       }
+      return cat8(b[0], b[1]);
+    };
+    // X fragments are requested PF MFMAs ahead of their use (a ring of PF fragments; the compiler's own schedule was "read, wait, MFMA")
+    constexpr int PF = 5;
+    u16x8 bf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) bf[i] = read_b(0, i);
+    u16x8 af[2] = {read_a(0), read_a(1)};
+    NR_SCHED_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 2 * NT32; ++i) {
+      const int ks = i / NT32, nt = i - ks * NT32;
+      acc[nt] = mfma_32x32x16_bf16(af[ks], bf[i % PF], acc[nt]);           // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
+      if (i + PF < 2 * NT32) bf[i % PF] = read_b((i + PF) / NT32, (i + PF) % NT32);
     }
     __syncthreads();
   }

@@ -415,6 +415,7 @@ def _wgrad_parts(a, b, name):
 # NR_WGRAD_GEMM: 1 (default) = the weight-gradient products dqkv^T @ [X | 1] and dpre^T @ [ctx | 1] of the NRMS encoders run in the hand-written
 # split-K kernel nr_tn_gemm (csrc/k_proj.h: transposing LDS reads, no transposed operand copies); 0 = chunked hipBLASLt batched GEMMs
 _WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '1'))
+_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '1'))       # the same for the conv text encoders (tap and pooling weight gradients)
 _zeros16 = {}
 
 
