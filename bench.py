@@ -412,7 +412,7 @@ def gather_point(lib, table, ids, device):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'nr_common.h'):
+    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_proj.h', 'k_pool2.h', 'nr_common.h'):
         with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -577,6 +577,23 @@ def main():
             roofline["traffic_note"] = "profiles/traffic.json entry is for other kernel sources / another workload: not reported"
     except (OSError, ValueError):
         pass
+    # MFMA-utilisation counters (north_star): SQ_VALU_MFMA_BUSY_CYCLES of the committed rocprofv3 --pmc passes, same keying (tools/pmc_sq.py)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'mfma_busy.json')) as f:
+            mb = json.load(f)
+        cur = {k: v for k, v in mb.items() if isinstance(v, dict) and v.get("source_hash") == kernel_source_hash()}
+        if dominant in cur:
+            roofline["mfma_busy_frac"] = cur[dominant]["mfma_busy_frac"]
+        roofline["mfma_busy_frac_by_kernel"] = {k: round(v["mfma_busy_frac"], 4) for k, v in cur.items()} or None
+    except (OSError, ValueError):
+        pass
+    # the dense contraction of the forward on its own (the dominant kernel above may be a bandwidth-bound one)
+    pj = prof.get('nr_qkv_proj_fwd[S=20]')
+    if pj is not None:
+        roofline["projection_gemm"] = {"kernel": "nr_qkv_proj_fwd[S=20]", "bound": "mfma", "avg_us": pj[1], "flop_per_launch": flops['nr_qkv_proj_fwd[S=20]'],
+                                       "achieved": flops['nr_qkv_proj_fwd[S=20]'] / (pj[1] * 1e-6) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": flops['nr_qkv_proj_fwd[S=20]'] / (pj[1] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF,
+                                       "timed_in": "the two profiled warm-up steps (HIP events)"}
 
     extras = {}
     if not args.no_extras:

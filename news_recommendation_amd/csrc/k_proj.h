@@ -409,18 +409,21 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
 // with a 4-row XOR swizzle of their 16-byte slots so that the fragment reads are bank-conflict free; the result leaves through LDS as whole
 // 640-byte rows.
 constexpr int DXK = 3 * KP;                 // 960 contraction columns
+// NW waves per workgroup: 4 (128 tokens, two workgroups per CU) or 8 (256 tokens, one per CU: the weight chunks are fetched half as often)
+template <int NW>
 struct DxGeom {
-  static constexpr int NWAVE = 4;
+  static constexpr int NWAVE = NW;
   static constexpr int TOKW = 32;
-  static constexpr int TOK_WG = NWAVE * TOKW;          // 128
+  static constexpr int TOK_WG = NWAVE * TOKW;          // 128 / 256
   static constexpr int KC = 2;                         // k-steps of 16 per chunk (32 columns = 64 bytes of a token row)
   static constexpr int NCH = DXK / (16 * KC);          // 30
-  static constexpr int A_BYTES = TOK_WG * KC * 32;     // 8,192 B: 128 rows x 64 B
+  static constexpr int A_BYTES = TOK_WG * KC * 32;     // 8,192 / 16,384 B: rows x 64 B
   static constexpr int W_BYTES = KC * NT32 * 1024;     // 20,480 B: 20 fragments
-  static constexpr int BUF_BYTES = A_BYTES + W_BYTES;  // 28,672 B
+  static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
   static constexpr int OROW = 656;                     // bytes per staged output row
-  static constexpr int OUT_BYTES = NWAVE * 16 * OROW;  // 41,984 B: 16 rows per wave at a time
-  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 B (>= OUT_BYTES): two workgroups per CU
+  static constexpr int ORP = NW == 4 ? 16 : 8;         // output rows per wave and epilogue pass
+  static constexpr int OUT_BYTES = NWAVE * ORP * OROW; // 41,984 B
+  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 / 73,728 B (>= OUT_BYTES)
   static_assert(SMEM >= OUT_BYTES, "epilogue staging fits the chunk buffers");
 };
 
@@ -446,8 +449,9 @@ struct DxParams {
   int64_t n_tok;
 };
 
-__global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
-  using Gm = DxGeom;
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void dx_gemm_kernel(DxParams p) {
+  using Gm = DxGeom<NW>;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
   const int64_t wg_tok0 = (int64_t)blockIdx.x * Gm::TOK_WG;
@@ -501,12 +505,12 @@ __global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
     }
     __syncthreads();
   }
-  // ---- epilogue: 16 token rows per wave at a time through LDS, each batch leaves as 16 x 640 contiguous bytes ---------------------------
-  unsigned char* ost = smem + w * 16 * Gm::OROW;
+  // ---- epilogue: ORP token rows per wave at a time through LDS, each batch leaves as ORP x 640 contiguous bytes ------------------------
+  unsigned char* ost = smem + w * Gm::ORP * Gm::OROW;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if ((li >> 4) == half) {
-      unsigned char* row = ost + (li & 15) * Gm::OROW;
+  for (int ps = 0; ps < Gm::TOKW / Gm::ORP; ++ps) {
+    if (li / Gm::ORP == ps) {
+      unsigned char* row = ost + (li % Gm::ORP) * Gm::OROW;
 #pragma unroll
       for (int nt = 0; nt < NT32; ++nt)
 #pragma unroll
@@ -514,12 +518,12 @@ __global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
           *(u16x4*)(row + (nt * 32 + 8 * q + 4 * h) * 2) = pack4(f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]});
     }
     wave_barrier();
-    const int64_t t0 = tile_tok0 + half * 16;
+    const int64_t t0 = tile_tok0 + ps * Gm::ORP;
 #pragma unroll
-    for (int i = 0; i < 16 * (KP / 8) / 64; ++i) {
+    for (int i = 0; i < (Gm::ORP * (KP / 8) + 63) / 64; ++i) {
       const int idx = l + 64 * i;
       const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
-      if (t0 + r < p.n_tok) *(u16x8*)(p.dX + t0 * KP + idx * 8) = *(const u16x8*)(ost + r * Gm::OROW + pc * 16);
+      if (idx < Gm::ORP * (KP / 8) && t0 + r < p.n_tok) *(u16x8*)(p.dX + t0 * KP + idx * 8) = *(const u16x8*)(ost + r * Gm::OROW + pc * 16);
     }
     wave_barrier();
   }
@@ -536,14 +540,16 @@ __global__ __launch_bounds__(256, 2) void dx_gemm_kernel(DxParams p) {
 //   chunk) with their 16-byte slots XOR-swizzled per row so that the four token rows a transposing read touches sit in different banks;
 //   the slabs of one partition run on one XCD (block id -> (xcd, slab, partition)), so that X comes from HBM once.
 // The fp32 partials [P][M][320] are what nr_wgrad_unpack reduces in a fixed order (deterministic, no atomics).
+template <int NW>
 struct TnGeom {
-  static constexpr int NWAVE = 4;
-  static constexpr int BM = NWAVE * 32;                // 128 output rows per workgroup
+  static constexpr int NWAVE = NW;                     // 4 (two workgroups per CU) or 8 (one: each X chunk serves a 256-row slab)
+  static constexpr int BM = NWAVE * 32;                // 128 / 256 output rows per workgroup
+  static constexpr int GS = BM / 8;                    // 16-byte slots per G row
   static constexpr int TC = 32;                        // tokens per chunk (2 k-steps of 16)
-  static constexpr int G_BYTES = TC * BM * 2;          // 8,192
+  static constexpr int G_BYTES = TC * BM * 2;          // 8,192 / 16,384
   static constexpr int X_BYTES = TC * KP * 2;          // 20,480
   static constexpr int BUF_BYTES = G_BYTES + X_BYTES;
-  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 B: two workgroups per CU
+  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 / 73,728 B
 };
 
 struct TnParams {
@@ -559,8 +565,9 @@ struct TnParams {
   int64_t tok_per_part;  // multiple of 32
 };
 
-__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(TnParams p) {
-  using Gm = TnGeom;
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void tn_gemm_kernel(TnParams p) {
+  using Gm = TnGeom<NW>;
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), h = l >> 5;
   // block id -> (xcd, slab, partition): ids that differ by a multiple of 8 share an XCD (round-robin dispatch); the slabs of a partition get
@@ -577,18 +584,18 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(TnParams p) {
     unsigned char* xbuf = gbuf + Gm::G_BYTES;
     const int64_t tok0 = t_begin + (int64_t)c * Gm::TC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                              // G: 32 rows x 16 slots; this wave copies rows 8 w + 4 i .. + 3
-      const int r = w * 8 + i * 4 + (l >> 4), s = l & 15;
+    for (int i = 0; i < 2; ++i) {                              // G: 32 rows x GS slots = 2 NW blocks of 64 slots; this wave copies blocks 2 w, 2 w + 1
+      const int gs = (w * 2 + i) * 64 + l;
+      const int r = gs / Gm::GS, s = gs - r * Gm::GS;
       const int col = slab * Gm::BM + ((s ^ (4 * (r & 3))) * 8);
       const u16* src = (tok0 + r < t_end && col < p.ldg) ? p.G + (tok0 + r) * p.ldg + col : p.zeros;
-      NR_GLDS16(src, gbuf + (w * 8 + i * 4) * 256);
+      NR_GLDS16(src, gbuf + (w * 2 + i) * 1024);
     }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {                              // X: 32 rows x 40 slots = 20 blocks of 64 slots; this wave copies blocks 5 w .. 5 w + 4
-      const int gs = (w * 5 + i) * 64 + l;
+    for (int blk = w; blk < 20; blk += Gm::NWAVE) {            // X: 32 rows x 40 slots = 20 blocks of 64 slots
+      const int gs = blk * 64 + l;
       const int r = gs / 40, s = gs - r * 40;
       const u16* src = tok0 + r < t_end ? p.X + (tok0 + r) * KP + ((s ^ (4 * ((r >> 1) & 1))) * 8) : p.zeros;
-      NR_GLDS16(src, xbuf + (w * 5 + i) * 1024);
+      NR_GLDS16(src, xbuf + blk * 1024);
     }
   };
   f32x16 acc[NT32];
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(TnParams p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * w + pcol;
-        a[t] = lds_tr16_b64((const u16*)(gbuf + (row * 16 + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
+        a[t] = lds_tr16_b64((const u16*)(gbuf + (row * Gm::GS + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
       }
       return cat8(a[0], a[1]);
     };

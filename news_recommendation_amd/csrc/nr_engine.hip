@@ -82,6 +82,13 @@ bool pool2_s50(int64_t n_seq) {
   return add_variant() == 4 && (v == 2 || (v == 1 && n_seq >= 2048));
 }
 
+// waves per workgroup of the hand-written GEMM kernels (nr_dx_gemm, nr_tn_gemm): A/B knob NR_GEMM_WAVES = 4 (default) or 8
+int gemm_waves() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NR_GEMM_WAVES"); v = (e && atoi(e) == 8) ? 8 : 4; }
+  return v;
+}
+
 template <typename K>
 int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
 
@@ -433,17 +440,24 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
   if (n_tok == 0) return NR_OK;
   nr::DxParams p;
   p.dqkv = dqkv; p.WdX = WdX; p.dX = dX; p.n_tok = n_tok;
-  using G = nr::DxGeom;
-  NR_LAUNCH(nr::dx_gemm_kernel, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
+  if (gemm_waves() == 8) {
+    using G = nr::DxGeom<8>;
+    if (allow_smem(nr::dx_gemm_kernel<8>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_dx_gemm: cannot reserve LDS");
+    NR_LAUNCH(nr::dx_gemm_kernel<8>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 512, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    using G = nr::DxGeom<4>;
+    NR_LAUNCH(nr::dx_gemm_kernel<4>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
+  }
   return check_launch("nr_dx_gemm");
 }
 
 int nr_tn_gemm_parts(int M, int64_t n_tok) {
   if (M <= 0 || n_tok < 0) return -1;
+  const int BM = (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32;      // narrow outputs (dpre: M = 208) always take the 128-row slabs
   // enough workgroups for two per CU (one per CU for narrow outputs, whose partials would otherwise outweigh the operands): partitions x
   // slabs ~ 512 / 256, partitions a multiple of 8, at least one 32-token chunk each when possible
-  const int nslab = (M + nr::TnGeom::BM - 1) / nr::TnGeom::BM;
-  int P = ((nslab >= 4 ? 512 : 256) + nslab - 1) / nslab;
+  const int nslab = (M + BM - 1) / BM;
+  int P = ((nslab * BM >= 512 ? (BM == 128 ? 512 : 256) : 256) + nslab - 1) / nslab;
   P = (P + 7) / 8 * 8;
   const int64_t maxp = (n_tok + 31) / 32;
   while (P > 8 && P > maxp) P -= 8;
@@ -456,9 +470,17 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
   if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)zeros) & 15) != 0) return fail(NR_ERR_BADARG, "nr_tn_gemm: operands must be 16-byte aligned");
   nr::TnParams p;
   p.G = G; p.ldg = ldg; p.M = M; p.X = X; p.zeros = zeros; p.out = out; p.n_tok = n_tok; p.P = P;
-  p.nslab = (M + nr::TnGeom::BM - 1) / nr::TnGeom::BM;
   p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32;
-  NR_LAUNCH(nr::tn_gemm_kernel, (int64_t)P * p.nslab, 256, nr::TnGeom::SMEM, (hipStream_t)stream, p);
+  if (gemm_waves() == 8 && M > 256) {
+    using G = nr::TnGeom<8>;
+    p.nslab = (M + G::BM - 1) / G::BM;
+    if (allow_smem(nr::tn_gemm_kernel<8>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");
+    NR_LAUNCH(nr::tn_gemm_kernel<8>, (int64_t)P * p.nslab, 512, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    using G = nr::TnGeom<4>;
+    p.nslab = (M + G::BM - 1) / G::BM;
+    NR_LAUNCH(nr::tn_gemm_kernel<4>, (int64_t)P * p.nslab, 256, G::SMEM, (hipStream_t)stream, p);
+  }
   return check_launch("nr_tn_gemm");
 }
 
