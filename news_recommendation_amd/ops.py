@@ -412,10 +412,15 @@ def _wgrad_parts(a, b, name):
     return _timed(name, run)
 
 
-# NR_WGRAD_GEMM: 1 (default) = the weight-gradient products dqkv^T @ [X | 1] and dpre^T @ [ctx | 1] of the NRMS encoders run in the hand-written
-# split-K kernel nr_tn_gemm (csrc/k_proj.h: transposing LDS reads, no transposed operand copies); 0 = chunked hipBLASLt batched GEMMs
-_WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '1'))
-_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '1'))       # the same for the conv text encoders (tap and pooling weight gradients)
+# NR_WGRAD_GEMM: 1 = the weight-gradient products dqkv^T @ [X | 1] and dpre^T @ [ctx | 1] of the NRMS encoders run in the hand-written split-K
+# kernel nr_tn_gemm (csrc/k_proj.h: transposing LDS reads, no transposed operand copies); 0 (default) = chunked hipBLASLt batched GEMMs.
+# Measured side by side on one MI355X (profiles/r03_ab_switches.txt, r03h / r03i / r03j): inside the NRMS step dWqkv 377 - 385 us hand-written
+# vs 356 - 368 us hipBLASLt, dWa 171 - 200 vs 160 - 177, partial-sum reduction 87 vs 58 us (64 vs 32 partitions): 3.85 vs 3.75 ms per step.
+# The hand-written kernel is correct to 4e-7 of the library result and free of LDS bank conflicts; it is not the faster one yet, so the library
+# call remains the default for these two products (the input gradient dX runs hand-written: NR_DX_GEMM).
+_WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '0'))
+# the same for the conv text encoders (tap and pooling weight gradients): NAML 11.29 ms with the hand-written kernel vs 10.34 ms (r03i)
+_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '0'))
 _zeros16 = {}
 
 
