@@ -44,7 +44,7 @@ fns = {
                                                     dqp.data_ptr(), WaT20.data_ptr(), dctx20.data_ptr(), T, 20, st())),
   'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
 }
-if name.startswith(('proj', 'attn_fwd', 'attn_bwd_hm')):      # split training forward (csrc/k_proj.h)
+if name.startswith(('proj', 'attn_fwd', 'attn_bwd_hm', 'dx_gemm', 'tn_gemm')):      # split training forward (csrc/k_proj.h)
     Wp32 = torch.empty(3 * NR_NP * NR_K16 * 16, dtype=torch.int16, device=dev); bp32 = torch.empty(3 * NR_NP, device=dev)
     ck(lib.nr_pack_qkv32(W[0].data_ptr(), bb[0].data_ptr(), W[1].data_ptr(), bb[1].data_ptr(), W[2].data_ptr(), bb[2].data_ptr(), Wp32.data_ptr(), bp32.data_ptr(), st()))
     qkv = torch.empty(T * NR_QKV_HM_SEQ, dtype=torch.int16, device=dev)
@@ -54,7 +54,17 @@ if name.startswith(('proj', 'attn_fwd', 'attn_bwd_hm')):      # split training f
     fns['proj_train'] = lambda: pj(0.2, True)
     fns['proj_noxs'] = lambda: pj(0.2, False)
     fns['attn_fwd'] = lambda: ck(lib.nr_attn_fwd(qkv.data_ptr(), ctx.data_ptr(), None, T, 20, 0.2, 1, st()))
+    WdX = torch.empty(60 * 10 * 64 * 8, dtype=torch.int16, device=dev)
+    ck(lib.nr_pack_qkv_dx(W[0].data_ptr(), W[1].data_ptr(), W[2].data_ptr(), WdX.data_ptr(), st()))
+    dX = torch.empty(T * 20, NR_KP, dtype=torch.int16, device=dev)
+    z16 = torch.zeros(64, dtype=torch.int16, device=dev)
+    P = lib.nr_tn_gemm_parts(NR_LDG, T * 20)
+    parts = torch.empty(P, NR_LDG, NR_KP, device=dev)
+    fns['dx_gemm'] = lambda: ck(lib.nr_dx_gemm(dqkv.data_ptr(), WdX.data_ptr(), dX.data_ptr(), T * 20, st()))
+    fns['tn_gemm'] = lambda: ck(lib.nr_tn_gemm(dqkv.data_ptr(), NR_LDG, NR_LDG, xsv.data_ptr(), z16.data_ptr(), parts.data_ptr(), T * 20, P, st()))
     fns['attn_bwd_hm'] = lambda: ck(lib.nr_attn_bwd_hm(qkv.data_ptr(), dctxk.data_ptr(), NR_KP, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), None, T, 20, 0.2, 1, st()))
+if name in ('dx_gemm', 'tn_gemm'):        # a realistic dqkv operand: the attention backward's output
+    fns['attn_bwd_hm']()
 if name.endswith('50'):          # abstract-shaped pooling: 27 k sequences of 50 ctx rows
     S = 50; Tn = B * 53
     ctx50 = torch.randn(Tn * S, NR_KP, generator=g).mul_(0.3).to(torch.bfloat16).view(torch.int16).to(dev)
