@@ -159,6 +159,7 @@ class Workload:
         tok = B * 53 * 20
         return {
             'nr_attn_fwd[S=20]': tok * (3 * 300 * 2 + 300 * 2),                      # Q, K, V in; ctx out
+            'nr_attn_pool_fwd[S=20]': tok * (3 * 300 * 2 + 300 * 2) + B * 53 * (300 + 20) * 4,   # + pooled vectors and attention weights out
             'nr_attn_bwd[S=20]': tok * (3 * 300 * 2 + 300 * 2 + 3 * 300 * 2),        # Q, K, V, dctx in; dQ, dK, dV out
             'nr_embed_scatter_sorted[S=20]': tok * (300 * 2 + 16),                   # dX rows + (id, position) in; table rows reduced in registers
         }

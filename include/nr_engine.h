@@ -155,6 +155,11 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
 /* ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) from a head-major qkv buffer;
  * ctx as nr_mhsa_fwd writes it (second dropout of news_encoder.py:43-45 applied when p_drop > 0, column D = 1.0). */
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
+/* nr_attn_fwd followed by the additive pooling of each title (additive.py:27-53; news_encoder.py:43-47) on the ctx rows while they are
+ * still in LDS: out f32[n_seq][out_stride] (first NR_D columns), attn_w f32[n_seq][S] or null; ctx is written as by nr_attn_fwd (the
+ * backward reads it).  ctx equals nr_attn_fwd bit for bit, out / attn_w equal nr_additive_fwd_v on it up to the order of fp32 additions (valid: as there).  Wap / bap / qvp: nr_pack_additive. */
+int nr_attn_pool_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, const uint16_t* Wap, const float* bap, const float* qvp,
+                     float* out, int64_t out_stride, float* attn_w, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, void* stream);
 /* nr_attn_bwd_len reading the head-major saves of nr_qkv_proj_fwd (S = 20). */
 int nr_attn_bwd_hm(const uint16_t* qkv, const uint16_t* dctx_gemm, int ldc, const float* attn_w, const float* g_out, uint16_t* dqkv,
                    const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);

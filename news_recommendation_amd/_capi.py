@@ -28,6 +28,7 @@ SIGNATURES = {
     'nr_tn_gemm_parts': ([c_int, c_int64], c_int),
     'nr_tn_gemm': ([_P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_attn_fwd': ([_P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
+    'nr_attn_pool_fwd': ([_P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_float, c_uint64, _P], c_int),
     'nr_attn_bwd_hm': ([_P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_fwd_v': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),

@@ -63,26 +63,15 @@ struct AdditiveBwdParams {
   float act_scale;       // 1 / (1 - p_drop)
 };
 
-template <int S, int NSEQ, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p) {
+// The pooling of a workgroup's NSEQ sequences once their ctx rows sit in LDS (Xs: [ROWS][XS] bf16, col D = 1.0, cols > D zero): scores,
+// softmax, weighted sum.  sc ([NW][ROWS] floats) and wl ([ROWS] floats) are LDS scratch; every wave of the workgroup must call it (it
+// synchronises the workgroup), whatever it did before.  Shared by additive_fwd_kernel (tile staged from HBM) and by the pooled form of
+// attn_fwd_kernel (k_proj.h: the tile is the attention output the workgroup has just produced).
+template <int S, int NSEQ, int NW>
+__device__ __forceinline__ void additive_pool_tile(const AdditiveParams& p, const u16* Xs, float* sc, float* wl, int64_t seq0) {
   using Gm = AddGeom<S, NSEQ, NW>;
   constexpr int WG = NW * 64;          // shadows nr::WG: 4 or 8 waves
-  NR_SMEM_DECL(smem);
-  u16* Xs = (u16*)smem;
-  float* sc = (float*)(smem + Gm::X_BYTES);            // [4][ROWS]
-  float* wl = (float*)(smem + Gm::X_BYTES + Gm::SC_BYTES);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
-  const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
-  const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
-
-  // ---- stage the ctx tile (16-B pieces, 41 per LDS row incl. the stride padding) ------------------------
-  constexpr int PCS = XS / 8;   // 41 16-B pieces per LDS row
-  for (int i = tid; i < Gm::ROWS * PCS; i += WG) {
-    int r = i / PCS, c = i - r * PCS;
-    u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < KP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.ctx + (tok0 + r) * KP + c * 8);
-    *(u16x8*)(Xs + r * XS + c * 8) = v;
-  }
   for (int i = tid; i < NW * Gm::ROWS; i += WG) sc[i] = 0.0f;
   __syncthreads();
 
@@ -166,6 +155,29 @@ __global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p)
         *(u16x4*)(p.out_b + (seq0 + seq) * p.out_b_stride + D + c * 4) = u16x4{(u16)(c == 0 ? 0x3F80 : 0), 0, 0, 0};
     }
   }
+}
+
+template <int S, int NSEQ, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void additive_fwd_kernel(AdditiveParams p) {
+  using Gm = AddGeom<S, NSEQ, NW>;
+  constexpr int WG = NW * 64;
+  NR_SMEM_DECL(smem);
+  u16* Xs = (u16*)smem;
+  float* sc = (float*)(smem + Gm::X_BYTES);            // [NW][ROWS]
+  float* wl = (float*)(smem + Gm::X_BYTES + Gm::SC_BYTES);
+  const int tid = threadIdx.x;
+  const int64_t seq0 = (int64_t)blockIdx.x * NSEQ;
+  const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
+
+  // ---- stage the ctx tile (16-B pieces, 41 per LDS row incl. the stride padding) ------------------------
+  constexpr int PCS = XS / 8;   // 41 16-B pieces per LDS row
+  for (int i = tid; i < Gm::ROWS * PCS; i += WG) {
+    int r = i / PCS, c = i - r * PCS;
+    u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < KP / 8 && r < Gm::TOK && tok0 + r < tok_total) v = *(const u16x8*)(p.ctx + (tok0 + r) * KP + c * 8);
+    *(u16x8*)(Xs + r * XS + c * 8) = v;
+  }
+  additive_pool_tile<S, NSEQ, NW>(p, Xs, sc, wl, seq0);
 }
 
 }  // namespace nr

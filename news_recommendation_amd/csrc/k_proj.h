@@ -25,6 +25,7 @@
 //   per (title, head) the blocks Q, K, V, each [token][d] row-major, back to back: 2,400 contiguous bytes per pair, 36,000 per title.
 #pragma once
 #include "nr_common.h"
+#include "k_additive_fwd.h"
 #include <type_traits>
 
 namespace nr {
@@ -264,6 +265,8 @@ struct AttnFwdParams {
   int64_t n_seq;
   DropCfg dc;              // dropout site 2
   int debug;               // profiling only (NR_ATTNF_DEBUG, DBG instantiation): 1 skip the operand loads, 2 skip the exp / normalisation, 4 skip the ctx stores
+  AdditiveParams pool;     // POOL instantiation: the additive pooling of the titles (k_additive_fwd.h) runs on the workgroup's ctx tiles while
+                           // they are still in LDS (pool.ctx / pool.n_seq unused: the tile and n_seq above are taken)
 };
 
 struct AttnFwdGeom {
@@ -278,10 +281,14 @@ struct AttnFwdGeom {
   static constexpr int OP_IT = (OPER_BYTES / 16 + 63) / 64;      // 3 sixteen-byte pieces per lane and pair
   static constexpr int WO_ROWS = S / 2;               // rows each of the title's two waves writes out
   static constexpr int WO_IT = (WO_ROWS * (KP / 8) + 63) / 64;   // 7 sixteen-byte pieces per lane
+  // pooled form: the TPB title tiles back to back ARE the [80][XS] token tile of AddGeom<S, TPB, WPB>; its scratch reuses the operand buffers
+  using Pool = AddGeom<S, TPB, WPB>;
+  static_assert(CROW == XS * 2 && TPB * TILE_BYTES == Pool::X_BYTES, "title tiles form the pooling kernel's token tile");
+  static_assert(Pool::SC_BYTES + Pool::W_BYTES <= WPB * OPER_BYTES, "pooling scratch fits the operand buffers");
 };
 
-template <bool DBG>
-__global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwdParams p) {
+template <bool DBG, bool POOL>
+__global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(AttnFwdParams p) {
   using Gm = AttnFwdGeom;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
@@ -290,12 +297,14 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   const int half = w & 1;                                         // this wave's share of the title's heads
   const int64_t seq = (int64_t)blockIdx.x * Gm::TPB + (w >> 1);
-  if (seq >= p.n_seq) return;                                     // (both waves of a title leave together; exited waves do not hold up the barrier)
+  const bool have = seq < p.n_seq;
+  if (!POOL && !have) return;                                     // (both waves of a title leave together; exited waves do not hold up the barrier)
   unsigned char* const tile = smem + (w >> 1) * Gm::TILE_BYTES;   // ctx rows of the title, shared by its two waves (disjoint columns)
   unsigned char* const oper = smem + Gm::TPB * Gm::TILE_BYTES + w * Gm::OPER_BYTES;      // operands of this wave's current pair
   const u16x4 Z4 = u16x4{0, 0, 0, 0};
   const int hd0 = half * Gm::HSPLIT, hd1 = half ? H : Gm::HSPLIT;
 
+  if (have) {                                                     // (a pooled workgroup keeps the waves of missing titles for the pooling)
   // K padding of the staged ctx rows: col D = 1.0 (bias-gradient column), cols D + 1 .. KP - 1 = 0
   if (half == 0)
     for (int i = l; i < S * 5; i += 64) {
@@ -388,8 +397,9 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
       }
     }
   }
+  }
   __syncthreads();                                   // both waves of the title have written their heads' columns
-  if (!(dbg & 4)) {
+  if (have && !(dbg & 4)) {
     u16* dst = p.ctx + (seq * S + half * Gm::WO_ROWS) * KP;       // this wave's 10 rows are 6,400 contiguous bytes
 #pragma unroll
     for (int i = 0; i < Gm::WO_IT; ++i) {
@@ -397,6 +407,14 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64) void attn_fwd_kernel(AttnFwd
       const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
       if (idx < Gm::WO_ROWS * (KP / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + (half * Gm::WO_ROWS + r) * Gm::CROW + pc * 16);
     }
+  }
+  if (POOL) {
+    // the operand buffers are free (every wave is past the barrier above): scores / softmax weights of the pooling live there
+    float* sc = (float*)(smem + Gm::TPB * Gm::TILE_BYTES);
+    float* wl = (float*)(smem + Gm::TPB * Gm::TILE_BYTES + Gm::Pool::SC_BYTES);
+    AdditiveParams ap = p.pool;
+    ap.n_seq = p.n_seq;
+    additive_pool_tile<S, Gm::TPB, Gm::WPB>(ap, (const u16*)smem, sc, wl, (int64_t)blockIdx.x * Gm::TPB);
   }
 }
 

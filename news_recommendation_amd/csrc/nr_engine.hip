@@ -33,6 +33,11 @@ int fail(int code, const char* msg) {
   return code;
 }
 
+int fail(int code, const char* who, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s%s", who, msg);
+  return code;
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -484,22 +489,42 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
   return check_launch("nr_tn_gemm");
 }
 
-int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
-  if (!qkv || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_attn_fwd: bad argument");
-  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_attn_fwd: dropout probability out of range");
-  if (S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_attn_fwd: instantiated for 20-token sequences");
+static int attn_fwd_launch(const char* who, const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
+                           uint64_t seed, const nr::AdditiveParams* pool, void* stream) {
+  if (!qkv || !ctx || n_seq < 0) return fail(NR_ERR_BADARG, who, ": bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, who, ": dropout probability out of range");
+  if (S != 20) return fail(NR_ERR_UNSUPPORTED, who, ": instantiated for 20-token sequences");
   if (n_seq == 0) return NR_OK;
   nr::AttnFwdParams p;
   p.qkv = qkv; p.ctx = ctx; p.key_len = key_len; p.n_seq = n_seq; p.dc = make_drop(p_drop, seed); p.debug = 0;
+  p.pool = nr::AdditiveParams{};
   using G = nr::AttnFwdGeom;
   const int64_t grid = (n_seq + G::TPB - 1) / G::TPB;
-  if (allow_smem(nr::attn_fwd_kernel<false>, G::SMEM) || allow_smem(nr::attn_fwd_kernel<true>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_fwd: cannot reserve LDS");
+  if (allow_smem(nr::attn_fwd_kernel<false, false>, G::SMEM) || allow_smem(nr::attn_fwd_kernel<true, false>, G::SMEM) ||
+      allow_smem(nr::attn_fwd_kernel<false, true>, G::SMEM))
+    return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
   const char* d = getenv("NR_ATTNF_DEBUG");         // profiling: phase switches (AttnFwdParams::debug), re-read per call
-  if (d != nullptr && atoi(d) != 0) {
+  if (pool != nullptr) {
+    p.pool = *pool;
+    NR_LAUNCH((nr::attn_fwd_kernel<false, true>), grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  } else if (d != nullptr && atoi(d) != 0) {
     p.debug = atoi(d);
-    NR_LAUNCH(nr::attn_fwd_kernel<true>, grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
-  } else NR_LAUNCH(nr::attn_fwd_kernel<false>, grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
-  return check_launch("nr_attn_fwd");
+    NR_LAUNCH((nr::attn_fwd_kernel<true, false>), grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  } else NR_LAUNCH((nr::attn_fwd_kernel<false, false>), grid, G::WPB * 64, G::SMEM, (hipStream_t)stream, p);
+  return check_launch(who);
+}
+
+int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
+  return attn_fwd_launch("nr_attn_fwd", qkv, ctx, key_len, n_seq, S, p_drop, seed, nullptr, stream);
+}
+
+int nr_attn_pool_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, const uint16_t* Wap, const float* bap, const float* qvp,
+                     float* out, int64_t out_stride, float* attn_w, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, void* stream) {
+  if (!Wap || !bap || !qvp || !out || valid < 1 || valid > S) return fail(NR_ERR_BADARG, "nr_attn_pool_fwd: bad argument");
+  if (out_stride < NR_D || (out_stride & 3)) return fail(NR_ERR_BADARG, "nr_attn_pool_fwd: bad output stride");
+  nr::AdditiveParams ap{};
+  ap.Wap = Wap; ap.bap = bap; ap.qvp = qvp; ap.out = out; ap.out_stride = out_stride; ap.attn_w = attn_w; ap.valid = valid;
+  return attn_fwd_launch("nr_attn_pool_fwd", qkv, ctx, key_len, n_seq, S, p_drop, seed, &ap, stream);
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {

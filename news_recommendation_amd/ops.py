@@ -465,6 +465,9 @@ def inplace_grads(params):
 # NR_FWD_SPLIT: 1 (default) = title encoders that need gradients run nr_qkv_proj_fwd + nr_attn_fwd (csrc/k_proj.h) instead of the
 # register-resident nr_mhsa_fwd kernel; 2 = inference too; 0 = never (A/B)
 _FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
+# NR_FWD_POOL: 1 = the split form pools the titles inside the attention kernel (nr_attn_pool_fwd: the ctx tile is pooled from LDS instead of
+# being read back by nr_additive_fwd); 0 = two launches.  Same results bit for bit.
+_FWD_POOL = int(os.environ.get('NR_FWD_POOL', '1'))
 
 # NR_DX_GEMM: 1 (default) = the input gradient dX = dqkv @ [Wq; Wk; Wv] runs in the hand-written kernel (nr_dx_gemm, csrc/k_proj.h); 0 = in
 # hipBLASLt through torch.  Measured side by side on one MI355X (profiles/r03_ab_switches.txt): 365 vs 462 us inside the NRMS step at B = 512,
@@ -660,6 +663,7 @@ class _EncoderFn(torch.autograd.Function):
         sp4 = (S + 3) // 4 * 4
         WaT = pack_additive_t(Wa) if need_grad else None
         WpT = None
+        pooled = False
         if need_grad:
             WpT = pack_qkv_dx(Wq, Wk, Wv) if _DX_GEMM else pack_qkv_t(Wq, bq, Wk, bk, Wv, bv)
         if split:
@@ -680,7 +684,14 @@ class _EncoderFn(torch.autograd.Function):
             Wp32, bp32 = pack_qkv32(Wq, bq, Wk, bk, Wv, bv)
             _call(f'nr_qkv_proj_fwd[S={S}]', lib.nr_qkv_proj_fwd, _ptr(ids_c), _ptr(tab), tab.shape[0], _ptr(Wp32), _ptr(bp32), _ptr(qs), _ptr(xb),
                   n_seq, S, p_drop, seed, _stream())
-            _call(f'nr_attn_fwd[S={S}]', lib.nr_attn_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
+            if _FWD_POOL:
+                out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+                aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+                _call(f'nr_attn_pool_fwd[S={S}]', lib.nr_attn_pool_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), _ptr(Wap), _ptr(bap), _ptr(qvp),
+                      _ptr(out), NR_D, _ptr(aw), n_seq, S, valid, p_drop, seed, _stream())
+                pooled = True
+            else:
+                _call(f'nr_attn_fwd[S={S}]', lib.nr_attn_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
             xd = None
         elif gather:
             ids_c = ids.contiguous()
@@ -694,10 +705,11 @@ class _EncoderFn(torch.autograd.Function):
             xd = _f32c(x_dense)
             _call(f'nr_mhsa_fwd[S={S}]', lib.nr_mhsa_fwd_len, None, None, 0, _ptr(xd), _ptr(Wp), _ptr(bp), _ptr(cbuf),
                                 _ptr(qs), _ptr(ks), _ptr(vts), _ptr(xb), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
-        out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
-        aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-        _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw),
-              n_seq, S, valid, _stream())
+        if not pooled:
+            out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+            aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+            _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw),
+                  n_seq, S, valid, _stream())
         if need_grad:
             ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather, split)

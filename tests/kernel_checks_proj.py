@@ -159,6 +159,43 @@ def check_attn_fwd_matches_fused(be, n_seq=6, V=300):
         assert (got[:, :NR_D] == ctx_ref[:, :NR_D]).mean() > 0.9
 
 
+def check_attn_pool(be, n_seq=9, V=300, p_drop=0.0, seed=0, with_key_len=False, valid=S):
+    """nr_attn_pool_fwd == nr_attn_fwd followed by nr_additive_fwd_v on the ctx it wrote: ctx bit for bit, attention weights and pooled
+    vectors to fp32 rounding (the pooled form runs the same pooling code on the same bf16 tile, taken from LDS instead of HBM).  n_seq not a multiple of 4 leaves
+    a partially filled workgroup whose title-less waves still take part in the pooling."""
+    params = kc.make_params(4, V)
+    rng = np.random.default_rng(29)
+    ids = rng.integers(0, V, size=(n_seq, S))
+    table = params['news_encoder.word_embedding.weight']
+    qkv, _ = run_proj(be, params, ids, table, p_drop=p_drop, seed=seed)
+    key_len = None
+    if with_key_len:
+        key_len = rng.integers(1, S + 1, size=n_seq).astype(np.int32)
+        key_len[0] = S
+    hl = be.dev(key_len) if key_len is not None else None
+    Wap, bap, qvp = kc.pack_additive(be, params, 'news_encoder.')
+    ctx0 = be.poison((n_seq * S, NR_KP), np.uint16)
+    kc.ck(be, be.lib.nr_attn_fwd(be.ptr(qkv), be.ptr(ctx0), be.ptr(hl), n_seq, S, p_drop, seed, be.stream))
+    out0, aw0 = be.poison((n_seq, NR_D), np.float32), be.poison((n_seq, S), np.float32)
+    kc.ck(be, be.lib.nr_additive_fwd_v(be.ptr(ctx0), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out0), NR_D, None, 0, be.ptr(aw0), n_seq, S, valid,
+                                       be.stream))
+    ctx1 = be.poison((n_seq * S, NR_KP), np.uint16)
+    out1, aw1 = be.poison((n_seq, NR_D), np.float32), be.poison((n_seq, S), np.float32)
+    kc.ck(be, be.lib.nr_attn_pool_fwd(be.ptr(qkv), be.ptr(ctx1), be.ptr(hl), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out1), NR_D, be.ptr(aw1),
+                                      n_seq, S, valid, p_drop, seed, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(ctx1), be.np(ctx0)), 'ctx of the pooled form differs'
+    # the per-token score is a sum of per-wave partial sums; 8 waves over 4 titles split the 13 x 5 (column tile, token tile) units differently
+    # from the stand-alone kernel's 4 waves over 2 titles, so the fp32 additions associate differently: a few ulps of the score
+    da = np.abs(be.np(aw1) - be.np(aw0)).max()
+    do = np.abs(be.np(out1) - be.np(out0)).max()
+    assert da <= 2e-6, f'attention weights of the pooled form differ by {da}'
+    assert do <= 1e-5 * max(1.0, np.abs(be.np(out0)).max()), f'pooled vectors of the pooled form differ by {do}'
+    assert np.isfinite(be.np(out1)).all() and be.np(out1).any()
+    if valid < S:
+        assert (be.np(aw1)[:, valid:] == 0).all()
+
+
 def check_attn_bwd_hm(be, n_seq=5, p_drop=0.0, seed=77, with_key_len=False):
     """nr_attn_bwd_hm on the head-major saves == nr_attn_bwd_len on the row-major saves of the same values, bit for bit."""
     params = kc.make_params(12)

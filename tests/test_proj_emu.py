@@ -23,6 +23,8 @@ def test_proj_attn(be): kp.check_proj_attn(be, n_seq=9)
 def test_proj_attn_dropout(be): kp.check_proj_attn(be, n_seq=6, p_drop=0.2)
 def test_proj_attn_key_len(be): kp.check_proj_attn(be, n_seq=7, with_key_len=True)
 def test_attn_fwd_matches_fused(be): kp.check_attn_fwd_matches_fused(be, n_seq=6)
+def test_attn_pool(be): kp.check_attn_pool(be, n_seq=9)                     # 2 full workgroups + one holding a single title
+def test_attn_pool_dropout_key_len_valid(be): kp.check_attn_pool(be, n_seq=6, p_drop=0.2, seed=5, with_key_len=True, valid=17)
 def test_attn_bwd_hm(be): kp.check_attn_bwd_hm(be, n_seq=5)
 def test_attn_bwd_hm_dropout_key_len(be): kp.check_attn_bwd_hm(be, n_seq=4, p_drop=0.2, with_key_len=True)
 def test_dx_gemm(be): kp.check_dx_gemm(be, n_tok=300)          # two full workgroups + 44 tokens

@@ -45,6 +45,14 @@ def test_attn_fwd_matches_fused(be):
     kp.check_attn_fwd_matches_fused(be, n_seq=403, V=2000)
 
 
+def test_attn_pool(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_attn_pool(be, n_seq=9)
+    kp.check_attn_pool(be, n_seq=1)
+    kp.check_attn_pool(be, n_seq=2050, V=2000, p_drop=0.2, seed=11, with_key_len=True)
+    kp.check_attn_pool(be, n_seq=402, valid=13)
+
+
 def test_attn_bwd_hm(be):
     from tests import kernel_checks_proj as kp
     kp.check_attn_bwd_hm(be, n_seq=5)

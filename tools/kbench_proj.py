@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from news_recommendation_amd import _capi
-from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_LDG, NR_QKV_HM_SEQ, NR_K16
+from news_recommendation_amd._capi import NR_D, NR_KP, NR_NP, NR_LDG, NR_QKV_HM_SEQ, NR_K16, NR_QP
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 V = 70976
@@ -37,6 +37,10 @@ dctx = torch.randn(ntok, NR_KP, generator=g).mul_(0.05).to(torch.bfloat16).to(de
 aw = torch.full((T, 20), 0.05, device=dev); go = torch.randn(T, NR_D, generator=g).to(dev)
 dqkv = torch.zeros(ntok, NR_LDG, dtype=torch.int16, device=dev)
 p = 0.2
+Wa = torch.randn(200, 300, generator=g).mul_(0.05).to(dev); ba = torch.zeros(200, device=dev); qv = torch.randn(200, generator=g).mul_(0.1).to(dev)
+Wap = torch.empty(NR_QP, NR_KP, dtype=torch.int16, device=dev); bap = torch.empty(NR_QP, device=dev); qvp = torch.empty(NR_QP, device=dev)
+ck(lib.nr_pack_additive(Wa.data_ptr(), ba.data_ptr(), qv.data_ptr(), 200, Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), st()))
+nv = torch.empty(T, NR_D, device=dev); awo = torch.empty(T, 20, device=dev)
 WdX = torch.empty(60 * 10 * 64 * 8, dtype=torch.int16, device=dev)
 ck(lib.nr_pack_qkv_dx(W[0].data_ptr(), W[1].data_ptr(), W[2].data_ptr(), WdX.data_ptr(), st()))
 Wall = torch.zeros(NR_LDG, NR_KP, device=dev)
@@ -58,6 +62,8 @@ kern = {
   'proj(no x_save,drop)': lambda: ck(lib.nr_qkv_proj_fwd(ids.data_ptr(), table.data_ptr(), V, Wp32.data_ptr(), bp32.data_ptr(), qkv.data_ptr(), None, T, 20, p, 1, st())),
   'proj(no x_save,no drop)': lambda: ck(lib.nr_qkv_proj_fwd(ids.data_ptr(), table.data_ptr(), V, Wp32.data_ptr(), bp32.data_ptr(), qkv.data_ptr(), None, T, 20, 0.0, 0, st())),
   'attn_fwd(drop)': lambda: ck(lib.nr_attn_fwd(qkv.data_ptr(), ctx.data_ptr(), None, T, 20, p, 1, st())),
+  'attn_pool_fwd(drop)': lambda: ck(lib.nr_attn_pool_fwd(qkv.data_ptr(), ctx.data_ptr(), None, Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), NR_D, awo.data_ptr(), T, 20, 20, p, 1, st())),
+  'additive_fwd': lambda: ck(lib.nr_additive_fwd(ctx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(), awo.data_ptr(), T, 20, st())),
   'attn_fwd(no drop)': lambda: ck(lib.nr_attn_fwd(qkv.data_ptr(), ctx.data_ptr(), None, T, 20, 0.0, 0, st())),
   'mhsa_fwd2_train(drop)': lambda: ck(lib.nr_mhsa_fwd_len(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), xs.data_ptr(), None, T, 20, p, 1, st())),
   'mhsa_fwd2_infer': lambda: ck(lib.nr_mhsa_fwd(ids.data_ptr(), table.data_ptr(), V, None, Wp.data_ptr(), bp.data_ptr(), ctx.data_ptr(), None, None, None, T, 20, 0.0, 0, st())),

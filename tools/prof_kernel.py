@@ -44,7 +44,7 @@ fns = {
                                                     dqp.data_ptr(), WaT20.data_ptr(), dctx20.data_ptr(), T, 20, st())),
   'attn_bwd': lambda: ck(lib.nr_attn_bwd(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_D, aw.data_ptr(), gout.data_ptr(), dqkv.data_ptr(), T, 20, 0.2, 1, st())),
 }
-if name.startswith(('proj', 'attn_fwd', 'attn_bwd_hm', 'dx_gemm', 'tn_gemm')):      # split training forward (csrc/k_proj.h)
+if name.startswith(('proj', 'attn_fwd', 'attn_pool', 'attn_bwd_hm', 'dx_gemm', 'tn_gemm')):      # split training forward (csrc/k_proj.h)
     Wp32 = torch.empty(3 * NR_NP * NR_K16 * 16, dtype=torch.int16, device=dev); bp32 = torch.empty(3 * NR_NP, device=dev)
     ck(lib.nr_pack_qkv32(W[0].data_ptr(), bb[0].data_ptr(), W[1].data_ptr(), bb[1].data_ptr(), W[2].data_ptr(), bb[2].data_ptr(), Wp32.data_ptr(), bp32.data_ptr(), st()))
     qkv = torch.empty(T * NR_QKV_HM_SEQ, dtype=torch.int16, device=dev)
@@ -54,6 +54,8 @@ if name.startswith(('proj', 'attn_fwd', 'attn_bwd_hm', 'dx_gemm', 'tn_gemm')):  
     fns['proj_train'] = lambda: pj(0.2, True)
     fns['proj_noxs'] = lambda: pj(0.2, False)
     fns['attn_fwd'] = lambda: ck(lib.nr_attn_fwd(qkv.data_ptr(), ctx.data_ptr(), None, T, 20, 0.2, 1, st()))
+    fns['attn_pool_fwd'] = lambda: ck(lib.nr_attn_pool_fwd(qkv.data_ptr(), ctx.data_ptr(), None, Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), nv.data_ptr(),
+                                                           NR_D, aw.data_ptr(), T, 20, 20, 0.2, 1, st()))
     WdX = torch.empty(60 * 10 * 64 * 8, dtype=torch.int16, device=dev)
     ck(lib.nr_pack_qkv_dx(W[0].data_ptr(), W[1].data_ptr(), W[2].data_ptr(), WdX.data_ptr(), st()))
     dX = torch.empty(T * 20, NR_KP, dtype=torch.int16, device=dev)
