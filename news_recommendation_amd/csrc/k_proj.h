@@ -547,6 +547,150 @@ __global__ __launch_bounds__(NW * 64, 2) void dx_gemm_kernel(DxParams p) {
   }
 }
 
+// dx_gemm with a RING of chunk buffers.  With two buffers a chunk's copies are issued one chunk of compute (~0.5 us of MFMA work per wave)
+// before they are needed -- less than the loaded memory latency, so every chunk waited for its data: 3,600 cycles per chunk and workgroup
+// against 640 of MFMA work, the same with 1 x 4 strips or 2 x 2 blocks of the waves (profiles/r03_ab_switches.txt, pass k).  Here: one workgroup of 8 waves
+// per CU (256 tokens: wave = 64 tokens x 160 columns, 2 x 5 accumulator tiles), FOUR buffers of 36 KB, copies issued THREE chunks ahead;
+// per chunk one counted wait (s_waitcnt vmcnt: this wave's copies of the chunk have landed, two younger chunks stay in flight) and one raw
+// s_barrier, which both publishes the chunk and frees the slot the next copies overwrite.  Same chunks, same k order per output: same bits.
+struct DxRingGeom {
+  static constexpr int NWAVE = 8;
+  static constexpr int TOK_WG = 256;
+  static constexpr int KC = 2;
+  static constexpr int NCH = DXK / (16 * KC);          // 30
+  static constexpr int A_BYTES = TOK_WG * KC * 32;     // 16,384
+  static constexpr int W_BYTES = KC * NT32 * 1024;     // 20,480
+  static constexpr int BUF_BYTES = A_BYTES + W_BYTES;  // 36,864
+  static constexpr int NB = 4;                         // ring slots; copies run NB - 1 chunks ahead
+  static constexpr int SMEM = NB * BUF_BYTES;          // 147,456 B
+  static constexpr int CP = 5;                         // copy instructions per wave and chunk (2 of A, 3 of W)
+  static constexpr int OROW = 656;
+  static_assert(SMEM <= 163840 && 128 * OROW <= SMEM && CP * (NB - 1) < 64, "ring fits the LDS, the epilogue staging fits the ring, vmcnt range");
+};
+
+// DBG (compile time; profiling only, NR_DXR_DEBUG): 1 only the first three chunks are copied, 2 no MFMAs, 4 no dX stores
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void dx_gemm_ring_kernel(DxParams p) {
+  using Gm = DxRingGeom;
+  constexpr int dbg = DBG;
+  constexpr int NTW = NT32 / 2;                                   // 5 column tiles per wave
+  NR_SMEM_DECL(smem);
+  const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
+  const int wc = w & 1, wr = w >> 1;                              // column half, token quarter
+  const int64_t wg_tok0 = (int64_t)blockIdx.x * Gm::TOK_WG;
+
+  auto piece = [&](int c, int i) {                                // copy i (0 .. CP - 1) of chunk c: two of the token rows, three of the weight fragments
+    unsigned char* abuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
+    if (i < 2) {
+      const int r = w * 32 + i * 16 + (l >> 2), s = l & 3;
+      int64_t tok = wg_tok0 + r;
+      tok = tok < p.n_tok ? tok : p.n_tok - 1;
+      const u16* src = p.dqkv + tok * DXK + c * (16 * Gm::KC) + ((s ^ ((r >> 2) & 3)) * 8);
+      NR_GLDS16(src, abuf + (w * 32 + i * 16) * 64);
+    } else {
+      int f = w + 8 * (i - 2);
+      f = f < Gm::KC * NT32 ? f : f - 8;                          // 20 fragments over 24 copies: waves 4 .. 7 repeat one (same bytes, same place)
+      NR_GLDS16(p.WdX + (size_t)c * Gm::KC * NT32 * 512 + l * 8 + f * 512, abuf + Gm::A_BYTES + f * 1024);
+    }
+  };
+  auto fetch = [&](int c) {                                       // exactly CP copy instructions per wave
+#pragma unroll
+    for (int i = 0; i < Gm::CP; ++i) piece(c, i);
+  };
+  fetch(0);
+  fetch(1);
+  fetch(2);
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
+  const int arow0 = wr * 64 + li, arow1 = arow0 + 32;
+  const int sw0 = (arow0 >> 2) & 3, sw1 = (arow1 >> 2) & 3;
+  // Fragment sets of one k-step: five weight fragments + two token fragments.  The loop is rotated so that a wave never arrives at a barrier
+  // with nothing to issue behind it: k-step 1 of chunk c - 1 is multiplied AFTER the barrier of chunk c, behind the LDS reads of chunk c's
+  // k-step 0 -- every block of ten MFMAs (320 cycles) hides the LDS latency of the fragments the next block needs.  (Unrotated, the first
+  // reads of a chunk were issued after the barrier and waited for by all waves at once: profiles/r03m, the loop with neither copies nor
+  // MFMAs took 189 of the kernel's 433 us, and MFMA time simply added to it.)
+  struct Frag { u16x8 wf[NTW], af[2]; };
+  auto read_frag = [&](int c, int ks) -> Frag {
+    const unsigned char* abuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
+    const unsigned char* wbuf = abuf + Gm::A_BYTES + (ks * NT32 + wc * NTW) * 1024 + l * 16;
+    Frag f;
+    f.af[0] = *(const u16x8*)(abuf + arow0 * 64 + (((ks * 2 + h) ^ sw0) * 16));
+    f.af[1] = *(const u16x8*)(abuf + arow1 * 64 + (((ks * 2 + h) ^ sw1) * 16));
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) f.wf[j] = *(const u16x8*)(wbuf + j * 1024);
+    return f;
+  };
+  // cnext >= 0: the CP copies of chunk cnext are issued one per MFMA pair, not as a burst behind the barrier (a copy instruction holds its
+  // wave's issue slot for 60 - 185 cycles, longer the more copies are queued: 428 - 434 vs 440 - 449 us, profiles/r03_ab_switches.txt pass m)
+  auto multiply = [&](const Frag& f, int cnext = -1) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (!(dbg & 2)) {
+        acc[0][j] = mfma_32x32x16_bf16(f.wf[j], f.af[0], acc[0][j]);
+        acc[1][j] = mfma_32x32x16_bf16(f.wf[j], f.af[1], acc[1][j]);
+      } else {
+        acc[0][j][0] += bf2f(f.wf[j][0]) + bf2f(f.af[0][0]);
+        acc[1][j][0] += bf2f(f.wf[j][1]) + bf2f(f.af[1][0]);
+      }
+      if (!(dbg & 1) && cnext >= 0 && cnext < Gm::NCH) { piece(cnext, j); NR_SCHED_BARRIER(); }
+    }
+  };
+  auto arrive = [&](int c) {
+    // this wave's copies of chunk c have landed once at most the copies of the chunks after it are outstanding
+    if (dbg & 1) NR_WAIT_VMCNT(0);
+    else if (c + 2 < Gm::NCH) NR_WAIT_VMCNT(2 * Gm::CP);
+    else if (c + 1 < Gm::NCH) NR_WAIT_VMCNT(Gm::CP);
+    else NR_WAIT_VMCNT(0);
+    NR_WAIT_LGKMCNT(0);                                           // this wave's reads of chunk c - 1 have RETURNED (requested a block of MFMAs ago)
+    NR_BARRIER_RAW();                                             // chunk c is complete for everybody; everybody has read chunk c - 1: its slot
+  };                                                              // takes the copies of chunk c + 3 (issued by multiply)
+  arrive(0);
+  if (!(dbg & 1)) fetch(3);
+  Frag f0 = read_frag(0, 0);
+  Frag f1 = read_frag(0, 1);
+  NR_SCHED_BARRIER();
+  multiply(f0);
+  for (int c = 1; c < Gm::NCH; ++c) {
+    // The waits sit BEFORE the next reads are issued: what is outstanding then was requested a whole block of MFMAs ago.  (Left to the
+    // compiler, the wait lands in front of the first MFMA that needs the data -- behind the next set's reads, whose latency it then exposes.)
+    arrive(c);                                                    // (f1 = k-step 1 of chunk c - 1 is in registers)
+    f0 = read_frag(c, 0);
+    NR_SCHED_BARRIER();
+    multiply(f1, c + 3);
+    NR_SCHED_BARRIER();
+    NR_WAIT_LGKMCNT(0);                                           // f0 is in registers
+    NR_SCHED_BARRIER();
+    f1 = read_frag(c, 1);
+    NR_SCHED_BARRIER();
+    multiply(f0);
+  }
+  multiply(f1);
+  // ---- epilogue: 128 token rows of the workgroup at a time (token tile a of the four token quarters) through LDS ------------------------
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    __syncthreads();                                               // the last chunk (a = 0) / the previous batch (a = 1) has been read
+    unsigned char* row = smem + (wr * 32 + li) * Gm::OROW + wc * (NTW * 64);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(u16x4*)(row + (j * 32 + 8 * q + 4 * h) * 2) = pack4(f32x4{acc[a][j][4 * q], acc[a][j][4 * q + 1], acc[a][j][4 * q + 2], acc[a][j][4 * q + 3]});
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 128 * (KP / 8) / 512; ++i) {               // 10 sixteen-byte pieces per thread
+      const int idx = threadIdx.x + 512 * i;
+      const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
+      const int64_t tok = wg_tok0 + (r >> 5) * 64 + a * 32 + (r & 31);
+      if (tok < p.n_tok && !(dbg & 4)) *(u16x8*)(p.dX + tok * KP + pc * 8) = *(const u16x8*)(smem + r * Gm::OROW + pc * 16);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Weight gradients as a hand-written "TN" GEMM with split K: out[part][m][n] = sum over the partition's tokens of G[tok][m] X[tok][n]
 // (autograd of the nn.Linear layers w.r.t. weight and bias -- multihead_self.py:53-55 with G = dqkv [tok][960], X = the masked token matrix
@@ -671,6 +815,173 @@ __global__ __launch_bounds__(NW * 64, 2) void tn_gemm_kernel(TnParams p) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
       if (slab * Gm::BM + 32 * w + m < p.M) obase[(size_t)m * KP + nt * 32] = acc[nt][r];
     }
+}
+
+// tn_gemm with a ring of FOUR chunk buffers, copies three chunks ahead, one counted wait + one raw barrier per chunk (see dx_gemm_ring_kernel).
+// One workgroup of NW = 4 waves per CU owns a 128-row slab; a wave owns 64 rows x 160 columns.  Used for NARROW outputs (dpre: M = 208, two
+// slabs): 129 vs 208 us for the two-buffer kernel and 155 us for hipBLASLt (profiles/r03_ab_switches.txt, pass m).  For the 960 rows of dqkv
+// the 8-wave form of this kernel (256-row slabs) needs 261 registers per lane -- its spills reload through vmcnt and drain the ring (582 vs
+// 538 us) -- so wide outputs stay with tn_gemm_kernel.  Same chunks, same k order per output element as tn_gemm_kernel: same bits.
+template <int NW>
+struct TnRingGeom : TnGeom<NW> {
+  static constexpr int NB = 4;
+  static constexpr int SMEM = NB * TnGeom<NW>::BUF_BYTES;          // 147,456 / 114,688 B
+  static constexpr int XCP = (20 + NW - 1) / NW;                   // copy instructions per wave and chunk: X blocks (3 / 5) ...
+  static constexpr int CP = 2 + XCP;                               // ... + 2 of G
+  static_assert(SMEM <= 163840 && CP * (NB - 1) < 64, "ring fits the LDS; vmcnt range");
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void tn_gemm_ring_kernel(TnParams p) {
+  using Gm = TnRingGeom<NW>;
+  constexpr int NTW = NT32 / 2;
+  NR_SMEM_DECL(smem);
+  const int l = lane_id(), w = wave_id(), h = l >> 5;
+  const int wc = w & 1, wr = w >> 1;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int slab = jb % p.nslab, part = (jb / p.nslab) * 8 + xcd;
+  const int64_t t_begin = (int64_t)part * p.tok_per_part;
+  int64_t t_end = t_begin + p.tok_per_part;
+  t_end = t_end < p.n_tok ? t_end : p.n_tok;
+  const int ntok = t_end > t_begin ? (int)(t_end - t_begin) : 0;             // tokens of this partition (< 2^31 / row length: 32-bit offsets below)
+  const int nchunk = (ntok + Gm::TC - 1) / Gm::TC;
+  const u16* const Gp = p.G + t_begin * p.ldg;
+  const u16* const Xp = p.X + t_begin * KP;
+
+  // per-lane element offsets of this wave's copies inside a chunk (row r of the chunk, swizzled 16-byte slot s): constant over the chunks
+  auto g_slot = [&](int i, int& r, int& col) {
+    const int gs = (w * 2 + i) * 64 + l;
+    r = gs / Gm::GS;
+    col = slab * Gm::BM + (((gs - r * Gm::GS) ^ (4 * (r & 3))) * 8);
+  };
+  auto x_slot = [&](int k, int& blk, int& r, int& off) {
+    blk = w + NW * k;
+    blk = blk < 20 ? blk : blk - NW;                             // 20 blocks over NW * XCP copies: the surplus repeats one (same bytes, same place)
+    const int gs = blk * 64 + l;
+    r = gs / 40;
+    off = r * KP + (((gs - r * 40) ^ (4 * ((r >> 1) & 1))) * 8);
+  };
+  int goff[2], xoff[Gm::XCP];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { int r, col; g_slot(i, r, col); goff[i] = r * p.ldg + col; }
+#pragma unroll
+  for (int k = 0; k < Gm::XCP; ++k) { int blk, r; x_slot(k, blk, r, xoff[k]); }
+  const bool slab_full = (slab + 1) * Gm::BM <= p.ldg;
+  auto fetch = [&](int c) {                                      // exactly CP copy instructions per wave
+    unsigned char* gbuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
+    unsigned char* xbuf = gbuf + Gm::G_BYTES;
+    const int t0 = c * Gm::TC;
+    const u16* const Gc = Gp + (int64_t)t0 * p.ldg;              // wave-uniform bases + 32-bit lane offsets
+    const u16* const Xc = Xp + (int64_t)t0 * KP;
+    if (slab_full && t0 + Gm::TC <= ntok) {                      // every row and column of the chunk exists (all but the last chunk / slab)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) NR_GLDS16(Gc + goff[i], gbuf + (w * 2 + i) * 1024);
+#pragma unroll
+      for (int k = 0; k < Gm::XCP; ++k) {
+        const int blk = w + NW * k < 20 ? w + NW * k : w + NW * k - NW;
+        NR_GLDS16(Xc + xoff[k], xbuf + blk * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int r, col;
+        g_slot(i, r, col);
+        NR_GLDS16((t0 + r < ntok && col < p.ldg) ? Gc + (r * p.ldg + col) : p.zeros, gbuf + (w * 2 + i) * 1024);
+      }
+#pragma unroll
+      for (int k = 0; k < Gm::XCP; ++k) {
+        int blk, r, off;
+        x_slot(k, blk, r, off);
+        NR_GLDS16(t0 + r < ntok ? Xc + off : p.zeros, xbuf + blk * 1024);
+      }
+    }
+  };
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
+  for (int c = 0; c < Gm::NB - 1; ++c)
+    if (c < nchunk) fetch(c);
+  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);
+  // fragment set of one k-step: five X fragments + two G fragments; the loop is rotated as in dx_gemm_ring_kernel (k-step 1 of chunk c - 1 is
+  // multiplied behind the barrier of chunk c; every wait sits in front of the next reads)
+  struct Frag { u16x8 bf[NTW], af[2]; };
+  auto read_frag = [&](int c, int ks) -> Frag {
+    const unsigned char* gbuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
+    const unsigned char* xbuf = gbuf + Gm::G_BYTES;
+    Frag f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      u16x4 v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (2 * wr + a) + pcol;
+        v[t] = lds_tr16_b64((const u16*)(gbuf + (row * Gm::GS + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
+      }
+      f.af[a] = cat8(v[0], v[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      u16x4 v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (wc * NTW + j) + pcol;
+        v[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
+      }
+      f.bf[j] = cat8(v[0], v[1]);
+    }
+    return f;
+  };
+  auto multiply = [&](const Frag& f) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      acc[0][j] = mfma_32x32x16_bf16(f.af[0], f.bf[j], acc[0][j]);            // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
+      acc[1][j] = mfma_32x32x16_bf16(f.af[1], f.bf[j], acc[1][j]);
+    }
+  };
+  auto arrive = [&](int c) {
+    if (c + 2 < nchunk) NR_WAIT_VMCNT(2 * Gm::CP);
+    else if (c + 1 < nchunk) NR_WAIT_VMCNT(Gm::CP);
+    else NR_WAIT_VMCNT(0);
+    NR_WAIT_LGKMCNT(0);                                          // this wave's reads of chunk c - 1 have returned
+    NR_BARRIER_RAW();                                            // chunk c complete for everybody; everybody has read chunk c - 1
+    if (c + 3 < nchunk) fetch(c + 3);
+  };
+  if (nchunk > 0) {
+    arrive(0);
+    Frag f0 = read_frag(0, 0);
+    Frag f1 = read_frag(0, 1);
+    NR_SCHED_BARRIER();
+    multiply(f0);
+    for (int c = 1; c < nchunk; ++c) {
+      arrive(c);                                                 // (f1 = k-step 1 of chunk c - 1 is in registers)
+      f0 = read_frag(c, 0);
+      NR_SCHED_BARRIER();
+      multiply(f1);
+      NR_SCHED_BARRIER();
+      NR_WAIT_LGKMCNT(0);                                        // f0 is in registers
+      NR_SCHED_BARRIER();
+      f1 = read_frag(c, 1);
+      NR_SCHED_BARRIER();
+      multiply(f0);
+    }
+    multiply(f1);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m0 = slab * Gm::BM + 32 * (2 * wr + a);
+    float* obase = p.out + ((size_t)part * p.M + m0) * KP + wc * (NTW * 32) + (l & 31);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m0 + m < p.M) obase[(size_t)m * KP + j * 32] = acc[a][j][r];
+      }
+  }
 }
 
 }  // namespace nr

@@ -451,14 +451,34 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
     NR_LAUNCH(nr::dx_gemm_kernel<8>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 512, G::SMEM, (hipStream_t)stream, p);
   } else {
     using G = nr::DxGeom<4>;
-    NR_LAUNCH(nr::dx_gemm_kernel<4>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
+    static int ring = -1;                        // NR_DX_RING: 1 (default) = ring kernel (one 8-wave workgroup per CU), 0 = two-buffer kernel; same bits (A/B)
+    if (ring < 0) { const char* e = getenv("NR_DX_RING"); ring = e ? atoi(e) : 1; }
+    if (ring) {
+      using R = nr::DxRingGeom;
+      const char* d = getenv("NR_DXR_DEBUG");    // profiling: phase switches (compile-time variants), re-read per call
+      const int dbg = d != nullptr ? atoi(d) : 0;
+      const int64_t grid = (n_tok + R::TOK_WG - 1) / R::TOK_WG;
+#define NR_DXR_CASE(D) case D: if (allow_smem(nr::dx_gemm_ring_kernel<D>, R::SMEM)) return fail(NR_ERR_LAUNCH, "nr_dx_gemm: cannot reserve LDS"); \
+                               NR_LAUNCH(nr::dx_gemm_ring_kernel<D>, grid, 512, R::SMEM, (hipStream_t)stream, p); break;
+      switch (dbg) { NR_DXR_CASE(1) NR_DXR_CASE(2) NR_DXR_CASE(3) NR_DXR_CASE(4) NR_DXR_CASE(7) default: NR_DXR_CASE(0) }
+#undef NR_DXR_CASE
+    } else
+      NR_LAUNCH(nr::dx_gemm_kernel<4>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
   }
   return check_launch("nr_dx_gemm");
 }
 
+// NR_TN_RING: 1 (default) = narrow outputs (M <= 256) run in tn_gemm_ring_kernel (one workgroup per CU), 0 = everything in the two-buffer kernels
+static int tn_ring() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NR_TN_RING"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static int tn_slab_rows(int M) { return (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32; }
+
 int nr_tn_gemm_parts(int M, int64_t n_tok) {
   if (M <= 0 || n_tok < 0) return -1;
-  const int BM = (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32;      // narrow outputs (dpre: M = 208) always take the 128-row slabs
+  const int BM = tn_slab_rows(M);                 // narrow outputs (dpre: M = 208) always take the 128-row slabs
   // enough workgroups for two per CU (one per CU for narrow outputs, whose partials would otherwise outweigh the operands): partitions x
   // slabs ~ 512 / 256, partitions a multiple of 8, at least one 32-token chunk each when possible
   const int nslab = (M + BM - 1) / BM;
@@ -476,7 +496,12 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
   nr::TnParams p;
   p.G = G; p.ldg = ldg; p.M = M; p.X = X; p.zeros = zeros; p.out = out; p.n_tok = n_tok; p.P = P;
   p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32;
-  if (gemm_waves() == 8 && M > 256) {
+  if (tn_ring() && M <= 256) {
+    using G = nr::TnRingGeom<4>;
+    p.nslab = (M + G::BM - 1) / G::BM;
+    if (allow_smem(nr::tn_gemm_ring_kernel<4>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");
+    NR_LAUNCH(nr::tn_gemm_ring_kernel<4>, (int64_t)P * p.nslab, 256, G::SMEM, (hipStream_t)stream, p);
+  } else if (gemm_waves() == 8 && M > 256) {
     using G = nr::TnGeom<8>;
     p.nslab = (M + G::BM - 1) / G::BM;
     if (allow_smem(nr::tn_gemm_kernel<8>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");

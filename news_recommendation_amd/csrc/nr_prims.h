@@ -22,6 +22,16 @@
 #define NR_GLDS16(gptr, lds_base) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
 
+// Counted wait for a RING of such copies: returns when at most n of this wave's vector-memory loads (LDS-DMA included; they complete in
+// issue order) are still in flight.  s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; the other two
+// counters are left unconstrained.  NR_BARRIER_RAW is s_barrier WITHOUT the fence __syncthreads() implies (that fence drains vmcnt to 0,
+// i.e. the whole ring): the caller orders its own LDS traffic -- every wave waits for its own copies of a slot (NR_WAIT_VMCNT), then the
+// barrier makes them mutually visible; the asm clobbers keep the compiler from moving LDS accesses across either.
+#define NR_WAIT_VMCNT(n) do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14)); asm volatile("" ::: "memory"); } while (0)
+// likewise for the LDS counter: at most n of this wave's LDS operations (in issue order) still outstanding
+#define NR_WAIT_LGKMCNT(n) __builtin_amdgcn_s_waitcnt(0xC07F | (((n) & 15) << 8))
+#define NR_BARRIER_RAW() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 #define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(bx)), (size_t)(smem), (stream), __VA_ARGS__)
 

@@ -412,15 +412,16 @@ def _wgrad_parts(a, b, name):
     return _timed(name, run)
 
 
-# NR_WGRAD_GEMM: 1 = the weight-gradient products dqkv^T @ [X | 1] and dpre^T @ [ctx | 1] of the NRMS encoders run in the hand-written split-K
-# kernel nr_tn_gemm (csrc/k_proj.h: transposing LDS reads, no transposed operand copies); 0 (default) = chunked hipBLASLt batched GEMMs.
-# Measured side by side on one MI355X (profiles/r03_ab_switches.txt, r03h / r03i / r03j): inside the NRMS step dWqkv 377 - 385 us hand-written
-# vs 356 - 368 us hipBLASLt, dWa 171 - 200 vs 160 - 177, partial-sum reduction 87 vs 58 us (64 vs 32 partitions): 3.85 vs 3.75 ms per step.
-# The hand-written kernel is correct to 4e-7 of the library result and free of LDS bank conflicts; it is not the faster one yet, so the library
-# call remains the default for these two products (the input gradient dX runs hand-written: NR_DX_GEMM).
+# NR_WGRAD_GEMM: which weight-gradient products of the NRMS encoders run in the hand-written split-K kernel nr_tn_gemm (csrc/k_proj.h:
+# transposing LDS reads, no transposed operand copies) instead of chunked hipBLASLt batched GEMMs: 0 (default) = none, 2 = the pooling layer's
+# dpre^T @ [ctx | 1] (208 output rows: the ring-buffered kernel), 1 = also the projections' dqkv^T @ [X | 1].  Measured side by side on one
+# MI355X (profiles/r03_ab_switches.txt): inside the NRMS step dWqkv 377 - 385 us hand-written vs 356 - 368 us hipBLASLt; dWa 163 vs 176 us,
+# but its 128 token partitions (one workgroup per CU) cost nr_wgrad_unpack 83 instead of 58 us: 3.74 vs 3.73 ms per step either way -- the
+# library calls stay the default here.  Both agree with the library result to 4e-7.
 _WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '0'))
-# the same for the conv text encoders (tap and pooling weight gradients): NAML 11.29 ms with the hand-written kernel vs 10.34 ms (r03i)
-_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '0'))
+# the same for the conv text encoders: 2 (default) = the pooling weight gradient (NAML 10.33 - 10.36 vs 10.41 ms, LSTUR 5.86 vs 5.88 ms: pass n),
+# 1 = also the three tap gradients (NAML 11.29 ms vs 10.34 ms with the library, r03i), 0 = none
+_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '2'))
 _zeros16 = {}
 
 
@@ -736,7 +737,7 @@ class _EncoderFn(torch.autograd.Function):
         sw = side_wgrad(dev)
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        if _WGRAD_GEMM:
+        if _WGRAD_GEMM in (1, 2):
             dWa_parts = _wgrad_parts_hand(dpre, NR_QP, cbuf, f'nr_tn_gemm_dWa[S={S}]')    # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         else:
             dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))
@@ -751,7 +752,7 @@ class _EncoderFn(torch.autograd.Function):
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)
-        if _WGRAD_GEMM:
+        if _WGRAD_GEMM == 1:
             dW_parts = _wgrad_parts_hand(dqkv, NR_LDG, Xb, f'nr_tn_gemm_dWqkv[S={S}]')     # [P, 960, KP]
         else:
             dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))

@@ -113,7 +113,7 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None, dy
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
     dpre_b, ctx_bb = _bf16(dpre), _bf16(ctx_b)
-    if ops._WGRAD_GEMM_CONV:                      # hand-written split-K kernel (nr_tn_gemm): partial products per token partition, summed here
+    if ops._WGRAD_GEMM_CONV in (1, 2):            # hand-written split-K kernel (nr_tn_gemm): partial products per token partition, summed here
         dWa_ext = ops._wgrad_parts_hand(dpre, NR_QP, ctx_b, f'nr_tn_gemm_dWa[{tag}]').sum(dim=0)
     elif sw is not None:
         dWa_ext = sw.run(lambda: ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]'))
@@ -144,7 +144,7 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
 
     def wgrad():
         taps = []
-        if ops._WGRAD_GEMM_CONV:     # hand-written split-K kernel: the tap shift is a row offset of the X operand
+        if ops._WGRAD_GEMM_CONV == 1:     # hand-written split-K kernel: the tap shift is a row offset of the X operand
             for w in range(3):
                 taps.append(ops._wgrad_parts_hand(dy, NR_KP, st.xstore[w:w + ra], f'nr_tn_gemm_dWconv[{tag}]').sum(dim=0))
             return taps

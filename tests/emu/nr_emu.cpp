@@ -34,6 +34,7 @@ static void fiber_entry() {
   BlockState* b = g_blk;
   b->body();
   Fiber& f = b->fibers[b->cur];
+  dma_land(0);
   f.done = true;
   b->alive--;
   // a thread that exits releases barriers the way a terminated wave does
@@ -71,6 +72,7 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
     for (int t = 0; t < nt; ++t) {
       Fiber& f = blk.fibers[t];
       f.done = false;
+      f.dma.clear();
       f.tid = Dim3{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
       unsigned char* top = stacks.data() + (size_t)(t + 1) * kStack;
       uintptr_t sp = ((uintptr_t)top & ~(uintptr_t)15);

@@ -41,11 +41,14 @@ namespace nr_emu {
 
 struct Dim3 { unsigned x, y, z; };
 
+struct PendingCopy { const void* src; void* dst; };
+
 struct Fiber {
   void* sp = nullptr;
   unsigned char* stack = nullptr;
   bool done = false;
   Dim3 tid{0, 0, 0};
+  std::vector<PendingCopy> dma;   // issued, not yet landed global -> LDS copies of this lane (oldest first)
 };
 
 struct WaveState {
@@ -76,11 +79,27 @@ extern "C" void nr_emu_switch(void** save_sp, void* load_sp);
 inline Fiber& cur_fiber() { return g_blk->fibers[g_blk->cur]; }
 inline void yield() { Fiber& f = cur_fiber(); nr_emu_switch(&f.sp, g_blk->sched_sp); }
 
-inline void block_sync() {
+// LDS-DMA model: a copy lands as LATE as the program allows -- at the s_waitcnt vmcnt(n) that covers it (all but the newest n of the lane's
+// copies land), at a __syncthreads() (the compiler's fence drains vmcnt) or when the lane exits -- so that a wait that is too weak, or a
+// raw barrier used where a drain was needed, shows up as stale LDS data.
+inline void dma_land(size_t keep) {
+  Fiber& f = cur_fiber();
+  if (f.dma.size() <= keep) return;
+  const size_t n = f.dma.size() - keep;
+  for (size_t i = 0; i < n; ++i) memcpy(f.dma[i].dst, f.dma[i].src, 16);
+  f.dma.erase(f.dma.begin(), f.dma.begin() + n);
+}
+inline void dma_issue(const void* src, void* dst) { cur_fiber().dma.push_back(PendingCopy{src, dst}); }
+
+inline void block_sync_raw() {
   BlockState* b = g_blk;
   unsigned my = b->gen;
   if (++b->arrived == b->alive) { b->arrived = 0; b->gen++; return; }
   while (b->gen == my) yield();
+}
+inline void block_sync() {
+  dma_land(0);
+  block_sync_raw();
 }
 inline void wave_sync() {
   BlockState* b = g_blk;
@@ -114,7 +133,10 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
 #define NR_ONE_WAVE_PER_SIMD
 
 // emulation of global_load_lds_dwordx4: every lane copies its 16 B to lds_base + 16 * lane
-#define NR_GLDS16(gptr, lds_base) memcpy((unsigned char*)(lds_base) + 16 * (threadIdx.x & 63), (const void*)(gptr), 16)
+#define NR_GLDS16(gptr, lds_base) nr_emu::dma_issue((const void*)(gptr), (unsigned char*)(lds_base) + 16 * (threadIdx.x & 63))
+#define NR_WAIT_VMCNT(n) nr_emu::dma_land(n)
+#define NR_WAIT_LGKMCNT(n) ((void)0)
+#define NR_BARRIER_RAW() nr_emu::block_sync_raw()
 
 #define NR_LAUNCH2(kern, gx, gy, bx, smem, stream, ...)                                                \
   nr_emu::launch(nr_emu::Dim3{(unsigned)(gx), (unsigned)(gy), 1}, nr_emu::Dim3{(unsigned)(bx), 1, 1},     \

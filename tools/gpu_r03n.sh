@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 3, pass n: hand-written pooling weight gradient (ring-buffered nr_tn_gemm, M = 208) as the default -- step A/B on the three models.
+export TMPDIR=/tmp
+O=gpurun_out/r03n
+mkdir -p $O
+timeout 900 python -m pytest tests/test_proj_gpu.py tests/test_model_gpu.py tests/test_naml_gpu.py tests/test_lstur_gpu.py -x -q -m gpu > $O/pytest.log 2>&1; echo "tests rc=$?" | tee -a $O/summary.txt; tail -3 $O/pytest.log
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); kb=d['kernel_breakdown_us_per_step']; print('$1', round(d['value']), round(d['ms_per_step'],3), {k: v for k, v in kb.items() if 'dx' in k or 'dW' in k or 'tn_' in k or 'unpack' in k})"; }
+for v in "NR_X=1" "NR_WGRAD_GEMM=0" "NR_DX_RING=0" "NR_X=2" "NR_WGRAD_GEMM=0 NR_DX_RING=0"; do
+  env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-extras 2>$O/bench.err | tee "$O/bench_$(echo $v | tr ' =' '__').json" | line "$v"
+done
+for m in NAML LSTUR; do
+for v in "NR_X=1" "NR_WGRAD_GEMM_CONV=0 NR_WGRAD_GEMM=0" "NR_X=2"; do
+  env $v timeout 300 python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-extras 2>$O/bench.err | tee "$O/bench_${m}_$(echo $v | tr ' =' '__').json" | line "$m $v"
+done; done
