@@ -344,6 +344,14 @@ int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* ga
 int nr_gru_seq_buffers(int B, int Hd, int T);
 int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
                      uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream);
+/* Inference sweep over histories that INDEX a table of per-item input projections (LSTUR evaluation, src/evaluate.py:218-233 +
+ * model/LSTUR/user_encoder.py:27-45: every clicked-news vector is a row of the news matrix, so x_t W_ih^T is computed once per news, not once per
+ * (history, position)): gi f32 [n_rows][3*Hg], gi_row int32 [B][N] (row of gi for sample b at step t); h_f f32 [B][Hp] holds h0 on entry and the
+ * state after len[b] steps on return (updated in place); h_t2: two tile-order bf16 buffers [ceil16(B)][Hp], the first holding h0
+ * (nr_tile_rows_bf16).  active (HOST pointer, optional): active[t] = number of leading samples with len > t when the samples are sorted by
+ * length, longest first -- step t is then launched for those rows only (pack_padded_sequence's batch_sizes). */
+int nr_gru_fwd_seq_rows(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
+                        uint16_t* h_t2, float* h_f, const int32_t* active, int B, int N, int Hd, int T, void* stream);
 int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                      uint16_t* dgh, uint16_t* dgh_t2, int n_buf, float* carry2, int B, int N, int Hd, int T, void* stream);
 

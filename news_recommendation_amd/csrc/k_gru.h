@@ -34,6 +34,8 @@ __host__ inline int gru_grid(int n_tiles, int n_groups) { return 8 * ((n_tiles +
 
 struct GruFwdParams {
   const float* gi;        // [B*N][3*Hg] f32, row b*N + t  (x_t W_ih^T, no bias)
+  const int* gi_row;      // optional [B*N]: the row of gi to take for (b, t) instead of b*N + t (evaluation: histories index a table of
+                          // per-news projections, nr_gru_fwd_seq_rows)
   const u16* Whh;         // bf16 [3*Hg][Hp], tile order
   const float* b_ih;      // [3*Hd]
   const float* b_hh;      // [3*Hd]
@@ -98,7 +100,8 @@ __device__ __forceinline__ void gru_fwd_step_impl(const GruFwdParams& p, int til
     hp[nb] = p.h_in_t + (size_t)(st >> 4) * p.Hp * 16 + l * 8;
     sb[nb] = st + li < p.B ? st + li : p.B - 1;
     len_s[nb] = p.len[sb[nb]];
-    const float* gi = p.gi + ((size_t)sb[nb] * p.N + p.t) * 3 * p.Hg + jb;
+    const size_t girow = p.gi_row != nullptr ? (size_t)p.gi_row[(size_t)sb[nb] * p.N + p.t] : (size_t)sb[nb] * p.N + p.t;
+    const float* gi = p.gi + girow * 3 * p.Hg + jb;
     gir[nb] = *(const f32x4*)gi; giz[nb] = *(const f32x4*)(gi + p.Hg); gin[nb] = *(const f32x4*)(gi + 2 * p.Hg);
     ho[nb] = *(const f32x4*)(p.h_in_f + (size_t)sb[nb] * p.Hp + jb);
     ar[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; az[nb] = ar[nb]; an[nb] = ar[nb];

@@ -884,15 +884,25 @@ static bool gru_persist_ok(int B, int Hd) {
          (Hg / 16) * ((B + 127) / 128) <= gru_cu_count();
 }
 
+static int gru_fwd_step_launch(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
+                               const uint16_t* h_in_t, uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B,
+                               int N, int Hd, int t, void* stream);
+
 int nr_gru_fwd_step(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, const uint16_t* h_in_t,
                     uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B, int N, int Hd, int t,
                     void* stream) {
+  return gru_fwd_step_launch(gi, nullptr, Whh, b_ih, b_hh, len, h_in_t, h_out_b, h_out_t, h_in_f, h_out_f, gates, B, N, Hd, t, stream);
+}
+
+static int gru_fwd_step_launch(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
+                               const uint16_t* h_in_t, uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B,
+                               int N, int Hd, int t, void* stream) {
   if (!gi || !Whh || !b_ih || !b_hh || !len || !h_in_t || !h_out_t || !h_in_f || !h_out_f || B < 0 || N <= 0 || Hd <= 0 || t < 0 || t >= N)
     return fail(NR_ERR_BADARG, "nr_gru_fwd_step: bad argument");
   if (B == 0) return NR_OK;
   nr::GruFwdParams p;
-  p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_t = h_in_t; p.h_out_b = h_out_b; p.h_out_t = h_out_t; p.h_in_f = h_in_f;
-  p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
+  p.gi = gi; p.gi_row = gi_row; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_in_t = h_in_t; p.h_out_b = h_out_b; p.h_out_t = h_out_t;
+  p.h_in_f = h_in_f; p.h_out_f = h_out_f; p.gates = gates; p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
   const int nb = gru_nb_knob() > 0 ? gru_nb_knob() : (B >= 256 ? 2 : 1);
   const int tiles = p.Hg / 16;
   const int ldsv = gru_lds_knob();      // W_hh-tile-in-LDS variant of the two-tile kernel (Hd = 900 / 450): the default
@@ -968,7 +978,7 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
   if (T > 0 && n_buf >= T + 1 && gru_persist_ok(B, Hd)) {
     if (!gi || !Whh || !b_ih || !b_hh || !len) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
     nr::GruFwdSeqParams q;
-    q.st.gi = gi; q.st.Whh = Whh; q.st.b_ih = b_ih; q.st.b_hh = b_hh; q.st.len = len; q.st.h_in_t = nullptr; q.st.h_out_b = nullptr; q.st.h_out_t = nullptr;
+    q.st.gi = gi; q.st.gi_row = nullptr; q.st.Whh = Whh; q.st.b_ih = b_ih; q.st.b_hh = b_hh; q.st.len = len; q.st.h_in_t = nullptr; q.st.h_out_b = nullptr; q.st.h_out_t = nullptr;
     q.st.h_in_f = nullptr; q.st.h_out_f = nullptr; q.st.gates = nullptr; q.st.B = B; q.st.N = N; q.st.Hd = Hd; q.st.Hg = Hg; q.st.Hp = Hp; q.st.t = 0;
     q.h_t = h_t2; q.H_all = H_all; q.h_f2 = h_f2; q.gates_all = gates;
     q.n_active = (unsigned)((Hg / 16) * ((B + 127) / 128));
@@ -978,6 +988,26 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
     const int rc = nr_gru_fwd_step(gi, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, H_all ? H_all + (size_t)(t + 1) * hf : nullptr,
                                    h_t2 + ((t + 1) & 1) * ht, h_f2 + (t & 1) * hf, h_f2 + ((t + 1) & 1) * hf,
                                    gates ? gates + (size_t)t * B * 4 * Hg : nullptr, B, N, Hd, t, stream);
+    if (rc) return rc;
+  }
+  return NR_OK;
+}
+
+int nr_gru_fwd_seq_rows(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
+                        uint16_t* h_t2, float* h_f, const int32_t* active, int B, int N, int Hd, int T, void* stream) {
+  if (!gi || !gi_row || !h_t2 || !h_f || T < 0 || T > N || B < 0 || Hd <= 0) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq_rows: bad argument");
+  const int Hp = ceil_to(Hd + 1, 32);
+  const size_t ht = (size_t)ceil_to(B, 16) * Hp;
+  for (int t = 0; t < T; ++t) {
+    int Bt = B;
+    if (active != nullptr) {
+      Bt = active[t];
+      if (Bt < 0 || Bt > B || (t > 0 && Bt > active[t - 1])) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq_rows: active[] must be non-increasing in [0, B]");
+    }
+    if (Bt == 0) break;
+    // the fp32 state is read and written by the same lane: one buffer, in place -- rows beyond Bt simply keep their final state
+    const int rc = gru_fwd_step_launch(gi, gi_row, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, nullptr, h_t2 + ((t + 1) & 1) * ht, h_f, h_f, nullptr, Bt, N,
+                                       Hd, t, stream);
     if (rc) return rc;
   }
   return NR_OK;

@@ -72,5 +72,9 @@ class LSTUR(torch.nn.Module):
         """[B], [B], [B, N, 3F] -> [B, 3F]   (evaluate.py:226-230; no masking at evaluation time, :103-105)."""
         return self.user_encoder(self._user_rows(user, False), clicked_news_length, clicked_news_vector)
 
+    def get_user_vector_rows(self, user, clicked_news_length, news_vectors, clicked_rows):
+        """get_user_vector for histories given as row indices into the news-vector matrix (engine-side batched evaluation only)."""
+        return self.user_encoder.forward_rows(self._user_rows(user, False), clicked_news_length, news_vectors, clicked_rows)
+
     def get_prediction(self, news_vector, user_vector):
         return self.click_predictor(news_vector.unsqueeze(dim=0), user_vector.unsqueeze(dim=0)).squeeze(dim=0)

@@ -22,3 +22,15 @@ class UserEncoder(torch.nn.Module):
             return ops_gru.gru_last_state(clicked_news_vector, user, clicked_news_length, self.gru)
         last_hidden = ops_gru.gru_last_state(clicked_news_vector, None, clicked_news_length, self.gru)
         return torch.cat((last_hidden, user), dim=1)
+
+    @torch.no_grad()
+    def forward_rows(self, user, clicked_news_length, news_vectors, clicked_rows):
+        """Evaluation-only form of forward() for histories given as ROW INDICES into a matrix of news vectors (news_vectors f32 [R, 3F] on
+        the GPU, clicked_rows integer [B, N]): same result as forward(user, length, news_vectors[clicked_rows]) without materialising the
+        [B, N, 3F] block (news_recommendation_amd.evaluate_fast, phase B)."""
+        lengths = clicked_news_length.clone()
+        lengths[lengths == 0] = 1
+        if self.config.long_short_term_method == 'ini':
+            return ops_gru.gru_last_state_rows(news_vectors, clicked_rows, user, lengths.numpy(), self.gru)
+        last_hidden = ops_gru.gru_last_state_rows(news_vectors, clicked_rows, None, lengths.numpy(), self.gru)
+        return torch.cat((last_hidden, user), dim=1)

@@ -15,6 +15,7 @@ maps sklearn over the impressions in a process pool (:267-268).  Here:
 the plan on the engine.  Quirks kept on purpose: ``count == max_count`` stops BEFORE scoring that row (:247-249), unknown users
 map to id 0 (:98-102), LSTUR uses the first user id seen with a history string.
 """
+import os
 import sys
 from ast import literal_eval
 from os import path
@@ -105,6 +106,14 @@ def run_plan(model, plan, batch, model_name):
     # phase B
     hidx = torch.from_numpy(plan.hist_idx).to(dev)
     uv = []
+    if model_name == 'LSTUR' and hasattr(model, 'get_user_vector_rows') and os.environ.get('NR_EVAL_ROWS', '1') == '1':
+        # all histories in one sweep: the GRU reads its input projections through the history's news indices (one GEMM over the news matrix
+        # instead of one over every (history, position)), longest histories first (ops_gru.gru_last_state_rows)
+        step = max(batch, 1 << 17)
+        for i in range(0, hidx.shape[0], step):
+            uv.append(model.get_user_vector_rows(torch.from_numpy(plan.hist_user[i:i + step]), torch.from_numpy(plan.hist_len[i:i + step].copy()),
+                                                 nvp, hidx[i:i + step]))
+        hidx = hidx[:0]
     for i in range(0, hidx.shape[0], batch):
         block = nvp[hidx[i:i + batch]]                                           # [b, N, D]
         if model_name == 'LSTUR':

@@ -167,3 +167,55 @@ def gru_last_state(x, h0, clicked_news_length, gru):
         T = int(lens.max())
         lens_dev = ops.to_device_async(lens.to(torch.int32), x.device)
     return _GruFn.apply(x, h0, lens_dev, T, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+
+
+@torch.no_grad()
+def gru_last_state_rows(table, rows, h0, lengths, gru):
+    """Inference form of gru_last_state for histories that index a table: x[b, t] = table[rows[b, t]] (table f32 [R, I] on the GPU, rows integer
+    [B, N], lengths host integers [B], already >= 1).  x_t W_ih^T is computed once per TABLE row (one GEMM over R rows instead of B * N),
+    the step kernels fetch it through the index (nr_gru_fwd_seq_rows), and the histories are processed longest first so that step t only
+    launches the rows that are still running -- pack_padded_sequence's own schedule (src/model/LSTUR/user_encoder.py:27-45)."""
+    import numpy as np
+    lib = _lib()
+    _require_cuda(table, "news vectors")
+    dev = table.device
+    B, N = rows.shape
+    I = table.shape[1]
+    W_ih, W_hh = gru.weight_ih_l0, gru.weight_hh_l0
+    Hd = W_hh.shape[1]
+    Hg, Hp, Kp = gru_dims(Hd)
+    Ip = _ceil(I + 1, 32)
+    if B == 0:
+        return torch.zeros(0, Hd, device=dev)
+
+    def build():
+        Wih_p = torch.empty(3 * Hg, Ip, dtype=_BF16_AS_I16, device=dev)
+        Whh_p = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
+        WhhT = torch.empty(Hp, Kp, dtype=_BF16_AS_I16, device=dev)
+        Wi, Wh = _f32c(W_ih), _f32c(W_hh)
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wi), Hd, I, Ip, _ptr(Wih_p), None, 0, _stream())
+        _call('nr_pack_gru', lib.nr_pack_gru, _ptr(Wh), Hd, Hd, Hp, _ptr(Whh_p), _ptr(WhhT), 1, _stream())
+        return Wih_p, Whh_p, WhhT
+    Wih_p, Whh_p, _ = ops._packed('gru', (W_ih, W_hh), build)
+    bi, bh = _f32c(gru.bias_ih_l0), _f32c(gru.bias_hh_l0)
+    Xb = rows_to_bf16(_f32c(table), I, Ip)
+    gi = _mm_f32(_bf16(Xb), _bf16(Wih_p).t(), 'gemm_gru_gi[table]')                          # [R][3*Hg] f32
+    lens = np.clip(np.asarray(lengths, dtype=np.int64), 1, N)
+    order = np.argsort(-lens, kind='stable')                                                 # longest first
+    T = int(lens[order[0]])
+    active = np.ascontiguousarray((lens[order][None, :] > np.arange(T)[:, None]).sum(axis=1).astype(np.int32))
+    order_d = torch.from_numpy(order).to(dev)
+    rows_s = rows.to(dev)[order_d].to(torch.int32).contiguous()
+    lens_s = torch.from_numpy(lens[order].astype(np.int32)).to(dev)
+    hf = torch.zeros(B, Hp, dtype=torch.float32, device=dev)
+    if h0 is not None:
+        hf[:, :Hd].copy_(h0[order_d])
+    ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)
+    hb = torch.empty(B, Hp, dtype=_BF16_AS_I16, device=dev)
+    _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf), Hp, Hd, _ptr(hb), Hp, B, _stream())
+    _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(hb), B, Hp, _ptr(ht[0]), _stream())
+    _call('nr_gru_fwd_seq_rows', lib.nr_gru_fwd_seq_rows, _ptr(gi), _ptr(rows_s), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_s), _ptr(ht), _ptr(hf),
+          active.ctypes.data, B, N, Hd, T, _stream())
+    out = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+    out[order_d] = hf[:, :Hd]
+    return out

@@ -216,3 +216,31 @@ def test_flat_gradient_buffer_inplace_table_gradients(model_name):
     crit(wl.forward(m2, b), y).backward()                      # no zero(): gradients accumulate
     for k, p in m2.named_parameters():
         torch.testing.assert_close(p.grad, 2 * ref[k], rtol=1e-5, atol=1e-7, msg=k)
+
+
+@pytest.mark.parametrize('method', ['ini', 'con'])
+def test_user_vector_rows_equals_user_vector(method):
+    """get_user_vector_rows (histories as row indices into the news matrix: per-news input projections, longest-first schedule) ==
+    get_user_vector on the gathered [B, N, 3F] block (src/evaluate.py:218-233 + model/LSTUR/user_encoder.py:27-45): same bf16 operands, same
+    fp32 recurrence; ragged lengths incl. 0 (-> 1), 1 and N, repeated and padded (zero-row) indices."""
+    c = dict(MIND, nusers=301, method=method)
+    params = random_lstur_params(7, c['V'], c['d'], c['ncat'], c['nusers'], c['F'], c['window'], c['Q'], method, emb_std=0.3)
+    m = build(c, params).eval()
+    rng = np.random.default_rng(7)
+    R, B, N = 400, 37, c['N']
+    nv = torch.from_numpy(rng.normal(0, 0.5, size=(R, 3 * c['F'])).astype(np.float32)).to(DEV)
+    nvp = torch.cat([nv, torch.zeros(1, nv.shape[1], device=DEV)])
+    lens = rng.integers(0, N + 1, size=B)
+    lens[:4] = [0, 1, N, N]
+    rows = rng.integers(0, R, size=(B, N))
+    for b in range(B):
+        rows[b, max(lens[b], 0):] = R                      # padded slots point at the zero row, like PADDED_NEWS
+    user = torch.from_numpy(rng.integers(0, c['nusers'], size=B).astype(np.int64))
+    rows_d = torch.from_numpy(rows).to(DEV)
+    with torch.no_grad():
+        ref = m.get_user_vector(user, torch.from_numpy(lens.copy()), nvp[rows_d])
+        got = m.get_user_vector_rows(user, torch.from_numpy(lens.copy()), nvp, rows_d)
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-6 * max(1.0, ref.abs().max().item()), f'{method}: user vectors differ by {err}'
