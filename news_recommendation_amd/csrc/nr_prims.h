@@ -90,6 +90,7 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return a + b;
 }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 // Lane exchange inside a row of 16 lanes (lanes with equal l >> 4) as ONE DPP-modified move: MODE 0: lane ^ 1, 1: lane ^ 2 (quad_perm),
 // 2: i <-> 7 - i inside each group of 8 (row_half_mirror), 3: i <-> 15 - i (row_mirror).  Every mode pairs lanes that differ in bit
 // MODE of the lane index and agree in the higher bits: enough for butterflies and recursive halving, no ds_bpermute round trip.

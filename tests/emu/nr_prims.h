@@ -253,6 +253,13 @@ __forceinline__ float shfl(float v, int src) {
   return r;
 }
 
+__forceinline__ uint32_t shfl_u32(uint32_t v, int src) {
+  float f; memcpy(&f, &v, 4);
+  f = shfl(f, src);
+  uint32_t r; memcpy(&r, &f, 4);
+  return r;
+}
+
 template <int MODE>
 __forceinline__ float row_xchg(float v) {            // partner: lane ^ 1, lane ^ 2, i <-> 7 - i (groups of 8), i <-> 15 - i (rows of 16)
   nr_emu::BlockState* blk = nr_emu::g_blk;
