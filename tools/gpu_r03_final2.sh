@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 measurement pass: parity tests, smoke, bench lines (all workloads), rocprofv3 kernel stats, HBM traffic and SQ counters of the dominant
-# kernels, the N > 1 code path of bench.py with two ranks sharing the one GPU (gloo).  Usage: bash tools/gpu_r03_final.sh [TAG]
+# Round-3 measurement pass: parity tests, smoke, HBM traffic and SQ counters of the dominant kernels (first: the bench lines quote them), bench
+# lines (all workloads), rocprofv3 kernel stats, the N > 1 code path of bench.py with two ranks sharing the one GPU (gloo).  Usage: bash tools/gpu_r03_final2.sh [TAG]
 export TMPDIR=/tmp
-TAG=${1:-r03final}
+TAG=${1:-r03final2}
 O=gpurun_out/$TAG
 mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
@@ -25,6 +25,19 @@ if "gather_roofline" in d:
 print("   kernels", dict(list(d["kernel_breakdown_us_per_step"].items())[:12]))
 PY
 }
+for K in proj_train attn_pool_fwd attn_bwd_hm additive_bwd; do
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${K}_fetch -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_fetch.log 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${K}_write -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_write.log 2>&1
+done
+python tools/pmc_traffic.py $O profiles/r03_pmc_traffic.txt | tee $O/pmc_traffic.txt
+rm -rf $O/pmc_*_fetch $O/pmc_*_write
+for K in "proj_train qkv_proj" "attn_pool_fwd attn_fwd_kernel" "attn_bwd_hm attn_bwd" "additive_bwd pool2_bwd" "additive_bwd50 pool2_bwd" "conv_abs conv3" "dx_gemm dx_gemm" "tn_gemm tn_gemm"; do
+  set -- $K
+  bash tools/pmc_kernel.sh $1 $2 $O/pmc_sq_$1 > /dev/null 2>&1
+done
+python tools/pmc_sq.py $O r03 | tee $O/pmc_sq_summary.txt
+# the bench lines below report traffic / mfma_busy only from files measured on THIS library (source hash): take the ones just made
+cp $O/traffic.json profiles/traffic.json; cp $O/mfma_busy.json profiles/mfma_busy.json
 timeout 900 python bench.py > $O/bench_line_NRMS_small.json 2> $O/bench_line_NRMS_small.err; q $O/bench_line_NRMS_small.json
 timeout 900 python bench.py --shape large > $O/bench_line_NRMS_large.json 2> $O/bench_line_NRMS_large.err; q $O/bench_line_NRMS_large.json
 timeout 1200 python bench.py --model LSTUR --shape large > $O/bench_line_LSTUR_large.json 2> $O/bench_line_LSTUR_large.err; q $O/bench_line_LSTUR_large.json
@@ -38,15 +51,4 @@ for W in "NRMS small" "NAML small" "LSTUR large"; do
   rm -rf $O/prof_$1_$2
 done
 head -14 $O/kernel_stats_NRMS_small.csv | cut -c1-170
-for K in proj_train attn_fwd attn_bwd_hm additive_bwd; do
-  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${K}_fetch -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_fetch.log 2>&1
-  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${K}_write -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_write.log 2>&1
-done
-python tools/pmc_traffic.py $O profiles/r03_pmc_traffic.txt | tee $O/pmc_traffic.txt
-rm -rf $O/pmc_*_fetch $O/pmc_*_write
-for K in "proj_train qkv_proj" "attn_fwd attn_fwd_kernel" "attn_bwd_hm attn_bwd" "additive_bwd pool2_bwd" "additive_fwd additive_fwd" "additive_bwd50 pool2_bwd" "conv_abs conv3" "dx_gemm dx_gemm" "tn_gemm tn_gemm"; do
-  set -- $K
-  bash tools/pmc_kernel.sh $1 $2 $O/pmc_sq_$1 > /dev/null 2>&1
-done
-python tools/pmc_sq.py $O r03 | tee $O/pmc_sq_summary.txt
 bash tools/gpu_two_ranks_one_gpu.sh > $O/two_ranks.log 2>&1; grep "^rc\[" $O/two_ranks.log; cp gpurun_out/two_ranks_NRMS.log gpurun_out/two_ranks_LSTUR.log $O/ 2>/dev/null
