@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement pass: parity tests, smoke, HBM traffic and SQ counters of the dominant kernels (first: the bench lines quote them), bench
-# lines (all workloads), rocprofv3 kernel stats, the N > 1 code path of bench.py with two ranks sharing the one GPU (gloo).  Usage: bash tools/gpu_r03_final2.sh [TAG]
+# lines (all workloads), rocprofv3 kernel stats, the N > 1 code path of bench.py with two ranks sharing the one GPU (gloo).  Usage: bash tools/gpu_final_pass.sh [TAG]
 export TMPDIR=/tmp
 TAG=${1:-r03final2}
 O=gpurun_out/$TAG
