@@ -474,7 +474,7 @@ static int tn_ring() {
   if (v < 0) { const char* e = getenv("NR_TN_RING"); v = e ? atoi(e) : 1; }
   return v;
 }
-static int tn_slab_rows(int M) { return (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32; }
+static int tn_slab_rows(int M) { return tn_ring() == 2 ? 128 : (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32; }
 
 int nr_tn_gemm_parts(int M, int64_t n_tok) {
   if (M <= 0 || n_tok < 0) return -1;
@@ -482,7 +482,7 @@ int nr_tn_gemm_parts(int M, int64_t n_tok) {
   // enough workgroups for two per CU (one per CU for narrow outputs, whose partials would otherwise outweigh the operands): partitions x
   // slabs ~ 512 / 256, partitions a multiple of 8, at least one 32-token chunk each when possible
   const int nslab = (M + BM - 1) / BM;
-  int P = ((nslab * BM >= 512 ? (BM == 128 ? 512 : 256) : 256) + nslab - 1) / nslab;
+  int P = ((nslab * BM >= 512 && tn_ring() != 2 ? (BM == 128 ? 512 : 256) : 256) + nslab - 1) / nslab;     // (ring kernels: one workgroup per CU)
   P = (P + 7) / 8 * 8;
   const int64_t maxp = (n_tok + 31) / 32;
   while (P > 8 && P > maxp) P -= 8;
@@ -496,7 +496,7 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
   nr::TnParams p;
   p.G = G; p.ldg = ldg; p.M = M; p.X = X; p.zeros = zeros; p.out = out; p.n_tok = n_tok; p.P = P;
   p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32;
-  if (tn_ring() && M <= 256) {
+  if (tn_ring() == 2 || (tn_ring() && M <= 256)) {          // NR_TN_RING=2: the 128-row ring kernel for wide outputs too (A/B)
     using G = nr::TnRingGeom<4>;
     p.nslab = (M + G::BM - 1) / G::BM;
     if (allow_smem(nr::tn_gemm_ring_kernel<4>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");
