@@ -352,6 +352,11 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
  * length, longest first -- step t is then launched for those rows only (pack_padded_sequence's batch_sizes). */
 int nr_gru_fwd_seq_rows(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
                         uint16_t* h_t2, float* h_f, const int32_t* active, int B, int N, int Hd, int T, void* stream);
+/* Gate stage of ONE step of the same sweep for large batches, where the recurrent product runs as a plain GEMM (gh f32 [B][3*Hg] =
+ * bf16(h) @ bf16(W_hh)^T, rows in nr_pack_gru's order): r, z, n and the state update of user_encoder.py:27-45 / torch.nn.GRU for the first B
+ * samples; h_f f32 [B][Hp] updated in place, h_b bf16 [B][Hp] = the new state (column Hd = 1.0), the next step's GEMM operand. */
+int nr_gru_gate_rows(const float* gi, const int32_t* gi_row, const float* gh, const float* b_ih, const float* b_hh, const int32_t* len, float* h_f,
+                     uint16_t* h_b, int B, int N, int Hd, int t, void* stream);
 int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                      uint16_t* dgh, uint16_t* dgh_t2, int n_buf, float* carry2, int B, int N, int Hd, int T, void* stream);
 

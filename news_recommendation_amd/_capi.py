@@ -70,6 +70,7 @@ SIGNATURES = {
     'nr_gru_seq_buffers': ([c_int, c_int, c_int], c_int),
     'nr_gru_fwd_seq_n': ([_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_fwd_seq_rows': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    'nr_gru_gate_rows': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_bwd_seq_n': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_gru_bwd_step': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     'nr_impression_metrics': ([_P, _P, _P, _P, c_int64, _P], c_int),

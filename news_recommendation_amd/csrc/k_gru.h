@@ -554,6 +554,52 @@ __global__ __launch_bounds__(WG) void gru_bwd_persist_kernel(GruBwdSeqParams q) 
 }
 
 // ---- operand packing --------------------------------------------------------------------------------------------------
+// Gate stage of one inference step for LARGE batches (evaluation: tens of thousands of histories at once).  The fused step kernel above
+// gives a workgroup 16 hidden units, so 57 workgroups per sample group each fetch the group's state rows: fine at B = 512, but at
+// B = 73,000 that is 7.7 GB of operand traffic per step.  There the recurrent product Gh = h W_hh^T runs as a plain library GEMM (its tiles
+// re-read the state 11 x) and this kernel does the rest: r, z, n, the state update -- the formulas and intrinsics of gru_fwd_step_impl -- on
+// (gi via the row index, gh), writing the fp32 state in place and its bf16 copy (the next step's GEMM operand; column Hd = 1.0 as
+// everywhere).  One lane = four consecutive units of one sample.
+struct GruGateParams {
+  const float* gi;        // [n_rows][3*Hg] f32
+  const int* gi_row;      // [B][N]
+  const float* gh;        // [B][3*Hg] f32 = bf16(h) @ bf16(W_hh)^T of this step
+  const float* b_ih;      // [3*Hd]
+  const float* b_hh;      // [3*Hd]
+  const int* len;         // [B]
+  float* h_f;             // [B][Hp] f32 state, in place
+  u16* h_b;               // [B][Hp] bf16 copy of the new state
+  int B, N, Hd, Hg, Hp, t;
+};
+
+__global__ __launch_bounds__(256) void gru_gate_rows_kernel(GruGateParams p) {
+  const int qpr = p.Hg / 4;                                   // unit quads per sample
+  const int64_t total = (int64_t)p.B * qpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i / qpr), jb = (int)(i - (int64_t)s * qpr) * 4;
+    if (jb >= p.Hd) continue;                                 // Hd % 4 == 0: a quad is either all real units or all padding
+    const bool active = p.t < p.len[s];
+    const float* gi = p.gi + (size_t)p.gi_row[(size_t)s * p.N + p.t] * 3 * p.Hg + jb;
+    const float* gh = p.gh + (size_t)s * 3 * p.Hg + jb;
+    const f32x4 gir = *(const f32x4*)gi, giz = *(const f32x4*)(gi + p.Hg), gin = *(const f32x4*)(gi + 2 * p.Hg);
+    const f32x4 ar = *(const f32x4*)gh, az = *(const f32x4*)(gh + p.Hg), an = *(const f32x4*)(gh + 2 * p.Hg);
+    const f32x4 ho = *(const f32x4*)(p.h_f + (size_t)s * p.Hp + jb);
+    f32x4 hn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jb + r;
+      const float rr = fast_sigmoid(gir[r] + p.b_ih[j] + ar[r] + p.b_hh[j]);
+      const float zz = fast_sigmoid(giz[r] + p.b_ih[p.Hd + j] + az[r] + p.b_hh[p.Hd + j]);
+      const float qq = an[r] + p.b_hh[2 * p.Hd + j];
+      const float nn = fast_tanh(gin[r] + p.b_ih[2 * p.Hd + j] + rr * qq);
+      hn[r] = active ? (1.0f - zz) * nn + zz * ho[r] : ho[r];
+    }
+    *(f32x4*)(p.h_f + (size_t)s * p.Hp + jb) = hn;
+    *(u16x4*)(p.h_b + (size_t)s * p.Hp + jb) = pack4(hn);
+    if (jb + 4 == p.Hd) p.h_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
+  }
+}
+
 // W f32 [3*Hd][K] (nn.GRU weight_ih_l0 / weight_hh_l0) -> dst bf16 [3*Hg][Kpad]: row q*Hg + j = W[q*Hd + j][:], zero padded.
 // dstT (optional) bf16 [Kpad_rows = Hp][Kp]: dstT[k][q*Hg + j] = W[q*Hd + j][k]   (the data-gradient operand).
 // tiled != 0: both in tile order (step-kernel operands); 0: row-major (GEMM operand).

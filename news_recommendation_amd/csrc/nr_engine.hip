@@ -1013,6 +1013,18 @@ int nr_gru_fwd_seq_rows(const float* gi, const int32_t* gi_row, const uint16_t* 
   return NR_OK;
 }
 
+int nr_gru_gate_rows(const float* gi, const int32_t* gi_row, const float* gh, const float* b_ih, const float* b_hh, const int32_t* len, float* h_f,
+                     uint16_t* h_b, int B, int N, int Hd, int t, void* stream) {
+  if (!gi || !gi_row || !gh || !b_ih || !b_hh || !len || !h_f || !h_b || B < 0 || N <= 0 || Hd <= 0 || (Hd & 3) || t < 0 || t >= N)
+    return fail(NR_ERR_BADARG, "nr_gru_gate_rows: bad argument");
+  if (B == 0) return NR_OK;
+  nr::GruGateParams p;
+  p.gi = gi; p.gi_row = gi_row; p.gh = gh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_f = h_f; p.h_b = h_b;
+  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.t = t;
+  NR_LAUNCH(nr::gru_gate_rows_kernel, grid_for((int64_t)B * (p.Hg / 4), 256, 16384), 256, 0, (hipStream_t)stream, p);
+  return check_launch("nr_gru_gate_rows");
+}
+
 int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                    uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream) {
   return nr_gru_bwd_seq_n(g_last, WhhT, gates, H_all, len, dgi, dgh, dgh_t2, 2, carry2, B, N, Hd, T, stream);

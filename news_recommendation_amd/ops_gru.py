@@ -6,6 +6,7 @@ time-independent products around it are plain bf16 GEMMs: the hoisted input proj
 dX = dGi W_ih, dW_ih = dGi^T X, dW_hh = dGh^T H.  No CPU path.
 """
 import ctypes
+import os
 import torch
 
 from . import ops
@@ -169,6 +170,10 @@ def gru_last_state(x, h0, clicked_news_length, gru):
     return _GruFn.apply(x, h0, lens_dev, T, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
 
 
+# from this many histories on, gru_last_state_rows runs the recurrent product as a library GEMM per step (NR_GRU_GEMM_MIN_B; 0 = never)
+_GEMM_STEP_MIN_B = int(os.environ.get('NR_GRU_GEMM_MIN_B', '8192')) or (1 << 62)
+
+
 @torch.no_grad()
 def gru_last_state_rows(table, rows, h0, lengths, gru):
     """Inference form of gru_last_state for histories that index a table: x[b, t] = table[rows[b, t]] (table f32 [R, I] on the GPU, rows integer
@@ -213,9 +218,28 @@ def gru_last_state_rows(table, rows, h0, lengths, gru):
     ht = torch.zeros(2, _ceil(B, 16) * Hp, dtype=_BF16_AS_I16, device=dev)
     hb = torch.empty(B, Hp, dtype=_BF16_AS_I16, device=dev)
     _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf), Hp, Hd, _ptr(hb), Hp, B, _stream())
-    _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(hb), B, Hp, _ptr(ht[0]), _stream())
-    _call('nr_gru_fwd_seq_rows', lib.nr_gru_fwd_seq_rows, _ptr(gi), _ptr(rows_s), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_s), _ptr(ht), _ptr(hf),
-          active.ctypes.data, B, N, Hd, T, _stream())
+    if B >= _GEMM_STEP_MIN_B:
+        # large batches: the recurrent product as a library GEMM per step + the gate kernel (csrc/k_gru.h gru_gate_rows_kernel): the fused
+        # step kernel's 16-unit workgroups would each re-read the state rows (57 x per step)
+        def build_rm():
+            Whh_rm = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
+            _call('nr_pack_gru', lib.nr_pack_gru, _ptr(_f32c(W_hh)), Hd, Hd, Hp, _ptr(Whh_rm), None, 0, _stream())
+            return (Whh_rm,)
+        (Whh_rm,) = ops._packed('gru_rm', (W_hh,), build_rm)
+        WT = _bf16(Whh_rm).t()
+        gh = torch.empty(B, 3 * Hg, dtype=torch.float32, device=dev)
+        hb_b = _bf16(hb)
+        for t in range(T):
+            Bt = int(active[t])
+            if Bt == 0:
+                break
+            torch.mm(hb_b[:Bt], WT, out_dtype=torch.float32, out=gh[:Bt])          # hipBLASLt, fp32 accumulation and result
+            _call('nr_gru_gate_rows', lib.nr_gru_gate_rows, _ptr(gi), _ptr(rows_s), _ptr(gh), _ptr(bi), _ptr(bh), _ptr(lens_s), _ptr(hf), _ptr(hb),
+                  Bt, N, Hd, t, _stream())
+    else:
+        _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(hb), B, Hp, _ptr(ht[0]), _stream())
+        _call('nr_gru_fwd_seq_rows', lib.nr_gru_fwd_seq_rows, _ptr(gi), _ptr(rows_s), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_s), _ptr(ht), _ptr(hf),
+              active.ctypes.data, B, N, Hd, T, _stream())
     out = torch.empty(B, Hd, dtype=torch.float32, device=dev)
     out[order_d] = hf[:, :Hd]
     return out
