@@ -176,3 +176,72 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     assert rel(np.einsum('tbk,tbj->kj', dGh, Hprev), enc.gru.weight_hh_l0.grad.numpy()) < 3e-2
     assert rel(dGh.sum((0, 1)), enc.gru.bias_hh_l0.grad.numpy()) < 3e-2
     return err
+
+
+def check_gru_rows(be, B=9, N=5, R=7, Hd=900, I=900, seed=3):
+    """nr_gru_fwd_seq_rows (histories index a table of per-item input projections, longest-first step schedule) == nr_gru_fwd_seq_n on the
+    gathered projections, bit for bit; nr_gru_gate_rows on gh = bf16(h) @ bf16(W_hh)^T (numpy) follows the same recurrence to fp32 rounding."""
+    rng = np.random.default_rng(seed)
+    Hg, Hp, Kp = dims(be, Hd)
+    k = 1.0 / np.sqrt(Hd)
+    W_hh = rng.uniform(-k, k, size=(3 * Hd, Hd)).astype(np.float32)
+    b_ih = rng.uniform(-k, k, size=3 * Hd).astype(np.float32)
+    b_hh = rng.uniform(-k, k, size=3 * Hd).astype(np.float32)
+    gi_tab = gate_pad(rng.normal(0, 0.5, size=(R + 1, 3 * Hd)).astype(np.float32), Hd, Hg)
+    gi_tab[R] = 0.0                                                    # the zero row padded slots point at
+    h0 = rng.normal(0, 0.5, size=(B, Hd)).astype(np.float32)
+    lens = np.sort(rng.integers(1, N + 1, size=B))[::-1].astype(np.int32).copy()       # longest first
+    lens[0] = N
+    T = int(lens[0])
+    rows = rng.integers(0, R, size=(B, N)).astype(np.int32)
+    for b in range(B):
+        rows[b, lens[b]:] = R
+    active = np.ascontiguousarray((lens[None, :] > np.arange(T)[:, None]).sum(axis=1).astype(np.int32))
+    Whh_p, Whh_rm = be.poison((3 * Hg, Hp), np.uint16), be.poison((3 * Hg, Hp), np.uint16)
+    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_p), None, 1, be.stream))
+    ck(be, be.lib.nr_pack_gru(be.ptr(be.dev(W_hh)), Hd, Hd, Hp, be.ptr(Whh_rm), None, 0, be.stream))
+    hb_ih, hb_hh, hlen = be.dev(b_ih), be.dev(b_hh), be.dev(lens)
+    h0p = np.zeros((B, Hp), dtype=np.float32); h0p[:, :Hd] = h0
+    B16 = (B + 15) // 16 * 16
+
+    def start():
+        hf = be.dev(h0p.copy())
+        hb = be.empty((B, Hp), np.uint16)
+        ck(be, be.lib.nr_rows_to_bf16(be.ptr(hf), Hp, Hd, be.ptr(hb), Hp, B, be.stream))
+        ht = be.dev(np.zeros((2, B16, Hp), dtype=np.uint16))
+        ck(be, be.lib.nr_tile_rows_bf16(be.ptr(hb), B, Hp, be.ptr(ht), be.stream))
+        return hf, hb, ht
+    # (a) reference: the gathered projections through the ordinary sweep
+    gi_g = be.dev(np.ascontiguousarray(gi_tab[rows].reshape(B * N, 3 * Hg)))
+    hf2 = be.dev(np.stack([h0p, np.zeros_like(h0p)]))
+    _, _, ht_a = start()
+    ck(be, be.lib.nr_gru_fwd_seq_n(be.ptr(gi_g), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(ht_a), 2, None, be.ptr(hf2), None,
+                                   B, N, Hd, T, be.stream))
+    be.sync()
+    ref = be.np(hf2).reshape(2, B, Hp)[T % 2][:, :Hd]
+    # (b) row-indexed sweep with the shrinking batch
+    hf_b, _, ht_b = start()
+    ck(be, be.lib.nr_gru_fwd_seq_rows(be.ptr(be.dev(gi_tab)), be.ptr(be.dev(rows)), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen),
+                                      be.ptr(ht_b), be.ptr(hf_b), active.ctypes.data, B, N, Hd, T, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(hf_b)[:, :Hd], ref), 'row-indexed sweep differs from the sweep on gathered projections'
+    bad = active.copy(); bad[-1] = B + 1
+    assert be.lib.nr_gru_fwd_seq_rows(be.ptr(be.dev(gi_tab)), be.ptr(be.dev(rows)), be.ptr(Whh_p), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen),
+                                      be.ptr(ht_b), be.ptr(hf_b), bad.ctypes.data, B, N, Hd, T, be.stream) != 0
+    # (c) gate kernel on a host-side recurrent product
+    hf_c, hb_c, _ = start()
+    Wq = bf16_to_f32(be.np(Whh_rm)).astype(np.float64)                 # [3*Hg][Hp]
+    h_gi, h_rows = be.dev(gi_tab), be.dev(rows)
+    for t in range(T):
+        Bt = int(active[t])
+        be.sync()
+        gh = (bf16_to_f32(be.np(hb_c))[:Bt].astype(np.float64) @ Wq.T).astype(np.float32)
+        ck(be, be.lib.nr_gru_gate_rows(be.ptr(h_gi), be.ptr(h_rows), be.ptr(be.dev(np.ascontiguousarray(gh))), be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen),
+                                       be.ptr(hf_c), be.ptr(hb_c), Bt, N, Hd, t, be.stream))
+    be.sync()
+    got = be.np(hf_c)[:, :Hd]
+    assert np.abs(got - ref).max() <= 1e-3, f'gate-kernel recurrence differs by {np.abs(got - ref).max()}'
+    hb_fin = be.np(hb_c)
+    assert (hb_fin[:, Hd] == 0x3F80).all() and np.array_equal(hb_fin[:, :Hd], f32_to_bf16(got))
+    assert be.lib.nr_gru_gate_rows(be.ptr(h_gi), be.ptr(h_rows), None, be.ptr(hb_ih), be.ptr(hb_hh), be.ptr(hlen), be.ptr(hf_c), be.ptr(hb_c), B, N, Hd, 0,
+                                   be.stream) != 0

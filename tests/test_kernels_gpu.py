@@ -102,6 +102,7 @@ from tests import kernel_checks_gru as kcg  # noqa: E402
 
 def test_gru_ini(be): kcg.check_gru(be, B=133, N=50, Hd=900, I=900)
 def test_gru_con_hidden_450(be): kcg.check_gru(be, B=70, N=20, Hd=450, I=900, seed=1)
+def test_gru_rows_and_gate(be): kcg.check_gru_rows(be, B=300, N=50, R=500, Hd=900); kcg.check_gru_rows(be, B=33, N=7, R=20, Hd=450, seed=5)
 
 
 def test_gru_lds_default_large_batch(be):
