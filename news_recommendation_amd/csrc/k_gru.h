@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void gru_gate_rows_kernel(GruGateParams p) {
   const int64_t total = (int64_t)p.B * qpr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(i / qpr), jb = (int)(i - (int64_t)s * qpr) * 4;
-    if (jb >= p.Hd) continue;                                 // Hd % 4 == 0: a quad is either all real units or all padding
+    if (jb >= p.Hd) continue;                                 // (a quad may straddle Hd -- Hd = 450 --: its units >= Hd stay 0, like the step kernel's)
     const bool active = p.t < p.len[s];
     const float* gi = p.gi + (size_t)p.gi_row[(size_t)s * p.N + p.t] * 3 * p.Hg + jb;
     const float* gh = p.gh + (size_t)s * 3 * p.Hg + jb;
@@ -587,15 +587,19 @@ __global__ __launch_bounds__(256) void gru_gate_rows_kernel(GruGateParams p) {
     f32x4 hn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = jb + r;
+      const bool ok = jb + r < p.Hd;
+      const int j = ok ? jb + r : p.Hd - 1;
       const float rr = fast_sigmoid(gir[r] + p.b_ih[j] + ar[r] + p.b_hh[j]);
       const float zz = fast_sigmoid(giz[r] + p.b_ih[p.Hd + j] + az[r] + p.b_hh[p.Hd + j]);
       const float qq = an[r] + p.b_hh[2 * p.Hd + j];
       const float nn = fast_tanh(gin[r] + p.b_ih[2 * p.Hd + j] + rr * qq);
-      hn[r] = active ? (1.0f - zz) * nn + zz * ho[r] : ho[r];
+      const float v = active ? (1.0f - zz) * nn + zz * ho[r] : ho[r];
+      hn[r] = ok ? v : 0.0f;
     }
     *(f32x4*)(p.h_f + (size_t)s * p.Hp + jb) = hn;
-    *(u16x4*)(p.h_b + (size_t)s * p.Hp + jb) = pack4(hn);
+    u16x4 hb = pack4(hn);
+    if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;           // column Hd = 1.0
+    *(u16x4*)(p.h_b + (size_t)s * p.Hp + jb) = hb;
     if (jb + 4 == p.Hd) p.h_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
   }
 }

@@ -1015,7 +1015,7 @@ int nr_gru_fwd_seq_rows(const float* gi, const int32_t* gi_row, const uint16_t* 
 
 int nr_gru_gate_rows(const float* gi, const int32_t* gi_row, const float* gh, const float* b_ih, const float* b_hh, const int32_t* len, float* h_f,
                      uint16_t* h_b, int B, int N, int Hd, int t, void* stream) {
-  if (!gi || !gi_row || !gh || !b_ih || !b_hh || !len || !h_f || !h_b || B < 0 || N <= 0 || Hd <= 0 || (Hd & 3) || t < 0 || t >= N)
+  if (!gi || !gi_row || !gh || !b_ih || !b_hh || !len || !h_f || !h_b || B < 0 || N <= 0 || Hd <= 0 || t < 0 || t >= N)
     return fail(NR_ERR_BADARG, "nr_gru_gate_rows: bad argument");
   if (B == 0) return NR_OK;
   nr::GruGateParams p;

@@ -121,7 +121,7 @@ from tests import kernel_checks_gru as kcg  # noqa: E402
 def test_gru_ini(be): kcg.check_gru(be, B=5, N=4, Hd=900, I=900, lens=[4, 1, 3, 2, 4])
 def test_gru_con_hidden_450(be): kcg.check_gru(be, B=3, N=3, Hd=450, I=900, seed=1)
 def test_gru_two_batch_tiles(be): kcg.check_gru(be, B=19, N=2, Hd=48, I=40, seed=2)
-def test_gru_rows_and_gate(be): kcg.check_gru_rows(be, B=9, N=4, R=7, Hd=48)     # row-indexed inference sweep, gate kernel (evaluation)
+def test_gru_rows_and_gate(be): kcg.check_gru_rows(be, B=9, N=4, R=7, Hd=48); kcg.check_gru_rows(be, B=5, N=3, R=4, Hd=450, seed=8)     # row-indexed inference sweep, gate kernel (evaluation); Hd % 4 != 0
 
 
 def test_gru_lds_variant():
