@@ -634,8 +634,7 @@ __global__ __launch_bounds__(NW * 64) void additive_bwd_kernel(AdditiveBwdParams
 __global__ __launch_bounds__(256) void gather_bf16_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                           int64_t num_rows, const float* __restrict__ x_dense,
                                                           u16* __restrict__ Xb, int64_t n_tokens, DropCfg dc) {
-  dc = drop_resolve(dc);
-  dc = drop_resolve(dc);
+  dc = drop_resolve(dc);          // exactly once: applied twice, the step counter's XOR into k0 cancels and k1 advances by two steps
   constexpr int PC = KP / 4;   // 80 quads per row
   const int64_t total = n_tokens * PC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -667,6 +666,7 @@ __global__ __launch_bounds__(256) void gather_bf16_kernel(const int64_t* __restr
 __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* __restrict__ ids, const u16* __restrict__ dx,
                                                                 int ldx, float* __restrict__ grad_table, int64_t num_rows,
                                                                 int64_t n_tokens, DropCfg dc) {
+  dc = drop_resolve(dc);          // same key as the forward's site-1 mask, also under a device step counter (HIP-graph replays)
   const int64_t total = n_tokens * D4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t tok = i / D4;

@@ -43,8 +43,8 @@ struct GruFwdParams {
   const u16* h_in_t;      // bf16 [ceil16(B)][Hp], tile order
   u16* h_out_b;           // bf16 [B][Hp] row-major (operand of the W_hh gradient GEMM and of the backward sweep), or null
   u16* h_out_t;           // bf16 [ceil16(B)][Hp], tile order: the next step's operand
-  const float* h_in_f;    // f32 [B][Hp]
-  float* h_out_f;         // f32 [B][Hp]
+  const float* h_in_f;    // f32 [B][Hp]   NEVER __restrict__: the row-indexed evaluation sweep (nr_gru_fwd_seq_rows) passes the SAME buffer as
+  float* h_out_f;         // f32 [B][Hp]   h_in_f and h_out_f (state updated in place; each element is read and written by one lane only)
   u16* gates;             // training: bf16 [B][4][Hg] of this step (r, z, n, q), or null
   int B, N, Hd, Hg, Hp, t;
 };

@@ -21,6 +21,9 @@ import torch
 from . import _capi, ops
 
 
+_attached = []        # counter tensors the library currently points at (at most one: the counter is process-global)
+
+
 class StepGraph:
     """``g = StepGraph(step_fn, example_inputs, optimizer)``; ``loss = g(*inputs)`` runs one training step.
 
@@ -31,6 +34,9 @@ class StepGraph:
     def __init__(self, step_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20):
         if optimizer.sparse:
             raise NotImplementedError("StepGraph: row-sparse tables (LSTUR) update from host-side row lists; not capturable")
+        if _attached:
+            raise RuntimeError("StepGraph: another StepGraph of this process still has its step counter attached (close() it first): the "
+                               "counter is process-global, every dropout kernel and nr_adam_flat reads it")
         if optimizer._dist_on():
             raise NotImplementedError("StepGraph: data-parallel steps are not captured (the collectives are graph boundaries)")
         self.lib = _capi.load()
@@ -45,6 +51,8 @@ class StepGraph:
         # the device counter mirrors optimizer.t: both are bumped at the START of a step
         self.ctr = torch.full((1,), optimizer.t, dtype=torch.int32, device=dev)
         _capi.check(self.lib, self.lib.nr_set_step_counter(self.ctr.data_ptr()))
+        _attached.append(self.ctr)              # module-level holder: the library keeps a RAW pointer to this tensor until close()
+        self._closed = False
         # warm-up on a side stream (lazy initialisation, LDS opt-ins, packed-operand caches, workspace growth) -- these are real steps
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -78,5 +86,27 @@ class StepGraph:
         return self.loss
 
     def close(self):
-        """Detach the counter: later launches of this process take seeds / step indices by value again."""
-        _capi.check(self.lib, self.lib.nr_set_step_counter(None))
+        """Detach the counter: later launches of this process take seeds / step indices by value again.  Idempotent; also run by the
+        context-manager exit and the finaliser, so that a StepGraph dropped after an exception never leaves the library pointing at freed
+        memory (the holder keeps the counter tensor alive until then)."""
+        if getattr(self, '_closed', True):
+            return
+        self._closed = True
+        try:
+            torch.cuda.synchronize(self.opt.device)             # no replay in flight still reads the counter
+            _capi.check(self.lib, self.lib.nr_set_step_counter(None))
+        finally:
+            if any(c is self.ctr for c in _attached):
+                _attached[:] = [c for c in _attached if c is not self.ctr]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -138,6 +138,7 @@ class EngineAdam:
             off += p.numel()
         self.regions = [_Region('small', 0, off)] if off else []
         shard_mult = _ALIGN * math.lcm(8, _world())        # a table region splits into `world` equal shards on 256-byte boundaries
+        self._world0 = _world()                             # the padding above is only valid for this world size: _shard() checks it
         for n, p in tables:
             off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
             self.slices[n] = (off, off + p.numel())
@@ -200,7 +201,11 @@ class EngineAdam:
 
     def _shard(self, region):
         """(lo, hi) of this rank's shard of a table region (table_rs)."""
-        sh = (region.end - region.lo) // _world()
+        w = _world()
+        if w != self._world0 or (region.end - region.lo) % (w * _ALIGN):
+            raise RuntimeError(f"EngineAdam: built for a process group of {self._world0} rank(s), running with {w}: the table regions were padded "
+                               "for the world size at construction -- build the optimiser after init_process_group")
+        sh = (region.end - region.lo) // w
         lo = region.lo + _rank() * sh
         return lo, lo + sh
 
@@ -387,19 +392,31 @@ class EngineAdam:
         st = next(s for s in self.sparse if s.name == n)
         return st.m, st.v
 
-    def _gather_moment_shards(self):
-        """table_rs: every rank maintains the Adam moments of its own shard only; collect the others' before the moments are read as a whole."""
-        if not (self.table_rs and self._dist_on()) or self.skip_comm:
+    def state_is_sharded(self):
+        """True when the Adam moments of the table regions live sharded across the ranks (table_rs under a process group): reading them as a
+        whole is then a COLLECTIVE -- every rank must call gather_state() before any rank calls state_dict()."""
+        return bool(self.table_rs and self._dist_on() and not self.skip_comm)
+
+    def gather_state(self):
+        """COLLECTIVE (all ranks, same order): collect the other ranks' shards of the table moments, so that a following state_dict() on
+        any subset of the ranks (rank 0 writing a checkpoint, train_fast.py) is purely local.  A no-op when nothing is sharded."""
+        if not self.state_is_sharded():
             return
         for r in self.regions:
             if r.name != 'small':
                 lo, hi = self._shard(r)
                 for buf in (self.flat_m, self.flat_v):
                     dist.all_gather_into_tensor(buf[r.lo:r.end], buf[lo:hi].clone())
+        self._gathered_t = self.t
 
     def state_dict(self):
+        """torch.optim.Adam's state layout.  Never issues a collective itself: with sharded moments (state_is_sharded) the caller must have
+        run gather_state() on EVERY rank since the last step -- a rank-0-only state_dict() that started all-gathers on its own would pair
+        them with whatever collective the other ranks issue next (hang / corrupted exchange)."""
         self.flush()
-        self._gather_moment_shards()
+        if self.state_is_sharded() and getattr(self, '_gathered_t', -1) != self.t:
+            raise RuntimeError("EngineAdam.state_dict(): the table moments are sharded across ranks (table_rs); call gather_state() on "
+                               "every rank first (it is a collective), then state_dict() where the checkpoint is written")
         state = {}
         if self.t > 0:
             for i in range(len(self.params)):

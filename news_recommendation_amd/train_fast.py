@@ -149,7 +149,7 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
                     f"average loss: {float(loss_sum) / i:.4f}, latest average loss: {float(recent[:min(i, 256)].mean()):.4f}, "
                     f"{seen / (time.time() - t0):.0f} impressions/s")
         if i % config.num_batches_validate == 0:
-            stop = torch.zeros(1, device=device)
+            stop = torch.zeros(2, device=device)           # [stop, save]: rank 0 decides, every rank learns both
             if rank == 0:
                 model.eval()
                 if val_plan is None:      # the validation files do not change during a run: parse them once
@@ -162,13 +162,19 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
                 early_stop, get_better = early_stopping(-auc)
                 if early_stop:
                     log('Early stop.')
-                    stop += 1
+                    stop[0] += 1
                 elif get_better:
-                    torch.save({'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(), 'step': step,
-                                'early_stop_value': -auc}, f"./checkpoint/{model_name}/ckpt-{step}.pth")
+                    stop[1] += 1
             if world > 1:
                 dist.broadcast(stop, src=0)
-            if stop.item() > 0:
+            flags = stop.tolist()
+            if flags[1] > 0:
+                # sharded Adam moments (NR_TABLE_RS): collecting them is a collective, so EVERY rank takes part before rank 0 writes the file
+                optimizer.gather_state()
+                if rank == 0:
+                    torch.save({'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(), 'step': step,
+                                'early_stop_value': -auc}, f"./checkpoint/{model_name}/ckpt-{step}.pth")
+            if flags[0] > 0:
                 break
     torch.cuda.synchronize()
     return {'steps': i, 'impressions_per_s': seen / max(time.time() - t0, 1e-9), 'last_loss': float(loss.item()), 'model': model}

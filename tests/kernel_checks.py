@@ -689,3 +689,72 @@ def check_dropout_mask_statistics(be):
         for i in range(4):
             for j in range(i + 1, 4):
                 assert abs(corr(q[:, i], q[:, j])) < 6e-3, (i, j)
+
+
+def check_dropout_under_step_counter(be, value=5):
+    """Every kernel that draws a dropout mask folds the device step counter into its key exactly ONCE (drop_resolve, csrc/nr_common.h): with a
+    counter attached (HIP-graph replays, graph.py) the site-1 mask of the separate gather pass, of both embedding scatters and of the
+    encoder's own x_save must still be the mask nr_dropout_mask exports -- and a different one from the counter-less call."""
+    n = 4096
+    plain = export_mask(be, n, 0.2, 99, 1)
+    ctr = be.dev(np.array([value], dtype=np.int32))
+    ck(be, be.lib.nr_set_step_counter(be.ptr(ctr)))
+    try:
+        with_ctr = export_mask(be, n, 0.2, 99, 1)
+        assert not np.array_equal(plain, with_ctr), 'the step counter does not reach the dropout key'
+        check_gather_bf16(be, n_tokens=129, V=200)
+        check_scatter_add(be, n_tokens=333, V=40)
+        check_scatter_sorted(be, n_tokens=333, V=40)
+        check_mhsa_x_save(be, n_seq=5)
+    finally:
+        ck(be, be.lib.nr_set_step_counter(None))
+    assert np.array_equal(plain, export_mask(be, n, 0.2, 99, 1))
+
+
+def check_additive_bwd_scale(be, S=20, n_seq=27136, chunk=2048):
+    """The pooling backward (nr_additive_bwd_ex: pool2_bwd_kernel from 2,048 sequences up) at the bench's launch size against the numpy
+    restatement of AdditiveAttention's autograd (additive.py:27-53) directly, the oracle evaluated in fp64 over chunks of sequences: dpre, the
+    fused dctx = dpre @ Wa and the query-vector gradient summed over ALL workgroups' partial rows (a dropped tile would show in all three)."""
+    params = make_params(14)
+    rng = np.random.default_rng(151)
+    ctx_u = np.zeros((n_seq * S, NR_KP), dtype=np.uint16)
+    ctx_u[:, :NR_D] = f32_to_bf16(rng.normal(0, 0.6, size=(n_seq * S, NR_D)).astype(np.float32))
+    ctx_u[:, NR_D] = 0x3F80
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    hctx = be.dev(ctx_u)
+    out = be.poison((n_seq, NR_D), np.float32)
+    aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), be.ptr(aw), n_seq, S, be.stream))
+    go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
+    nwg = be.lib.nr_additive_bwd_grid(n_seq, S)
+    dpre = be.empty((n_seq * S, NR_QP), np.uint16)
+    dqp = be.poison((nwg, NR_QP), np.float32)
+    a_ = 'news_encoder.additive_attention.'
+    WaT = be.poison((NR_KP, 224), np.uint16)
+    ck(be, be.lib.nr_pack_additive_t(be.ptr(be.dev(params[a_ + 'linear.weight'])), 200, be.ptr(WaT), be.stream))
+    dctx = be.poison((n_seq * S, NR_KP), np.uint16)
+    ck(be, be.lib.nr_additive_bwd_ex(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)),
+                                     be.ptr(dpre), be.ptr(dqp), be.ptr(WaT), be.ptr(dctx), n_seq, S, be.stream))
+    be.sync()
+    dpre_n, dctx_n, aw_n = be.np(dpre), be.np(dctx), be.np(aw)
+    W = bf16_round(params[a_ + 'linear.weight']).astype(np.float64)
+    b = params[a_ + 'linear.bias'].astype(np.float64)
+    qv = params[a_ + 'attention_query_vector'].astype(np.float64)
+    dq_ref = np.zeros(200)
+    for lo in range(0, n_seq, chunk):
+        hi = min(lo + chunk, n_seq)
+        x = bf16_to_f32(ctx_u[lo * S:hi * S, :NR_D]).astype(np.float64).reshape(hi - lo, S, NR_D)
+        _, w, temp = onp.additive(x, W, b, qv)
+        np.testing.assert_allclose(aw_n[lo:hi], w, rtol=0, atol=2e-5, err_msg=f'attention weights, seqs {lo}..{hi}')
+        g = go[lo:hi].astype(np.float64)
+        dw = np.einsum('bd,bsd->bs', g, x)
+        ds = w * (dw - (w * dw).sum(1, keepdims=True))
+        dpre_ref = ds[:, :, None] * qv[None, None, :] * (1 - temp * temp)
+        dq_ref += np.einsum('bs,bsq->q', ds, temp)
+        got = bf16_to_f32(dpre_n[lo * S:hi * S])
+        close_bf16(got[:, :200], dpre_ref.reshape(-1, 200), f'pooling bwd dpre, seqs {lo}..{hi}', rel=2.0 ** -7, floor=2e-3)
+        assert not got[:, 200:].any()
+        dref = got[:, :200].astype(np.float64) @ W
+        close_bf16(bf16_to_f32(dctx_n[lo * S:hi * S, :NR_D]), dref, f'pooling bwd fused dctx, seqs {lo}..{hi}', rel=2.0 ** -7, floor=1e-3)
+    dq = be.np(dqp).astype(np.float64).sum(0)
+    np.testing.assert_allclose(dq[:200], dq_ref, rtol=2e-3, atol=2e-4 * np.abs(dq_ref).max())

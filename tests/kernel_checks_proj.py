@@ -286,3 +286,51 @@ def check_proj_bad_args(be):
     assert be.lib.nr_attn_bwd_hm(pa, pa, NR_D, pa, pa, pa, None, 1, 50, 0.0, 0, be.stream) == -1
     assert be.lib.nr_attn_bwd_hm(None, pa, NR_D, pa, pa, pa, None, 1, 20, 0.0, 0, be.stream) != 0
     assert be.lib.nr_qkv_proj_fwd(pa, pa, 10, pa, pa, pa, None, 0, 20, 0.0, 0, be.stream) == 0          # empty batch: nothing launched
+
+
+def check_attn_bwd_hm_oracle(be, n_seq=7, p_drop=0.0, seed=78, with_key_len=False, chunk=2048):
+    """nr_attn_bwd_hm against the numpy restatement of ScaledDotProductAttention's autograd (multihead_self.py:15-23) DIRECTLY -- not through
+    another kernel -- on random head-major Q | K | V, at any size: the oracle runs in fp64 over chunks of sequences, so the bench's 27,136
+    titles (grid caps, persistent loops, the last partial round of heads) take seconds on the host."""
+    rng = np.random.default_rng(seed)
+    qkv_u = f32_to_bf16(rng.normal(0, 0.8, size=(n_seq, H, 3, S * DK)).astype(np.float32))
+    dg_u = np.full((n_seq * S, NR_KP), 0x7FC0, dtype=np.uint16)                 # padding columns hold NaN: never read as data
+    dg_u[:, :NR_D] = f32_to_bf16(rng.normal(0, 0.05, size=(n_seq * S, NR_D)).astype(np.float32))
+    aw = rng.random(size=(n_seq, S)).astype(np.float32)
+    aw /= aw.sum(1, keepdims=True)
+    go = rng.normal(0, 1.0, size=(n_seq, NR_D)).astype(np.float32)
+    key_len = None
+    if with_key_len:
+        key_len = rng.integers(1, S + 1, size=n_seq).astype(np.int32)
+        key_len[0] = S
+    hl = be.dev(key_len) if key_len is not None else None
+    got_h = be.empty((n_seq * S, NR_LDG), np.uint16)
+    kc.ck(be, be.lib.nr_attn_bwd_hm(be.ptr(be.dev(qkv_u.reshape(-1))), be.ptr(be.dev(dg_u)), NR_KP, be.ptr(be.dev(aw)), be.ptr(be.dev(go)),
+                                    be.ptr(got_h), be.ptr(hl), n_seq, S, p_drop, seed, be.stream))
+    be.sync()
+    out = be.np(got_h)
+    mask2 = kc.export_mask(be, n_seq * S * NR_D, p_drop, seed, 2).reshape(n_seq, S, NR_D) if p_drop > 0 else None
+    worst = [0.0, 0.0, 0.0]
+    for lo in range(0, n_seq, chunk):
+        hi = min(lo + chunk, n_seq)
+        n = hi - lo
+        q, k, v = hm_split(qkv_u[lo:hi], n)
+        dC = bf16_to_f32(dg_u[lo * S:hi * S, :NR_D]).astype(np.float64).reshape(n, S, NR_D) + aw[lo:hi, :, None].astype(np.float64) * go[lo:hi, None, :]
+        if mask2 is not None:
+            dC = dC * mask2[lo:hi] * np.float32(1.0 / (1.0 - p_drop))
+        g = bf16_round(dC.astype(np.float32)).astype(np.float64).reshape(n, S, H, DK).transpose(0, 2, 1, 3)
+        e = np.exp(np.minimum(q @ np.swapaxes(k, -1, -2) / np.sqrt(np.float32(DK)).astype(np.float64), 80.0))
+        if key_len is not None:
+            e = e * (np.arange(S)[None, :] < key_len[lo:hi, None])[:, None, None, :]
+        attn = e / (e.sum(-1, keepdims=True) + 1e-8)
+        dattn = g @ np.swapaxes(v, -1, -2)
+        dv = np.swapaxes(attn, -1, -2) @ g
+        dS = attn * (dattn - (attn * dattn).sum(-1, keepdims=True)) / np.sqrt(DK)
+        dq = dS @ k
+        dkk = np.swapaxes(dS, -1, -2) @ q
+        mg = lambda t: t.transpose(0, 2, 1, 3).reshape(n * S, NR_D)
+        for i, (name, ref) in enumerate((('dQ', dq), ('dK', dkk), ('dV', dv))):
+            blk = out[lo * S:hi * S, i * NR_KP:(i + 1) * NR_KP]
+            worst[i] = max(worst[i], kc.close_bf16(bf16_to_f32(blk[:, :NR_D]), mg(ref), f'attn_bwd_hm {name} seqs {lo}..{hi}'))
+            assert not blk[:, NR_D:].any()
+    return worst

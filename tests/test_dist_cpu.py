@@ -167,7 +167,14 @@ def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False):
         assert not opt.flat_g.any()
     assert opt.comm_bytes['small'] > 0 and opt.comm_bytes['word_embedding.weight'] >= 480 * 4 and opt.comm_bytes['user_embedding.weight'] == world * 5 * (8 + 32)
     sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
-    osd = opt.state_dict()                      # (collective under table_rs: the moment shards are gathered)
+    if table_rs:                                # a rank-local state_dict() must not start collectives on its own
+        try:
+            opt.state_dict()
+            raise AssertionError('state_dict() of sharded moments did not ask for gather_state()')
+        except RuntimeError as e:
+            assert 'gather_state' in str(e)
+    opt.gather_state()                          # collective under table_rs: the moment shards are gathered on every rank ...
+    osd = opt.state_dict()                      # ... so that this is local (and raises if the gather was skipped)
     for i, st in osd['state'].items():
         sd[f'opt/{i}/exp_avg'] = st['exp_avg'].numpy().copy()
         sd[f'opt/{i}/exp_avg_sq'] = st['exp_avg_sq'].numpy().copy()

@@ -38,6 +38,7 @@ def test_attn_bwd_s20_dctx_through_lds(be): kc.check_attn_bwd(be, S=20, n_seq=7,
 def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=2, p_drop=0.2)
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=1)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=6)
+def test_additive_bwd_scale_check_small(be): kc.check_additive_bwd_scale(be, S=20, n_seq=5, chunk=2)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=3)
 def test_additive_bwd_valid_length(be): kc.check_additive_bwd(be, S=20, n_seq=6, valid=13); kc.check_additive_bwd(be, S=50, n_seq=3, valid=37)
 def test_additive_bwd_s50_register_resident():
@@ -69,6 +70,7 @@ def test_gather_bf16(be): kc.check_gather_bf16(be)
 def test_scatter_add(be): kc.check_scatter_add(be)
 def test_score_bwd(be): kc.check_score_bwd(be)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be)
+def test_dropout_under_step_counter(be): kc.check_dropout_under_step_counter(be)
 def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=130, V=9, p_drop=0.0)
 
 

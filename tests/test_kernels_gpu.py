@@ -41,6 +41,7 @@ def test_attn_bwd_s20_dropout(be): kc.check_attn_bwd(be, S=20, n_seq=57, p_drop=
 def test_attn_bwd_s50(be): kc.check_attn_bwd(be, S=50, n_seq=37)
 def test_additive_bwd_s20(be): kc.check_additive_bwd(be, S=20, n_seq=1027)
 def test_additive_bwd_s50(be): kc.check_additive_bwd(be, S=50, n_seq=131)
+def test_additive_bwd_at_bench_scale(be): kc.check_additive_bwd_scale(be, S=20, n_seq=27136); kc.check_additive_bwd_scale(be, S=50, n_seq=27136 // 2 + 3)     # NRMS titles / NAML abstracts launch sizes vs the numpy oracle, chunked
 def test_additive_bwd_valid_length(be): kc.check_additive_bwd(be, S=20, n_seq=1027, valid=13); kc.check_additive_bwd(be, S=50, n_seq=131, valid=37); kc.check_additive_bwd(be, S=50, n_seq=2051, valid=41)
 def test_additive_bwd_s50_register_resident(be): kc.check_additive_bwd(be, S=50, n_seq=2051)      # k_pool2.h <50, 1, 4> (the default from 2048 sequences up): 4 per workgroup, the last one partly filled
 
@@ -62,6 +63,7 @@ def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
 def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
 def test_score_bwd(be): kc.check_score_bwd(be, B=513)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be, n_tokens=200001, V=3000)
+def test_dropout_under_step_counter(be): kc.check_dropout_under_step_counter(be)
 def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=54321, V=70976, p_drop=0.0)
 
 

@@ -31,3 +31,6 @@ def test_dx_gemm(be): kp.check_dx_gemm(be, n_tok=300)          # two full workgr
 def test_tn_gemm_dqkv(be): kp.check_tn_gemm(be, n_tok=300, M=960, P=8)          # 8 slabs x 8 partitions, ragged last chunk
 def test_tn_gemm_dpre(be): kp.check_tn_gemm(be, n_tok=77, M=208, P=8)           # 2 slabs (128 + 80 rows), mostly empty partitions
 def test_proj_bad_args(be): kp.check_proj_bad_args(be)
+def test_attn_bwd_hm_vs_numpy_oracle(be):
+    kp.check_attn_bwd_hm_oracle(be, n_seq=3)
+    kp.check_attn_bwd_hm_oracle(be, n_seq=3, p_drop=0.2, with_key_len=True)

@@ -130,3 +130,10 @@ def test_encoder_autograd_split_vs_fused():
         scale = np.abs(b[k]).max() + 1e-30
         err = np.abs(a[k] - b[k]).max()
         assert err <= 1e-2 * scale + (floor if k.endswith('bias') else 0.0), f'{k}: max diff {err:.3g} on scale {scale:.3g}'
+
+
+def test_attn_bwd_hm_vs_numpy_oracle_at_bench_scale(be):
+    """The dominant kernel of the NRMS step at the launch size of BASELINE configs[1] (B = 512: 27,136 titles, 407,040 (title, head) pairs)
+    against the numpy oracle directly; plus a dropout + key-length case whose n_seq leaves a partial last grid round."""
+    kp.check_attn_bwd_hm_oracle(be, n_seq=27136)
+    kp.check_attn_bwd_hm_oracle(be, n_seq=3001, p_drop=0.2, with_key_len=True)
