@@ -204,10 +204,10 @@ def cpu_baseline(wl, shape, vocab, budget=24.0):
         return {"value": None, "unit": "impressions/s", "cores": None, "kind": "port", "sample": f"cpu baseline child failed: {e!r}"}
 
 
-def eval_set(wl, n_news, n_impr, seed=3):
+def eval_set(wl, n_news, n_impr, seed=3, news_seed=2):
     from news_recommendation_amd import synth
     rng = np.random.default_rng(seed)
-    news = {k: v for k, v in news_table(wl.cfg, 2, n_news).items() if k in wl.attrs}
+    news = {k: v for k, v in news_table(wl.cfg, news_seed, n_news).items() if k in wl.attrs}
     hist, cands, ptr = synth.eval_impressions(rng, n_news, n_impr)
     users = rng.integers(1, wl.cfg.num_users, size=n_impr).astype(np.int64)
     return news, hist, cands, ptr, users
@@ -285,6 +285,96 @@ def parity_eval(wl, states, device, n_news=4000, n_impr=5000):
     out["worst_abs_diff_auc_n1000"], out["worst_abs_diff_ndcg10_n1000"] = worst[1000]
     out[f"worst_abs_diff_auc_n{n_impr}"], out[f"worst_abs_diff_ndcg10_n{n_impr}"] = worst[n_impr]
     out["within_tolerance"] = bool(max(worst[1000] + worst[n_impr]) < 1e-3)
+    return out
+
+
+def parity_seeds(wl, states, device, seeds=8, n_news=2000, n_impr=1000):
+    """The 1e-3 claim as a statistic, not a single draw: for every weight state, `seeds` independent evaluation sets of BASELINE configs[0]'s
+    size (n = 1,000 eval-shaped impressions; each seed draws its own news table, histories, candidate lists and teacher labels); per state
+    the max AND the mean of |dAUC| and |dnDCG@10| over the seeds; `within_tolerance` is judged on the max over all states and seeds."""
+    from news_recommendation_amd import synth
+    from oracle import metrics
+    out = {"seeds": seeds, "n_impr": n_impr, "n_news": n_news, "tolerance": 1e-3, "states": {}}
+    gmax = [0.0, 0.0]
+    for name, model in states.items():
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        da, dn = [], []
+        for s_ in range(seeds):
+            es = eval_set(wl, n_news, n_impr, seed=100 + 7 * s_, news_seed=200 + s_)
+            ptr = es[3]
+            sc = engine_scores(wl, model, device, es)
+            sc_ref = oracle_scores(wl, sd, es)
+            labels = synth.teacher_labels(np.random.default_rng(300 + s_), sc_ref.astype(np.float64), ptr)
+            split = lambda a: [a[ptr[i]:ptr[i + 1]] for i in range(n_impr)]
+            auc_r, _, _, nd_r = metrics.evaluate_impressions(split(labels), split(sc_ref))
+            auc_e, _, _, nd_e = metrics.evaluate_impressions(split(labels), split(sc))
+            da.append(abs(auc_r - auc_e))
+            dn.append(abs(nd_r - nd_e))
+        out["states"][name] = {"abs_diff_auc": {"max": max(da), "mean": float(np.mean(da)), "all": da},
+                               "abs_diff_ndcg10": {"max": max(dn), "mean": float(np.mean(dn)), "all": dn}}
+        gmax = [max(gmax[0], max(da)), max(gmax[1], max(dn))]
+    out["max_abs_diff_auc"], out["max_abs_diff_ndcg10"] = gmax
+    out["mean_abs_diff_auc"] = float(np.mean([v["abs_diff_auc"]["mean"] for v in out["states"].values()]))
+    out["mean_abs_diff_ndcg10"] = float(np.mean([v["abs_diff_ndcg10"]["mean"] for v in out["states"].values()]))
+    out["within_tolerance"] = bool(max(gmax) < 1e-3)
+    return out
+
+
+def train_parity(device, steps=200, B=16, lr=1e-3, engine_seeds=(0, 1), oracle=True):
+    """Statistical training parity: the engine and the CPU oracle train NRMS for `steps` steps with dropout ON from
+    the same initial weights on the same teacher-labelled batches (oracle/train_parity.py: the reference's loop, src/train.py:202-233, with
+    torch.optim.Adam and torch's dropout; the engine with EngineAdam and its own counter-based dropout), then both trained models rank the
+    same held-out eval-shaped impressions.  The two cannot agree bit for bit (different dropout streams, bf16 vs fp32): what is compared is
+    AUC / nDCG@10 of the trained models, next to the engine's own seed-to-seed spread.  lr = 1e-3 (10 x src/config.py:19) so that
+    200 small steps move AUC from 0.51 to ~0.75 (teacher: 0.87); vocabulary 6,000 keeps the oracle's dense table gradients cheap."""
+    from news_recommendation_amd import ops
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle import train_parity as tp
+    t0 = time.perf_counter()
+    task = tp.make_task(steps=steps, B=B)
+    st0 = tp.init_state(task["num_words"])
+    cfg = make_cfg('NRMS', 'small', vocab=task["num_words"])
+    wl = Workload('NRMS', cfg)
+    crit = torch.nn.CrossEntropyLoss()
+    target = torch.zeros(B, dtype=torch.long, device=device)
+    cand_d = torch.from_numpy(task["cand_ids"]).to(device)
+    click_d = torch.from_numpy(task["click_ids"]).to(device)
+    es = ({'title': task["titles"]}, task["eval_hist"], task["eval_cands"], task["eval_ptr"], None)
+
+    def engine_run(seed):
+        m = wl.make_model().to(device)
+        m.load_state_dict(st0)
+        m.train()
+        opt = EngineAdam(m, lr=lr)
+        torch.manual_seed(1000 + seed)                   # ops.new_seed() draws the kernels' dropout seeds from torch's CPU generator
+        losses = []
+        for i in range(steps):
+            loss = crit(m.forward_ids(cand_d[i], click_d[i]), target)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        sc = engine_scores(wl, m, device, es)
+        return tp.eval_metrics(task, sc), float(torch.stack(losses[-10:]).mean())
+    out = {"steps": steps, "batch": B, "lr": lr, "dropout": cfg.dropout_probability, "vocab": task["num_words"], "eval_impressions": len(task["eval_ptr"]) - 1,
+           "auc_teacher": float(tp.eval_metrics(task, task["teacher_scores"])[0])}
+    runs = [engine_run(s_) for s_ in engine_seeds]
+    out["engine"] = [{"auc": float(r[0][0]), "ndcg10": float(r[0][3]), "last10_loss": r[1]} for r in runs]
+    out["engine_seed_spread_auc"] = float(max(r["auc"] for r in out["engine"]) - min(r["auc"] for r in out["engine"]))
+    ops.invalidate_packed()
+    if oracle:
+        init_m = tp.eval_metrics(task, tp.oracle_eval_scores(task, st0))
+        trained, losses = tp.train_oracle(task, st0, lr=lr, p_drop=cfg.dropout_probability)
+        om = tp.eval_metrics(task, tp.oracle_eval_scores(task, trained))
+        out["auc_init"] = float(init_m[0])
+        out["oracle"] = {"auc": float(om[0]), "ndcg10": float(om[3]), "last10_loss": float(np.mean(losses[-10:]))}
+        ea = float(np.mean([r["auc"] for r in out["engine"]]))
+        en = float(np.mean([r["ndcg10"] for r in out["engine"]]))
+        out["abs_diff_auc"] = abs(ea - out["oracle"]["auc"])
+        out["abs_diff_ndcg10"] = abs(en - out["oracle"]["ndcg10"])
+        # two trainings with different dropout streams differ by the seed-to-seed spread (oracle vs oracle: 3e-3 AUC at 100 steps on the build host)
+        out["tolerance_auc"] = 1.5e-2
+        out["within_noise"] = bool(out["abs_diff_auc"] < out["tolerance_auc"] and ea > out["auc_init"] + 0.1)
+    out["seconds"] = time.perf_counter() - t0
     return out
 
 
@@ -413,7 +503,7 @@ def gather_point(lib, table, ids, device):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_proj.h', 'k_pool2.h', 'nr_common.h'):
+    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_proj.h', 'k_pool2.h', 'k_misc.h', 'nr_common.h'):
         with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -431,9 +521,11 @@ def main():
     ap.add_argument('--vocab', type=int, default=0, help='override the vocabulary size of the shape (rows of the word-embedding table)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-train-parity', action='store_true', help='skip the 200-step engine-vs-oracle training leg (~1 min of host time)')
+    ap.add_argument('--parity-seeds', type=int, default=8, help='independent n = 1000 evaluation sets per weight state of the parity leg')
     ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
     ap.add_argument('--no-graph', action='store_true',
-                    help='issue the step kernel by kernel (default on 1 GPU for NRMS / NAML: one HIP graph of forward + backward + Adam, replayed)')
+                    help='issue the step kernel by kernel (default on 1 GPU: one HIP graph of forward + backward + Adam, replayed)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -479,18 +571,25 @@ def main():
     hand = {k: v for k, v in prof.items() if k.startswith('nr_') and not k.startswith(('nr_pack', 'nr_sort', 'nr_adam', 'nr_row_adam'))}
     dominant = max(hand, key=lambda k: hand[k][2]) if hand else 'nr_mhsa_fwd[S=20]'
 
-    # ---- single GPU, dense models: the step as ONE HIP graph (news_recommendation_amd/graph.py); the per-kernel HIP-event pass that the
+    # ---- single GPU: the step as ONE HIP graph (news_recommendation_amd/graph.py); the per-kernel HIP-event pass that the
     # roofline needs then runs as an eager pass of the same K steps AFTER the timed region (events cannot bracket nodes of a replayed graph)
-    use_graph = world == 1 and args.model != 'LSTUR' and not args.no_graph
+    use_graph = world == 1 and not args.no_graph
     sg = None
     if use_graph:
         from news_recommendation_amd.graph import StepGraph
-        flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs]
+        if args.model == 'LSTUR':          # the captured step keeps user ids and history lengths on the device (graph.py)
+            for b in batches:
+                b['length_dev'] = b['length'].to(device)
+        flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if args.model == 'LSTUR' else [])
 
         def step_fn(*xs):
             n = len(wl.attrs)
-            cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:]))
-            l_ = crit(model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click), target)
+            cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
+            if args.model == 'LSTUR':
+                lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
+            else:
+                lg_ = model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click)
+            l_ = crit(lg_, target)
             l_.backward()
             opt.step()
             return l_
@@ -618,6 +717,18 @@ def main():
             "note": "achieved / frac count the algorithmic READ bytes (1200 B row + 8 B id per token); the stand-alone kernel also writes the "
                     "gathered rows to HBM (read_plus_write_GBs).  In NRMS training the gather is fused into nr_mhsa_fwd (rows go straight into "
                     "MFMA operand registers); this kernel is the north_star's stand-alone roofline probe"}
+        # HBM traffic of the probe from the committed rocprofv3 passes (tools/gather_prof.sh -> profiles/gather_traffic.json), same keying as above
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'gather_traffic.json')) as f:
+                gt = json.load(f)
+            if gt.get("hbm", {}).get("source_hash") == kernel_source_hash():
+                extras["gather_roofline"]["traffic"] = gt["hbm"].get("traffic_bytes")
+                extras["gather_roofline"]["rocprof"] = {k: {kk: v[kk] for kk in ("avg_us_rocprof", "achieved_GBs", "frac_of_8TBs", "traffic_bytes", "hbm_GBs_moved") if kk in v}
+                                                        for k, v in gt.items()}
+            else:
+                extras["gather_roofline"]["traffic"] = None
+        except (OSError, ValueError):
+            extras["gather_roofline"]["traffic"] = None
         # ---- the same training step through the real boundary: model(candidate_news, clicked_news) on CPU list-of-dicts ------------------
         # (single-GPU runs only: a training step is a collective operation, and the other ranks have left by now)
         if world == 1:
@@ -692,6 +803,10 @@ def main():
         pre = torch.randn(cfg.num_words, 300)                               # data_preprocess.py:272-277: N(0,1) rows incl. row 0
         states["pretrained_table"] = wl.make_model(seed=1, pretrained=pre).to(device)
         out["parity"] = parity_eval(wl, states, device)
+        ps = parity_seeds(wl, states, device, seeds=args.parity_seeds)
+        out["parity"]["seeds"] = ps["seeds"]
+        out["parity"]["multi_seed_n1000"] = ps
+        out["parity"]["within_tolerance"] = bool(out["parity"]["within_tolerance"] and ps["within_tolerance"])
         del states, m0
         # the other two model families of the hot path, initial weights, n = 1,000 impressions (BASELINE configs[0] size), in the SAME line
         # the driver records (the full three-state tables of all models: bench.py --model NAML / LSTUR)
@@ -707,6 +822,8 @@ def main():
                              "within_tolerance": pe["within_tolerance"]}
             del mo, wo
         out["parity_models"] = others
+        if not args.no_train_parity:
+            out["train_parity"] = train_parity(device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, shape, args.vocab)
     else:

@@ -382,7 +382,11 @@ int nr_adam_flat(float* p, float* g, float* m, float* v, int64_t n, const float*
  *   nr_row_adam_flush    every row with state -> current as of `upto` (before state_dict() / checkpoints / full-table reads).
  *   nr_row_adam_step     optimiser step `step` for the rows that received gradients: (id, gradient row) pairs of all ranks, sorted by id
  *                        (ids_sorted int64[n], perm = index of the pair's row in rows f32[.][ld]).  Rows of one id are summed in
- *                        sorted-position order (deterministic), scaled by grad_scale; ids <= pad_row are skipped (padding_idx). */
+ *                        sorted-position order (deterministic), scaled by grad_scale; ids <= pad_row are skipped (padding_idx).
+ * With a device step counter attached (nr_set_step_counter) nr_row_adam_step takes `step` from *ctr and nr_row_adam_catchup takes `upto`
+ * = *ctr - 1 (the counter is bumped at the START of a step, so inside a step one step fewer has been taken): a row-sparse training step
+ * captured into a HIP graph then advances at every replay.  While a counter is attached, call nr_row_adam_catchup only from inside a step;
+ * nr_row_adam_flush always uses its by-value argument. */
 int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
                         int64_t upto, double beta1, double beta2, double eps, void* stream);
 int nr_row_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched, int64_t upto, double beta1,

@@ -22,8 +22,9 @@
 namespace nr {
 
 struct AdamCfg {
-  const uint32_t* t_dev; // optional device-resident step counter (nr_set_step_counter): the dense kernel then takes its step index from it
-                        // instead of its by-value argument, so that a step captured into a HIP graph advances at every replay
+  const uint32_t* t_dev; // optional device-resident step counter (nr_set_step_counter): the dense kernel and the row-sparse step / catch-up
+                        // kernels then take their step index from it instead of their by-value argument, so that a step captured into a
+                        // HIP graph advances at every replay (the flush kernel is never part of a step and keeps its argument)
   const float* sched;   // [2 * (max_step + 1)]
   float om_b1;          // 1 - beta1
   float b2, om_b2;      // beta2, 1 - beta2
@@ -121,8 +122,11 @@ __device__ __forceinline__ void row_replay(RowState& r, const AdamCfg& c, int64_
 __global__ __launch_bounds__(256) void row_adam_catchup_kernel(const int64_t* __restrict__ ids, int64_t n, float* __restrict__ p,
                                                                float* __restrict__ m, float* __restrict__ v, int* __restrict__ last,
                                                                int64_t num_rows, int d, int64_t upto, AdamCfg c) {
+  // with a device step counter attached (HIP-graph replays, graph.py) the counter was bumped at the START of the step this launch belongs
+  // to: the steps taken so far are one less
+  if (c.t_dev != nullptr) upto = (int64_t)*c.t_dev - 1;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave_id();
-  if (i >= n) return;
+  if (i >= n || upto <= 0) return;
   const int l = lane_id();
   const int64_t row = ids[i];
   if (row < 0 || row >= num_rows) return;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256) void row_adam_step_kernel(const int64_t* __res
                                                             float* __restrict__ m, float* __restrict__ v, int* __restrict__ last,
                                                             int64_t num_rows, int d, int64_t step, AdamCfg c, float grad_scale,
                                                             int pad_row) {
+  if (c.t_dev != nullptr) step = (int64_t)*c.t_dev;             // as in adam_flat_kernel: the step index of a replayed graph comes from the counter
   const int64_t a = (int64_t)blockIdx.x * 4 + wave_id();
   if (a >= n) return;
   const int l = lane_id();

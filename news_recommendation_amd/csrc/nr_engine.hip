@@ -1100,9 +1100,10 @@ int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float
                         int64_t upto, double beta1, double beta2, double eps, void* stream) {
   if (!ids || !p || !m || !v || !last || !sched || n < 0 || num_rows <= 0 || d <= 0 || d > 64 * nr::ROW_EPL || upto < 0 || bad_betas(beta1, beta2, eps))
     return fail(NR_ERR_BADARG, "nr_row_adam_catchup: bad argument");
-  if (n == 0 || upto == 0) return NR_OK;
-  NR_LAUNCH(nr::row_adam_catchup_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids, n, p, m, v, (int*)last, num_rows, d, upto,
-            make_adam(sched, beta1, beta2, eps));
+  if (n == 0 || (upto == 0 && g_step_ctr == nullptr)) return NR_OK;
+  nr::AdamCfg cfg = make_adam(sched, beta1, beta2, eps);
+  cfg.t_dev = g_step_ctr;                  // device step counter attached: `upto` is read from it (counter - 1) by the kernel
+  NR_LAUNCH(nr::row_adam_catchup_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids, n, p, m, v, (int*)last, num_rows, d, upto, cfg);
   return check_launch("nr_row_adam_catchup");
 }
 
@@ -1123,8 +1124,10 @@ int nr_row_adam_step(const int64_t* ids_sorted, const int64_t* perm, int64_t n, 
       ld < d || step < 1 || pad_row < -1 || bad_betas(beta1, beta2, eps))
     return fail(NR_ERR_BADARG, "nr_row_adam_step: bad argument");
   if (n == 0) return NR_OK;
+  nr::AdamCfg cfg = make_adam(sched, beta1, beta2, eps);
+  cfg.t_dev = g_step_ctr;
   NR_LAUNCH(nr::row_adam_step_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, n, rows, ld, p, m, v, (int*)last, num_rows, d,
-            step, make_adam(sched, beta1, beta2, eps), grad_scale, pad_row);
+            step, cfg, grad_scale, pad_row);
   return check_launch("nr_row_adam_step");
 }
 

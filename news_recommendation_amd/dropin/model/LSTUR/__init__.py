@@ -34,9 +34,18 @@ class LSTUR(torch.nn.Module):
         if masked:
             # F.dropout2d on the [1, B, D] user tensor (:74-77) = one Bernoulli draw per sample, survivors scaled by 1/(1-p)
             p = float(self.config.masking_probability)
-            keep = (torch.rand(ids.shape[0]) >= p).to(torch.float32)
-            self.last_user_keep = keep
-            scale = ops.to_device_async(keep / (1.0 - p), dev)            # a blocking copy would drain the stream every step
+            if user.is_cuda and 0.0 < p < 1.0:
+                # ids already resident on the device (forward_ids / the engine's trainer): the draw stays there too -- the engine's counter-based
+                # generator (site 3, one element per sample), which follows the device step counter like every other mask, so that the
+                # step can be captured into a HIP graph (graph.py) and replayed with a fresh mask
+                keep = torch.empty(ids.shape[0], dtype=torch.float32, device=dev)
+                ops._call('nr_dropout_mask[user]', ops._lib().nr_dropout_mask, keep.data_ptr(), ids.shape[0], p, ops.new_seed(), 3, ops._stream())
+                self.last_user_keep = keep
+                scale = keep / (1.0 - p)
+            else:
+                keep = (torch.rand(ids.shape[0]) >= p).to(torch.float32)
+                self.last_user_keep = keep
+                scale = ops.to_device_async(keep / (1.0 - p), dev)        # a blocking copy would drain the stream every step
         return ops_gru.user_rows(ids, self.user_embedding.weight, scale)
 
     def forward(self, user, clicked_news_length, candidate_news, clicked_news):

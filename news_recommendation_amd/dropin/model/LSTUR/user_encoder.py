@@ -17,7 +17,10 @@ class UserEncoder(torch.nn.Module):
     def forward(self, user, clicked_news_length, clicked_news_vector):
         """user: [B, 3F] ('ini') or [B, 1.5F] ('con'); clicked_news_length: [B] (CPU, as the reference requires for packing);
         clicked_news_vector: [B, N, 3F] -> [B, 3F].  pack_padded_sequence semantics: the first length[b] slots are consumed."""
-        clicked_news_length[clicked_news_length == 0] = 1            # in place, like the reference (:27)
+        if clicked_news_length.is_cuda:
+            clicked_news_length.clamp_(min=1)                        # same effect; a boolean-mask assignment would synchronise the stream
+        else:
+            clicked_news_length[clicked_news_length == 0] = 1        # in place, like the reference (:27)
         if self.config.long_short_term_method == 'ini':
             return ops_gru.gru_last_state(clicked_news_vector, user, clicked_news_length, self.gru)
         last_hidden = ops_gru.gru_last_state(clicked_news_vector, None, clicked_news_length, self.gru)

@@ -13,8 +13,11 @@ What has to be true for a captured step to remain a TRAINING step when replayed:
 The counter is bumped by the graph's first node, so replay k uses counter value t0 + k: exactly what the eager loop below (`eager_step`)
 does with one nr_step_counter_add launch per step -- which is how the tests hold replays to the eager path bit for bit.
 
-Scope: single process (world = 1), dense parameters (NRMS, NAML).  Data-parallel steps keep their RCCL calls outside any graph
-(collectives are the natural graph boundaries); LSTUR's step depends on host-side history lengths and is not captured.
+Scope: single process (world = 1); NRMS, NAML and LSTUR.  LSTUR's step is capturable when its inputs are device tensors: the history
+lengths stay on the device (the recurrence then always runs all N steps; finished samples keep their state, same result), the whole-row
+user mask is drawn by the engine's counter-based generator (nr_dropout_mask, site 3) instead of the host's, and the row-sparse Adam of the
+user table reads its step index from the same counter (nr_row_adam_catchup / nr_row_adam_step, csrc/k_optim.h); its (row id, gradient row)
+list never leaves the device.  Data-parallel steps are captured in SEGMENTS around their RCCL calls (SegmentedStep below).
 """
 import torch
 
@@ -28,12 +31,10 @@ class StepGraph:
     """``g = StepGraph(step_fn, example_inputs, optimizer)``; ``loss = g(*inputs)`` runs one training step.
 
     step_fn(*inputs) must run forward, ``loss.backward()`` and ``optimizer.step()`` and return the (device) loss tensor; `optimizer` is
-    an ``optim.EngineAdam`` without row-sparse tables.  ``max_steps`` sizes the optimiser's per-step scalar table once (its address is
+    an ``optim.EngineAdam`` (row-sparse tables included: their kernels follow the device step counter).  ``max_steps`` sizes the optimiser's per-step scalar table once (its address is
     frozen into the graph)."""
 
     def __init__(self, step_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20):
-        if optimizer.sparse:
-            raise NotImplementedError("StepGraph: row-sparse tables (LSTUR) update from host-side row lists; not capturable")
         if _attached:
             raise RuntimeError("StepGraph: another StepGraph of this process still has its step counter attached (close() it first): the "
                                "counter is process-global, every dropout kernel and nr_adam_flat reads it")

@@ -1,0 +1,108 @@
+"""Statistical training parity (TEST INFRASTRUCTURE; SURVEY.md section 7 step 5: "AUC after N steps with dropout on").
+
+The reference trains with fp32 arithmetic and torch's dropout RNG (src/train.py:182-233); the engine trains with bf16 operands and its own
+counter-based dropout RNG, so trained weights cannot agree bit for bit -- what must agree is the QUALITY of the trained model.  This
+module holds the CPU half of that comparison: a learnable synthetic task (clicks sampled from a seeded teacher model), the oracle's
+training loop (the reference's loop: CrossEntropyLoss on the positive-first candidate list, torch.optim.Adam), and the scoring of a held-out
+eval-shaped impression set with the reference's metrics.  bench.py's `train_parity` leg and tests/test_training_parity_gpu.py run the
+engine on the SAME batches from the SAME initial weights and compare AUC / nDCG@10 of the two trained models.
+
+Only tests/, bench.py and __graft_entry__.smoke() may import this package (oracle/__init__.py)."""
+import numpy as np
+import torch
+
+from oracle import metrics
+from oracle.nrms_torch import OracleNRMS
+
+
+def make_task(num_words=6000, n_news=2500, steps=200, B=16, n_eval=1000, seed=0, beta=3.0, neg_k=2, num_clicked=50, title_len=20):
+    """A learnable NRMS task: a teacher (OracleNRMS, its own seed) scores every (history, candidate) pair; the clicked candidate of a
+    training impression is sampled ~ softmax(beta * z) over its 1 + K candidates (z = teacher logits z-scored per impression) and put FIRST
+    (data_preprocess.py:63-66); eval impressions get Bernoulli labels from the same teacher (synth.teacher_labels).
+    Returns a dict of numpy arrays (token ids) + the teacher's state_dict."""
+    from news_recommendation_amd import synth          # pure numpy generator (no device code): shared with bench.py
+    rng = np.random.default_rng(seed)
+    titles = synth.news_titles(rng, n_news, title_len, num_words)
+    torch.manual_seed(10_000 + seed)
+    teacher = OracleNRMS(num_words, 300, 15, 200, 0.0).eval()
+    with torch.no_grad():
+        nv = torch.cat([teacher.news_encoder(torch.from_numpy(titles[i:i + 512])) for i in range(0, n_news, 512)])
+        nvp = torch.cat([nv, torch.zeros(1, 300)])
+
+        def user_vecs(hist):
+            idx = torch.from_numpy(np.where(hist < 0, n_news, hist))
+            return torch.cat([teacher.user_encoder(nvp[idx[i:i + 256]]) for i in range(0, len(hist), 256)])
+        n_train = steps * B
+        cand = rng.integers(0, n_news, size=(n_train, 1 + neg_k))
+        hl = synth.history_lengths(rng, n_train, num_clicked)
+        hist = rng.integers(0, n_news, size=(n_train, num_clicked))
+        hist[np.arange(num_clicked)[None, :] < (num_clicked - hl)[:, None]] = -1
+        uv = user_vecs(hist)
+        z = torch.einsum('bcd,bd->bc', nv[torch.from_numpy(cand)], uv).numpy().astype(np.float64)
+        z = (z - z.mean(1, keepdims=True)) / (z.std(1, keepdims=True) + 1e-9)
+        pr = np.exp(beta * z)
+        pr /= pr.sum(1, keepdims=True)
+        pick = (rng.random(n_train)[:, None] > np.cumsum(pr, axis=1)).sum(1).clip(max=neg_k)
+        first = cand[np.arange(n_train), pick].copy()
+        cand[np.arange(n_train), pick] = cand[:, 0]
+        cand[:, 0] = first
+        e_hist, e_cands, e_ptr = synth.eval_impressions(rng, n_news, n_eval, num_clicked)
+        e_uv = user_vecs(e_hist)
+        e_sc = np.concatenate([(nv[e_cands[e_ptr[i]:e_ptr[i + 1]]] @ e_uv[i]).numpy() for i in range(n_eval)])
+    labels = synth.teacher_labels(np.random.default_rng(seed + 77), e_sc.astype(np.float64), e_ptr)
+    cand_ids, click_ids = synth.batch_token_ids(titles, cand, hist)
+    return {"titles": titles, "cand_ids": cand_ids.reshape(steps, B, 1 + neg_k, title_len), "click_ids": click_ids.reshape(steps, B, num_clicked, title_len),
+            "eval_hist": e_hist, "eval_cands": e_cands, "eval_ptr": e_ptr, "eval_labels": labels, "teacher_scores": e_sc,
+            "num_words": num_words, "steps": steps, "B": B}
+
+
+def init_state(num_words, seed=1):
+    """Initial student weights (the reference's own initialisers: nn.Embedding N(0, 1) with a zero padding row, xavier / default Linear)."""
+    torch.manual_seed(20_000 + seed)
+    return {k: v.clone() for k, v in OracleNRMS(num_words, 300, 15, 200, 0.2).state_dict().items()}
+
+
+def as_lists(ids):
+    return [{'title': torch.from_numpy(np.ascontiguousarray(ids[:, j]))} for j in range(ids.shape[1])]
+
+
+def train_oracle(task, state, lr=1e-3, p_drop=0.2, torch_seed=0, steps=None):
+    """The reference's training loop on the CPU oracle (src/train.py:127-128,202-233): dropout on, torch.optim.Adam.  Returns the trained
+    state_dict and the per-step losses."""
+    m = OracleNRMS(task["num_words"], 300, 15, 200, p_drop)
+    m.load_state_dict(state)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    crit = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(torch_seed)
+    B = task["B"]
+    target = torch.zeros(B, dtype=torch.long)
+    losses = []
+    for i in range(task["steps"] if steps is None else steps):
+        loss = crit(m(as_lists(task["cand_ids"][i]), as_lists(task["click_ids"][i])), target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}, losses
+
+
+def oracle_eval_scores(task, state):
+    m = OracleNRMS(task["num_words"], 300, 15, 200, 0.0)
+    m.load_state_dict(state)
+    m.eval()
+    titles, hist, cands, ptr = task["titles"], task["eval_hist"], task["eval_cands"], task["eval_ptr"]
+    n_news = titles.shape[0]
+    with torch.no_grad():
+        nv = torch.cat([m.news_encoder(torch.from_numpy(titles[i:i + 512])) for i in range(0, n_news, 512)])
+        nvp = torch.cat([nv, torch.zeros(1, 300)])
+        idx = torch.from_numpy(np.where(hist < 0, n_news, hist))
+        uv = torch.cat([m.user_encoder(nvp[idx[i:i + 256]]) for i in range(0, len(hist), 256)])
+        return np.concatenate([(nv[cands[ptr[i]:ptr[i + 1]]] @ uv[i]).numpy() for i in range(len(hist))])
+
+
+def eval_metrics(task, scores):
+    """(AUC, MRR, nDCG@5, nDCG@10) of `scores` on the task's held-out impressions (src/evaluate.py:160-168, 262-272)."""
+    ptr, lab = task["eval_ptr"], task["eval_labels"]
+    split = lambda a: [a[ptr[i]:ptr[i + 1]] for i in range(len(ptr) - 1)]
+    return metrics.evaluate_impressions(split(lab), split(np.asarray(scores)))

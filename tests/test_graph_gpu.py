@@ -1,5 +1,6 @@
 """HIP graph of the training step (news_recommendation_amd/graph.py): replays == the eager loop on the same device step counter -- new
-dropout masks and the right Adam step index at every replay -- for NRMS and NAML.  "Equal" up to the run-to-run noise of the embedding
+dropout masks and the right Adam step index at every replay -- for NRMS, NAML and LSTUR (whose row-sparse Adam, whole-row user mask and history
+lengths all stay on the device).  "Equal" up to the run-to-run noise of the embedding
 scatter's fp32 atomics (measured with a second eager run): a replay that reused a mask or a step index would be off by the size of an
 update (1e-3), not by last bits."""
 import os
@@ -32,11 +33,14 @@ B = 48
 batches = wl.batches(0, 3, B, dev)
 target = torch.zeros(B, dtype=torch.long, device=dev)
 crit = torch.nn.CrossEntropyLoss()
-flat = lambda b: [b[s][a] for s in ('cand', 'click') for a in wl.attrs]
+flat = lambda b: [b[s][a] for s in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length'].to(dev)] if model_name == 'LSTUR' else [])
 def step_fn(*xs):
     n = len(wl.attrs)
-    cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:]))
-    logits = model.forward_ids(cand['title'], click['title']) if model_name == 'NRMS' else model.forward_ids(cand, click)
+    cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
+    if model_name == 'LSTUR':          # device-resident user ids and history lengths: nothing in the step touches the host (graph.py)
+        logits = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
+    else:
+        logits = model.forward_ids(cand['title'], click['title']) if model_name == 'NRMS' else model.forward_ids(cand, click)
     loss = crit(logits, target)
     loss.backward()
     opt.step()
@@ -49,6 +53,7 @@ for i in range(5):
     loss = g(*xs) if mode == 'graph' else g.eager_step(*xs)
     losses.append(float(loss.item()))
     assert not opt.flat_g.any()
+    assert all(not st.pending for st in opt.sparse)
 assert opt.t == 7 and int(g.ctr.item()) == 7, (opt.t, int(g.ctr.item()))
 # masks are reproducible through the exported-mask entry point under the counter, and differ from step to step
 m7 = torch.empty(4096, device=dev); lib = g.lib
@@ -80,7 +85,7 @@ def _run(mode, model_name, tmp_path):
     return dict(np.load(out))
 
 
-@pytest.mark.parametrize('model_name', ['NRMS', 'NAML'])
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
 def test_step_graph_replays_equal_eager_steps(tmp_path, model_name):
     eager, graph = _run('eager', model_name, tmp_path), _run('graph', model_name, tmp_path)
     again = _run('eager', model_name, tmp_path)

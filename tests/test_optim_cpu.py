@@ -73,10 +73,23 @@ def test_adam_flat_rejects_bad_args(emu):
     assert emu.lib.nr_adam_flat(a.ctypes.data, a.ctypes.data, a.ctypes.data, a.ctypes.data, 8, s.ctypes.data, 1, 1.5, 0.999, 1e-8, 1.0, 1, None) != 0
 
 
-def test_row_lazy_adam_equals_dense_bitwise(emu):
+@pytest.mark.parametrize('with_counter', [False, True])
+def test_row_lazy_adam_equals_dense_bitwise(emu, with_counter):
     """The lazy row kernels replay exactly what the dense kernel does to rows without gradient: same bits after 12 steps in which
-    rows go idle for up to 11 steps, are re-read (catch-up), re-touched, duplicated within a step, and finally flushed."""
+    rows go idle for up to 11 steps, are re-read (catch-up), re-touched, duplicated within a step, and finally flushed.
+    with_counter: the step index comes from a device step counter bumped at the START of every step (HIP-graph replays, graph.py) --
+    the by-value step arguments are then frozen at their capture-time values (here: 1) and must be ignored."""
     rng = np.random.default_rng(1)
+    ctr = np.zeros(1, dtype=np.uint32)
+    if with_counter:
+        assert emu.lib.nr_set_step_counter(ctr.ctypes.data) == 0
+    try:
+        _row_lazy_body(emu, rng, ctr, with_counter)
+    finally:
+        assert emu.lib.nr_set_step_counter(None) == 0
+
+
+def _row_lazy_body(emu, rng, ctr, with_counter):
     R, d, T = 23, 130, 12
     p0 = rng.normal(size=(R, d)).astype(F)
     sched = np.ascontiguousarray(_sched(1e-3, (0.9, 0.999), T + 2))
@@ -94,8 +107,10 @@ def test_row_lazy_adam_equals_dense_bitwise(emu):
         # forward would read these rows first: catch them up to t - 1
         read = np.unique(np.concatenate([ids, rng.integers(0, R, size=2)])).astype(np.int64)
         before = pl.copy()
+        ctr[0] = t                                                    # the step's first node bumps the counter
+        tv = 1 if with_counter else t                                 # by-value step index: frozen under a counter
         assert lib.nr_row_adam_catchup(read.ctypes.data, len(read), pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d,
-                                       sched.ctypes.data, t - 1, 0.9, 0.999, 1e-8, None) == 0
+                                       sched.ctypes.data, tv - 1, 0.9, 0.999, 1e-8, None) == 0
         assert np.array_equal(pl[read], pd[read]), f"rows not current before the forward of step {t}"
         untouched = np.setdiff1d(np.arange(R), read)
         assert np.array_equal(pl[untouched], before[untouched])
@@ -104,12 +119,12 @@ def test_row_lazy_adam_equals_dense_bitwise(emu):
         for i, r in zip(ids, rows):
             if i > 0:
                 g[i] += r
-        assert lib.nr_adam_flat(pd.ctypes.data, g.ctypes.data, md.ctypes.data, vd.ctypes.data, R * d, sched.ctypes.data, t, 0.9, 0.999, 1e-8,
+        assert lib.nr_adam_flat(pd.ctypes.data, g.ctypes.data, md.ctypes.data, vd.ctypes.data, R * d, sched.ctypes.data, tv, 0.9, 0.999, 1e-8,
                                 0.5, 1, None) == 0
         order = np.argsort(ids, kind='stable')
         ids_sorted, perm = ids[order].copy(), order.astype(np.int64)
         assert lib.nr_row_adam_step(ids_sorted.ctypes.data, perm.ctypes.data, nb, rows.ctypes.data, d,
-                                    pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d, sched.ctypes.data, t,
+                                    pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d, sched.ctypes.data, tv,
                                     0.9, 0.999, 1e-8, 0.5, 0, None) == 0
     assert not np.array_equal(pl, pd)                                 # lazy table is stale somewhere before the flush ...
     assert lib.nr_row_adam_flush(pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d, sched.ctypes.data, T,
