@@ -152,6 +152,25 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
  * P: a multiple of 8; nr_tn_gemm_parts(M, n_tok) gives the library's choice (enough workgroups for two per CU). */
 int nr_tn_gemm_parts(int M, int64_t n_tok);
 int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream);
+/* General bf16 GEMMs with fp32 accumulation and fp32 results (csrc/k_gemm.h) -- the products the reference leaves to nn.GRU / torch.autograd:
+ *   nr_gemm_nt   C f32[M][ldc] = A bf16[M][lda] . B bf16[N][ldb]^T, both operands K-contiguous, K a multiple of 32 (padding columns of both
+ *                operands must be finite; zero where the product must not see them), row strides multiples of 8 elements.  Replaces:
+ *                the hoisted input projection x W_ih^T of nn.GRU (src/model/LSTUR/user_encoder.py:11-14,43-45), autograd's
+ *                dX = dGi W_ih (B = W_ih^T, re-packed by nr_transpose_bf16), and the recurrent product h W_hh^T of the evaluation sweep.
+ *   nr_gemm_tn   out f32[P][M][ldo], out[p][m][n] = sum over the tokens of partition p of G[tok][m] * X[tok + n / tapw][n % tapw]: weight
+ *                gradients with split K (sum over p = the gradient; nr_sum_parts reduces in a fixed order).  taps = 1: X bf16[n_tok][ldx],
+ *                N = tapw <= ldx columns (dW_ih = dGi^T X, dW_hh = dGh^T H of nn.GRU; the nn.Linear weights of multihead_self.py:53-55 /
+ *                additive.py:35).  taps = 3: X is a seqpad buffer (nr_conv3_fwd's x_save) with n_tok + 2 readable rows, and the N = 3 tapw
+ *                result columns are the three tap gradients of Conv2d(1, F, (3, D)) side by side (src/model/NAML/news_encoder.py:27-28,
+ *                src/model/LSTUR/news_encoder.py:26-30): one pass over G for all taps.  P: multiple of 8 (nr_gemm_tn_parts = one workgroup
+ *                per CU); zeros: 16 zero bytes in device memory.
+ *   nr_transpose_bf16  dst[c][r] = src[r][c] (weight re-packing, once per optimiser step); nr_sum_parts  out[i] (+)= sum_p parts[p][i]. */
+int nr_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* stream);
+int nr_gemm_tn_parts(int M, int N, int64_t n_tok);
+int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t ldx, int tapw, int taps, const uint16_t* zeros, float* out,
+               int64_t ldo, int64_t n_tok, int P, void* stream);
+int nr_transpose_bf16(const uint16_t* src, int R, int C, int64_t lds, uint16_t* dst, int64_t ldd, void* stream);
+int nr_sum_parts(const float* parts, int P, int64_t n, float* out, int accumulate, void* stream);
 /* ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) from a head-major qkv buffer;
  * ctx as nr_mhsa_fwd writes it (second dropout of news_encoder.py:43-45 applied when p_drop > 0, column D = 1.0). */
 int nr_attn_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);

@@ -79,6 +79,11 @@ SIGNATURES = {
     'nr_row_adam_flush': ([_P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double, _P], c_int),
     'nr_row_adam_step': ([_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double,
                           c_float, c_int, _P], c_int),
+    'nr_gemm_nt': ([_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P], c_int),
+    'nr_gemm_tn_parts': ([c_int, c_int, c_int64], c_int),
+    'nr_gemm_tn': ([_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, c_int64, c_int64, c_int, _P], c_int),
+    'nr_transpose_bf16': ([_P, c_int, c_int, c_int64, _P, c_int64, _P], c_int),
+    'nr_sum_parts': ([_P, c_int, c_int64, _P, c_int, _P], c_int),
     'nr_sort_ids_workspace': ([c_int64, c_int64], c_int64),
     'nr_sort_ids': ([_P, c_int64, c_int64, _P, _P, _P, c_int64, _P], c_int),
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),

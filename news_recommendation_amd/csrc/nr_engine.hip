@@ -5,6 +5,7 @@
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
 #include "k_proj.h"
+#include "k_gemm.h"
 #include "k_conv.h"
 #include "k_naml.h"
 #include "k_gru.h"
@@ -96,6 +97,15 @@ int gemm_waves() {
 
 template <typename K>
 int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
+
+// ---- general ring GEMMs (csrc/k_gemm.h) --------------------------------------------------------------------------------------------
+template <int MODE, int WR, int TM, int TN_>
+static int launch_gemm(const nr::GemmParams& p, int64_t grid, void* stream, const char* who) {
+  using G = nr::GemmGeom<MODE, WR, TM, TN_>;
+  if (allow_smem(nr::gemm_ring_kernel<MODE, WR, TM, TN_>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
+  NR_LAUNCH((nr::gemm_ring_kernel<MODE, WR, TM, TN_>), grid, 512, G::SMEM, (hipStream_t)stream, p);
+  return check_launch(who);
+}
 
 template <int S, int NSEQ, int NW>
 int launch_conv_t(nr::ConvParams& p, void* stream) {
@@ -512,6 +522,71 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
     NR_LAUNCH(nr::tn_gemm_kernel<4>, (int64_t)P * p.nslab, 256, G::SMEM, (hipStream_t)stream, p);
   }
   return check_launch("nr_tn_gemm");
+}
+
+// ---- general ring GEMMs (csrc/k_gemm.h; launch_gemm is defined above, outside the extern "C" block) -----------------------------------
+int nr_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* stream) {
+  if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || (K & 31) || lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7))
+    return fail(NR_ERR_BADARG, "nr_gemm_nt: bad argument (K must be a multiple of 32, row strides multiples of 8 elements)");
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return fail(NR_ERR_BADARG, "nr_gemm_nt: operands must be 16-byte aligned");
+  if (M == 0) return NR_OK;
+  nr::GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.tapw = 1 << 30;
+  using G = nr::GemmGeom<0, 4, 2, 4>;
+  p.tiles_m = (int)((M + G::BM - 1) / G::BM); p.tiles_n = (N + G::BN - 1) / G::BN;
+  const int64_t grid = (int64_t)((p.tiles_m + 7) / 8) * 8 * p.tiles_n;
+  return launch_gemm<0, 4, 2, 4>(p, grid, stream, "nr_gemm_nt");
+}
+
+// output tile of the TN kernel: 320 x 256 (2 x 4 waves of 5 x 2 tiles) for M <= 320 (conv tap gradients: 320 filters x 3 x 320), 256 x 320
+// (4 x 2 waves of 2 x 5 tiles) for N <= 320 (projection gradients: 960 x 320), else 256 x 256
+static void gemm_tn_tile(int M, int N, int* bm, int* bn) {
+  *bm = M <= 320 ? 320 : 256;
+  *bn = (M > 320 && N > 256 && N <= 320) ? 320 : 256;
+}
+
+int nr_gemm_tn_parts(int M, int N, int64_t n_tok) {
+  if (M <= 0 || N <= 0 || n_tok < 0) return -1;
+  int BM, BN;
+  gemm_tn_tile(M, N, &BM, &BN);
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int P = (256 + tiles - 1) / tiles;            // one workgroup per CU
+  P = (P + 7) / 8 * 8;
+  const int64_t maxp = (n_tok + 31) / 32;
+  while (P > 8 && P > maxp) P -= 8;
+  return P;
+}
+
+int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t ldx, int tapw, int taps, const uint16_t* zeros, float* out,
+               int64_t ldo, int64_t n_tok, int P, void* stream) {
+  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || (ldx & 7) || tapw <= 0 || tapw > ldx || (tapw & 7) || taps < 1 || taps > 3 ||
+      n_tok < 0 || P <= 0 || (P & 7) || ldo < (int64_t)taps * tapw)
+    return fail(NR_ERR_BADARG, "nr_gemm_tn: bad argument");
+  if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)zeros) & 15) != 0) return fail(NR_ERR_BADARG, "nr_gemm_tn: operands must be 16-byte aligned");
+  nr::GemmParams p{};
+  p.A = G; p.B = X; p.C = out; p.lda = ldg; p.ldb = ldx; p.ldc = ldo; p.M = M; p.N = taps * tapw; p.K = 0; p.zeros = zeros; p.n_tok = n_tok;
+  p.P = P; p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32; p.tapw = taps == 1 ? (1 << 30) : tapw;
+  int BM, BN;
+  gemm_tn_tile(M, p.N, &BM, &BN);
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  const int64_t grid = (int64_t)P * p.tiles_m * p.tiles_n;
+  if (BM == 320) return launch_gemm<1, 2, 5, 2>(p, grid, stream, "nr_gemm_tn");
+  if (BN == 320) return launch_gemm<1, 4, 2, 5>(p, grid, stream, "nr_gemm_tn");
+  return launch_gemm<1, 4, 2, 4>(p, grid, stream, "nr_gemm_tn");
+}
+
+int nr_transpose_bf16(const uint16_t* src, int R, int C, int64_t lds, uint16_t* dst, int64_t ldd, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || lds < C || ldd < R) return fail(NR_ERR_BADARG, "nr_transpose_bf16: bad argument");
+  NR_LAUNCH2(nr::transpose_bf16_kernel, (C + 31) / 32, (R + 31) / 32, 256, 32 * 33 * 2, (hipStream_t)stream, src, R, C, lds, dst, ldd);
+  return check_launch("nr_transpose_bf16");
+}
+
+int nr_sum_parts(const float* parts, int P, int64_t n, float* out, int accumulate, void* stream) {
+  if (!parts || !out || P <= 0 || n < 0 || (n & 3)) return fail(NR_ERR_BADARG, "nr_sum_parts: bad argument (n must be a multiple of 4)");
+  if ((((uintptr_t)parts | (uintptr_t)out) & 15) != 0) return fail(NR_ERR_BADARG, "nr_sum_parts: buffers must be 16-byte aligned");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::sum_parts_kernel, grid_for(n / 4, 256, 4096), 256, 0, (hipStream_t)stream, parts, P, n / 4, out, accumulate);
+  return check_launch("nr_sum_parts");
 }
 
 static int attn_fwd_launch(const char* who, const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len, int64_t n_seq, int S, float p_drop,

@@ -438,6 +438,48 @@ def _wgrad_parts_hand(G, M, X, name):
     return out
 
 
+# NR_GEMM_HAND: which of the former library GEMMs run in the general hand-written ring kernels of csrc/k_gemm.h (bit mask; default all):
+#   1  LSTUR's GRU products: x W_ih^T (forward), dGi W_ih, dGi^T X, dGh^T H (backward)        [ops_gru.py]
+#   2  the three tap gradients of the conv text encoders as ONE 3-tap GEMM                      [ops_conv.py]
+#   4  the projection weight gradients dqkv^T [X | 1] of the NRMS encoders (256 x 320 tiles)
+#   8  the recurrent product h W_hh^T of LSTUR's batched evaluation sweep
+_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '15'))
+
+
+def gemm_nt(A, B, M, N, K, name, out=None, ldc=None):
+    """C f32 [M, ldc] = A[:M, :K] @ B[:N, :K]^T for int16-typed bf16 matrices (row strides = their second dims), hand-written (nr_gemm_nt)."""
+    ldc = N if ldc is None else ldc
+    C = torch.empty(M, ldc, dtype=torch.float32, device=A.device) if out is None else out
+    _call(name, _lib().nr_gemm_nt, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), ldc, M, N, K, _stream())
+    return C
+
+
+def gemm_tn_parts(G, M, X, ncol, name, taps=1, n_tok=None):
+    """G[:, :M]^T @ X[:, :ncol] (taps = 3: the three shifted products of a seqpad X side by side) as fp32 partials [P, M, taps * ncol] over P token
+    partitions (nr_gemm_tn); the sum over dim 0 is the gradient."""
+    lib = _lib()
+    n = G.shape[0] if n_tok is None else n_tok
+    N = taps * ncol
+    P = lib.nr_gemm_tn_parts(M, N, n)
+    out = torch.empty(P, M, N, dtype=torch.float32, device=G.device)
+    z = _zeros16.get(G.device)
+    if z is None:
+        z = _zeros16[G.device] = torch.zeros(64, dtype=_BF16_AS_I16, device=G.device)
+    _call(name, lib.nr_gemm_tn, _ptr(G), G.stride(0), M, _ptr(X), X.stride(0), ncol, taps, _ptr(z), _ptr(out), N, n, P, _stream())
+    return out
+
+
+def sum_parts(parts, name='nr_sum_parts'):
+    """Sum of the split-K partials over dim 0 in a fixed order (deterministic), one launch."""
+    P = parts.shape[0]
+    n = parts[0].numel()
+    if n % 4:
+        return parts.sum(dim=0)
+    out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
+    _call(name, _lib().nr_sum_parts, _ptr(parts), P, n, _ptr(out), 0, _stream())
+    return out
+
+
 def _wgrad(a, b, name):
     """a^T @ b with fp32 result (chunk partials summed in fp32)."""
     parts = _wgrad_parts(a, b, name)
@@ -752,7 +794,9 @@ class _EncoderFn(torch.autograd.Function):
         dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
         Xb_b = _bf16(Xb)
-        if _WGRAD_GEMM == 1:
+        if _GEMM_HAND & 4:
+            dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')   # [P, 960, KP]: 256 x 320 tiles of the ring kernel (k_gemm.h)
+        elif _WGRAD_GEMM == 1:
             dW_parts = _wgrad_parts_hand(dqkv, NR_LDG, Xb, f'nr_tn_gemm_dWqkv[S={S}]')     # [P, 960, KP]
         else:
             dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))

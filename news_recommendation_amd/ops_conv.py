@@ -144,6 +144,11 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
 
     def wgrad():
         taps = []
+        if ops._GEMM_HAND & 2:
+            # ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap shift is a row offset
+            # of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three taps
+            both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, st.xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
+            return [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
         if ops._WGRAD_GEMM_CONV == 1:     # hand-written split-K kernel: the tap shift is a row offset of the X operand
             for w in range(3):
                 taps.append(ops._wgrad_parts_hand(dy, NR_KP, st.xstore[w:w + ra], f'nr_tn_gemm_dWconv[{tag}]').sum(dim=0))
