@@ -597,15 +597,44 @@ def main():
         for i in range(2):
             sg(*flat(batches[i % len(batches)]))
 
+    # ---- N > 1: the data-parallel step as TWO HIP graphs with the RCCL collectives between them (graph.SegmentedStep); every rank takes the
+    # same branch (same code, same arguments); a failure to build it falls back to the kernel-by-kernel step and says so in the line
+    seg, seg_note = None, None
+    if world > 1 and not args.no_graph:
+        try:
+            from news_recommendation_amd.graph import SegmentedStep
+            if args.model == 'LSTUR':
+                for b in batches:
+                    b['length_dev'] = b['length'].to(device)
+            flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if args.model == 'LSTUR' else [])
+
+            def fwd_bwd(*xs):
+                n = len(wl.attrs)
+                cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
+                if args.model == 'LSTUR':
+                    lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
+                else:
+                    lg_ = model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click)
+                l_ = crit(lg_, target)
+                l_.backward()
+                return l_
+            seg = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=1)
+            for i in range(2):
+                seg(*flat(batches[i % len(batches)]))
+        except Exception as e:               # noqa: BLE001 -- the measured line matters more than the issue mode
+            seg, seg_note = None, f"segmented graphs unavailable ({e!r}): kernel-by-kernel step"
+            opt.overlap = True
+
     barrier()
     t0 = time.perf_counter()
     # the GRU steps are issued as one C call per recurrence in the timed region (per-step launches from Python make the LSTUR step
     # host-bound): the event pair then brackets T (+1) launches and the per-launch average is total / launches
     SEQ = {'nr_gru_fwd_step': 'nr_gru_fwd_seq', 'nr_gru_bwd_step': 'nr_gru_bwd_seq'}
     timed_name = SEQ.get(dominant, dominant)
-    if sg is not None:
+    if sg is not None or seg is not None:
+        run_ = sg if sg is not None else seg
         for i in range(args.steps):
-            loss = sg(*flat(batches[i % len(batches)]))
+            loss = run_(*flat(batches[i % len(batches)]))
         rec2 = None
     else:
         with ops.profile(only={timed_name}) as rec2:
@@ -630,6 +659,13 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if seg is not None:
+        # per-kernel HIP events cannot bracket graph nodes: the dominant kernel's duration comes from a short eager pass on the same counter
+        # protocol (collective steps: every rank takes part)
+        with ops.profile(only={timed_name}) as rec2:
+            for i in range(min(args.steps, 5)):
+                seg.eager_step(*flat(batches[i % len(batches)]))
+        barrier()
     dom = rec2.summary().get(timed_name, (0, float('nan'), 0.0))
     if timed_name != dominant:
         per_call = ops.seq_launches.get(timed_name, 1)
@@ -638,7 +674,10 @@ def main():
     comm = None
     if world > 1:
         # ---- how much of the step is EXPOSED gradient exchange, and what the buckets achieve on the wire (all ranks, still in the group) ----
-        comm = comm_probe(opt, step, barrier, world, min(args.steps, 10), dt / args.steps * 1e3, device)
+        step_probe = (lambda i: seg(*flat(batches[i % len(batches)]))) if seg is not None else step
+        comm = comm_probe(opt, step_probe, barrier, world, min(args.steps, 10), dt / args.steps * 1e3, device)
+        if seg is not None:
+            seg.close()
     if world > 1:
         # every rank leaves the process group here: what follows on rank 0 (roofline probes, scoring throughput) is local work, and a
         # rank that kept the group open would wait in its destructor for peers that are still measuring
@@ -781,7 +820,9 @@ def main():
                    "dropout": cfg.dropout_probability, "parallelism": f"dp{world}"},
         "roofline": roofline,
         "step_issue": ("one HIP graph per step (forward + backward + Adam), replayed; roofline durations from an eager pass of the same "
-                       f"{args.steps} steps after the timed region" if sg is not None else "kernel by kernel"),
+                       f"{args.steps} steps after the timed region" if sg is not None else
+                       ("two HIP graphs per step ([forward + backward] | RCCL collectives | [Adam]), replayed" if seg is not None else
+                        (seg_note or "kernel by kernel"))),
         "ms_per_step_eager": eager_ms,
         "loss": float(loss.item()),
         "grad_exchange": {"dense_allreduce_bytes": opt.dense_nbytes, "buckets": [[r.name, (r.hi - r.lo) * 4] for r in opt.regions],

@@ -111,3 +111,79 @@ class StepGraph:
             self.close()
         except Exception:
             pass
+
+
+class SegmentedStep:
+    """A DATA-PARALLEL training step as two HIP graphs with the RCCL collectives between them:
+
+        graph A   counter bump, forward, backward (gradients land in the optimiser's flat buffer), touched rows staged for the exchange
+        eager     all-reduce of the table bucket(s), all-gather of the touched rows, all-reduce of the small bucket   (RCCL, its own stream)
+        graph B   fused Adam over the dense buckets, row-sparse Adam over the gathered rows
+
+    Issued kernel by kernel, the step costs 2.2 ms (NRMS) of host time -- under a 3.6 ms step at B = 512 today, but the first thing an 8-GPU
+    run would be bound by once the kernels get faster; in this form the host issues two graph launches and three to five collectives.  What
+    it gives up: the table all-reduce no longer starts from INSIDE the backward (it starts when graph A has finished, i.e. after the
+    weight-gradient GEMMs that used to cover it: ~0.5 ms of overlap), which `bench.py --gpus N` reports as `exposed_comm_ms`.
+    Same arithmetic as ``EngineAdam.step()``; ``eager_step`` is that path on the same counter protocol (the tests hold the two together)."""
+
+    def __init__(self, fwd_bwd_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20):
+        if not optimizer._dist_on():
+            raise RuntimeError("SegmentedStep: no process group (single process: use StepGraph)")
+        if _attached:
+            raise RuntimeError("SegmentedStep: another captured step of this process still has its step counter attached (close() it first)")
+        self.lib = _capi.load()
+        self.opt = optimizer
+        self.fn = fwd_bwd_fn
+        dev = optimizer.device
+        optimizer.overlap = False            # the table collective is issued between the segments, not from inside the backward
+        self.static = [torch.empty_like(x) for x in example_inputs]
+        for s, x in zip(self.static, example_inputs):
+            s.copy_(x)
+        optimizer.sched.ensure(optimizer.t + max_steps)
+        self.max_t = optimizer.t + max_steps
+        self.ctr = torch.full((1,), optimizer.t, dtype=torch.int32, device=dev)
+        _capi.check(self.lib, self.lib.nr_set_step_counter(self.ctr.data_ptr()))
+        _attached.append(self.ctr)
+        self._closed = False
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # real steps; the first one also agrees the per-rank row capacity of the touched-row exchange
+                self.eager_step(*self.static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        optimizer.prepare_segments()
+        ops.invalidate_packed()
+        # thread_local: RCCL's watchdog thread polls events of its own while this thread captures
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
+            self.loss = fwd_bwd_fn(*self.static)
+            optimizer.stage_rows()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+            optimizer.apply_all()
+
+    def eager_step(self, *inputs):
+        _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
+        loss = self.fn(*inputs)
+        self.opt.step()
+        return loss
+
+    def __call__(self, *inputs):
+        if self.opt.t + 1 > self.max_t:
+            raise RuntimeError("SegmentedStep: max_steps exhausted (the optimiser's step table is sized at capture)")
+        for s, x in zip(self.static, inputs):
+            if s.data_ptr() != x.data_ptr():
+                s.copy_(x, non_blocking=True)
+        self.graph_a.replay()
+        self.opt.begin_step()
+        self.opt.exchange_all()
+        self.graph_b.replay()
+        ops.invalidate_packed()
+        return self.loss
+
+    close = StepGraph.close
+    __enter__ = StepGraph.__enter__
+    __exit__ = StepGraph.__exit__
+    __del__ = StepGraph.__del__

@@ -84,7 +84,7 @@ class _Region:
 
 
 class _SparseTable:
-    __slots__ = ('name', 'param', 'm', 'v', 'last', 'pending', 'pad_row')
+    __slots__ = ('name', 'param', 'm', 'v', 'last', 'pending', 'pad_row', 'send_ids', 'send_rows', 'recv_ids', 'recv_rows')
 
 
 class EngineAdam:
@@ -310,6 +310,81 @@ class EngineAdam:
                 rows = torch.cat([r for _, r in st.pending])
                 st.pending.clear()
                 self._row_step(st, ids, rows, 1.0)
+
+    # ---- segmented form of a data-parallel step (graph.SegmentedStep): [forward + backward] | collectives | [update] -----------------------
+    # The two bracketed segments are HIP graphs; the collectives between them are issued eagerly (RCCL's calls are the graph boundaries).
+    # Same arithmetic as step(): all-reduce (sum) of the dense buckets, fixed-capacity all-gather of the touched rows, Adam with the
+    # 1 / world scale folded in.
+    def prepare_segments(self):
+        """Static send / receive buffers of the touched-row exchange (their addresses are frozen into the graphs).  Needs the per-rank row
+        capacity: agreed by the first eager exchange, or set_row_capacity()."""
+        if self.table_rs:
+            raise NotImplementedError("EngineAdam: the segmented step supports the all-reduce form of the table bucket (table_rs=False)")
+        world = _world()
+        for st in self.sparse:
+            cap = self._row_cap.get(st.name)
+            if cap is None:
+                raise RuntimeError(f"EngineAdam.prepare_segments: no row capacity for {st.name} yet: run one eager step or set_row_capacity()")
+            d = st.param.shape[1]
+            st.send_ids = torch.zeros(cap, dtype=torch.int64, device=self.device)
+            st.send_rows = torch.zeros(cap, d, dtype=torch.float32, device=self.device)
+            st.recv_ids = torch.zeros(world * cap, dtype=torch.int64, device=self.device)
+            st.recv_rows = torch.zeros(world * cap, d, dtype=torch.float32, device=self.device)
+
+    def stage_rows(self):
+        """Tail of the backward segment: this rank's (row id, gradient row) pairs into the static send buffers, padded with id 0 (the padding
+        row, which the update skips) -- device work only, so that it is part of the first graph."""
+        for st in self.sparse:
+            cap = st.send_ids.shape[0]
+            st.send_ids.zero_()
+            st.send_rows.zero_()
+            if st.pending:
+                ids = torch.cat([i for i, _ in st.pending]).to(torch.int64)
+                rows = torch.cat([r for _, r in st.pending]).to(torch.float32)
+                if ids.numel() > cap:
+                    raise RuntimeError(f"EngineAdam: {ids.numel()} gradient rows for {st.name}, capacity {cap}")
+                st.send_ids[:ids.numel()].copy_(ids)
+                st.send_rows[:ids.numel()].copy_(rows)
+            st.pending.clear()
+
+    def begin_step(self):
+        """Host bookkeeping of a step whose launches live in graphs: the step index (the kernels read it from the device counter)."""
+        self.t += 1
+        self.sched.ensure(self.t)
+        ops.invalidate_packed()
+
+    def exchange_all(self):
+        """Every collective of the step, issued between the two graph segments; returns once the current stream waits for all of them."""
+        if self.skip_comm:
+            return
+        works = []
+        world = _world()
+        for r in self.regions:
+            if r.name != 'small':
+                self.comm_bytes[r.name] = (r.hi - r.lo) * 4
+                works.append(dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True))
+        for st in self.sparse:
+            cap, d = st.send_ids.shape[0], st.param.shape[1]
+            if cap:
+                self.comm_bytes[st.name] = world * cap * (8 + 4 * d)
+                works.append(dist.all_gather_into_tensor(st.recv_ids, st.send_ids, async_op=True))
+                works.append(dist.all_gather_into_tensor(st.recv_rows, st.send_rows, async_op=True))
+        for r in self.regions:
+            if r.name == 'small':
+                self.comm_bytes['small'] = (r.hi - r.lo) * 4
+                works.append(dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+
+    def apply_all(self):
+        """The update launches of the step (second graph segment): fused Adam over every dense bucket with the 1 / world scale, the
+        row-sparse step over the gathered rows."""
+        scale = 1.0 / _world()
+        for r in self.regions:
+            self._adam(r.lo, r.end, scale)
+        for st in self.sparse:
+            if st.recv_ids.numel():
+                self._row_step(st, st.recv_ids, st.recv_rows, scale)
 
     def _exchange_rows(self, st):
         """All ranks' (row id, gradient row) pairs, in rank order: B x (8 + 4 d) bytes per rank instead of a table-sized all-reduce."""

@@ -69,6 +69,17 @@ def as_lists(ids):
 def train_oracle(task, state, lr=1e-3, p_drop=0.2, torch_seed=0, steps=None):
     """The reference's training loop on the CPU oracle (src/train.py:127-128,202-233): dropout on, torch.optim.Adam.  Returns the trained
     state_dict and the per-step losses."""
+    # small batches of the 53-call per-position loop: with every hardware thread of a 128-thread host in torch's intra-op pool the
+    # synchronisation costs 10 x the arithmetic (measured: 647 s on the GPU box's host vs 64 s on 8 cores) -- cap the pool for this loop
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthr))
+    try:
+        return _train_oracle(task, state, lr, p_drop, torch_seed, steps)
+    finally:
+        torch.set_num_threads(nthr)
+
+
+def _train_oracle(task, state, lr, p_drop, torch_seed, steps):
     m = OracleNRMS(task["num_words"], 300, 15, 200, p_drop)
     m.load_state_dict(state)
     m.train()

@@ -147,7 +147,7 @@ def _toy_batches(rank, steps, ragged=False):
     return out
 
 
-def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False):
+def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False, segmented=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     from news_recommendation_amd import dist as nrdist, optim
@@ -161,9 +161,19 @@ def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False):
                            table_rs=table_rs)
     assert [r.name for r in opt.regions] == ['small', 'word_embedding.weight']
     assert (opt.regions[1].end - opt.regions[1].lo) % (world * 64) == 0 and opt.regions[1].hi - opt.regions[1].lo == 480
+    if segmented:                               # the protocol of graph.SegmentedStep, issued by hand (the graphs themselves need a GPU)
+        opt.overlap = False
+        opt.set_row_capacity(5)
+        opt.prepare_segments()
     for words, users, y in _toy_batches(rank, 4, ragged):
         torch.nn.functional.cross_entropy(model(words, users), y).backward()
-        opt.step()
+        if segmented:
+            opt.stage_rows()                    # (tail of graph A)
+            opt.begin_step()
+            opt.exchange_all()                  # the collectives between the segments
+            opt.apply_all()                     # (graph B)
+        else:
+            opt.step()
         assert not opt.flat_g.any()
     assert opt.comm_bytes['small'] > 0 and opt.comm_bytes['word_embedding.weight'] >= 480 * 4 and opt.comm_bytes['user_embedding.weight'] == world * 5 * (8 + 32)
     sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
@@ -236,11 +246,11 @@ def _assert_equals_single_process(got, ragged=False):
         np.testing.assert_allclose(got[k], v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
 
 
-def _run_world2(overlap, table_rs=False, ragged=False):
+def _run_world2(overlap, table_rs=False, ragged=False, segmented=False):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, overlap, q, table_rs, ragged)) for r in range(world)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, overlap, q, table_rs, ragged, segmented)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in procs)
@@ -270,3 +280,16 @@ def test_engine_adam_unequal_row_counts_keep_one_protocol():
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), f"replicas diverged in {k}"
     _assert_equals_single_process(res[0], ragged=True)
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_engine_adam_segmented_step_equals_step(ragged):
+    """The segmented form of the data-parallel step (graph.SegmentedStep: [backward + row staging] | collectives | [update]) leaves the
+    replicas bit-identical to each other AND to EngineAdam.step() -- parameters and Adam moments, also when a rank's batch is shorter than the
+    agreed row capacity (its send buffer is padded with the padding row)."""
+    import numpy as np
+    seg, ref = _run_world2(False, ragged=ragged, segmented=True), _run_world2(True, ragged=ragged)
+    assert any(k.startswith('opt/') for k in seg[0])
+    for k in ref[0]:
+        assert np.array_equal(seg[0][k], seg[1][k]), f"replicas diverged in {k}"
+        assert np.array_equal(seg[0][k], ref[0][k]), f"segmented step differs from step() in {k}"

@@ -152,7 +152,7 @@ def test_bench_scale_backward_vs_torch_oracle():
     assert not ge[untouched].any(), 'gradient written to rows no token of the batch refers to'
     big = nr > 0.05 * np.median(nr)                                         # rows whose reference gradient is not itself rounding-sized
     ratio = ne[big] / nr[big]
-    # bf16 operands: a row's gradient is a sum of dX rows each ~1 % accurate; measured median ~1.5 %, worst row ~8 %.  A lost token: >= 30 % in its row
+    # bf16 operands: a row's gradient is a sum of dX rows each ~1 % accurate.  A lost token: >= 30 % in its row
     stats = {"tensor_rel_err": {k: float(v) for k, v in errs.items()}, "rows": int(big.sum()), "row_err_median": float(np.median(ratio)),
              "row_err_p999": float(np.quantile(ratio, 0.999)), "row_err_max": float(ratio.max())}
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
@@ -160,7 +160,7 @@ def test_bench_scale_backward_vs_torch_oracle():
         import json
         with open(os.path.join(out_dir, 'bench_scale_backward.json'), 'w') as f:
             json.dump(stats, f, indent=1)
-    assert np.median(ratio) < 0.04 and ratio.max() < 0.25, stats
+    assert np.median(ratio) < 0.02 and ratio.max() < 0.15, stats                # measured on MI355X (r04a): median 0.56 %, worst row 5.4 %
 
 
 def test_training_mode_dropout_matches_oracle_with_exported_masks():

@@ -135,5 +135,6 @@ def test_encoder_autograd_split_vs_fused():
 def test_attn_bwd_hm_vs_numpy_oracle_at_bench_scale(be):
     """The dominant kernel of the NRMS step at the launch size of BASELINE configs[1] (B = 512: 27,136 titles, 407,040 (title, head) pairs)
     against the numpy oracle directly; plus a dropout + key-length case whose n_seq leaves a partial last grid round."""
+    from tests import kernel_checks_proj as kp
     kp.check_attn_bwd_hm_oracle(be, n_seq=27136)
     kp.check_attn_bwd_hm_oracle(be, n_seq=3001, p_drop=0.2, with_key_len=True)
