@@ -509,6 +509,15 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def gather_source_hash():
+    """Hash of the sources of the stand-alone gather probe only (profiles/gather_traffic.json stays valid while other kernels change)."""
+    h = hashlib.sha256()
+    for f in ('k_misc.h', 'nr_common.h', 'nr_prims.h'):
+        with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -760,7 +769,7 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'gather_traffic.json')) as f:
                 gt = json.load(f)
-            if gt.get("hbm", {}).get("source_hash") == kernel_source_hash():
+            if gt.get("hbm", {}).get("source_hash") == gather_source_hash():
                 extras["gather_roofline"]["traffic"] = gt["hbm"].get("traffic_bytes")
                 extras["gather_roofline"]["rocprof"] = {k: {kk: v[kk] for kk in ("avg_us_rocprof", "achieved_GBs", "frac_of_8TBs", "traffic_bytes", "hbm_GBs_moved") if kk in v}
                                                         for k, v in gt.items()}

@@ -131,10 +131,11 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
   }
 
   AttnBwdRegs<Gm::IT, Gm::ITV> rg;
-  auto load_regs = [&](int64_t pr) {
+  // (seq, hd) are passed in, not derived from the pair index: the TILE form knows both, and a 64-bit division by H per call -- two calls per
+  // pair -- was most of the 258 scalar instructions per pair that profiles/r03_pmc_sq_attn_bwd_hm.txt shows
+  auto load_regs = [&](int64_t seq, int hd) {
     if (dbg & 1) return;
-    const int64_t seq = pr / H;
-    const int hd = (int)(pr - seq * H);
+    const int64_t pr = seq * H + hd;
     const int64_t tok0 = seq * S;
     // (wave-uniform 64-bit base) + (32-bit lane offset that does not depend on the pair): the per-lane 64-bit multiply-adds of
     // `(tok0 + r) * KP` were a quarter-rate instruction per address
@@ -174,9 +175,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     }
   };
   // registers -> wave-private LDS, all 8-B row-major stores; dC assembled with its direct term and dropout
-  auto store_lds = [&](int64_t pr) {
-    const int64_t seq = pr / H;
-    const int hd = (int)(pr - seq * H);
+  auto store_lds = [&](int64_t seq, int hd) {
     const int64_t tok0 = seq * S;
 #pragma unroll
     for (int it = 0; it < Gm::IT; ++it) {
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     }
   };
 
-  if (pair < n_pairs) load_regs(pair);
+  if (pair < n_pairs) load_regs(pair / H, (int)(pair % H));
   // zero the wave-private scratch ONCE: padding columns must be finite (zero); real positions are rewritten per pair
   for (int i = l; i < Gm::WAVE_BYTES / 16; i += 64) *(u16x8*)(base + i * 8) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   wave_barrier();
@@ -257,10 +256,10 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const bool act = !TILE || w + rnd * WPB < H;
     if (TILE) pair = seq_t * H + w + rnd * WPB;
     const int64_t seq = TILE ? seq_t : pair / H;
-    const int hd = (int)(pair - seq * H);
+    const int hd = TILE ? w + rnd * WPB : (int)(pair - seq * H);
     const int64_t tok0 = seq * S;
     const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
-    if (act) store_lds(pair);
+    if (act) store_lds(seq, hd);
     if (TILE && staged && rnd == Gm::ROUNDS - 1) {          // every wave has taken its last pieces of this sequence's dctx rows
       __syncthreads();
       if (seq_t + gridDim.x < p.n_seq) stage_dctx(seq_t + gridDim.x);
@@ -268,7 +267,10 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     // TILE: the wave's next head of this sequence, then its first head of the workgroup's next sequence
     const int64_t next = !TILE ? pair + stride : (hd + WPB < H ? pair + WPB : (seq + gridDim.x) * H + w);
     if (act) {
-    if (next < n_pairs) load_regs(next);          // prefetch the next pair while this one is computed
+    if (next < n_pairs) {                         // prefetch the next pair while this one is computed
+      if (TILE) load_regs(hd + WPB < H ? seq : seq + gridDim.x, hd + WPB < H ? hd + WPB : w);
+      else load_regs(next / H, (int)(next % H));
+    }
     wave_barrier();
 
     // ---- operand preparation ----------------------------------------------------------------------------------------

@@ -58,6 +58,8 @@ __device__ __forceinline__ int tn_swz(int r) { return (SL % 16 == 0) ? 4 * (r & 
 
 struct GemmYes { static constexpr bool v = true; };
 struct GemmNo { static constexpr bool v = false; };
+template <bool B> struct GemmTag { using type = GemmYes; };
+template <> struct GemmTag<false> { using type = GemmNo; };
 
 template <int MODE, int WR, int TM, int TN_>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
@@ -149,73 +151,74 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
 
-  // Fragment set of one k-step (16 contraction indices): TM fragments of A, TN_ of B.  ONE set lives in registers: while the MFMAs of a row
-  // group (one A fragment x the TN_ B fragments) run, the A fragment they just consumed is re-read for the NEXT k-step into the same registers;
-  // the next B fragments arrive in a second small set.  (Two whole sets, as dx_gemm_ring_kernel keeps them, cost 2 x 28 registers beside the
-  // 160 accumulator registers of the 320 x 256 tile: 98 spills, and spill reloads travel through vmcnt and drain the copy ring.)
-  u16x8 af[TM], bf[TN_];
-  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);       // TN: geometry of the transposing reads (see lds_tr16_b64)
-  auto read_a = [&](int c, int ks, int a) -> u16x8 {
-    const unsigned char* abuf = smem + (c & (Gm::NB - 1)) * Gm::BUF;
-    if (!TN) {
-      const int row = (wr * TM + a) * 32 + li;
-      return *(const u16x8*)(abuf + row * 64 + (((ks * 2 + h) ^ ((row >> 2) & 3)) * 16));
-    }
-    u16x4 v[2];
+  // Fragment sets of one k-step (16 contraction indices): TM fragments of A, TN_ of B.  The LONGER operand side lives in ONE set that is
+  // refilled in place -- while the MFMAs of a group (one fragment of the long side x all fragments of the short side) run, the fragment they
+  // just consumed is re-read for the NEXT k-step into the same registers; the short side alternates between two sets (parity P of the
+  // k-step).  (Two whole sets, as dx_gemm_ring_kernel keeps them, cost 2 x 28 registers beside the 160 accumulator registers of the
+  // 320 x 256 tile: 98 spills, and spill reloads travel through vmcnt and drain the copy ring.)
+  constexpr bool AMAJ = TM >= TN_;
+  constexpr int NO = AMAJ ? TM : TN_, NI = AMAJ ? TN_ : TM;       // long / short side
+  u16x8 lg[NO], sh[2][NI];
+  // TN: geometry of the transposing reads (see lds_tr16_b64): the lane supplies the piece (row k0 + prow, columns n0 + pcol .. + 3) of the
+  // 4 x 16 block its 16-lane group transposes.  The swizzle term of a row depends on its low two bits only, i.e. on prow (k-step, half and
+  // piece pair move the row by multiples of 4): per fragment ONE lane-dependent byte offset, everything else is the instruction's offset field.
+  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);
+  int tbase[TM + TN_];                                            // TN: byte offset of fragment idx (A: 0 .. TM - 1, B: TM ..) inside a chunk buffer, k-step 0, piece pair 0
+  if (TN) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (wr * TM + a) + pcol;
-      v[t] = lds_tr16_b64((const u16*)(abuf + (row * Gm::SLA + ((col >> 3) ^ tn_swz<Gm::SLA>(row))) * 16 + (col & 7) * 2));
+    for (int i = 0; i < TM + TN_; ++i) {
+      const bool isA = i < TM;
+      const int tile = isA ? wr * TM + i : wc * TN_ + (i - TM);
+      const int SL = isA ? Gm::SLA : Gm::SLB, row = 8 * h + prow, col = 32 * tile + pcol;
+      const int swz = isA ? tn_swz<Gm::SLA>(row) : tn_swz<Gm::SLB>(row);
+      tbase[i] = (isA ? 0 : Gm::A_BYTES) + (row * SL + ((col >> 3) ^ swz)) * 16 + (col & 7) * 2;
     }
-    return cat8(v[0], v[1]);
-  };
-  auto read_b = [&](int c, int ks, int j) -> u16x8 {
-    const unsigned char* bbuf = smem + (c & (Gm::NB - 1)) * Gm::BUF + Gm::A_BYTES;
+  }
+  // fragment `idx` of operand side A / B (tag) for k-step 0 / 1 (tag) of chunk c.  TN: asynchronous transposing reads, waited for by hand
+  auto read_op = [&](auto a_tag, auto ks_tag, int c, int idx) -> u16x8 {
+    constexpr bool isA = decltype(a_tag)::v;
+    constexpr int ks = decltype(ks_tag)::v ? 1 : 0;
+    const unsigned char* buf = smem + (c & (Gm::NB - 1)) * Gm::BUF;
     if (!TN) {
-      const int row = (wc * TN_ + j) * 32 + li;
-      return *(const u16x8*)(bbuf + row * 64 + (((ks * 2 + h) ^ ((row >> 2) & 3)) * 16));
+      const int row = (isA ? wr * TM + idx : wc * TN_ + idx) * 32 + li;
+      return *(const u16x8*)(buf + (isA ? 0 : Gm::A_BYTES) + row * 64 + (((ks * 2 + h) ^ ((row >> 2) & 3)) * 16));
     }
-    u16x4 v[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (wc * TN_ + j) + pcol;
-      v[t] = lds_tr16_b64((const u16*)(bbuf + (row * Gm::SLB + ((col >> 3) ^ tn_swz<Gm::SLB>(row))) * 16 + (col & 7) * 2));
-    }
-    return cat8(v[0], v[1]);
+    constexpr int SL = isA ? Gm::SLA : Gm::SLB;
+    const u16* pa = (const u16*)(buf + tbase[isA ? idx : TM + idx]);
+    return cat8(lds_tr16_b64_async<(16 * ks) * SL * 16>(pa), lds_tr16_b64_async<(16 * ks + 4) * SL * 16>(pa));
   };
   static_assert(TM * TN_ >= Gm::CP, "one copy per MFMA at most");
-  // the MFMAs of the k-step in registers; NEXT: its fragments are replaced by those of k-step (nc, nks) on the way; cnext >= 0: the CP copies of
-  // chunk cnext are issued between the MFMAs, not as a burst behind the barrier (a copy holds the issue slot: see dx_gemm_ring_kernel)
-  auto multiply = [&](auto next_tag, int nc, int nks, int cnext) {
+  // One k-step of MFMAs on the fragments in registers (short side: set P).  NEXT: on the way the fragments of k-step (nc, nks) replace them
+  // (short side into set 1 - P).  cnext >= 0: the CP copies of chunk cnext are issued between the MFMAs, not as a burst behind the barrier.
+  // TN waits (reads return in issue order, 2 per fragment): before group o the refill of lg[o] from the PREVIOUS call must have landed;
+  // younger than it are the previous call's refills o + 1 .. NO - 1, this call's short-side reads and its refills 0 .. o - 1:
+  // 2 (NO - 1 + NI) reads may stay in flight -- the same count for every group.
+  using LongTag = typename GemmTag<AMAJ>::type;                   // operand side of the long / short fragment set
+  using ShortTag = typename GemmTag<!AMAJ>::type;
+  // par_tag: parity of the k-step in registers (= which short-side set holds it); the k-step being fetched is the other one: 1 - P
+  auto multiply = [&](auto next_tag, auto par_tag, int nc, int cnext) {
     constexpr bool next = decltype(next_tag)::v;                  // compile time: no control flow around the accumulators
-    constexpr bool AMAJ = TM >= TN_;                              // the LONGER operand side is refilled in place, the shorter one through a second set
-    constexpr int NO = AMAJ ? TM : TN_, NI = AMAJ ? TN_ : TM;
-    u16x8 nin[NI];
+    constexpr int P = decltype(par_tag)::v ? 1 : 0;
+    using NextKs = typename GemmTag<P == 0>::type;
     if (next) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) nin[i] = AMAJ ? read_b(nc, nks, i) : read_a(nc, nks, i);
+      for (int i = 0; i < NI; ++i) sh[1 - P][i] = read_op(ShortTag{}, NextKs{}, nc, i);
+    } else if (TN) {
+      NR_SCHED_BARRIER();
+      NR_WAIT_LGKMCNT(0);
     }
     NR_SCHED_BARRIER();
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
+      if (TN && next) { NR_SCHED_BARRIER(); NR_WAIT_LGKMCNT(2 * (NO - 1 + NI)); NR_SCHED_BARRIER(); }      // (pinned: the scheduler may otherwise hoist an MFMA above the wait -- its operands come from asm it cannot see through)
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int a = AMAJ ? o : i, j = AMAJ ? i : o;
-        acc[a][j] = mfma_32x32x16_bf16(af[a], bf[j], acc[a][j]);                // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
+        acc[a][j] = mfma_32x32x16_bf16(AMAJ ? lg[o] : sh[P][i], AMAJ ? sh[P][i] : lg[o], acc[a][j]);     // C[m][n]: lane = column n, rows 8 q + 4 h + e
         if (o * NI + i < Gm::CP && cnext >= 0 && cnext < nchunk) piece(cnext, o * NI + i);           // (compile-time copy index)
       }
-      if (next) {
-        if (AMAJ) af[o] = read_a(nc, nks, o);
-        else bf[o] = read_b(nc, nks, o);
-      }
+      if (next) lg[o] = read_op(LongTag{}, NextKs{}, nc, o);
       NR_SCHED_BARRIER();
-    }
-    if (next) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        if (AMAJ) bf[i] = nin[i];
-        else af[i] = nin[i];
-      }
     }
   };
   auto arrive = [&](int c) {
@@ -232,18 +235,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     arrive(0);
     if (Gm::NB - 1 < nchunk) fetch(Gm::NB - 1);
 #pragma unroll
-    for (int a = 0; a < TM; ++a) af[a] = read_a(0, 0, a);
+    for (int o = 0; o < NO; ++o) lg[o] = read_op(LongTag{}, GemmNo{}, 0, o);
 #pragma unroll
-    for (int j = 0; j < TN_; ++j) bf[j] = read_b(0, 0, j);
+    for (int i = 0; i < NI; ++i) sh[0][i] = read_op(ShortTag{}, GemmNo{}, 0, i);
+    if (TN) { NR_SCHED_BARRIER(); NR_WAIT_LGKMCNT(0); NR_SCHED_BARRIER(); }      // (the counted waits in multiply assume refill order)
     int c = 0;
     for (; c + 1 < nchunk; ++c) {
       // registers hold k-step 0 of chunk c; the slot of chunk c - 1 is free (arrive(c) has passed): chunk c + 3 goes there
-      multiply(GemmYes{}, c, 1, c >= 1 ? c + Gm::NB - 1 : -1);
+      multiply(GemmYes{}, GemmNo{}, c, c >= 1 ? c + Gm::NB - 1 : -1);          // MFMAs of (c, 0), fetching (c, 1)
       arrive(c + 1);
-      multiply(GemmYes{}, c + 1, 0, -1);
+      multiply(GemmYes{}, GemmYes{}, c + 1, -1);                                // MFMAs of (c, 1), fetching (c + 1, 0)
     }
-    multiply(GemmYes{}, c, 1, -1);                                // the last chunk: nothing left to copy
-    multiply(GemmNo{}, 0, 0, -1);
+    multiply(GemmYes{}, GemmNo{}, c, -1);                         // the last chunk: nothing left to copy
+    multiply(GemmNo{}, GemmYes{}, 0, -1);
   }
   // ---- results: dword stores, the 32 lanes of a half-wave write 128 contiguous bytes of one output row ---------------------------------
   float* cbase = p.C + (TN ? (size_t)part * p.M * p.ldc : 0);

@@ -74,6 +74,20 @@ __device__ __forceinline__ u16x4 lds_tr16_b64(const u16* piece) {
   return __builtin_bit_cast(u16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)piece));
 }
 
+// The same read as inline asm, for kernels that keep LDS-DMA copies in flight (a copy RING): given the builtin form, the compiler's waitcnt
+// pass sees an LDS read without a memory operand and drains vmcnt to 0 in front of it whenever a global_load_lds is outstanding -- every
+// fragment read then waits for the whole ring (measured: the TN form of gemm_ring_kernel at 0.23 of the MFMA peak).  Contract: the caller
+// orders the read against the copies itself (counted vmcnt wait + barrier before the first read of a chunk) and waits for the RESULT with
+// NR_WAIT_LGKMCNT before its first use -- the compiler inserts neither.
+// OFF: compile-time byte offset added to `piece` through the instruction's offset field (no address arithmetic, no register per offset).
+template <int OFF>
+__device__ __forceinline__ u16x4 lds_tr16_b64_async(const u16* piece) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read offset field");
+  u16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)piece), "n"(OFF) : "memory");
+  return v;
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 // sum over the four 16-lane rows of the wave (= over lane ^ 16 and lane ^ 32), result in every lane: two VALU lane swaps
 // (v_permlane32_swap / v_permlane16_swap, gfx950) instead of two ds_bpermute round trips through the LDS crossbar

@@ -69,6 +69,7 @@ class StepGraph:
             self.loss = step_fn(*self.static)
         # the capture ran the Python side of one step (optimizer.t advanced) without executing a kernel: take it back
         self.opt.t -= 1
+        ops.invalidate_packed()                 # (operands cached during the capture were recorded, not computed)
 
     def eager_step(self, *inputs):
         """The same step without the graph, on the same counter protocol (used for warm-up and as the reference in tests)."""
@@ -163,6 +164,9 @@ class SegmentedStep:
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
             optimizer.apply_all()
+        # the capture RECORDED the packing launches without running them: the operands it left in the cache hold no data yet (a replay fills
+        # them; an eager step taken now must not find them)
+        ops.invalidate_packed()
 
     def eager_step(self, *inputs):
         _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))

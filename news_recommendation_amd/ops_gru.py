@@ -144,6 +144,7 @@ class _GruFn(torch.autograd.Function):
         Xb, H_all, gates, lens_dev, Wih_p, WhhT = ctx.saved_tensors
         B, N, I, Hd, T, has_h0 = ctx.meta
         Hg, Hp, Kp = gru_dims(Hd)
+        Ip = Xb.shape[1]
         dev = g.device
         g = g.to(torch.float32).contiguous()
         dgi = _workspace('gru_dgi', (B * N, Kp), _BF16_AS_I16, dev, zero=True)                # K padding stays zero

@@ -231,6 +231,9 @@ __forceinline__ u16x4 lds_tr16_b64(const u16* piece) {
   return o;
 }
 
+template <int OFF>
+__forceinline__ u16x4 lds_tr16_b64_async(const u16* piece) { return lds_tr16_b64((const u16*)((const unsigned char*)piece + OFF)); }     // (the emulator's LDS reads complete at once)
+
 __forceinline__ float shfl_xor(float v, int mask) {
   nr_emu::BlockState* blk = nr_emu::g_blk;
   int l = lane_id();

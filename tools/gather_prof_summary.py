@@ -28,7 +28,7 @@ for p in ('workload', 'hbm'):
     us = sum(durs) / len(durs) / 1e3
     alg = TOK * 1208
     e = {"avg_us_rocprof": us, "launches": len(durs), "algorithmic_read_bytes": alg, "achieved_GBs": alg / us / 1e3, "frac_of_8TBs": alg / us / 1e3 / 8000.0,
-         "fetch_kib_raw": cnt['fetch'], "write_kib_raw": cnt['write'], "source_hash": bench.kernel_source_hash()}
+         "fetch_kib_raw": cnt['fetch'], "write_kib_raw": cnt['write'], "source_hash": bench.gather_source_hash()}
     if cnt['fetch'] is not None and cnt['write'] is not None:
         e["traffic_bytes"] = int((2 * cnt['fetch'] + cnt['write']) * 1024)
         e["hbm_GBs_moved"] = e["traffic_bytes"] / us / 1e3
