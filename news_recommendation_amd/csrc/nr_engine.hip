@@ -538,11 +538,12 @@ int nr_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, f
   return launch_gemm<0, 4, 2, 4>(p, grid, stream, "nr_gemm_nt");
 }
 
-// output tile of the TN kernel: 320 x 256 (2 x 4 waves of 5 x 2 tiles) for M <= 320 (conv tap gradients: 320 filters x 3 x 320), 256 x 320
-// (4 x 2 waves of 2 x 5 tiles) for N <= 320 (projection gradients: 960 x 320), else 256 x 256
+// output tile of the TN kernel: 256 x 320 (4 x 2 waves of 2 x 5 tiles) when the output has at most 320 columns (projection gradients 960 x 320,
+// pooling gradients 208 x 320), 320 x 256 (2 x 4 waves of 5 x 2 tiles) for 257 .. 320 rows (conv tap gradients: 320 filters x 3 x 320), else 256 x 256
 static void gemm_tn_tile(int M, int N, int* bm, int* bn) {
-  *bm = M <= 320 ? 320 : 256;
-  *bn = (M > 320 && N > 256 && N <= 320) ? 320 : 256;
+  if (N > 256 && N <= 320) { *bm = 256; *bn = 320; return; }     // one column tile of 320: projection (960 x 320) and pooling (208 x 320) gradients
+  *bm = (M > 256 && M <= 320) ? 320 : 256;                       // conv taps: 320 filters x (3 x 320)
+  *bn = 256;
 }
 
 int nr_gemm_tn_parts(int M, int N, int64_t n_tok) {
@@ -552,9 +553,9 @@ int nr_gemm_tn_parts(int M, int N, int64_t n_tok) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int P = (256 + tiles - 1) / tiles;            // one workgroup per CU
   P = (P + 7) / 8 * 8;
-  const int64_t maxp = (n_tok + 31) / 32;
-  while (P > 8 && P > maxp) P -= 8;
-  return P;
+  while (P > 8 && n_tok / P < 512) P -= 8;      // short token lists (the user encoder's 25,600 rows): at least 16 chunks per partition --
+  return P;                                     // every partition costs a full M x N block of fp32 partials
+
 }
 
 int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t ldx, int tapw, int taps, const uint16_t* zeros, float* out,

@@ -443,7 +443,11 @@ def _wgrad_parts_hand(G, M, X, name):
 #   2  the three tap gradients of the conv text encoders as ONE 3-tap GEMM                      [ops_conv.py]
 #   4  the projection weight gradients dqkv^T [X | 1] of the NRMS encoders (256 x 320 tiles)
 #   8  the recurrent product h W_hh^T of LSTUR's batched evaluation sweep
-_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '15'))
+#  16  the pooling layers' weight gradients dpre^T [ctx | 1] (208 x 320: one 256 x 320 tile per token partition)
+# Measured against hipBLASLt inside the training steps on one MI355X (profiles/r04_ab_gemm.txt): conv taps 603 vs 1,254 us (abstracts), 264 vs 590 us
+# (titles); projection gradients 290 vs 358 us; GRU x W_ih^T 188 vs 230, dW_hh 176 vs 197, dW_ih 170 vs 196, dX 165 vs 163 us (fp32 result, no
+# conversion pass).  0 = the library calls (A/B).
+_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '31'))
 
 
 def gemm_nt(A, B, M, N, K, name, out=None, ldc=None):
@@ -779,7 +783,9 @@ class _EncoderFn(torch.autograd.Function):
         sw = side_wgrad(dev)
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        if _WGRAD_GEMM in (1, 2):
+        if _GEMM_HAND & 16:
+            dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')   # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+        elif _WGRAD_GEMM in (1, 2):
             dWa_parts = _wgrad_parts_hand(dpre, NR_QP, cbuf, f'nr_tn_gemm_dWa[S={S}]')    # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
         else:
             dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))
@@ -954,6 +960,7 @@ class _MhsaFn(torch.autograd.Function):
                             _ptr(key_len), n_seq, S, 0.0, 0, _stream())
         if need_grad:
             ctx.save_for_backward(xd, qs, ks, vts, Wp, key_len)
+            ctx.WdX = pack_qkv_dx(Wq, Wk, Wv) if _GEMM_HAND else None
         return _bf16(cbuf)[:, :NR_D].float().view(n_seq, S, NR_D)
 
     @staticmethod
@@ -972,10 +979,16 @@ class _MhsaFn(torch.autograd.Function):
         dqkv_b = _bf16(dqkv)
         Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
         _call('nr_gather_bf16', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
-        dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
+        if _GEMM_HAND:          # the engine's own GEMMs: split-K TN kernel for dW = dqkv^T [X | 1], nr_dx_gemm for dX = dqkv [Wq; Wk; Wv]
+            dW_ext = sum_parts(gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, 'nr_gemm_tn_dWqkv'))
+            dXb = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
+            _call('nr_dx_gemm', lib.nr_dx_gemm, _ptr(dqkv), _ptr(ctx.WdX), _ptr(dXb), ntok, _stream())
+            dX = dXb[:, :NR_D].float().view(n_seq, S, NR_D)
+        else:
+            dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
+            dX = torch.mm(dqkv_b, _bf16(untile(Wp, 3 * NR_NP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D)
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
-        dX = torch.mm(dqkv_b, _bf16(untile(Wp, 3 * NR_NP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D)
         return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], None
 
 
@@ -1022,6 +1035,7 @@ class _AdditiveFn(torch.autograd.Function):
               valid, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp)
         ctx.qdim = Wa.shape[0]
+        ctx.WaT = pack_additive_t(Wa) if _GEMM_HAND else None
         return out
 
     @staticmethod
@@ -1035,10 +1049,18 @@ class _AdditiveFn(torch.autograd.Function):
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
         dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
         qdim = ctx.qdim
-        dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
-        dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
+        if _GEMM_HAND:          # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
+            dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
+            _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
+                  _ptr(ctx.WaT), _ptr(dgemm), n_seq, S, _stream())
+            dx = torch.empty(n_seq, S, NR_D, dtype=torch.float32, device=dev)
+            _call('nr_additive_dx', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dx), n_seq, S, 0, _stream())
+            dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
+        else:
+            _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
+            dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
+            dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
         return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim], None
 
 

@@ -113,7 +113,9 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None, dy
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
     dpre_b, ctx_bb = _bf16(dpre), _bf16(ctx_b)
-    if ops._WGRAD_GEMM_CONV in (1, 2):            # hand-written split-K kernel (nr_tn_gemm): partial products per token partition, summed here
+    if ops._GEMM_HAND & 16:                        # general ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
+        dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
+    elif ops._WGRAD_GEMM_CONV in (1, 2):          # hand-written split-K kernel (nr_tn_gemm): partial products per token partition, summed here
         dWa_ext = ops._wgrad_parts_hand(dpre, NR_QP, ctx_b, f'nr_tn_gemm_dWa[{tag}]').sum(dim=0)
     elif sw is not None:
         dWa_ext = sw.run(lambda: ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]'))

@@ -52,6 +52,7 @@ for i in range(4):
 if mode != 'local':
     assert opt.comm_bytes and all(v > 0 for v in opt.comm_bytes.values()), opt.comm_bytes
 sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+opt.gather_state()                                # collective when the moments are sharded (mode 'rs'); a no-op otherwise
 osd = opt.state_dict()
 for i, st in osd['state'].items():
     sd[f'opt/{i}/exp_avg'] = st['exp_avg'].cpu().numpy()
