@@ -256,6 +256,11 @@ int nr_conv3_fwd_v(const int64_t* ids, const float* table, int64_t num_rows, con
                    uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
 /* Data gradient of the convolution: dx bf16 [n_seq*S][NR_KP] (cols < D) from dy_pad (seqpad) and Wd. */
 int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int64_t n_seq, int S, void* stream);
+/* The same data gradient as ONE GEMM (csrc/k_gemm.h, NT3 form: the virtual operand row [dy[i], dy[i + 1], dy[i + 2]] makes the three taps a
+ * contraction of length 3 * NR_KP): Wd2 bf16 [NR_KP][3 * NR_KP] row-major from nr_pack_conv_dgrad (Wd2[d][t * NR_KP + f] = W[f][2 - t][d]).
+ * Same result as nr_conv3_dgrad up to the order of the fp32 additions; columns >= D of dx come out as exact zeros. */
+int nr_pack_conv_dgrad(const float* W, int F, int D, uint16_t* Wd2, void* stream);
+int nr_conv3_dgrad_gemm(const uint16_t* dy_pad, const uint16_t* Wd2, uint16_t* dx, int64_t n_seq, int S, void* stream);
 /* Gradient through dropout+relu: dy_pad[row(q,s)] = (dact_gemm[t] + attn_w[t] * g_out[q]) * [act[t] != 0] / (1 - p_drop);
  * dact_gemm bf16 [n_seq*S][ldc] = dpre @ Wa (plain GEMM by the caller), g_out f32 rows of stride g_stride. */
 int nr_conv_act_bwd(const uint16_t* act, const uint16_t* dact_gemm, int ldc, const float* attn_w, const float* g_out, int64_t g_stride,

@@ -11,6 +11,10 @@
 //        token partitions): fragments by the transposing LDS read ds_read_b64_tr_b16; with taps = 3 the X operand is the VIRTUAL row
 //        [x[tok], x[tok + 1], x[tok + 2]] of a seqpad buffer (k_conv.h), so that the three tap gradients of a convolution are ONE GEMM with
 //        N = 3 * 320 whose G tile is fetched once for all taps.
+//   NT3  (MODE 2) the data gradient of the 3-tap convolution (k_conv.h) as a GEMM: C^T[d][row] = sum_{tap, f} Wd2[d][tap * 320 + f] dY[row + tap][f] --
+//        A = the flipped / transposed filter bank, row-major [320][960]; B = the VIRTUAL row [dy[i], dy[i + 1], dy[i + 2]] of the seqpad gradient
+//        buffer (chunk c of the contraction reads columns 32 (c % 10) of row i + c / 10); the result leaves as bf16 rows in plain token layout
+//        (separator rows dropped), staged through LDS so that every store is a 16-byte piece of a contiguous 640-byte row.
 // Three tile shapes (8 waves as WR x WC, a wave owns TM x TN 32 x 32 accumulator tiles): 256 x 256 (4 x 2 waves of 2 x 4 tiles), 320 x 256
 // (2 x 4 waves of 5 x 2 tiles: the conv tap gradients have M = 320 rows) and 256 x 320 (4 x 2 waves of 2 x 5 tiles: N = 320 columns).
 #pragma once
@@ -33,6 +37,9 @@ struct GemmParams {
   int P;                 // token partitions (multiple of 8)
   int tapw;              // columns per tap of the virtual X row (taps = 1: >= N)
   int tiles_m, tiles_n;
+  // MODE 2 only (data gradient of the 3-tap convolution): bf16 result rows in plain token layout
+  u16* Cb;               // [n_seq * S][KP]
+  int S;                 // tokens per sequence: virtual row i is seqpad row i + 1; rows with (i + 1) % (S + 1) == 0 are separators (not stored)
 };
 
 template <int MODE, int WR, int TM, int TN_>
@@ -76,6 +83,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     const int nt = p.tiles_m * p.tiles_n, t = jb % nt;
     part = (jb / nt) * 8 + xcd;
     tm = t % p.tiles_m; tn = t / p.tiles_m;
+  } else if (MODE == 2) {
+    tm = 0; tn = blockIdx.x;                                      // one row tile (the 320 filters): every block is a tile of 256 token rows
   } else {
     tm = (jb / p.tiles_n) * 8 + xcd; tn = jb % p.tiles_n;
     if (tm >= p.tiles_m) return;
@@ -133,6 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     if (TN) {
       const u16* cb = isA ? baseA + (int64_t)c * 32 * p.lda : baseB + (int64_t)c * 32 * p.ldb;      // wave-uniform
       s_ = (off[i] >= 0 && c * 32 + trow[i] < ntok) ? cb + off[i] : p.zeros;
+    } else if (MODE == 2 && !isA) {
+      constexpr int CPT = KP / 32;                                // chunks per tap: chunk c = columns 32 (c % CPT) of the row c / CPT below
+      s_ = baseB + (int64_t)(c / CPT) * p.ldb + (c % CPT) * 32 + off[i];
     } else {
       s_ = (isA ? baseA : baseB) + c * 32 + off[i];
     }
@@ -249,6 +261,34 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     multiply(GemmYes{}, GemmNo{}, c, -1);                         // the last chunk: nothing left to copy
     multiply(GemmNo{}, GemmYes{}, 0, -1);
   }
+  if constexpr (MODE == 2) {
+    // ---- bf16 rows in plain token layout: TN_ passes of 128 virtual rows (token tile jt of the four wave columns) through LDS.  The lane holds
+    // 4 consecutive filters-in (d) of ONE row: 8-byte staging writes; the rows then leave as 16-byte pieces of contiguous 640-byte runs -------
+    constexpr int OROW = 656;
+    static_assert(Gm::WC * 32 * OROW <= Gm::SMEM && Gm::BM == KP, "staging fits the ring; one row tile = all KP columns");
+#pragma unroll
+    for (int jt = 0; jt < TN_; ++jt) {
+      __syncthreads();                                            // the ring (jt = 0) / the previous pass has been read
+      unsigned char* row = smem + (wc * 32 + li) * OROW;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(u16x4*)(row + ((wr * TM + a) * 32 + 8 * q + 4 * h) * 2) =
+              pack4(f32x4{acc[a][jt][4 * q], acc[a][jt][4 * q + 1], acc[a][jt][4 * q + 2], acc[a][jt][4 * q + 3]});
+      __syncthreads();
+      constexpr int PCS = KP / 8;                                 // 40 sixteen-byte pieces per row
+#pragma unroll
+      for (int i = 0; i < Gm::WC * 32 * PCS / 512; ++i) {
+        const int idx = threadIdx.x + 512 * i;
+        const int r = idx / PCS, pc = idx - r * PCS;
+        const int64_t vr = n0 + (r >> 5) * (TN_ * 32) + jt * 32 + (r & 31);      // virtual row = seqpad row vr + 1
+        const int64_t sp = vr + 1, sq = sp / (p.S + 1);
+        if (vr < p.N && sp != sq * (p.S + 1)) *(u16x8*)(p.Cb + (sp - sq - 1) * KP + pc * 8) = *(const u16x8*)(smem + r * OROW + pc * 16);
+      }
+    }
+    return;
+  }
   // ---- results: dword stores, the 32 lanes of a half-wave write 128 contiguous bytes of one output row ---------------------------------
   float* cbase = p.C + (TN ? (size_t)part * p.M * p.ldc : 0);
 #pragma unroll
@@ -276,6 +316,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const u16* __restri
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
     if (bx + i < C && by + tx < R) dst[(int64_t)(bx + i) * ldd + by + tx] = tile[tx * 33 + i];
+}
+
+// A operand of the NT3 form: Wd2[d][tap * KP + f] = W[f][2 - tap][d] (Conv2d weight f32 [F][1][3][D]; flipped taps, transposed filters), bf16
+// row-major [KP][3 * KP], zero padded
+__global__ __launch_bounds__(256) void pack_conv_dgrad_kernel(const float* __restrict__ W, int F_, int D_, u16* __restrict__ Wd2) {
+  const int total = KP * 3 * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int d = i / (3 * KP), rem = i - d * 3 * KP, tap = rem / KP, f = rem - tap * KP;
+    Wd2[i] = f2bf((d < D_ && f < F_) ? W[((size_t)f * 3 + (2 - tap)) * D_ + d] : 0.0f);
+  }
 }
 
 // out[m][n] (+)= sum_p parts[p][m][n]: the split-K partials of the TN kernel summed in a fixed order (deterministic); float4 per lane

@@ -576,6 +576,26 @@ int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t
   return launch_gemm<1, 4, 2, 4>(p, grid, stream, "nr_gemm_tn");
 }
 
+int nr_pack_conv_dgrad(const float* W, int F, int D, uint16_t* Wd2, void* stream) {
+  if (!W || !Wd2 || F <= 0 || F > NR_KP || D <= 0 || D > NR_KP) return fail(NR_ERR_BADARG, "nr_pack_conv_dgrad: bad argument");
+  NR_LAUNCH(nr::pack_conv_dgrad_kernel, 300, 256, 0, (hipStream_t)stream, W, F, D, Wd2);
+  return check_launch("nr_pack_conv_dgrad");
+}
+
+int nr_conv3_dgrad_gemm(const uint16_t* dy_pad, const uint16_t* Wd2, uint16_t* dx, int64_t n_seq, int S, void* stream) {
+  if (!dy_pad || !Wd2 || !dx || n_seq < 0 || S < 1) return fail(NR_ERR_BADARG, "nr_conv3_dgrad_gemm: bad argument");
+  if ((((uintptr_t)dy_pad | (uintptr_t)Wd2 | (uintptr_t)dx) & 15) != 0) return fail(NR_ERR_BADARG, "nr_conv3_dgrad_gemm: buffers must be 16-byte aligned");
+  if (n_seq == 0) return NR_OK;
+  nr::GemmParams p{};
+  p.A = Wd2; p.lda = 3 * NR_KP; p.B = dy_pad; p.ldb = NR_KP; p.M = NR_KP; p.K = 3 * NR_KP; p.tapw = 1 << 30;
+  const int64_t rows = n_seq * (S + 1) + 1 - 2;                  // virtual rows i = seqpad rows 1 .. rp - 2 (the last seqpad row is a separator)
+  if (rows > 0x7FFFFFFF) return fail(NR_ERR_BADARG, "nr_conv3_dgrad_gemm: too many rows");
+  p.N = (int)rows; p.Cb = dx; p.S = S;
+  using G = nr::GemmGeom<2, 2, 5, 2>;
+  p.tiles_m = 1; p.tiles_n = (p.N + G::BN - 1) / G::BN;
+  return launch_gemm<2, 2, 5, 2>(p, p.tiles_n, stream, "nr_conv3_dgrad_gemm");
+}
+
 int nr_transpose_bf16(const uint16_t* src, int R, int C, int64_t lds, uint16_t* dst, int64_t ldd, void* stream) {
   if (!src || !dst || R <= 0 || C <= 0 || lds < C || ldd < R) return fail(NR_ERR_BADARG, "nr_transpose_bf16: bad argument");
   NR_LAUNCH2(nr::transpose_bf16_kernel, (C + 31) / 32, (R + 31) / 32, 256, 32 * 33 * 2, (hipStream_t)stream, src, R, C, lds, dst, ldd);

@@ -444,10 +444,11 @@ def _wgrad_parts_hand(G, M, X, name):
 #   4  the projection weight gradients dqkv^T [X | 1] of the NRMS encoders (256 x 320 tiles)
 #   8  the recurrent product h W_hh^T of LSTUR's batched evaluation sweep
 #  16  the pooling layers' weight gradients dpre^T [ctx | 1] (208 x 320: one 256 x 320 tile per token partition)
+#  32  the data gradient of the conv text encoders as ONE GEMM over virtual 3-tap rows (nr_conv3_dgrad_gemm) instead of the LDS-tile conv kernel
 # Measured against hipBLASLt inside the training steps on one MI355X (profiles/r04_ab_gemm.txt): conv taps 603 vs 1,254 us (abstracts), 264 vs 590 us
 # (titles); projection gradients 290 vs 358 us; GRU x W_ih^T 188 vs 230, dW_hh 176 vs 197, dW_ih 170 vs 196, dX 165 vs 163 us (fp32 result, no
 # conversion pass).  0 = the library calls (A/B).
-_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '31'))
+_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '63'))
 
 
 def gemm_nt(A, B, M, N, K, name, out=None, ldc=None):

@@ -37,6 +37,15 @@ def pack_conv(W, b):
     return ops._packed('conv', (W, b), build)
 
 
+def pack_conv_dgrad(W):
+    """Conv2d weight -> the A operand of the data gradient in GEMM form (nr_conv3_dgrad_gemm): bf16 [KP][3 KP] row-major, cached per state."""
+    def build():
+        Wd2 = torch.empty(NR_KP, 3 * NR_KP, dtype=_BF16_AS_I16, device=W.device)
+        _call('nr_pack_conv_dgrad', _lib().nr_pack_conv_dgrad, _ptr(_f32c(W)), W.shape[0], W.shape[3], _ptr(Wd2), _stream())
+        return (Wd2,)
+    return ops._packed('conv_dgrad', (W,), build)[0]
+
+
 def _seqpad_alloc(n_seq, S):
     """(seqpad rows, chunk count, allocated rows = chunk count x chunk rows)."""
     rp = n_seq * (S + 1) + 1
@@ -47,7 +56,7 @@ def _seqpad_alloc(n_seq, S):
 
 class _TextState:
     """What one text encoder keeps between forward and backward."""
-    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset')
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset')
 
 
 def pad_text(ids, what):
@@ -70,6 +79,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     st = _TextState()
     st.S, st.n_seq, st.tok_offset, st.qdim = S, n_seq, tok_offset, Wa.shape[0]
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
+    st.Wd2 = pack_conv_dgrad(conv_w) if (need_grad and ops._GEMM_HAND & 32) else None
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
     st.WaT = ops.pack_additive_t(Wa) if need_grad else None
     st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
@@ -163,7 +173,10 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
                 taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
         return taps
     taps = sw.run(lambda: _timed(f'gemm_dWconv[{tag}]', wgrad))
-    _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
+    if st.Wd2 is not None:       # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
+        _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
+    else:
+        _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
     sw.join(*taps, *sw.pending)
     d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
     d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows

@@ -154,6 +154,40 @@ def check_conv_dgrad(be, S=20, n_seq=5):
     assert (err <= 2.0 ** -7 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all(), f'conv dgrad S={S}: max err {err.max():.3g}'
 
 
+def check_conv_dgrad_gemm(be, S=20, n_seq=5):
+    """nr_conv3_dgrad_gemm (the data gradient as ONE GEMM over virtual 3-tap rows, csrc/k_gemm.h) against numpy; columns >= D exact zeros; rows
+    of the token layout complete (every token written once, separator rows of the seqpad input dropped)."""
+    W, b = conv_params(5)
+    rng = np.random.default_rng(6)
+    dy = rng.normal(0, 0.3, size=(n_seq * S, NR_D)).astype(np.float32)
+    dy[rng.random(size=dy.shape) < 0.4] = 0.0
+    dyu = np.zeros((n_seq * S, NR_KP), dtype=np.uint16)
+    dyu[:, :NR_D] = f32_to_bf16(dy)
+    dyu[:, NR_D] = 0x3F80            # junk in the padding columns must be ignored (the packed filters are zero there)
+    dy_pad = to_seqpad(dyu, n_seq, S)
+    Wd2 = be.poison((NR_KP, 3 * NR_KP), np.uint16)
+    ck(be, be.lib.nr_pack_conv_dgrad(be.ptr(be.dev(W)), W.shape[0], W.shape[3], be.ptr(Wd2), be.stream))
+    dx = be.poison((n_seq * S, NR_KP), np.uint16)
+    ck(be, be.lib.nr_conv3_dgrad_gemm(be.ptr(be.dev(dy_pad)), be.ptr(Wd2), be.ptr(dx), n_seq, S, be.stream))
+    be.sync()
+    w2 = be.np(Wd2).reshape(NR_KP, 3, NR_KP)
+    for t in range(3):
+        assert np.array_equal(w2[:NR_D, t, :NR_D], f32_to_bf16(W[:, 0, 2 - t, :]).T) and not w2[NR_D:, t].any() and not w2[:, t, NR_D:].any()
+    dyq = bf16_to_f32(dyu[:, :NR_D]).astype(np.float64).reshape(n_seq, S, NR_D)
+    Wq = bf16_round(W).astype(np.float64)
+    dyp = np.zeros((n_seq, S + 2, NR_D))
+    dyp[:, 1:S + 1] = dyq
+    ref = np.zeros((n_seq, S, NR_D))
+    for w in range(3):
+        ref += dyp[:, 2 - w:2 - w + S] @ Wq[:, 0, w, :]
+    out = be.np(dx)
+    assert not out[:, NR_D:].any(), 'padding columns of dx must be exact zeros'
+    got = bf16_to_f32(out[:, :NR_D]).astype(np.float64).reshape(ref.shape)
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -7 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all(), f'conv dgrad (GEMM form) S={S}: max err {err.max():.3g}'
+    assert be.lib.nr_conv3_dgrad_gemm(None, be.ptr(Wd2), be.ptr(dx), n_seq, S, be.stream) != 0 and b'nr_conv3_dgrad_gemm' in be.lib.nr_last_error()
+
+
 def check_conv_act_bwd(be, S=20, n_seq=7, p_drop=0.2):
     rng = np.random.default_rng(7)
     act = np.maximum(rng.normal(size=(n_seq * S, NR_D)), 0).astype(np.float32)
