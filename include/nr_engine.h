@@ -357,14 +357,9 @@ int nr_gru_fwd_seq(const float* gi, const uint16_t* Whh, const float* b_ih, cons
 int nr_gru_bwd_seq(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                    uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream);
 
-/* The same with n_buf tile-order step buffers instead of the ping-pong pair (h_t2 / dgh_t2 then hold n_buf buffers; all zeroed once, h_0
- * in the first).  With n_buf >= T + 1 = nr_gru_seq_buffers(B, Hd, T) the whole sweep runs as ONE persistent launch: a workgroup keeps its
- * W_hh (W_hh^T) tile in LDS for all steps, a grid-wide barrier separates the steps, step t reads buffer t and writes buffer t + 1 (each
- * address is written once, write-through, before anyone reads it: see csrc/k_gru.h).  That needs every workgroup resident at once --
- * (Hd/16 unit tiles) x (B/128 sample groups) <= CUs of the device, B >= 256, Hd = 900 or 450 -- and is OPT-IN (NR_GRU_PERSIST=1): on
- * MI355X the barrier costs more than the launch gaps it removes (LSTUR step 6.4-6.5 vs 6.1 ms).  Otherwise, or with n_buf = 2, the steps
- * are separate launches on buffers t % 2 as above; nr_gru_seq_buffers says which form a shape gets (T + 1 or 2).  One process per GPU: two persistent kernels of different processes on one device can starve each other (the barrier then traps
- * after ~2 s instead of hanging).  Results are bit-identical to the per-step launches. */
+/* The same entry points with an explicit buffer count (n_buf >= 2 tile-order step buffers; the sweep uses buffers t % 2).  Rounds 2-3 ran the whole
+ * sweep as ONE persistent launch when n_buf >= T + 1 (grid-wide barrier between the steps); that form measured slower on MI355X in every variant
+ * and was removed in round 4 (csrc/k_gru.h): nr_gru_seq_buffers now always answers 2. */
 int nr_gru_seq_buffers(int B, int Hd, int T);
 int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
                      uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream);

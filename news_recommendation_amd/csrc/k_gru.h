@@ -71,9 +71,8 @@ __device__ __forceinline__ void gru_fwd_fetch_w(const GruFwdParams& p, int tile)
   }
 }
 
-// One step for the workgroup (unit tile, sample group).  PERSIST: called from the persistent kernel, whose W_hh tile is already in LDS
-// and visible (no fetch, no workgroup barrier here).
-template <int KS_CT, int NB, bool WLDS, bool PERSIST>
+// One step for the workgroup (unit tile, sample group).
+template <int KS_CT, int NB, bool WLDS>
 __device__ __forceinline__ void gru_fwd_step_impl(const GruFwdParams& p, int tile, int group) {
   // NB sample tiles per wave share every W_hh fragment (NB = 2: 5 loads per 6 MFMAs instead of 4 per 3; the step is bound by the
   // L2 -> L1 operand volume, ~15 TB/s measured)
@@ -81,7 +80,7 @@ __device__ __forceinline__ void gru_fwd_step_impl(const GruFwdParams& p, int til
   const int s0r = (group * 4 + w) * NB * 16;
   const bool idle = s0r >= p.B;                                // no samples left for this wave
   const int s0 = idle ? 0 : s0r;                               // (an idle wave of a WLDS workgroup stays for the barrier and recomputes tile 0, discarded)
-  if constexpr (WLDS && KS_CT > 0 && !PERSIST) gru_fwd_fetch_w<KS_CT>(p, tile);
+  if constexpr (WLDS && KS_CT > 0) gru_fwd_fetch_w<KS_CT>(p, tile);
   if (idle && !(WLDS && KS_CT > 0)) return;
   const int j0 = tile * 16, jb = j0 + 4 * g;
   // fragment pointers in tile order: k-step ks of an operand tile is the 1 KB at + ks * 512 elements
@@ -125,7 +124,7 @@ __device__ __forceinline__ void gru_fwd_step_impl(const GruFwdParams& p, int til
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) fh[nb][i] = *(const u16x8*)(hp[nb] + i * 512);
       }
-    if (!PERSIST) __syncthreads();                             // drains the global -> LDS copies of all four waves
+    __syncthreads();                                           // drains the global -> LDS copies of all four waves
     u16x8 a0 = *(const u16x8*)wl, a1 = *(const u16x8*)(wl + KS_CT * 512), a2 = *(const u16x8*)(wl + 2 * KS_CT * 512);
     NR_SCHED_BARRIER();
 #pragma unroll
@@ -212,11 +211,10 @@ __device__ __forceinline__ void gru_fwd_step_impl(const GruFwdParams& p, int til
       *(f32x4*)(p.h_out_f + (size_t)s * p.Hp + jb) = hn;
       u16x4 hb = pack4(hn);
       if (jb <= p.Hd && p.Hd < jb + 4) hb[p.Hd - jb] = 0x3F80;        // column Hd = 1.0
-      // the tile-order state is the next step's MFMA operand of EVERY unit tile: in the persistent kernel it crosses workgroups
-      if (PERSIST) st_agent4(p.h_out_t + tile_off(s, jb, p.Hp), hb); else *(u16x4*)(p.h_out_t + tile_off(s, jb, p.Hp)) = hb;
+      *(u16x4*)(p.h_out_t + tile_off(s, jb, p.Hp)) = hb;           // the tile-order state: the next step's MFMA operand of every unit tile
       if (p.h_out_b != nullptr) *(u16x4*)(p.h_out_b + (size_t)s * p.Hp + jb) = hb;
       if (jb + 4 == p.Hd) {                                          // Hd % 4 == 0: the lane owning the last units also sets column Hd
-        if (PERSIST) st_agent1(p.h_out_t + tile_off(s, p.Hd, p.Hp), 0x3F80); else p.h_out_t[tile_off(s, p.Hd, p.Hp)] = 0x3F80;
+        p.h_out_t[tile_off(s, p.Hd, p.Hp)] = 0x3F80;
         if (p.h_out_b != nullptr) p.h_out_b[(size_t)s * p.Hp + p.Hd] = 0x3F80;
       }
     }
@@ -234,52 +232,12 @@ template <int KS_CT, int NB, bool WLDS = false>
 __global__ __launch_bounds__(WG) void gru_fwd_step_kernel(GruFwdParams p) {
   int tile, group;
   if (!gru_tile_of_wg(p.Hg / 16, (p.B + 64 * NB - 1) / (64 * NB), tile, group)) return;
-  gru_fwd_step_impl<KS_CT, NB, WLDS, false>(p, tile, group);
+  gru_fwd_step_impl<KS_CT, NB, WLDS>(p, tile, group);
 }
 
-// ---- persistent form: ALL steps of the recurrence in one launch -------------------------------------------------------------------
-// The workgroup keeps its W_hh tile in LDS for the whole sequence (one 87 KB fetch instead of one per step) and the steps are separated
-// by a grid-wide barrier instead of a kernel boundary (launch gap + ramp-up / drain of a 15 us kernel, 50 times).  Requires every active
-// workgroup to be resident at once: one per CU (the LDS tile allows no second one), so n_tiles * n_groups <= number of CUs -- the host
-// checks that and falls back to one launch per step otherwise.
-// Cross-workgroup data (see grid_barrier in nr_prims.h): the tile-order state h_t is written by all unit tiles and read by all of them
-// in the next step.  It is stored write-through at agent scope (st_agent*), and EVERY STEP HAS ITS OWN BUFFER (T + 1 of them instead of
-// the ping-pong pair): an address is then read only after its final content has reached memory and was never cached before in this
-// launch, so plain L2-cached loads are safe -- no stale line can exist -- and the 228 workgroups' re-reads of the state are served by their
-// XCD's L2 as in the per-step kernels.  (Measured alternatives on MI355X, LSTUR step at B = 512: agent-scope fences around the barrier
-// +3.6 ms, ping-pong buffers read with agent-scope (L2-bypassing) loads +0.7 ms.)  The f32 state and the carry are re-read only by the
-// thread that wrote them.
-struct GruFwdSeqParams {
-  GruFwdParams st;        // the step-invariant fields; the per-step pointers below replace h_* / gates / t
-  u16* h_t;               // bf16 (T+1) x [ceil16(B)][Hp] tile order: buffer t = h_t (buffer 0 is the caller's h_0)
-  u16* H_all;             // bf16 [T+1][B][Hp] row-major, or null
-  float* h_f2;            // f32 2 x [B][Hp], ping-pong
-  u16* gates_all;         // bf16 [T][B][4][Hg], or null
-  int t0, t1;             // steps [t0, t1)
-  unsigned* sync;         // grid barrier counter (zeroed before the launch)
-  unsigned n_active;      // workgroups that take part in the barrier (n_tiles * n_groups)
-};
-
-template <int KS_CT, int NB>
-__global__ __launch_bounds__(WG) void gru_fwd_persist_kernel(GruFwdSeqParams q) {
-  int tile, group;
-  if (!gru_tile_of_wg(q.st.Hg / 16, (q.st.B + 64 * NB - 1) / (64 * NB), tile, group)) return;
-  gru_fwd_fetch_w<KS_CT>(q.st, tile);
-  __syncthreads();
-  const size_t ht = (size_t)((q.st.B + 15) & ~15) * q.st.Hp, hf = (size_t)q.st.B * q.st.Hp;
-  for (int t = q.t0; t < q.t1; ++t) {
-    GruFwdParams p = q.st;
-    p.t = t;
-    p.h_in_t = q.h_t + (size_t)t * ht;
-    p.h_out_t = q.h_t + (size_t)(t + 1) * ht;
-    p.h_in_f = q.h_f2 + (t & 1) * hf;
-    p.h_out_f = q.h_f2 + ((t + 1) & 1) * hf;
-    p.h_out_b = q.H_all ? q.H_all + (size_t)(t + 1) * hf : nullptr;
-    p.gates = q.gates_all ? q.gates_all + (size_t)t * q.st.B * 4 * q.st.Hg : nullptr;
-    gru_fwd_step_impl<KS_CT, NB, true, true>(p, tile, group);
-    if (t + 1 < q.t1) grid_barrier(q.sync, (unsigned)(t - q.t0 + 1) * q.n_active);
-  }
-}
+// (A persistent whole-sequence form of both sweeps -- W_hh tile resident in LDS, a grid-wide barrier between the steps -- was built in round 2,
+// bit-identical, and measured 0.3-0.4 ms per LSTUR step SLOWER in every form tried: back-to-back launches of a 15 us kernel cost ~3-4 us of gap
+// each on this stack, a grid barrier across 228 workgroups with non-coherent L2s ~7 us.  Removed in round 4; the record is DESIGN.md 5.3.)
 
 struct GruBwdParams {
   const float* g_last;     // [B][Hd] gradient of the returned hidden state (used when first != 0)
@@ -297,7 +255,6 @@ struct GruBwdParams {
 };
 
 // Gate derivatives of step t for lane (sample s, units jb .. jb+3) given dh_t; shared by the step kernels.
-template <bool AGENT = false>
 __device__ __forceinline__ void gru_bwd_finish(const GruBwdParams& p, int s, int jb, f32x4 dh, int len_s, u16x4 rb, u16x4 zb, u16x4 nb,
                                                u16x4 qb, u16x4 hb) {
   if (p.gates == nullptr) {                    // t = -1: dh_0
@@ -333,15 +290,9 @@ __device__ __forceinline__ void gru_bwd_finish(const GruBwdParams& p, int s, int
   *(u16x4*)gh = pr;
   *(u16x4*)(gh + p.Hg) = pz;
   *(u16x4*)(gh + 2 * p.Hg) = pn;
-  if (AGENT) {        // persistent kernel: the tile-order copy is the next step's MFMA operand of every unit tile (crosses workgroups)
-    st_agent4(p.dgh_t + tile_off(s, jb, p.Kp), pr);
-    st_agent4(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp), pz);
-    st_agent4(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp), pn);
-  } else {
-    *(u16x4*)(p.dgh_t + tile_off(s, jb, p.Kp)) = pr;
-    *(u16x4*)(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp)) = pz;
-    *(u16x4*)(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp)) = pn;
-  }
+  *(u16x4*)(p.dgh_t + tile_off(s, jb, p.Kp)) = pr;               // tile-order copy: the next launch's MFMA operand
+  *(u16x4*)(p.dgh_t + tile_off(s, p.Hg + jb, p.Kp)) = pz;
+  *(u16x4*)(p.dgh_t + tile_off(s, 2 * p.Hg + jb, p.Kp)) = pn;
 }
 
 template <int KS_CT>
@@ -431,7 +382,7 @@ __device__ __forceinline__ void gru_bwd_fetch_w(const GruBwdParams& p, int tile)
   for (int blk = w; blk < KS_CT; blk += 4) NR_GLDS16(p.WhhT + (size_t)tile * p.Kp * 16 + blk * 512 + l * 8, smem + blk * 1024);
 }
 
-template <int KS_CT, bool PERSIST>
+template <int KS_CT>
 __device__ __forceinline__ void gru_bwd_step_lds_impl(const GruBwdParams& p, int tile, int group) {
   constexpr int NB = 2;
   NR_SMEM_DECL(smem);
@@ -440,7 +391,7 @@ __device__ __forceinline__ void gru_bwd_step_lds_impl(const GruBwdParams& p, int
   const bool idle = s0r >= p.B;
   const int s0 = idle ? 0 : s0r;
   const int j0 = tile * 16, jb = j0 + 4 * g, jc = jb < p.Hg ? jb : 0;
-  if (!p.first && !PERSIST) gru_bwd_fetch_w<KS_CT>(p, tile);
+  if (!p.first) gru_bwd_fetch_w<KS_CT>(p, tile);
   // epilogue operands of both tiles, requested ahead of the k pipeline
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const u16x4 z4 = u16x4{0, 0, 0, 0};
@@ -472,7 +423,7 @@ __device__ __forceinline__ void gru_bwd_step_lds_impl(const GruBwdParams& p, int
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) fd[nb][i] = *(const u16x8*)(dp[nb] + i * 512);
       }
-    if (!PERSIST) __syncthreads();                             // drains the global -> LDS copies of all four waves
+    __syncthreads();                                           // drains the global -> LDS copies of all four waves
     const u16* wl = (const u16*)smem + l * 8;
     u16x8 a = *(const u16x8*)wl;
     NR_SCHED_BARRIER();
@@ -502,7 +453,7 @@ __device__ __forceinline__ void gru_bwd_step_lds_impl(const GruBwdParams& p, int
     } else {
       dh = (acc[nb][0] + acc[nb][1]) + cn[nb];
     }
-    gru_bwd_finish<PERSIST>(p, s, jb, dh, len_s[nb], rb[nb], zb[nb], nb_[nb], qb[nb], hb[nb]);
+    gru_bwd_finish(p, s, jb, dh, len_s[nb], rb[nb], zb[nb], nb_[nb], qb[nb], hb[nb]);
   }
 }
 
@@ -510,47 +461,7 @@ template <int KS_CT>
 __global__ __launch_bounds__(WG) void gru_bwd_step_lds_kernel(GruBwdParams p) {
   int tile, group;
   if (!gru_tile_of_wg(p.Hg / 16, (p.B + 127) / 128, tile, group)) return;
-  gru_bwd_step_lds_impl<KS_CT, false>(p, tile, group);
-}
-
-// Persistent form of the backward sweep (see gru_fwd_persist_kernel): launch i of the T + 1 handles step t = T - 1 - i (t = -1: only
-// dh_0); the W_hh^T tile stays in LDS, a grid barrier separates the steps; carry rotates as in nr_gru_bwd_seq, dGh has a buffer per step.
-struct GruBwdSeqParams {
-  GruBwdParams st;         // step-invariant fields (WhhT, len, dgi, g_last, sizes)
-  const u16* gates_all;    // bf16 [T][B][4][Hg]
-  const u16* H_all;        // bf16 [T+1][B][Hp]
-  u16* dgh_all;            // bf16 [T][B][Kp]
-  u16* dgh_t;              // bf16 (T+1) x [ceil16(B)][Kp] tile order: buffer i = dGh of sweep position i (own buffer per step, see above)
-  float* carry2;           // f32 2 x [B][Hp], ping-pong
-  int T, i0, i1;           // sweep positions [i0, i1) of 0 .. T
-  unsigned* sync;
-  unsigned n_active;
-};
-
-template <int KS_CT>
-__global__ __launch_bounds__(WG) void gru_bwd_persist_kernel(GruBwdSeqParams q) {
-  int tile, group;
-  if (!gru_tile_of_wg(q.st.Hg / 16, (q.st.B + 127) / 128, tile, group)) return;
-  gru_bwd_fetch_w<KS_CT>(q.st, tile);
-  __syncthreads();
-  const int B = q.st.B;
-  const size_t dt = (size_t)((B + 15) & ~15) * q.st.Kp, cf = (size_t)B * q.st.Hp, gb = (size_t)B * 4 * q.st.Hg, db = (size_t)B * q.st.Kp;
-  for (int i = q.i0; i < q.i1; ++i) {
-    const int t = q.T - 1 - i;
-    GruBwdParams p = q.st;
-    p.t = t;
-    p.first = i == 0;
-    p.dgh_next = p.first ? nullptr : q.dgh_t + (size_t)(i - 1) * dt;
-    p.carry_next = p.first ? nullptr : q.carry2 + ((i + 1) & 1) * cf;
-    p.gates = t >= 0 ? q.gates_all + (size_t)t * gb : nullptr;
-    p.h_prev_b = t >= 0 ? q.H_all + (size_t)t * cf : nullptr;
-    p.dgh = t >= 0 ? q.dgh_all + (size_t)t * db : nullptr;
-    p.dgh_t = t >= 0 ? q.dgh_t + (size_t)i * dt : nullptr;
-    p.carry = q.carry2 + (i & 1) * cf;
-    if (t < 0) p.dgi = nullptr;
-    gru_bwd_step_lds_impl<KS_CT, true>(p, tile, group);
-    if (i + 1 < q.i1) grid_barrier(q.sync, (unsigned)(i - q.i0 + 1) * q.n_active);
-  }
+  gru_bwd_step_lds_impl<KS_CT>(p, tile, group);
 }
 
 // ---- operand packing --------------------------------------------------------------------------------------------------

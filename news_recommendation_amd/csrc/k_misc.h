@@ -89,32 +89,47 @@ struct WgradUnpackParams {
   float* gq;             // [qdim]
 };
 constexpr int WGU_ROWS = 2;                      // output rows per workgroup: 80 lanes x 4 packed columns each
-constexpr int WGU_THREADS = WGU_ROWS * (KP / 4);
+constexpr int WGU_PG = 4;                        // partition groups per workgroup: group g sums partials g, g + 4, ...; combined through LDS
+constexpr int WGU_LANES = WGU_ROWS * (KP / 4);   // 160 (row, column quad) slots
+constexpr int WGU_THREADS = WGU_LANES * WGU_PG;  // 640
+constexpr int WGU_SMEM = WGU_PG * WGU_LANES * 16;
 constexpr int WGU_DQ_COLS = 16, WGU_DQ_PH = 32;  // dq kernel: 16 entries x 32 row phases per workgroup
 __device__ __host__ __forceinline__ int wgrad_unpack_grid(int qdim) { return (3 * D + qdim + WGU_ROWS - 1) / WGU_ROWS; }
 
 // VEC: all destinations are 16-byte aligned (float4 read-modify-write); otherwise element by element.
+// (Round 3 gave every output quad ONE thread that walked all partials: with the 256 token partitions of the ring GEMM's pooling gradient that
+// was a chain of 64 dependent trips on 15 k threads -- 93 us for 146 MB.  Four partition groups per quad, fixed combination order.)
 template <bool VEC>
 __global__ __launch_bounds__(WGU_THREADS) void wgrad_unpack_kernel(WgradUnpackParams p) {
-  const int t = threadIdx.x, rr = t / (KP / 4), c4 = t - rr * (KP / 4);
+  NR_SMEM_DECL(smem);
+  f32x4* red = (f32x4*)smem;                                 // [WGU_PG][WGU_LANES]
+  const int t = threadIdx.x % WGU_LANES, pg = threadIdx.x / WGU_LANES, rr = t / (KP / 4), c4 = t - rr * (KP / 4);
   const int b = blockIdx.x * WGU_ROWS + rr;                  // output row: [0, 3D) projections, [3D, 3D + qdim) pooling linear
-  if (b >= 3 * D + p.qdim || c4 > D / 4) return;             // columns > D are padding
+  const bool live = b < 3 * D + p.qdim && c4 <= D / 4;       // columns > D are padding
   const bool proj = b < 3 * D;
   const int i = proj ? b / D : 0, r = proj ? b - i * D : b - 3 * D;
-  const float* src = (proj ? p.dW + ((size_t)(i * KP + r)) * KP : p.dWa + (size_t)r * KP) + c4 * 4;
-  const size_t cs = proj ? (size_t)3 * KP * KP : (size_t)QP * KP;
-  const int nc = proj ? p.ncW : p.ncA;
-  // four independent partial sums: up to 4 x 16 B per lane in flight per trip (fixed order -> deterministic)
-  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-  int c = 0;
-  for (; c + 4 <= nc; c += 4) {
-    a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
-    a1 = a1 + *(const f32x4*)(src + (size_t)(c + 1) * cs);
-    a2 = a2 + *(const f32x4*)(src + (size_t)(c + 2) * cs);
-    a3 = a3 + *(const f32x4*)(src + (size_t)(c + 3) * cs);
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const float* src = (proj ? p.dW + ((size_t)(i * KP + r)) * KP : p.dWa + (size_t)r * KP) + c4 * 4;
+    const size_t cs = proj ? (size_t)3 * KP * KP : (size_t)QP * KP;
+    const int nc = proj ? p.ncW : p.ncA;
+    // four independent partial sums: up to 4 x 16 B per lane in flight per trip (fixed order -> deterministic)
+    f32x4 a0 = a, a1 = a, a2 = a, a3 = a;
+    int c = pg;
+    for (; c + 3 * WGU_PG < nc; c += 4 * WGU_PG) {
+      a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
+      a1 = a1 + *(const f32x4*)(src + (size_t)(c + WGU_PG) * cs);
+      a2 = a2 + *(const f32x4*)(src + (size_t)(c + 2 * WGU_PG) * cs);
+      a3 = a3 + *(const f32x4*)(src + (size_t)(c + 3 * WGU_PG) * cs);
+    }
+    for (; c < nc; c += WGU_PG) a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
+    a = (a0 + a1) + (a2 + a3);
   }
-  for (; c < nc; ++c) a0 = a0 + *(const f32x4*)(src + (size_t)c * cs);
-  const f32x4 a = (a0 + a1) + (a2 + a3);
+  red[pg * WGU_LANES + t] = a;
+  __syncthreads();
+  if (pg != 0 || !live) return;
+#pragma unroll
+  for (int g = 1; g < WGU_PG; ++g) a = a + red[g * WGU_LANES + t];
   if (c4 == D / 4) {                                         // packed column D: the bias gradient
     float* dst = (proj ? p.gb[i] : p.gba) + r;
     *dst += a[0];

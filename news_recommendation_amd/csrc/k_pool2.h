@@ -1,4 +1,4 @@
-// Register-resident additive-attention pooling for titles (S = 20), forward and backward, gfx950.  Same math and outputs as
+// Register-resident additive-attention pooling BACKWARD for titles (S = 20) and 50-token sequences, gfx950.  Same math and outputs as
 // additive_fwd_kernel / additive_bwd_kernel (src/model/general/attention/additive.py:27-53 and its autograd) with the mapping of
 // k_mhsa_fwd2.h: the LDS-tile kernels give a workgroup 2-4 titles and make it re-read the whole projection matrix from L2
 // (133 KB per workgroup, 1.8 GB per launch at B = 512: they run at 5-10 % of the MFMA peak, bound by that traffic and by the
@@ -66,137 +66,8 @@ __device__ __forceinline__ void pool2_load_x(const u16* __restrict__ ctx, int64_
   }
 }
 
-template <typename Gm>
-__global__ __launch_bounds__(Gm::THREADS) void pool2_fwd_kernel(AdditiveParams p) {
-  constexpr int S = Gm::S, MT = Gm::MT;
-  NR_SMEM_DECL(smem);
-  const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
-  const int64_t seq0 = ((int64_t)blockIdx.x * Gm::NWAVE + w) * Gm::TPW;
-  const int64_t tok0 = seq0 * S, tok_total = p.n_seq * S;
-  float* sc = (float*)(smem + 2 * Gm::CH_BYTES) + w * Gm::WV_FLOATS;       // [80] scores
-  float* wl = sc + Gm::TOKW;                                               // [80] softmax weights
-
-  // Wa chunk c (n-tiles 5c ..): global -> LDS directly; Wap is in tile order, so a chunk is a contiguous run of 1 KiB fragment blocks
-  auto chunk_fetch = [&](int c, int buf) {
-    const int nt0 = c * Gm::CH_NT, ntc = (Gm::NTQ - nt0) < Gm::CH_NT ? (Gm::NTQ - nt0) : Gm::CH_NT;
-    const u16* src = p.Wap + (size_t)nt0 * KSTEPS * 512 + l * 8;
-    unsigned char* dst = smem + buf * Gm::CH_BYTES;
-    for (int blk = w; blk < ntc * KSTEPS; blk += Gm::NWAVE) NR_GLDS16(src + (size_t)blk * 512, dst + blk * 1024);
-  };
-  chunk_fetch(0, 0);
-  u16x8 xf[MT][KSTEPS];
-  pool2_load_x<MT, Gm::TOKW>(p.ctx, tok0, tok_total, xf);
-  __syncthreads();
-
-  // ---- scores: sum_n tanh(x . Wa[n] + ba[n]) * qv[n] -------------------------------------------------------------------------------
-  float score[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) score[m] = 0.0f;
-  for (int c = 0; c < Gm::NCH; ++c) {
-    if (c + 1 < Gm::NCH) chunk_fetch(c + 1, (c + 1) & 1);
-    const int nt0 = c * Gm::CH_NT, ntc = (Gm::NTQ - nt0) < Gm::CH_NT ? (Gm::NTQ - nt0) : Gm::CH_NT;
-    const u16* Wc = (const u16*)(smem + (c & 1) * Gm::CH_BYTES);
-    for (int nt = 0; nt < ntc; ++nt) {
-      const int wrow = (nt0 + nt) * 16 + 4 * g;
-      const f32x4 b4 = *(const f32x4*)(p.bap + wrow), q4 = *(const f32x4*)(p.qvp + wrow);
-      f32x4 acc[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = b4;
-      const u16* wp = Wc + (nt * KSTEPS) * 512 + l * 8;
-      u16x8 a = *(const u16x8*)wp;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const u16x8 an = ks + 1 < KSTEPS ? *(const u16x8*)(wp + (ks + 1) * 512) : a;       // next fragment in flight during the MFMAs
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, xf[m][ks], acc[m]);
-        a = an;
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) score[m] += fast_tanh(acc[m][r]) * q4[r];
-      }
-    }
-    __syncthreads();                        // next chunk visible; everybody done with the buffer the chunk after it will overwrite
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const float s = sum_rows4(score[m]);    // over the four lane groups (the 16 query rows of every n-tile)
-    if (g == 0 && m * 16 + li < Gm::TOKW) sc[m * 16 + li] = s;
-  }
-  wave_barrier();
-
-  // ---- softmax over the 20 tokens of each title: lane l owns token l (and l + 64 for l < 16) ---------------------------------------------
-  const int nvalid = (p.valid > 0 && p.valid < S) ? p.valid : S;       // AdditiveParams::valid
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int t = l + 64 * k;
-    if (t < Gm::TOKW) {
-      const int base = (t / S) * S;
-      float mx = -3.0e38f;
-#pragma unroll 4
-      for (int j = 0; j < S; ++j) mx = j < nvalid ? fmaxf(mx, sc[base + j]) : mx;
-      float sum = 0.0f;
-#pragma unroll 4
-      for (int j = 0; j < S; ++j) sum += j < nvalid ? fast_exp(sc[base + j] - mx) : 0.0f;
-      const float wt = t - base < nvalid ? fast_exp(sc[t] - mx) / sum : 0.0f;
-      wl[t] = wt;
-      if (p.attn_w != nullptr && tok0 + t < tok_total) p.attn_w[tok0 + t] = wt;
-    }
-  }
-  wave_barrier();
-  NR_SCHED_BARRIER();
-
-  // ---- weighted sum out[title][:] = sum_s w[s] x[s][:], straight from the fragment registers: title sq lives in token tiles
-  //      (20 sq) / 16 and the next one; a lane adds its token's share (80 partial sums: 10 k-steps x 8 features), then the 16 lanes of a
-  //      row are combined by RECURSIVE HALVING (reduce-scatter): at level b the lane keeps the half of its values that its lane-index
-  //      bit b selects and adds the partner's copy of that half -- about 80 exchanges instead of the 4 x 80 of an all-reduce butterfly ----
-  const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
-#pragma unroll
-  for (int sq = 0; sq < Gm::TPW; ++sq) {
-    const int m0 = (sq * S) / 16;
-    float wm[2];
-#pragma unroll
-    for (int dm = 0; dm < 2; ++dm) {
-      const int t = (m0 + dm) * 16 + li;
-      wm[dm] = (t >= sq * S && t < (sq + 1) * S) ? wl[t] : 0.0f;
-    }
-    // two halves of 5 k-steps (40 partial sums each) keep the live set small enough for two waves per SIMD: halving on lane bits 3, 2, 1
-    // (40 -> 20 -> 10 -> 5 values), then the pair of lanes that differ in bit 0 adds up and the even one stores
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float v[40];
-#pragma unroll
-      for (int i = 0; i < 40; ++i) v[i] = 0.0f;
-#pragma unroll
-      for (int dm = 0; dm < 2; ++dm)
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[ks * 8 + j] += wm[dm] * bf2f(xf[m0 + dm][5 * h + ks][j]);
-      float k1[20], k2[10], k3[5];
-#pragma unroll
-      for (int i = 0; i < 20; ++i) k1[i] = (b3 ? v[20 + i] : v[i]) + row_xchg<3>(b3 ? v[i] : v[20 + i]);
-#pragma unroll
-      for (int i = 0; i < 10; ++i) k2[i] = (b2 ? k1[10 + i] : k1[i]) + row_xchg<2>(b2 ? k1[i] : k1[10 + i]);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) k3[i] = (b1 ? k2[5 + i] : k2[i]) + row_xchg<1>(b1 ? k2[i] : k2[5 + i]);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) k3[i] += row_xchg<0>(k3[i]);
-      NR_SCHED_BARRIER();
-      if (!b0 && seq0 + sq < p.n_seq) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          const int idx = 5 * (li >> 1) + i;               // flat (k-step in the half, feature-in-fragment) index this lane pair ended up with
-          const int c = (5 * h + (idx >> 3)) * 32 + g * 8 + (idx & 7);
-          if (p.out != nullptr && c < D) p.out[(seq0 + sq) * p.out_stride + c] = k3[i];
-          if (p.out_b != nullptr)                          // bf16 ctx-layout copy: cols < D data, col D = 1.0, rest of the K padding 0
-            p.out_b[(seq0 + sq) * p.out_b_stride + c] = c < D ? f2bf(k3[i]) : (c == D ? BF16_ONE : (u16)0);
-        }
-      }
-    }
-  }
-}
+// (The register-resident pooling FORWARD of rounds 2-3 -- pool2_fwd_kernel, NR_POOL2_FWD=1 -- measured 286 / 271 / 304 us in its three forms against
+// 252-265 us for the LDS-tile additive_fwd_kernel, two rounds running, and is gone: profiles/r02_ab_switches.txt)
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // DBG = true: a second instantiation with phase switches for timing decompositions (NR_POOL_DEBUG -> dbgv; tools/prof_kernel.py):

@@ -421,31 +421,13 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Input gradient of the three projections as a hand-written GEMM: dX[tok][n] = sum_k dqkv[tok][k] Wall[k][n], k = (which, feature) over the
 // 960 columns of the dQ | dK | dV rows, n < 320 (autograd of multihead_self.py:53-55 w.r.t. its input; the reference leaves it to
-// torch.autograd, src/train.py:231).  Accumulator-stationary: a wave owns 32 tokens x all 320 output columns (10 v_mfma_f32_32x32x16_bf16
-// tiles = 160 VGPRs); the contraction runs in 30 chunks of 32 columns: the token rows' 64-byte pieces and the 20 weight fragments of a
-// chunk are copied global -> LDS directly (global_load_lds_dwordx4, double buffered, one barrier per chunk); the token pieces are placed
-// with a 4-row XOR swizzle of their 16-byte slots so that the fragment reads are bank-conflict free; the result leaves through LDS as whole
-// 640-byte rows.
+// torch.autograd, src/train.py:231).  Accumulator-stationary: the contraction runs in 30 chunks of 32 columns: the token rows' 64-byte pieces
+// and the 20 weight fragments of a chunk are copied global -> LDS directly (global_load_lds_dwordx4); the token pieces are placed with a 4-row
+// XOR swizzle of their 16-byte slots so that the fragment reads are bank-conflict free; the result leaves through LDS as whole 640-byte rows.
+// (The two-buffer form of round 3 -- 4 or 8 waves, one barrier per chunk -- lost to the ring below in every measurement and is gone:
+// profiles/r03_ab_switches.txt.)
 constexpr int DXK = 3 * KP;                 // 960 contraction columns
-// NW waves per workgroup: 4 (128 tokens, two workgroups per CU) or 8 (256 tokens, one per CU: the weight chunks are fetched half as often)
-template <int NW>
-struct DxGeom {
-  static constexpr int NWAVE = NW;
-  static constexpr int TOKW = 32;
-  static constexpr int TOK_WG = NWAVE * TOKW;          // 128 / 256
-  static constexpr int KC = 2;                         // k-steps of 16 per chunk (32 columns = 64 bytes of a token row)
-  static constexpr int NCH = DXK / (16 * KC);          // 30
-  static constexpr int A_BYTES = TOK_WG * KC * 32;     // 8,192 / 16,384 B: rows x 64 B
-  static constexpr int W_BYTES = KC * NT32 * 1024;     // 20,480 B: 20 fragments
-  static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
-  static constexpr int OROW = 656;                     // bytes per staged output row
-  static constexpr int ORP = NW == 4 ? 16 : 8;         // output rows per wave and epilogue pass
-  static constexpr int OUT_BYTES = NWAVE * ORP * OROW; // 41,984 B
-  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 / 73,728 B (>= OUT_BYTES)
-  static_assert(SMEM >= OUT_BYTES, "epilogue staging fits the chunk buffers");
-};
-
-// packed operand of dx_gemm_kernel: WdX bf16 [60 k-steps][10 n-tiles][64 lanes][8]: lane l of block (ks, nt) holds
+// packed operand of dx_gemm_ring_kernel: WdX bf16 [60 k-steps][10 n-tiles][64 lanes][8]: lane l of block (ks, nt) holds
 // Wall[k = 16 ks + 8 (l >> 5) + j][n = 32 nt + (l & 31)], j = 0..7, Wall[which * KP + f][n] = W_which[f][n] (zero for f, n >= D)
 __global__ __launch_bounds__(256) void pack_qkv_dx_kernel(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                           u16* __restrict__ WdX) {
@@ -466,86 +448,6 @@ struct DxParams {
   u16* dX;               // [n_tok][KP] bf16: columns >= D come out as exact zeros
   int64_t n_tok;
 };
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void dx_gemm_kernel(DxParams p) {
-  using Gm = DxGeom<NW>;
-  NR_SMEM_DECL(smem);
-  const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
-  const int64_t wg_tok0 = (int64_t)blockIdx.x * Gm::TOK_WG;
-  const int64_t tile_tok0 = wg_tok0 + w * Gm::TOKW;
-
-  // chunk c -> buffer b: this wave copies its own 32 token rows (2 instructions: 16 rows x 4 slots each) and 5 of the 20 weight fragments.
-  // Slot s of row r holds the row's 16-byte piece s ^ ((r >> 2) & 3).
-  auto fetch = [&](int c, int b) {
-    unsigned char* abuf = smem + b * Gm::BUF_BYTES;
-    unsigned char* wbuf = abuf + Gm::A_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = w * Gm::TOKW + i * 16 + (l >> 2), s = l & 3;
-      int64_t tok = wg_tok0 + r;
-      tok = tok < p.n_tok ? tok : p.n_tok - 1;                       // rows past the end repeat the last row (never stored)
-      const u16* src = p.dqkv + tok * DXK + c * (16 * Gm::KC) + ((s ^ ((r >> 2) & 3)) * 8);
-      NR_GLDS16(src, abuf + (w * Gm::TOKW + i * 16) * 64);
-    }
-    const u16* wsrc = p.WdX + (size_t)c * Gm::KC * NT32 * 512 + l * 8;
-    for (int f = w; f < Gm::KC * NT32; f += Gm::NWAVE) NR_GLDS16(wsrc + f * 512, wbuf + f * 1024);
-  };
-  fetch(0, 0);
-  f32x16 acc[NT32];
-#pragma unroll
-  for (int nt = 0; nt < NT32; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-  __syncthreads();
-  const int arow = w * Gm::TOKW + li;
-  for (int c = 0; c < Gm::NCH; ++c) {
-    if (c + 1 < Gm::NCH) fetch(c + 1, (c + 1) & 1);
-    const unsigned char* abuf = smem + (c & 1) * Gm::BUF_BYTES;
-    const unsigned char* wbuf = abuf + Gm::A_BYTES;
-    // all ten weight fragments of a k-step are requested before its first MFMA and refilled for the next k-step as they are consumed
-    // (the compiler's own schedule was "two reads, wait, two MFMAs": an LDS round trip exposed every 64 MFMA cycles)
-    u16x8 wf[NT32];
-#pragma unroll
-    for (int nt = 0; nt < NT32; ++nt) wf[nt] = *(const u16x8*)(wbuf + nt * 1024 + l * 16);
-    u16x8 af = *(const u16x8*)(abuf + arow * 64 + ((h ^ ((arow >> 2) & 3)) * 16));
-    NR_SCHED_BARRIER();
-#pragma unroll
-    for (int ks = 0; ks < Gm::KC; ++ks) {
-      u16x8 afn = af;
-      if (ks + 1 < Gm::KC) afn = *(const u16x8*)(abuf + arow * 64 + ((((ks + 1) * 2 + h) ^ ((arow >> 2) & 3)) * 16));
-#pragma unroll
-      for (int nt = 0; nt < NT32; ++nt) {
-        acc[nt] = mfma_32x32x16_bf16(wf[nt], af, acc[nt]);           // C[n][token]: the lane holds 4 x 4 consecutive columns of ITS token's row
-        if (ks + 1 < Gm::KC) wf[nt] = *(const u16x8*)(wbuf + ((ks + 1) * NT32 + nt) * 1024 + l * 16);
-      }
-      af = afn;
-    }
-    __syncthreads();
-  }
-  // ---- epilogue: ORP token rows per wave at a time through LDS, each batch leaves as ORP x 640 contiguous bytes ------------------------
-  unsigned char* ost = smem + w * Gm::ORP * Gm::OROW;
-#pragma unroll
-  for (int ps = 0; ps < Gm::TOKW / Gm::ORP; ++ps) {
-    if (li / Gm::ORP == ps) {
-      unsigned char* row = ost + (li % Gm::ORP) * Gm::OROW;
-#pragma unroll
-      for (int nt = 0; nt < NT32; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(u16x4*)(row + (nt * 32 + 8 * q + 4 * h) * 2) = pack4(f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]});
-    }
-    wave_barrier();
-    const int64_t t0 = tile_tok0 + ps * Gm::ORP;
-#pragma unroll
-    for (int i = 0; i < (Gm::ORP * (KP / 8) + 63) / 64; ++i) {
-      const int idx = l + 64 * i;
-      const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
-      if (idx < Gm::ORP * (KP / 8) && t0 + r < p.n_tok) *(u16x8*)(p.dX + t0 * KP + idx * 8) = *(const u16x8*)(ost + r * Gm::OROW + pc * 16);
-    }
-    wave_barrier();
-  }
-}
 
 // dx_gemm with a RING of chunk buffers.  With two buffers a chunk's copies are issued one chunk of compute (~0.5 us of MFMA work per wave)
 // before they are needed -- less than the loaded memory latency, so every chunk waited for its data: 3,600 cycles per chunk and workgroup
@@ -688,299 +590,6 @@ __global__ __launch_bounds__(512, 2) void dx_gemm_ring_kernel(DxParams p) {
       const int64_t tok = wg_tok0 + (r >> 5) * 64 + a * 32 + (r & 31);
       if (tok < p.n_tok && !(dbg & 4)) *(u16x8*)(p.dX + tok * KP + pc * 8) = *(const u16x8*)(smem + r * Gm::OROW + pc * 16);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Weight gradients as a hand-written "TN" GEMM with split K: out[part][m][n] = sum over the partition's tokens of G[tok][m] X[tok][n]
-// (autograd of the nn.Linear layers w.r.t. weight and bias -- multihead_self.py:53-55 with G = dqkv [tok][960], X = the masked token matrix
-// [tok][320] whose column D is 1.0 (bias gradient); additive.py:35 with G = dpre [tok][208], X = ctx).  Both operands are token-major, i.e. the
-// contraction index runs along the ROWS of both: the MFMA fragments (8 consecutive tokens of one column per lane) are taken from row-major
-// LDS tiles with the transposing LDS read ds_read_b64_tr_b16 (lds_tr16_b64) -- no transposed copy of either operand exists anywhere.
-//   workgroup = a 128-row slab of the output (one 32-row tile per wave) x all 320 columns (160 accumulator VGPRs per wave) x one partition
-//   of the tokens, walked in chunks of 32 tokens; G [32][128] and X [32][320] of a chunk arrive by LDS-DMA (double buffered, one barrier per
-//   chunk) with their 16-byte slots XOR-swizzled per row so that the four token rows a transposing read touches sit in different banks;
-//   the slabs of one partition run on one XCD (block id -> (xcd, slab, partition)), so that X comes from HBM once.
-// The fp32 partials [P][M][320] are what nr_wgrad_unpack reduces in a fixed order (deterministic, no atomics).
-template <int NW>
-struct TnGeom {
-  static constexpr int NWAVE = NW;                     // 4 (two workgroups per CU) or 8 (one: each X chunk serves a 256-row slab)
-  static constexpr int BM = NWAVE * 32;                // 128 / 256 output rows per workgroup
-  static constexpr int GS = BM / 8;                    // 16-byte slots per G row
-  static constexpr int TC = 32;                        // tokens per chunk (2 k-steps of 16)
-  static constexpr int G_BYTES = TC * BM * 2;          // 8,192 / 16,384
-  static constexpr int X_BYTES = TC * KP * 2;          // 20,480
-  static constexpr int BUF_BYTES = G_BYTES + X_BYTES;
-  static constexpr int SMEM = 2 * BUF_BYTES;           // 57,344 / 73,728 B
-};
-
-struct TnParams {
-  const u16* G;          // [n_tok][ldg] bf16
-  int ldg;               // row stride of G in elements (multiple of 8)
-  int M;                 // output rows = columns of G used (<= ldg)
-  const u16* X;          // [n_tok][KP] bf16
-  const u16* zeros;      // >= 16 zero bytes: what lanes beyond a partition's tokens / G's columns copy
-  float* out;            // [P][M][KP] fp32 partial products
-  int64_t n_tok;
-  int P;                 // token partitions (multiple of 8)
-  int nslab;             // ceil(M / 128)
-  int64_t tok_per_part;  // multiple of 32
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void tn_gemm_kernel(TnParams p) {
-  using Gm = TnGeom<NW>;
-  NR_SMEM_DECL(smem);
-  const int l = lane_id(), w = wave_id(), h = l >> 5;
-  // block id -> (xcd, slab, partition): ids that differ by a multiple of 8 share an XCD (round-robin dispatch); the slabs of a partition get
-  // consecutive such ids, run side by side on that XCD and find each other's X chunks in its L2
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int slab = j % p.nslab, part = (j / p.nslab) * 8 + xcd;
-  const int64_t t_begin = (int64_t)part * p.tok_per_part;
-  int64_t t_end = t_begin + p.tok_per_part;
-  t_end = t_end < p.n_tok ? t_end : p.n_tok;
-  const int nchunk = t_end > t_begin ? (int)((t_end - t_begin + Gm::TC - 1) / Gm::TC) : 0;
-
-  auto fetch = [&](int c, int b) {
-    unsigned char* gbuf = smem + b * Gm::BUF_BYTES;
-    unsigned char* xbuf = gbuf + Gm::G_BYTES;
-    const int64_t tok0 = t_begin + (int64_t)c * Gm::TC;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                              // G: 32 rows x GS slots = 2 NW blocks of 64 slots; this wave copies blocks 2 w, 2 w + 1
-      const int gs = (w * 2 + i) * 64 + l;
-      const int r = gs / Gm::GS, s = gs - r * Gm::GS;
-      const int col = slab * Gm::BM + ((s ^ (4 * (r & 3))) * 8);
-      const u16* src = (tok0 + r < t_end && col < p.ldg) ? p.G + (tok0 + r) * p.ldg + col : p.zeros;
-      NR_GLDS16(src, gbuf + (w * 2 + i) * 1024);
-    }
-    for (int blk = w; blk < 20; blk += Gm::NWAVE) {            // X: 32 rows x 40 slots = 20 blocks of 64 slots
-      const int gs = blk * 64 + l;
-      const int r = gs / 40, s = gs - r * 40;
-      const u16* src = tok0 + r < t_end ? p.X + (tok0 + r) * KP + ((s ^ (4 * ((r >> 1) & 1))) * 8) : p.zeros;
-      NR_GLDS16(src, xbuf + blk * 1024);
-    }
-  };
-  f32x16 acc[NT32];
-#pragma unroll
-  for (int nt = 0; nt < NT32; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-  if (nchunk > 0) fetch(0, 0);
-  __syncthreads();
-  // per-lane geometry of the transposing reads: the lane supplies the piece (row k0 + (l & 15) / 4, columns n0 + 4 (l & 3) .. + 3) of the
-  // 4 x 16 block its 16-lane group transposes, and receives column n0 + (l & 15), rows k0 .. k0 + 3
-  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);
-  for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) fetch(c + 1, (c + 1) & 1);
-    const unsigned char* gbuf = smem + (c & 1) * Gm::BUF_BYTES;
-    const unsigned char* xbuf = gbuf + Gm::G_BYTES;
-    auto read_a = [&](int ks) -> u16x8 {
-      u16x4 a[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * w + pcol;
-        a[t] = lds_tr16_b64((const u16*)(gbuf + (row * Gm::GS + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
-      }
-      return cat8(a[0], a[1]);
-    };
-    auto read_b = [&](int ks, int nt) -> u16x8 {
-      u16x4 b[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * nt + pcol;
-        b[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
-      }
-      return cat8(b[0], b[1]);
-    };
-    // X fragments are requested PF MFMAs ahead of their use (a ring of PF fragments; the compiler's own schedule was "read, wait, MFMA")
-    constexpr int PF = 5;
-    u16x8 bf[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) bf[i] = read_b(0, i);
-    u16x8 af[2] = {read_a(0), read_a(1)};
-    NR_SCHED_BARRIER();
-#pragma unroll
-    for (int i = 0; i < 2 * NT32; ++i) {
-      const int ks = i / NT32, nt = i - ks * NT32;
-      acc[nt] = mfma_32x32x16_bf16(af[ks], bf[i % PF], acc[nt]);           // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
-      if (i + PF < 2 * NT32) bf[i % PF] = read_b((i + PF) / NT32, (i + PF) % NT32);
-    }
-    __syncthreads();
-  }
-  float* obase = p.out + ((size_t)part * p.M + slab * Gm::BM + 32 * w) * KP + (l & 31);
-#pragma unroll
-  for (int nt = 0; nt < NT32; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (slab * Gm::BM + 32 * w + m < p.M) obase[(size_t)m * KP + nt * 32] = acc[nt][r];
-    }
-}
-
-// tn_gemm with a ring of FOUR chunk buffers, copies three chunks ahead, one counted wait + one raw barrier per chunk (see dx_gemm_ring_kernel).
-// One workgroup of NW = 4 waves per CU owns a 128-row slab; a wave owns 64 rows x 160 columns.  Used for NARROW outputs (dpre: M = 208, two
-// slabs): 129 vs 208 us for the two-buffer kernel and 155 us for hipBLASLt (profiles/r03_ab_switches.txt, pass m).  For the 960 rows of dqkv
-// the 8-wave form of this kernel (256-row slabs) needs 261 registers per lane -- its spills reload through vmcnt and drain the ring (582 vs
-// 538 us) -- so wide outputs stay with tn_gemm_kernel.  Same chunks, same k order per output element as tn_gemm_kernel: same bits.
-template <int NW>
-struct TnRingGeom : TnGeom<NW> {
-  static constexpr int NB = 4;
-  static constexpr int SMEM = NB * TnGeom<NW>::BUF_BYTES;          // 147,456 / 114,688 B
-  static constexpr int XCP = (20 + NW - 1) / NW;                   // copy instructions per wave and chunk: X blocks (3 / 5) ...
-  static constexpr int CP = 2 + XCP;                               // ... + 2 of G
-  static_assert(SMEM <= 163840 && CP * (NB - 1) < 64, "ring fits the LDS; vmcnt range");
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void tn_gemm_ring_kernel(TnParams p) {
-  using Gm = TnRingGeom<NW>;
-  constexpr int NTW = NT32 / 2;
-  NR_SMEM_DECL(smem);
-  const int l = lane_id(), w = wave_id(), h = l >> 5;
-  const int wc = w & 1, wr = w >> 1;
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int slab = jb % p.nslab, part = (jb / p.nslab) * 8 + xcd;
-  const int64_t t_begin = (int64_t)part * p.tok_per_part;
-  int64_t t_end = t_begin + p.tok_per_part;
-  t_end = t_end < p.n_tok ? t_end : p.n_tok;
-  const int ntok = t_end > t_begin ? (int)(t_end - t_begin) : 0;             // tokens of this partition (< 2^31 / row length: 32-bit offsets below)
-  const int nchunk = (ntok + Gm::TC - 1) / Gm::TC;
-  const u16* const Gp = p.G + t_begin * p.ldg;
-  const u16* const Xp = p.X + t_begin * KP;
-
-  // per-lane element offsets of this wave's copies inside a chunk (row r of the chunk, swizzled 16-byte slot s): constant over the chunks
-  auto g_slot = [&](int i, int& r, int& col) {
-    const int gs = (w * 2 + i) * 64 + l;
-    r = gs / Gm::GS;
-    col = slab * Gm::BM + (((gs - r * Gm::GS) ^ (4 * (r & 3))) * 8);
-  };
-  auto x_slot = [&](int k, int& blk, int& r, int& off) {
-    blk = w + NW * k;
-    blk = blk < 20 ? blk : blk - NW;                             // 20 blocks over NW * XCP copies: the surplus repeats one (same bytes, same place)
-    const int gs = blk * 64 + l;
-    r = gs / 40;
-    off = r * KP + (((gs - r * 40) ^ (4 * ((r >> 1) & 1))) * 8);
-  };
-  int goff[2], xoff[Gm::XCP];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { int r, col; g_slot(i, r, col); goff[i] = r * p.ldg + col; }
-#pragma unroll
-  for (int k = 0; k < Gm::XCP; ++k) { int blk, r; x_slot(k, blk, r, xoff[k]); }
-  const bool slab_full = (slab + 1) * Gm::BM <= p.ldg;
-  auto fetch = [&](int c) {                                      // exactly CP copy instructions per wave
-    unsigned char* gbuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
-    unsigned char* xbuf = gbuf + Gm::G_BYTES;
-    const int t0 = c * Gm::TC;
-    const u16* const Gc = Gp + (int64_t)t0 * p.ldg;              // wave-uniform bases + 32-bit lane offsets
-    const u16* const Xc = Xp + (int64_t)t0 * KP;
-    if (slab_full && t0 + Gm::TC <= ntok) {                      // every row and column of the chunk exists (all but the last chunk / slab)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) NR_GLDS16(Gc + goff[i], gbuf + (w * 2 + i) * 1024);
-#pragma unroll
-      for (int k = 0; k < Gm::XCP; ++k) {
-        const int blk = w + NW * k < 20 ? w + NW * k : w + NW * k - NW;
-        NR_GLDS16(Xc + xoff[k], xbuf + blk * 1024);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int r, col;
-        g_slot(i, r, col);
-        NR_GLDS16((t0 + r < ntok && col < p.ldg) ? Gc + (r * p.ldg + col) : p.zeros, gbuf + (w * 2 + i) * 1024);
-      }
-#pragma unroll
-      for (int k = 0; k < Gm::XCP; ++k) {
-        int blk, r, off;
-        x_slot(k, blk, r, off);
-        NR_GLDS16(t0 + r < ntok ? Xc + off : p.zeros, xbuf + blk * 1024);
-      }
-    }
-  };
-  f32x16 acc[2][NTW];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
-  for (int c = 0; c < Gm::NB - 1; ++c)
-    if (c < nchunk) fetch(c);
-  const int prow = (l & 15) >> 2, pcol = 16 * ((l >> 4) & 1) + 4 * (l & 3);
-  // fragment set of one k-step: five X fragments + two G fragments; the loop is rotated as in dx_gemm_ring_kernel (k-step 1 of chunk c - 1 is
-  // multiplied behind the barrier of chunk c; every wait sits in front of the next reads)
-  struct Frag { u16x8 bf[NTW], af[2]; };
-  auto read_frag = [&](int c, int ks) -> Frag {
-    const unsigned char* gbuf = smem + (c & (Gm::NB - 1)) * Gm::BUF_BYTES;
-    const unsigned char* xbuf = gbuf + Gm::G_BYTES;
-    Frag f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      u16x4 v[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (2 * wr + a) + pcol;
-        v[t] = lds_tr16_b64((const u16*)(gbuf + (row * Gm::GS + ((col >> 3) ^ (4 * (row & 3)))) * 16 + (col & 7) * 2));
-      }
-      f.af[a] = cat8(v[0], v[1]);
-    }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      u16x4 v[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 16 * ks + 8 * h + 4 * t + prow, col = 32 * (wc * NTW + j) + pcol;
-        v[t] = lds_tr16_b64((const u16*)(xbuf + (row * 40 + ((col >> 3) ^ (4 * ((row >> 1) & 1)))) * 16 + (col & 7) * 2));
-      }
-      f.bf[j] = cat8(v[0], v[1]);
-    }
-    return f;
-  };
-  auto multiply = [&](const Frag& f) {
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      acc[0][j] = mfma_32x32x16_bf16(f.af[0], f.bf[j], acc[0][j]);            // C[m][n]: the lane holds column n = l & 31, rows 8 q + 4 h + e
-      acc[1][j] = mfma_32x32x16_bf16(f.af[1], f.bf[j], acc[1][j]);
-    }
-  };
-  auto arrive = [&](int c) {
-    if (c + 2 < nchunk) NR_WAIT_VMCNT(2 * Gm::CP);
-    else if (c + 1 < nchunk) NR_WAIT_VMCNT(Gm::CP);
-    else NR_WAIT_VMCNT(0);
-    NR_WAIT_LGKMCNT(0);                                          // this wave's reads of chunk c - 1 have returned
-    NR_BARRIER_RAW();                                            // chunk c complete for everybody; everybody has read chunk c - 1
-    if (c + 3 < nchunk) fetch(c + 3);
-  };
-  if (nchunk > 0) {
-    arrive(0);
-    Frag f0 = read_frag(0, 0);
-    Frag f1 = read_frag(0, 1);
-    NR_SCHED_BARRIER();
-    multiply(f0);
-    for (int c = 1; c < nchunk; ++c) {
-      arrive(c);                                                 // (f1 = k-step 1 of chunk c - 1 is in registers)
-      f0 = read_frag(c, 0);
-      NR_SCHED_BARRIER();
-      multiply(f1);
-      NR_SCHED_BARRIER();
-      NR_WAIT_LGKMCNT(0);                                        // f0 is in registers
-      NR_SCHED_BARRIER();
-      f1 = read_frag(c, 1);
-      NR_SCHED_BARRIER();
-      multiply(f0);
-    }
-    multiply(f1);
-  }
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int m0 = slab * Gm::BM + 32 * (2 * wr + a);
-    float* obase = p.out + ((size_t)part * p.M + m0) * KP + wc * (NTW * 32) + (l & 31);
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m0 + m < p.M) obase[(size_t)m * KP + j * 32] = acc[a][j][r];
-      }
   }
 }
 

@@ -20,8 +20,7 @@ namespace nr {
 // defined in nr_mhsa2.hip: its own translation unit because the register-resident kernel wants the AGPR half of the register
 // file as storage (default MFMA form), while every other kernel is built with -amdgpu-mfma-vgpr-form
 int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream);
-int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream);      // k_pool2.h, same translation unit
-int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream);
+int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream);   // k_pool2.h, same translation unit
 int launch_pool2_bwd50(const AdditiveBwdParams& p, hipStream_t stream);
 }
 
@@ -88,13 +87,6 @@ bool pool2_s50(int64_t n_seq) {
   return add_variant() == 4 && (v == 2 || (v == 1 && n_seq >= 2048));
 }
 
-// waves per workgroup of the hand-written GEMM kernels (nr_dx_gemm, nr_tn_gemm): A/B knob NR_GEMM_WAVES = 4 (default) or 8
-int gemm_waves() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NR_GEMM_WAVES"); v = (e && atoi(e) == 8) ? 8 : 4; }
-  return v;
-}
-
 template <typename K>
 int allow_smem(K kern, int bytes) { return nr::set_max_dynamic_lds((const void*)kern, bytes); }   // > 64 KiB needs the opt-in
 
@@ -113,44 +105,6 @@ int launch_conv_t(nr::ConvParams& p, void* stream) {
   if (allow_smem(nr::conv3_kernel<S, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
   NR_LAUNCH((nr::conv3_kernel<S, NSEQ, NW>), (p.n_seq + NSEQ - 1) / NSEQ, NW * 64, G::SMEM, (hipStream_t)stream, p);
   return NR_OK;
-}
-
-template <int KS_CT>
-static int launch_gru_fwd_persist(nr::GruFwdSeqParams& q, int T, hipStream_t stream) {
-  const int grid = nr::gru_grid(q.st.Hg / 16, (q.st.B + 127) / 128), smem = 3 * q.st.Hp * 16 * 2;
-  if (allow_smem(nr::gru_fwd_persist_kernel<KS_CT, 2>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot reserve LDS");
-  if (nr::kGridBarrier) {
-    q.sync = nr::grid_barrier_word(stream);
-    if (!q.sync) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot set up the grid barrier counter");
-    q.t0 = 0; q.t1 = T;
-    NR_LAUNCH2((nr::gru_fwd_persist_kernel<KS_CT, 2>), grid, 1, nr::WG, smem, stream, q);
-  } else {                                  // no grid barrier on this target (the emulator): the same kernel, one step per launch
-    q.sync = nullptr;
-    for (int t = 0; t < T; ++t) {
-      q.t0 = t; q.t1 = t + 1;
-      NR_LAUNCH2((nr::gru_fwd_persist_kernel<KS_CT, 2>), grid, 1, nr::WG, smem, stream, q);
-    }
-  }
-  return check_launch("nr_gru_fwd_seq");
-}
-
-template <int KS_CT>
-static int launch_gru_bwd_persist(nr::GruBwdSeqParams& q, hipStream_t stream) {
-  const int grid = nr::gru_grid(q.st.Hg / 16, (q.st.B + 127) / 128), smem = q.st.Kp * 16 * 2;
-  if (allow_smem(nr::gru_bwd_persist_kernel<KS_CT>, smem)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot reserve LDS");
-  if (nr::kGridBarrier) {
-    q.sync = nr::grid_barrier_word(stream);
-    if (!q.sync) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot set up the grid barrier counter");
-    q.i0 = 0; q.i1 = q.T + 1;
-    NR_LAUNCH2(nr::gru_bwd_persist_kernel<KS_CT>, grid, 1, nr::WG, smem, stream, q);
-  } else {
-    q.sync = nullptr;
-    for (int i = 0; i <= q.T; ++i) {
-      q.i0 = i; q.i1 = i + 1;
-      NR_LAUNCH2(nr::gru_bwd_persist_kernel<KS_CT>, grid, 1, nr::WG, smem, stream, q);
-    }
-  }
-  return check_launch("nr_gru_bwd_seq");
 }
 
 }  // namespace
@@ -195,9 +149,9 @@ int nr_wgrad_unpack(const float* dW_parts, int nc_w, const float* dWa_parts, int
   p.dW = dW_parts; p.dWa = dWa_parts; p.dq = dq_part; p.ncW = nc_w; p.ncA = nc_a; p.qdim = qdim; p.nwg = nwg;
   p.gW[0] = gWq; p.gW[1] = gWk; p.gW[2] = gWv; p.gb[0] = gbq; p.gb[1] = gbk; p.gb[2] = gbv; p.gWa = gWa; p.gba = gba; p.gq = gq;
   const uintptr_t al = (uintptr_t)gWq | (uintptr_t)gWk | (uintptr_t)gWv | (uintptr_t)gWa | (uintptr_t)dW_parts | (uintptr_t)dWa_parts;
-  if ((al & 15) == 0) NR_LAUNCH(nr::wgrad_unpack_kernel<true>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, 0, (hipStream_t)stream, p);
+  if ((al & 15) == 0) NR_LAUNCH(nr::wgrad_unpack_kernel<true>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, nr::WGU_SMEM, (hipStream_t)stream, p);
   else if ((((uintptr_t)dW_parts | (uintptr_t)dWa_parts) & 15) == 0)
-    NR_LAUNCH(nr::wgrad_unpack_kernel<false>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, 0, (hipStream_t)stream, p);
+    NR_LAUNCH(nr::wgrad_unpack_kernel<false>, nr::wgrad_unpack_grid(qdim), nr::WGU_THREADS, nr::WGU_SMEM, (hipStream_t)stream, p);
   else return fail(NR_ERR_BADARG, "nr_wgrad_unpack: the partial-product buffers must be 16-byte aligned");
   NR_LAUNCH(nr::wgrad_dq_kernel, (qdim + nr::WGU_DQ_COLS - 1) / nr::WGU_DQ_COLS, nr::WGU_DQ_COLS * nr::WGU_DQ_PH,
             nr::WGU_DQ_COLS * nr::WGU_DQ_PH * 4, (hipStream_t)stream, p);
@@ -292,14 +246,7 @@ int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
   p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq; p.valid = valid;
-  // NR_POOL2_FWD=1 selects the register-resident forward (k_pool2.h).  Measured at B = 512: 286 us vs 265 us for the LDS-tile kernel
-  // below -- one workgroup per CU alternates between loading its 205 KB of ctx rows and computing, with nothing to overlap either phase,
-  // while 5 small workgroups per CU interleave naturally; the BACKWARD of k_pool2.h is the default (400 us vs 570 us).
-  static int p2f = -1;
-  if (p2f < 0) { const char* e = getenv("NR_POOL2_FWD"); p2f = e ? atoi(e) : 0; }
-  if (S == 20 && add_variant() == 4 && p2f) {
-    if (nr::launch_pool2_fwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
-  } else if (S == 20 && add_variant() == 1) {
+  if (S == 20 && add_variant() == 1) {
     constexpr int NSEQ = 8, NW = 8;
     using G = nr::AddGeom<20, NSEQ, NW>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
@@ -455,73 +402,15 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
   if (n_tok == 0) return NR_OK;
   nr::DxParams p;
   p.dqkv = dqkv; p.WdX = WdX; p.dX = dX; p.n_tok = n_tok;
-  if (gemm_waves() == 8) {
-    using G = nr::DxGeom<8>;
-    if (allow_smem(nr::dx_gemm_kernel<8>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_dx_gemm: cannot reserve LDS");
-    NR_LAUNCH(nr::dx_gemm_kernel<8>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 512, G::SMEM, (hipStream_t)stream, p);
-  } else {
-    using G = nr::DxGeom<4>;
-    static int ring = -1;                        // NR_DX_RING: 1 (default) = ring kernel (one 8-wave workgroup per CU), 0 = two-buffer kernel; same bits (A/B)
-    if (ring < 0) { const char* e = getenv("NR_DX_RING"); ring = e ? atoi(e) : 1; }
-    if (ring) {
-      using R = nr::DxRingGeom;
-      const char* d = getenv("NR_DXR_DEBUG");    // profiling: phase switches (compile-time variants), re-read per call
-      const int dbg = d != nullptr ? atoi(d) : 0;
-      const int64_t grid = (n_tok + R::TOK_WG - 1) / R::TOK_WG;
+  using R = nr::DxRingGeom;
+  const char* d = getenv("NR_DXR_DEBUG");      // profiling: phase switches (compile-time variants), re-read per call
+  const int dbg = d != nullptr ? atoi(d) : 0;
+  const int64_t grid = (n_tok + R::TOK_WG - 1) / R::TOK_WG;
 #define NR_DXR_CASE(D) case D: if (allow_smem(nr::dx_gemm_ring_kernel<D>, R::SMEM)) return fail(NR_ERR_LAUNCH, "nr_dx_gemm: cannot reserve LDS"); \
                                NR_LAUNCH(nr::dx_gemm_ring_kernel<D>, grid, 512, R::SMEM, (hipStream_t)stream, p); break;
-      switch (dbg) { NR_DXR_CASE(1) NR_DXR_CASE(2) NR_DXR_CASE(3) NR_DXR_CASE(4) NR_DXR_CASE(7) default: NR_DXR_CASE(0) }
+  switch (dbg) { NR_DXR_CASE(1) NR_DXR_CASE(2) NR_DXR_CASE(3) NR_DXR_CASE(4) NR_DXR_CASE(7) default: NR_DXR_CASE(0) }
 #undef NR_DXR_CASE
-    } else
-      NR_LAUNCH(nr::dx_gemm_kernel<4>, (n_tok + G::TOK_WG - 1) / G::TOK_WG, 256, G::SMEM, (hipStream_t)stream, p);
-  }
   return check_launch("nr_dx_gemm");
-}
-
-// NR_TN_RING: 1 (default) = narrow outputs (M <= 256) run in tn_gemm_ring_kernel (one workgroup per CU), 0 = everything in the two-buffer kernels
-static int tn_ring() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NR_TN_RING"); v = e ? atoi(e) : 1; }
-  return v;
-}
-static int tn_slab_rows(int M) { return tn_ring() == 2 ? 128 : (gemm_waves() == 8 && M > 256 ? 8 : 4) * 32; }
-
-int nr_tn_gemm_parts(int M, int64_t n_tok) {
-  if (M <= 0 || n_tok < 0) return -1;
-  const int BM = tn_slab_rows(M);                 // narrow outputs (dpre: M = 208) always take the 128-row slabs
-  // enough workgroups for two per CU (one per CU for narrow outputs, whose partials would otherwise outweigh the operands): partitions x
-  // slabs ~ 512 / 256, partitions a multiple of 8, at least one 32-token chunk each when possible
-  const int nslab = (M + BM - 1) / BM;
-  int P = ((nslab * BM >= 512 && tn_ring() != 2 ? (BM == 128 ? 512 : 256) : 256) + nslab - 1) / nslab;     // (ring kernels: one workgroup per CU)
-  P = (P + 7) / 8 * 8;
-  const int64_t maxp = (n_tok + 31) / 32;
-  while (P > 8 && P > maxp) P -= 8;
-  return P;
-}
-
-int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream) {
-  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || n_tok < 0 || P <= 0 || (P & 7))
-    return fail(NR_ERR_BADARG, "nr_tn_gemm: bad argument");
-  if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)zeros) & 15) != 0) return fail(NR_ERR_BADARG, "nr_tn_gemm: operands must be 16-byte aligned");
-  nr::TnParams p;
-  p.G = G; p.ldg = ldg; p.M = M; p.X = X; p.zeros = zeros; p.out = out; p.n_tok = n_tok; p.P = P;
-  p.tok_per_part = ((n_tok + P - 1) / P + 31) / 32 * 32;
-  if (tn_ring() == 2 || (tn_ring() && M <= 256)) {          // NR_TN_RING=2: the 128-row ring kernel for wide outputs too (A/B)
-    using G = nr::TnRingGeom<4>;
-    p.nslab = (M + G::BM - 1) / G::BM;
-    if (allow_smem(nr::tn_gemm_ring_kernel<4>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");
-    NR_LAUNCH(nr::tn_gemm_ring_kernel<4>, (int64_t)P * p.nslab, 256, G::SMEM, (hipStream_t)stream, p);
-  } else if (gemm_waves() == 8 && M > 256) {
-    using G = nr::TnGeom<8>;
-    p.nslab = (M + G::BM - 1) / G::BM;
-    if (allow_smem(nr::tn_gemm_kernel<8>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_tn_gemm: cannot reserve LDS");
-    NR_LAUNCH(nr::tn_gemm_kernel<8>, (int64_t)P * p.nslab, 512, G::SMEM, (hipStream_t)stream, p);
-  } else {
-    using G = nr::TnGeom<4>;
-    p.nslab = (M + G::BM - 1) / G::BM;
-    NR_LAUNCH(nr::tn_gemm_kernel<4>, (int64_t)P * p.nslab, 256, G::SMEM, (hipStream_t)stream, p);
-  }
-  return check_launch("nr_tn_gemm");
 }
 
 // ---- general ring GEMMs (csrc/k_gemm.h; launch_gemm is defined above, outside the extern "C" block) -----------------------------------
@@ -576,6 +465,13 @@ int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t
   return launch_gemm<1, 4, 2, 4>(p, grid, stream, "nr_gemm_tn");
 }
 
+// The round-3 entry points of the weight-gradient GEMM (X with NR_KP columns): the same general kernel
+int nr_tn_gemm_parts(int M, int64_t n_tok) { return nr_gemm_tn_parts(M, NR_KP, n_tok); }
+int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream) {
+  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || n_tok < 0 || P <= 0 || (P & 7)) return fail(NR_ERR_BADARG, "nr_tn_gemm: bad argument");
+  return nr_gemm_tn(G, ldg, M, X, NR_KP, NR_KP, 1, zeros, out, NR_KP, n_tok, P, stream);
+}
+
 int nr_pack_conv_dgrad(const float* W, int F, int D, uint16_t* Wd2, void* stream) {
   if (!W || !Wd2 || F <= 0 || F > NR_KP || D <= 0 || D > NR_KP) return fail(NR_ERR_BADARG, "nr_pack_conv_dgrad: bad argument");
   NR_LAUNCH(nr::pack_conv_dgrad_kernel, 300, 256, 0, (hipStream_t)stream, W, F, D, Wd2);
@@ -606,7 +502,7 @@ int nr_sum_parts(const float* parts, int P, int64_t n, float* out, int accumulat
   if (!parts || !out || P <= 0 || n < 0 || (n & 3)) return fail(NR_ERR_BADARG, "nr_sum_parts: bad argument (n must be a multiple of 4)");
   if ((((uintptr_t)parts | (uintptr_t)out) & 15) != 0) return fail(NR_ERR_BADARG, "nr_sum_parts: buffers must be 16-byte aligned");
   if (n == 0) return NR_OK;
-  NR_LAUNCH(nr::sum_parts_kernel, grid_for(n / 4, 256, 4096), 256, 0, (hipStream_t)stream, parts, P, n / 4, out, accumulate);
+  NR_LAUNCH(nr::sum_parts_kernel, grid_for(n / 4, 64, 4096), 256, 4 * 64 * 16, (hipStream_t)stream, parts, P, n / 4, out, accumulate);
   return check_launch("nr_sum_parts");
 }
 
@@ -963,22 +859,9 @@ int nr_tile_rows_bf16(const uint16_t* src, int n, int K, uint16_t* dst, void* st
 }
 
 // GRU tuning knobs, read once.  NR_GRU_NB: sample tiles per wave in the forward step (default 2 from 256 samples up); NR_GRU_LDS=0:
-// register-only step kernels instead of the W_hh-tile-in-LDS ones (Hd = 900 / 450); NR_GRU_PERSIST=1: the persistent whole-sequence
-// kernels instead of one launch per step.  Off by default: measured on MI355X (LSTUR, B = 512, T = 50, A/B on one box, twice) the
-// persistent form is bit-identical but SLOWER, 6.43-6.52 vs 6.13-6.14 ms per training step: back-to-back step launches cost ~3-4 us of
-// gap each, the grid-wide barrier (write-through drain + 228 arrivals on one counter + polling) costs more than that.
+// register-only step kernels instead of the W_hh-tile-in-LDS ones (Hd = 900 / 450).
 static int gru_nb_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_NB"); v = e ? atoi(e) : 0; } return v; }
 static int gru_lds_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_LDS"); v = e ? atoi(e) : 1; } return v; }
-static int gru_persist_knob() { static int v = -1; if (v < 0) { const char* e = getenv("NR_GRU_PERSIST"); v = e ? atoi(e) : 0; } return v; }
-static int gru_cu_count() { static int v = -1; if (v < 0) v = nr::device_cu_count(); return v; }
-// the persistent kernels need the LDS-tile step form (two sample tiles per wave, Hd = 900 / 450) and every active workgroup resident at
-// once: one per CU
-static bool gru_persist_ok(int B, int Hd) {
-  const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
-  const int nb = gru_nb_knob() > 0 ? gru_nb_knob() : (B >= 256 ? 2 : 1);
-  return gru_persist_knob() == 1 && gru_lds_knob() == 1 && nb == 2 && (Hp == 29 * 32 || Hp == 15 * 32) && B > 0 &&
-         (Hg / 16) * ((B + 127) / 128) <= gru_cu_count();
-}
 
 static int gru_fwd_step_launch(const float* gi, const int32_t* gi_row, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len,
                                const uint16_t* h_in_t, uint16_t* h_out_b, uint16_t* h_out_t, const float* h_in_f, float* h_out_f, uint16_t* gates, int B,
@@ -1054,7 +937,7 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   return check_launch("nr_gru_bwd_step");
 }
 
-int nr_gru_seq_buffers(int B, int Hd, int T) { return (T > 0 && gru_persist_ok(B, Hd)) ? T + 1 : 2; }
+int nr_gru_seq_buffers(int B, int Hd, int T) { (void)B; (void)Hd; (void)T; return 2; }      // a ping-pong pair (the per-step buffers of the removed persistent form are gone)
 
 int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
                      uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream);
@@ -1071,15 +954,6 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
   if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0 || n_buf < 2) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
   const size_t ht = (size_t)ceil_to(B, 16) * Hp, hf = (size_t)B * Hp;
-  if (T > 0 && n_buf >= T + 1 && gru_persist_ok(B, Hd)) {
-    if (!gi || !Whh || !b_ih || !b_hh || !len) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
-    nr::GruFwdSeqParams q;
-    q.st.gi = gi; q.st.gi_row = nullptr; q.st.Whh = Whh; q.st.b_ih = b_ih; q.st.b_hh = b_hh; q.st.len = len; q.st.h_in_t = nullptr; q.st.h_out_b = nullptr; q.st.h_out_t = nullptr;
-    q.st.h_in_f = nullptr; q.st.h_out_f = nullptr; q.st.gates = nullptr; q.st.B = B; q.st.N = N; q.st.Hd = Hd; q.st.Hg = Hg; q.st.Hp = Hp; q.st.t = 0;
-    q.h_t = h_t2; q.H_all = H_all; q.h_f2 = h_f2; q.gates_all = gates;
-    q.n_active = (unsigned)((Hg / 16) * ((B + 127) / 128));
-    return Hp == 29 * 32 ? launch_gru_fwd_persist<29>(q, T, (hipStream_t)stream) : launch_gru_fwd_persist<15>(q, T, (hipStream_t)stream);
-  }
   for (int t = 0; t < T; ++t) {
     const int rc = nr_gru_fwd_step(gi, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, H_all ? H_all + (size_t)(t + 1) * hf : nullptr,
                                    h_t2 + ((t + 1) & 1) * ht, h_f2 + (t & 1) * hf, h_f2 + ((t + 1) & 1) * hf,
@@ -1132,16 +1006,6 @@ int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* 
     return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32), Kp = ceil_to(3 * Hg, 32);
   const size_t dt = (size_t)ceil_to(B, 16) * Kp, cf = (size_t)B * Hp, hb = (size_t)B * Hp, gb = (size_t)B * 4 * Hg, db = (size_t)B * Kp;
-  if (n_buf >= T + 1 && gru_persist_ok(B, Hd)) {
-    if (!WhhT || !len) return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
-    nr::GruBwdSeqParams q;
-    q.st.g_last = g_last; q.st.dgh_next = nullptr; q.st.carry_next = nullptr; q.st.WhhT = WhhT; q.st.gates = nullptr; q.st.h_prev_b = nullptr;
-    q.st.len = len; q.st.dgi = dgi; q.st.dgh = nullptr; q.st.dgh_t = nullptr; q.st.carry = nullptr; q.st.B = B; q.st.N = N; q.st.Hd = Hd; q.st.Hg = Hg;
-    q.st.Hp = Hp; q.st.Kp = Kp; q.st.t = 0; q.st.first = 0;
-    q.gates_all = gates; q.H_all = H_all; q.dgh_all = dgh; q.dgh_t = dgh_t2; q.carry2 = carry2; q.T = T;
-    q.n_active = (unsigned)((Hg / 16) * ((B + 127) / 128));
-    return Kp == 86 * 32 ? launch_gru_bwd_persist<86>(q, (hipStream_t)stream) : launch_gru_bwd_persist<44>(q, (hipStream_t)stream);
-  }
   int i = 0;
   for (int t = T - 1; t >= -1; --t, ++i) {
     const int first = i == 0;

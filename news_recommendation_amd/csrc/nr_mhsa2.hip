@@ -23,20 +23,14 @@ int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
 }
 
 // register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup, as 8 waves x 2 titles (28: two waves per SIMD) or
-// 4 waves x 4 titles (44: one wave per SIMD).  Measured at B = 512, A/B on one box (gpurun_out/r02i): backward 368 us (28) vs 415 us (44);
-// forward 304 us (28) vs 271 us (44).  NR_POOL2_GEOM overrides both defaults.
+// 4 waves x 4 titles (44: one wave per SIMD).  Measured at B = 512, A/B on one box (gpurun_out/r02i): backward 368 us (28) vs 415 us (44).
+// NR_POOL2_GEOM overrides the default.
 static int pool2_geom(int dflt) {
   static int v = -2;
   if (v == -2) { const char* e = getenv("NR_POOL2_GEOM"); v = e ? atoi(e) : -1; }
   return v > 0 ? v : dflt;
 }
 
-template <typename G>
-static int launch_pool2_fwd_t(const AdditiveParams& p, hipStream_t stream) {
-  if (set_max_dynamic_lds((const void*)pool2_fwd_kernel<G>, G::FWD_SMEM)) return -1;
-  NR_LAUNCH(pool2_fwd_kernel<G>, (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::FWD_SMEM, stream, p);
-  return 0;
-}
 template <typename G>
 static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
   const char* d = getenv("NR_POOL_DEBUG");         // profiling: phase switches of pool2_bwd_kernel (re-read per call)
@@ -48,10 +42,6 @@ static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
   if (set_max_dynamic_lds((const void*)pool2_bwd_kernel<G, false>, G::BWD_SMEM)) return -1;
   NR_LAUNCH((pool2_bwd_kernel<G, false>), (p.n_seq + G::PER_WG - 1) / G::PER_WG, G::THREADS, G::BWD_SMEM, stream, p, 0);
   return 0;
-}
-
-int launch_pool2_fwd(const AdditiveParams& p, hipStream_t stream) {
-  return pool2_geom(44) == 28 ? launch_pool2_fwd_t<Pool2Geom<20, 2, 8>>(p, stream) : launch_pool2_fwd_t<Pool2Geom<20, 4, 4>>(p, stream);
 }
 
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {

@@ -171,61 +171,4 @@ inline int set_max_dynamic_lds(const void* kernel, int bytes) {
 __device__ __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
 
-// ---- grid-wide barrier for persistent kernels (all ACTIVE workgroups must be co-resident: the caller launches at most one per CU) -----
-// counter: device word zeroed before the launch; the k-th barrier of the launch passes when it reaches k * n_active.
-// Coherence contract: the XCDs' L2s are not coherent with each other, and the agent-scope release / acquire fences that would make
-// plain accesses safe across the barrier (buffer_wbl2 / buffer_inv: write back and invalidate the WHOLE L2, per wave) measured ~36 us
-// per barrier on MI355X -- more than the kernel boundary they replace.  So the barrier carries no fence; data that crosses workgroups
-// between two barriers must be written with st_agent* (write-through to memory) to an address nobody has read earlier in the launch
-// (then no L2 can hold a stale copy and plain loads are safe); everything else a workgroup re-reads across the barrier must be its own.
-// The spin is bounded (~2 s of the 100 MHz wall clock): a launch that can never become co-resident (two persistent kernels of
-// different processes sharing one GPU) traps and fails the call instead of hanging the device.
-constexpr bool kGridBarrier = true;
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
-  __syncthreads();                            // every wave's stores have been issued and acknowledged (s_waitcnt vmcnt(0) precedes the barrier)
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
-    }
-  }
-  __syncthreads();
-}
-// agent-scope (write-through) stores for data exchanged between workgroups inside one launch (see grid_barrier)
-__device__ __forceinline__ void st_agent4(u16* p, u16x4 v) {
-  __hip_atomic_store((uint64_t*)p, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent1(u16* p, u16 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// host side of the barrier: number of CUs of the current device (a persistent launch must fit, one workgroup per CU), and the zeroed
-// counter word of a launch on `stream` (one word per (device, stream): sequences on different streams must not share a counter;
-// launches on one stream are ordered, so they reuse theirs).  Returns null when the device calls fail.
-inline int device_cu_count() {
-  int dev = 0;
-  hipDeviceProp_t pr;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-  return pr.multiProcessorCount;
-}
-inline unsigned* grid_barrier_word(hipStream_t stream) {
-  struct Slot { int dev; hipStream_t st; unsigned* w; };
-  static Slot slots[64];
-  static int n_slots = 0;
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  unsigned* w = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < n_slots; ++i)
-      if (slots[i].dev == dev && slots[i].st == stream) w = slots[i].w;
-    if (w == nullptr) {
-      if (n_slots == 64 || hipMalloc((void**)&w, 256) != hipSuccess) return nullptr;
-      slots[n_slots++] = Slot{dev, stream, w};
-    }
-  }
-  return hipMemsetAsync(w, 0, 4, stream) == hipSuccess ? w : nullptr;
-}
-
 }  // namespace nr

@@ -377,7 +377,6 @@ def _mm(a, b, name='gemm'):
     return _timed(name, lambda: torch.mm(a, b))
 
 
-_WGRAD_NC = int(os.environ.get('NR_WGRAD_NC', '0'))        # A/B knob: upper bound of the chunk count (0 = the measured rule below)
 
 
 def _wgrad_chunks(n, M, N):
@@ -385,7 +384,7 @@ def _wgrad_chunks(n, M, N):
     dim is cut into nc independent products.  Measured on MI355X (n = 542,720): the best nc puts ~300 output tiles of ~192 x 256
     in flight -- M=960,N=320: nc=32 (422 us vs 727 us at nc=256); M=208,N=320: nc=64 (154 us vs 210 us)."""
     tiles = ((M + 191) // 192) * ((N + 255) // 256)
-    want = _WGRAD_NC if _WGRAD_NC > 0 else max(1, 320 // tiles)
+    want = max(1, 320 // tiles)
     best = 1
     for c in (2, 4, 8, 16, 32, 64, 128, 256):
         if n % c == 0 and n // c >= 512 and c <= want:
@@ -412,30 +411,7 @@ def _wgrad_parts(a, b, name):
     return _timed(name, run)
 
 
-# NR_WGRAD_GEMM: which weight-gradient products of the NRMS encoders run in the hand-written split-K kernel nr_tn_gemm (csrc/k_proj.h:
-# transposing LDS reads, no transposed operand copies) instead of chunked hipBLASLt batched GEMMs: 0 (default) = none, 2 = the pooling layer's
-# dpre^T @ [ctx | 1] (208 output rows: the ring-buffered kernel), 1 = also the projections' dqkv^T @ [X | 1].  Measured side by side on one
-# MI355X (profiles/r03_ab_switches.txt): inside the NRMS step dWqkv 377 - 385 us hand-written vs 356 - 368 us hipBLASLt; dWa 163 vs 176 us,
-# but its 128 token partitions (one workgroup per CU) cost nr_wgrad_unpack 83 instead of 58 us: 3.74 vs 3.73 ms per step either way -- the
-# library calls stay the default here.  Both agree with the library result to 4e-7.
-_WGRAD_GEMM = int(os.environ.get('NR_WGRAD_GEMM', '0'))
-# the same for the conv text encoders: 2 (default) = the pooling weight gradient (NAML 10.33 - 10.36 vs 10.41 ms, LSTUR 5.86 vs 5.88 ms: pass n),
-# 1 = also the three tap gradients (NAML 11.29 ms vs 10.34 ms with the library, r03i), 0 = none
-_WGRAD_GEMM_CONV = int(os.environ.get('NR_WGRAD_GEMM_CONV', '2'))
 _zeros16 = {}
-
-
-def _wgrad_parts_hand(G, M, X, name):
-    """G^T @ X for bf16 (int16-typed) G [n, ldg >= M], X [n, KP]: fp32 partial products [P, M, KP] over P token partitions."""
-    lib = _lib()
-    n, ldg = G.shape
-    P = lib.nr_tn_gemm_parts(M, n)
-    out = torch.empty(P, M, NR_KP, dtype=torch.float32, device=G.device)
-    z = _zeros16.get(G.device)
-    if z is None:
-        z = _zeros16[G.device] = torch.zeros(64, dtype=_BF16_AS_I16, device=G.device)
-    _call(name, lib.nr_tn_gemm, _ptr(G), ldg, M, _ptr(X), _ptr(z), _ptr(out), n, P, _stream())
-    return out
 
 
 # NR_GEMM_HAND: which of the former library GEMMs run in the general hand-written ring kernels of csrc/k_gemm.h (bit mask; default all):
@@ -517,56 +493,8 @@ _FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
 # being read back by nr_additive_fwd); 0 = two launches.  Same results bit for bit.
 _FWD_POOL = int(os.environ.get('NR_FWD_POOL', '1'))
 
-# NR_DX_GEMM: 1 (default) = the input gradient dX = dqkv @ [Wq; Wk; Wv] runs in the hand-written kernel (nr_dx_gemm, csrc/k_proj.h); 0 = in
-# hipBLASLt through torch.  Measured side by side on one MI355X (profiles/r03_ab_switches.txt): 365 vs 462 us inside the NRMS step at B = 512,
-# bit-identical results
-_DX_GEMM = int(os.environ.get('NR_DX_GEMM', '1'))
-
 _ws = {}
 _side = {}
-_wg_side = {}
-# NR_WGRAD_OVERLAP=1 puts the weight-gradient GEMMs on a second stream (see side_wgrad).  Measured on MI355X at B = 512 (NRMS 5.51 vs
-# 5.55 ms, LSTUR 6.15 vs 6.10, NAML 11.07 vs 11.06 ms per step, A/B on one box): no gain -- each of these kernels fills the GPU on its own
-# -- and in data-parallel runs the GEMMs are more useful AFTER the embedding scatter, where they cover the table all-reduce.  Off by default.
-_WGRAD_OVERLAP = os.environ.get('NR_WGRAD_OVERLAP', '0') == '1'
-
-
-class side_wgrad:
-    """Weight-gradient GEMMs on a second HIP stream.  In the backward of an encoder the chain that matters for latency is
-    pooling backward -> attention backward -> dX GEMM -> embedding scatter (-> gradient exchange); the weight gradients
-    (dpre^T @ ctx, dqkv^T @ X: plain library GEMMs, MFMA bound) only have to be ready when the backward returns.  Issued on a side
-    stream they share the GPU with the VALU / bandwidth-bound kernels of the chain instead of extending it.
-
-        sw = side_wgrad(device)
-        dWa = sw.run(lambda: _wgrad(...))      # starts after everything enqueued on the current stream so far
-        ...                                    # more work on the current stream
-        sw.join(dWa, ...)                      # current stream waits; tensors handed over to it
-    """
-
-    def __init__(self, device):
-        self.cur = torch.cuda.current_stream(device)
-        self.st = None
-        if _WGRAD_OVERLAP:
-            self.st = _wg_side.get(device)
-            if self.st is None:
-                self.st = _wg_side[device] = torch.cuda.Stream(device=device)
-
-    def run(self, fn):
-        if self.st is None:
-            return fn()
-        self.st.wait_stream(self.cur)
-        with torch.cuda.stream(self.st):
-            return fn()
-
-    def join(self, *tensors):
-        if self.st is None:
-            return
-        self.cur.wait_stream(self.st)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.cur)
-
-
 def grad_target(param):
     """Where a large table gradient goes.  Default: a fresh zeroed tensor handed back to autograd (which then adds it into
     ``param.grad``: for the 85 MB word table that is a 85 MB fill plus a 255 MB read-add-write per step, 180 / 540 MB for LSTUR's user
@@ -586,15 +514,6 @@ def table_grad_ready(param):
     cb = getattr(param, '_nr_grad_ready', None)
     if cb is not None:
         cb()
-
-
-def pack_qkv_t(Wq, bq, Wk, bk, Wv, bv):
-    """[KP, 960] row-major transpose of the packed QKV operand for the library GEMM of the input gradient dX = dqkv @ W (the 'linear'
-    operand form is the fastest hipBLASLt path for it); cached on the same parameter state as pack_qkv."""
-    def build():
-        Wp, _ = pack_qkv(Wq, bq, Wk, bk, Wv, bv)
-        return _bf16(untile(Wp, 3 * NR_NP, NR_KP)).t().contiguous()
-    return _packed('qkv_t', (Wq, bq, Wk, bk, Wv, bv), build)
 
 
 def sort_ids_async(ids, num_rows=None):
@@ -713,7 +632,7 @@ class _EncoderFn(torch.autograd.Function):
         WpT = None
         pooled = False
         if need_grad:
-            WpT = pack_qkv_dx(Wq, Wk, Wv) if _DX_GEMM else pack_qkv_t(Wq, bq, Wk, bk, Wv, bv)
+            WpT = pack_qkv_dx(Wq, Wk, Wv)
         if split:
             qs = torch.empty(n_seq * NR_QKV_HM_SEQ, dtype=_BF16_AS_I16, device=dev)      # head-major Q | K | V^T
             ks = vts = None
@@ -781,15 +700,13 @@ class _EncoderFn(torch.autograd.Function):
         dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
         _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                                 _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
-        sw = side_wgrad(dev)
-        # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1], on the side stream while the attention backward runs
+        # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1]: split-K ring kernel (csrc/k_gemm.h), partials [P, QP, KP]; column D =
+        # bias gradient (ctx[:, D] == 1).  NR_GEMM_HAND bits off: the same products as chunked hipBLASLt batched GEMMs (A/B only)
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
         if _GEMM_HAND & 16:
-            dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')   # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
-        elif _WGRAD_GEMM in (1, 2):
-            dWa_parts = _wgrad_parts_hand(dpre, NR_QP, cbuf, f'nr_tn_gemm_dWa[S={S}]')    # [P, QP, KP]; column D = bias gradient (ctx[:, D] == 1)
+            dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')
         else:
-            dWa_parts = sw.run(lambda: _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]'))
+            dWa_parts = _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]')
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         if split:
@@ -799,21 +716,16 @@ class _EncoderFn(torch.autograd.Function):
             _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                   _ptr(key_len), n_seq, S, p_drop, seed, _stream())
         dqkv_b = _bf16(dqkv)
-        # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1], on the side stream while dX and the scatter run
+        # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1]: 256 x 320 tiles of the ring kernel, partials [P, 960, KP]
         Xb_b = _bf16(Xb)
         if _GEMM_HAND & 4:
-            dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')   # [P, 960, KP]: 256 x 320 tiles of the ring kernel (k_gemm.h)
-        elif _WGRAD_GEMM == 1:
-            dW_parts = _wgrad_parts_hand(dqkv, NR_LDG, Xb, f'nr_tn_gemm_dWqkv[S={S}]')     # [P, 960, KP]
+            dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')
         else:
-            dW_parts = sw.run(lambda: _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]'))
-        # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv], then the embedding scatter.  The table gradient is the large message of the
+            dW_parts = _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]')
+        # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] (nr_dx_gemm), then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
-        if _DX_GEMM:
-            dX = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
-            _call(f'nr_dx_gemm[S={S}]', lib.nr_dx_gemm, _ptr(dqkv), _ptr(WpT), _ptr(dX), ntok, _stream())
-        else:
-            dX = _timed(f'gemm_dX[S={S}]', lambda: torch.nn.functional.linear(dqkv_b, WpT))       # [ntok, KP] bf16
+        dX = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
+        _call(f'nr_dx_gemm[S={S}]', lib.nr_dx_gemm, _ptr(dqkv), _ptr(WpT), _ptr(dX), ntok, _stream())
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:
@@ -826,7 +738,6 @@ class _EncoderFn(torch.autograd.Function):
                 table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
-        sw.join(dWa_parts, dW_parts)
         # ---- the nine weight gradients.  A trainer with persistent gradient buffers: summed over the chunks and accumulated there in one
         # launch; plain autograd: chunk sums, then slices of the packed geometry that AccumulateGrad adds into .grad one by one ----------
         dst = inplace_grads(ctx.wparams) if all(ctx.needs_input_grad[3:12]) else None

@@ -101,10 +101,9 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None, dy=None, p_drop=0.0):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
-    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.  With ``sw`` (ops.side_wgrad) the
-    weight-gradient GEMM runs on the side stream and the CALLER joins it (before the shared dpre workspace is written again).
+    Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.
     With ``dy`` (seqpad buffer of a conv text encoder whose activations ctx_b are) the gradient goes on through the relu / dropout stage
     into dy in the same call (nr_additive_bwd_act: fused into the pooling kernel's epilogue where the register-resident kernels run);
     dgemm is then only scratch."""
@@ -122,16 +121,10 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, sw=None, dy
         _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_act, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
-    dpre_b, ctx_bb = _bf16(dpre), _bf16(ctx_b)
-    if ops._GEMM_HAND & 16:                        # general ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
+    if ops._GEMM_HAND & 16:                        # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
         dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
-    elif ops._WGRAD_GEMM_CONV in (1, 2):          # hand-written split-K kernel (nr_tn_gemm): partial products per token partition, summed here
-        dWa_ext = ops._wgrad_parts_hand(dpre, NR_QP, ctx_b, f'nr_tn_gemm_dWa[{tag}]').sum(dim=0)
-    elif sw is not None:
-        dWa_ext = sw.run(lambda: ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]'))
-        sw.pending.append(dWa_ext)
-    else:
-        dWa_ext = ops._wgrad(dpre_b, ctx_bb, f'gemm_dWa[{tag}]')
+    else:                                          # A/B only: chunked hipBLASLt
+        dWa_ext = ops._wgrad(_bf16(dpre), _bf16(ctx_b), f'gemm_dWa[{tag}]')
     return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
 
 
@@ -141,30 +134,22 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     lib = _lib()
     n_seq, S = st.n_seq, st.S
     dev = st.act.device
-    # additive backward needs contiguous [n_seq][D] gradients.  The two weight-gradient GEMMs of this level (pooling, conv taps) go to the
-    # side stream: they overlap with the activation backward and the data-gradient conv, and are joined before this function returns
-    sw = ops.side_wgrad(dev)
-    sw.pending = []
     if g_stride != NR_D:
         raise ValueError("text_bwd: the pooled-vector gradient must be contiguous [n_seq, D]")
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
-    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, sw, dy=dy, p_drop=p)
-    dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
-    xs_b = _bf16(st.xstore)
+    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p)
 
     def wgrad():
-        taps = []
         if ops._GEMM_HAND & 2:
             # ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap shift is a row offset
             # of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three taps
             both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, st.xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
             return [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
-        if ops._WGRAD_GEMM_CONV == 1:     # hand-written split-K kernel: the tap shift is a row offset of the X operand
-            for w in range(3):
-                taps.append(ops._wgrad_parts_hand(dy, NR_KP, st.xstore[w:w + ra], f'nr_tn_gemm_dWconv[{tag}]').sum(dim=0))
-            return taps
+        taps = []                   # A/B only: three chunked hipBLASLt batched GEMMs on shifted views
+        dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
+        xs_b = _bf16(st.xstore)
         for w in range(3):          # dW[:, w, :] = dY^T @ X[row + w - 1]: the tap shift is a row offset into the seqpad store
             xw = xs_b[w:w + ra].view(nc, ra // nc, NR_KP)
             try:
@@ -172,12 +157,11 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
             except (TypeError, RuntimeError):
                 taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
         return taps
-    taps = sw.run(lambda: _timed(f'gemm_dWconv[{tag}]', wgrad))
+    taps = _timed(f'gemm_dWconv[{tag}]', wgrad)
     if st.Wd2 is not None:       # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
         _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
     else:
         _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
-    sw.join(*taps, *sw.pending)
     d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
     d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
     return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv

@@ -312,13 +312,4 @@ inline int set_max_dynamic_lds(const void*, int) { return 0; }
 __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
 
-// persistent kernels: the emulator runs one workgroup at a time, so there is no grid-wide barrier; host code checks kGridBarrier and
-// issues such kernels one step per launch instead (the step loop inside the kernel then never reaches the barrier)
-constexpr bool kGridBarrier = false;
-inline void grid_barrier(unsigned*, unsigned) { fprintf(stderr, "nr_emu: grid_barrier reached\n"); abort(); }
-__forceinline__ void st_agent4(u16* p, u16x4 v) { *(u16x4*)p = v; }
-__forceinline__ void st_agent1(u16* p, u16 v) { *p = v; }
-inline int device_cu_count() { return 1 << 20; }
-inline unsigned* grid_barrier_word(hipStream_t) { static unsigned w; w = 0; return &w; }
-
 }  // namespace nr

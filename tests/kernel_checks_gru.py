@@ -91,9 +91,9 @@ def check_gru(be, B=5, N=4, Hd=900, I=900, seed=0, lens=None):
     assert np.array_equal(be.np(hf2_d)[T % 2], be.np(hf[T % 2]))
     assert all(np.array_equal(be.np(Hs_d)[t], be.np(H_all[t])) for t in range(T + 1))
     assert all(np.array_equal(be.np(gs_d)[t], be.np(gates[t])) for t in range(T))
-    # ... and with one tile-order buffer per step (nr_gru_fwd_seq_n): the form that runs as ONE persistent launch when the shape allows it
+    # ... and through the n-buffer entry point (nr_gru_fwd_seq_n; n_buf = 2 since the persistent form was removed: the ping-pong pair)
     nbuf = be.lib.nr_gru_seq_buffers(B, Hd, T)
-    assert nbuf in (2, T + 1)
+    assert nbuf == 2
     htn = np.zeros((nbuf, B16, Hp), dtype=np.uint16)
     htn_d = be.dev(htn)
     ck(be, be.lib.nr_tile_rows_bf16(be.ptr(H_all[0]), B, Hp, be.ptr(htn_d), be.stream))

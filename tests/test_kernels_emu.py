@@ -130,33 +130,21 @@ def test_gru_rows_and_gate(be): kcg.check_gru_rows(be, B=9, N=4, R=7, Hd=48); kc
 def test_gru_lds_variant():
     """NR_GRU_LDS=1: the W_hh / W_hh^T tile staged in LDS and two sample tiles per wave (experimental knob) against the same oracle."""
     import subprocess, sys, os
-    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2', NR_GRU_PERSIST='1')     # + the persistent kernels, one step per launch here
-    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_gru as k; be = EmuBackend(); assert be.lib.nr_gru_seq_buffers(37, 900, 3) == 4; "
+    env = dict(os.environ, NR_GRU_LDS='1', NR_GRU_NB='2')
+    code = ("from tests.backends import EmuBackend; from tests import kernel_checks_gru as k; be = EmuBackend(); assert be.lib.nr_gru_seq_buffers(37, 900, 3) == 2; "
             "k.check_gru(be, B=37, N=3, seed=4); k.check_gru(be, B=5, N=4, Hd=450, I=900, seed=5)")
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-
-
-def test_pool2_fwd_variant():
-    """NR_POOL2_FWD=1: the register-resident pooling forward of csrc/k_pool2.h (the backward of that file is the default and is
-    covered by test_additive_bwd_s20) against the same oracle; knobs are read once per process, hence the subprocess."""
-    import subprocess, sys, os
-    env = dict(os.environ, NR_POOL2_FWD='1')
-    code = ("from tests.backends import EmuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = EmuBackend(); "
-            "k.check_additive(be, S=20, n_seq=6); k.check_additive(be, S=20, n_seq=19); kc.check_additive_ex(be, S=20, n_seq=5); "
-            "k.check_additive_valid(be, S=20, n_seq=5, valid=7)")
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize('geom', ['28', '44'])
 def test_pool2_geometries(geom):
-    """Both instantiations of csrc/k_pool2.h, forward and backward: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
+    """Both instantiations of the pooling backward of csrc/k_pool2.h: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
     backward) and 4 waves x 4 titles (one wave per SIMD)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NR_POOL2_GEOM=geom, NR_POOL2_FWD='1')
+    env = dict(os.environ, NR_POOL2_GEOM=geom)
     code = ("from tests.backends import EmuBackend as B; from tests import kernel_checks as k, kernel_checks_conv as kc; be = B(); "
             "k.check_additive(be, S=20, n_seq=6); k.check_additive_valid(be, S=20, n_seq=5, valid=7); kc.check_additive_ex(be, S=20, n_seq=5); "
             "k.check_additive_bwd(be, S=20, n_seq=6); k.check_additive_bwd(be, S=20, n_seq=17)")

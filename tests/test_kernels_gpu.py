@@ -114,19 +114,11 @@ def test_gru_lds_default_large_batch(be):
     kcg.check_gru(be, B=270, N=8, Hd=450, I=900, seed=4)
 
 
-def test_gru_persistent_full_grid():
-    """NR_GRU_PERSIST=1, B = 512: nr_gru_fwd_seq_n / nr_gru_bwd_seq_n run as ONE persistent launch each (57 unit tiles x 4 sample groups =
-    228 workgroups, one per CU, W_hh tile resident in LDS, grid-wide barrier between the steps) and must reproduce the per-step
-    launches bit for bit -- check_gru compares the two forms; a stale read across the barrier would show up there.  (Knobs are read
-    once per process, hence the subprocess.)"""
-    import subprocess, sys, os
-    env = dict(os.environ, NR_GRU_PERSIST='1')
-    code = ("from tests.backends import GpuBackend; from tests import kernel_checks_gru as k; be = GpuBackend(); "
-            "assert be.lib.nr_gru_seq_buffers(512, 900, 12) == 13 and be.lib.nr_gru_seq_buffers(100, 900, 12) == 2; "
-            "k.check_gru(be, B=512, N=12, Hd=900, I=900, seed=6); "
-            "k.check_gru(be, B=512, N=9, Hd=450, I=900, seed=7, lens=[1 + (7 * i) % 9 for i in range(512)])")
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+def test_gru_full_grid_batch_512(be):
+    """B = 512 (57 unit tiles x 4 sample groups = 228 workgroups, one per CU): the whole-sweep entry points nr_gru_fwd_seq_n / nr_gru_bwd_seq_n
+    against the per-step launches, bit for bit, with ragged lengths."""
+    kcg.check_gru(be, B=512, N=12, Hd=900, I=900, seed=6)
+    kcg.check_gru(be, B=512, N=9, Hd=450, I=900, seed=7, lens=[1 + (7 * i) % 9 for i in range(512)])
 
 
 def test_gru_register_only_variant():
@@ -143,28 +135,14 @@ def test_gru_register_only_variant():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-def test_pool2_fwd_variant():
-    """NR_POOL2_FWD=1: the register-resident pooling forward (csrc/k_pool2.h; off by default, its backward is the default)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, NR_POOL2_FWD='1')
-    code = ("from tests.backends import GpuBackend; from tests import kernel_checks as k, kernel_checks_conv as kc; be = GpuBackend(); "
-            "k.check_additive(be, S=20, n_seq=1027); k.check_additive(be, S=20, n_seq=3); kc.check_additive_ex(be, S=20, n_seq=131); "
-            "k.check_additive_valid(be, S=20, n_seq=515, valid=7)")
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-
-
 @pytest.mark.parametrize('geom', ['28', '44'])
 def test_pool2_geometries(geom):
-    """Both instantiations of csrc/k_pool2.h, forward and backward: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
+    """Both instantiations of the pooling backward of csrc/k_pool2.h: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
     backward) and 4 waves x 4 titles (one wave per SIMD)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NR_POOL2_GEOM=geom, NR_POOL2_FWD='1')
+    env = dict(os.environ, NR_POOL2_GEOM=geom)
     code = ("from tests.backends import GpuBackend as B; from tests import kernel_checks as k, kernel_checks_conv as kc; be = B(); "
             "k.check_additive(be, S=20, n_seq=1027); k.check_additive_valid(be, S=20, n_seq=5, valid=7); kc.check_additive_ex(be, S=20, n_seq=5); "
             "k.check_additive_bwd(be, S=20, n_seq=1027); k.check_additive_bwd(be, S=20, n_seq=17)")
