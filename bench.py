@@ -510,12 +510,12 @@ def kernel_source_hash():
 
 
 def gather_source_hash():
-    """Hash of the sources of the stand-alone gather probe only (profiles/gather_traffic.json stays valid while other kernels change)."""
-    h = hashlib.sha256()
-    for f in ('k_misc.h', 'nr_common.h', 'nr_prims.h'):
-        with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Hash of the stand-alone gather probe's kernel source only (the text of gather_rows_kernel in csrc/k_misc.h): profiles/gather_traffic.json
+    stays valid while other kernels of that file change."""
+    with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', 'k_misc.h')) as fh:
+        src = fh.read()
+    a = src.index('void gather_rows_kernel(')
+    return hashlib.sha256(src[a:src.index('\n}\n', a)].encode()).hexdigest()[:16]
 
 
 def main():

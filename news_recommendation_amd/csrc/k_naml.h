@@ -41,16 +41,24 @@ __global__ __launch_bounds__(256) void element_table_bwd_kernel(const float* __r
       const int f = rem / dcat, k = rem - f * dcat;
       const float* Ew = E + (size_t)which * ncat * F_;
       const float* dEw = dE + (size_t)which * ncat * F_;
-      float a = 0.0f;
-      for (int c = 0; c < ncat; ++c) a += (Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f) * emb[(size_t)c * dcat + k];
-      dW[i] = a;
+      // four independent partial sums: a single accumulator made this a chain of ncat (275) dependent load -> FMA round trips per thread
+      // (236 us per NAML step for 0.1 GFLOP); fixed combination order -> deterministic
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      auto term = [&](int c) { return (Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f) * emb[(size_t)c * dcat + k]; };
+      int c = 0;
+      for (; c + 4 <= ncat; c += 4) { a0 += term(c); a1 += term(c + 1); a2 += term(c + 2); a3 += term(c + 3); }
+      for (; c < ncat; ++c) a0 += term(c);
+      dW[i] = (a0 + a1) + (a2 + a3);
     } else if (i < nW + nb) {
       const int j = i - nW, which = j / F_, f = j - which * F_;
       const float* Ew = E + (size_t)which * ncat * F_;
       const float* dEw = dE + (size_t)which * ncat * F_;
-      float a = 0.0f;
-      for (int c = 0; c < ncat; ++c) a += Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f;
-      db[j] = a;
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      auto term = [&](int c) { return Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f; };
+      int c = 0;
+      for (; c + 4 <= ncat; c += 4) { a0 += term(c); a1 += term(c + 1); a2 += term(c + 2); a3 += term(c + 3); }
+      for (; c < ncat; ++c) a0 += term(c);
+      db[j] = (a0 + a1) + (a2 + a3);
     } else {
       const int j = i - nW - nb, c = j / dcat, k = j - c * dcat;
       float a = 0.0f;
@@ -59,7 +67,12 @@ __global__ __launch_bounds__(256) void element_table_bwd_kernel(const float* __r
           const float* Ew = E + ((size_t)which * ncat + c) * F_;
           const float* dEw = dE + ((size_t)which * ncat + c) * F_;
           const float* W = which ? W1 : W0;
-          for (int f = 0; f < F_; ++f) a += (Ew[f] > 0.0f ? dEw[f] : 0.0f) * W[(size_t)f * dcat + k];
+          float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+          auto term = [&](int f) { return (Ew[f] > 0.0f ? dEw[f] : 0.0f) * W[(size_t)f * dcat + k]; };
+          int f = 0;
+          for (; f + 4 <= F_; f += 4) { b0 += term(f); b1 += term(f + 1); b2 += term(f + 2); b3 += term(f + 3); }
+          for (; f < F_; ++f) b0 += term(f);
+          a += (b0 + b1) + (b2 + b3);
         }
       }
       demb[j] = a;
