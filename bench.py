@@ -503,7 +503,7 @@ def gather_point(lib, table, ids, device):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_proj.h', 'k_pool2.h', 'k_misc.h', 'nr_common.h'):
+    for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_proj.h', 'k_gemm.h', 'k_pool2.h', 'k_misc.h', 'k_conv.h', 'k_gru.h', 'nr_common.h'):
         with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -723,6 +723,15 @@ def main():
             roofline["traffic_source"] = tr["source"]
         elif tr is not None:
             roofline["traffic_note"] = "profiles/traffic.json entry is for other kernel sources / another workload: not reported"
+    except (OSError, ValueError):
+        pass
+    # HBM traffic of the WHOLE step (rocprofv3 PMC over an eager run of the same workload: tools/pmc_step_traffic.py), same keying
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'step_traffic.json')) as f:
+            stt = json.load(f).get(f"{args.model}_{shape}")
+        if stt is not None and stt.get("source_hash") == kernel_source_hash():
+            roofline["traffic_total_per_step"] = stt["bytes_per_step"]
+            roofline["traffic_top_kernels"] = stt["top"]
     except (OSError, ValueError):
         pass
     # MFMA-utilisation counters (north_star): SQ_VALU_MFMA_BUSY_CYCLES of the committed rocprofv3 --pmc passes, same keying (tools/pmc_sq.py)

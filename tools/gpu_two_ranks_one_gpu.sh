@@ -4,8 +4,7 @@
 # scaling measurements -- both ranks share one GPU and the exchange goes through host memory.
 set -u
 mkdir -p gpurun_out
-# NR_GRU_PERSIST=0: two processes on one GPU must not both run persistent (grid-barrier) kernels -- neither might become fully resident
-export NR_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 NR_GRU_PERSIST=0
+export NR_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 for m in NRMS LSTUR; do
   timeout 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
       bench.py --gpus 2 --steps 10 --warmup 3 --model $m > gpurun_out/two_ranks_$m.log 2>&1
