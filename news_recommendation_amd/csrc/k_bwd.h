@@ -65,7 +65,6 @@ struct AttnBwdParams {
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
   int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
   int debug;             // profiling only (NR_ATTNB_DEBUG, DBG instantiation): 1 skip the global loads, 4 skip the dqkv stores
-  int raw_b3;            // TILE form: 1 = the barrier behind a sequence's write-out does not drain the stores (see the kernel)
   int hm;                // 1: q_save is the head-major [n_seq][H][3][S][DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V of a pair, each
                          // [token][d] row-major, are 2,400 contiguous bytes (k_save / vt_save unused)
 };
@@ -441,10 +440,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
           if (idx < S * (LDG / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + r * Gm::TROW + pc * 16);
         }
       }
-      // The tile may be overwritten once every wave has READ its pieces (LDS -> registers: lgkmcnt); the 38 KB of global stores can stay in
-      // flight into the next sequence.  __syncthreads() would also drain them (its fence waits vmcnt(0)): ~1 us per sequence with all four waves
-      // idle.  (The dctx rows staged for the next sequence were waited for by the __syncthreads() in front of the write-out.)
-      if (p.raw_b3) { NR_WAIT_LGKMCNT(0); NR_BARRIER_RAW(); } else __syncthreads();
+      __syncthreads();
     }
     if (TILE) {
       if (++rnd == Gm::ROUNDS) { rnd = 0; seq_t += gridDim.x; }

@@ -306,7 +306,6 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm; p.debug = 0;
   // head-major saves: a pair's operands are contiguous, nothing is shared between the heads of a token row except the dqkv row that is written
   { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
-  { static int rb = -1; if (rb < 0) { const char* e = getenv("NR_ATTN_RAWB"); rb = e ? atoi(e) != 0 : 0; } p.raw_b3 = rb; }      // A/B knob (round 4)
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
   // grid (used by the tests to force many pairs per wave on small inputs).
