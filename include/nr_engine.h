@@ -277,6 +277,19 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
                         uint16_t* dpre, float* dq_part, const uint16_t* WaT, uint16_t* dctx_scratch, uint16_t* dy_pad, float p_drop,
                         int64_t n_seq, int S, void* stream);
 
+/* The pooling backward over a FLAT token stream (csrc/k_pool3.h; autograd of additive.py:27-53): every output of nr_additive_bwd_ex /
+ * nr_additive_bwd_act for ANY sequence length S >= 2 from one persistent kernel.  The sum inside the softmax backward,
+ * sum_s w[s] (g_out . x[s]), equals g_out[seq] . y[seq] with y the pooled vector of the FORWARD (nr_additive_fwd*'s `out`: f32 rows of stride
+ * y_stride), so token rows are independent and are dealt to waves 48 at a time regardless of sequence boundaries.  tot: f32 [n_seq]
+ * scratch (receives g_out . y).  dq_part: f32 [nr_additive_bwd_flat_grid(n_seq * S)][NR_QP] partial rows.  Exactly one of, or neither of,
+ * dctx (bf16 [n_seq*S][NR_KP] = dpre @ Wa, columns < D written) and dy_pad (the fused activation gradient of nr_additive_bwd_act, scaled by
+ * 1 / (1 - p_drop)) may be given; with neither the call stops at dpre / dq.  Needs no Wa^T operand: the kernel reads Wa through LDS
+ * transposing reads. */
+int64_t nr_additive_bwd_flat_grid(int64_t n_tok);
+int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
+                         const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
+                         float p_drop, int64_t n_seq, int S, void* stream);
+
 /* nr_additive_fwd with strided outputs: out f32 rows of stride out_stride (may be NULL) and/or out_b, a bf16 copy in the
  * ctx layout (row i at out_b + i*out_b_stride: cols 0..D-1, col D = 1.0, rest 0) that can feed another pooling level
  * directly (NAML final_attention over the 4 views, news_encoder.py:108-114; NAML user encoder, user_encoder.py:18). */

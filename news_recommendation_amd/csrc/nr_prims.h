@@ -15,6 +15,8 @@
 
 // one wave per SIMD: the whole 512-entry register file for a register-resident kernel
 #define NR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// makes a 32-bit per-lane value opaque to the optimiser at this point: it is recomputed here instead of being hoisted out of the enclosing loop
+#define NR_OPAQUE(x) asm volatile("" : "+v"(x))
 #define NR_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 // async global -> LDS copy of 16 B per lane (global_load_lds_dwordx4): lane i's 16 B land at lds_base + 16 i (wave-uniform base,
@@ -169,6 +171,18 @@ inline int set_max_dynamic_lds(const void* kernel, int bytes) {
 }
 
 __device__ __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+// compute units of the current device: the grid of the persistent kernels (one workgroup per CU)
+inline int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
 
 
 }  // namespace nr

@@ -467,6 +467,28 @@ def _wgrad(a, b, name):
     return parts[0] if parts.shape[0] == 1 else parts.sum(dim=0)
 
 
+# NR_POOL_FLAT: 1 (default) = the pooling backward over the flat token stream (csrc/k_pool3.h: persistent kernel, Wa resident in LDS, any
+# sequence length); 0 = the sequence-shaped kernels of rounds 1-3 (A/B only)
+_POOL_FLAT = os.environ.get('NR_POOL_FLAT', '1') == '1'
+
+
+def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, want_dctx=True, dy=None, p_drop=0.0):
+    """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
+    y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused
+    activation gradient goes there instead of dgemm."""
+    lib = _lib()
+    dev = ctx_b.device
+    ntok = n_seq * S
+    nwg = lib.nr_additive_bwd_flat_grid(ntok)
+    dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+    dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+    tot = _workspace('pool_tot', (n_seq,), torch.float32, dev)
+    dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev) if (want_dctx and dy is None) else None
+    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), y_ptr, y_stride,
+          _ptr(tot), _ptr(dpre), _ptr(dq_part), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
+    return dpre, dq_part, dgemm
+
+
 _WGRAD_UNPACK = os.environ.get('NR_WGRAD_UNPACK', '1') == '1'       # A/B knob: 0 = hand the nine weight gradients to autograd
 
 
@@ -628,7 +650,7 @@ class _EncoderFn(torch.autograd.Function):
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
-        WaT = pack_additive_t(Wa) if need_grad else None
+        WaT = pack_additive_t(Wa) if (need_grad and not _POOL_FLAT) else None
         WpT = None
         pooled = False
         if need_grad:
@@ -678,7 +700,7 @@ class _EncoderFn(torch.autograd.Function):
             _call(f'nr_additive_fwd[S={S}]', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw),
                   n_seq, S, valid, _stream())
         if need_grad:
-            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len)
+            ctx.save_for_backward(ids_c, table if gather else None, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, xb, WaT, key_len, out)
             ctx.meta = (S, p_drop, seed, n_seq, Wa.shape[0], gather, split)
             ctx.table_param = table                 # the caller's tensor object (the nn.Parameter): see grad_target()
             ctx.wparams = (Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv)        # likewise: inplace_grads()
@@ -688,18 +710,22 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT, key_len = ctx.saved_tensors
+        ids, table, xd, cbuf, qs, ks, vts, aw, WpT, Wap, bap, qvp, Xb, WaT, key_len, y = ctx.saved_tensors
         S, p_drop, seed, n_seq, qdim, gather, split = ctx.meta
         dev = cbuf.device
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
         # ---- additive attention backward: dpre (kernel), then two plain GEMMs ---------------------------------
-        nwg = lib.nr_additive_bwd_grid(n_seq, S)
-        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
-        _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
-                                _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
+        if _POOL_FLAT:
+            dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, f'S={S}')
+            nwg = dq_part.shape[0]
+        else:
+            nwg = lib.nr_additive_bwd_grid(n_seq, S)
+            dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+            dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+            dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
+            _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
+                  _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1]: split-K ring kernel (csrc/k_gemm.h), partials [P, QP, KP]; column D =
         # bias gradient (ctx[:, D] == 1).  NR_GEMM_HAND bits off: the same products as chunked hipBLASLt batched GEMMs (A/B only)
         dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
@@ -945,32 +971,39 @@ class _AdditiveFn(torch.autograd.Function):
         aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
         _call('nr_additive_fwd', lib.nr_additive_fwd_v, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0, _ptr(aw), n_seq, S,
               valid, _stream())
-        ctx.save_for_backward(cbuf, aw, Wap, bap, qvp)
+        ctx.save_for_backward(cbuf, aw, Wap, bap, qvp, out)
         ctx.qdim = Wa.shape[0]
-        ctx.WaT = pack_additive_t(Wa) if _GEMM_HAND else None
+        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not _POOL_FLAT) else None
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib()
-        cbuf, aw, Wap, bap, qvp = ctx.saved_tensors
+        cbuf, aw, Wap, bap, qvp, y = ctx.saved_tensors
         n_seq, S = aw.shape
         dev = cbuf.device
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
-        nwg = lib.nr_additive_bwd_grid(n_seq, S)
-        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
         qdim = ctx.qdim
+        if not _POOL_FLAT:
+            nwg = lib.nr_additive_bwd_grid(n_seq, S)
+            dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+            dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
         if _GEMM_HAND:          # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
-            dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
-            _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
-                  _ptr(ctx.WaT), _ptr(dgemm), n_seq, S, _stream())
+            if _POOL_FLAT:
+                dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense')
+            else:
+                dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
+                _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
+                      _ptr(ctx.WaT), _ptr(dgemm), n_seq, S, _stream())
             dx = torch.empty(n_seq, S, NR_D, dtype=torch.float32, device=dev)
             _call('nr_additive_dx', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dx), n_seq, S, 0, _stream())
             dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
         else:
-            _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
+            if _POOL_FLAT:
+                dpre, dq_part, _ = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense', want_dctx=False)
+            else:
+                _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
             dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
             dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
         return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim], None

@@ -56,7 +56,7 @@ def _seqpad_alloc(n_seq, S):
 
 class _TextState:
     """What one text encoder keeps between forward and backward."""
-    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset')
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset', 'y', 'y_ptr', 'y_stride')
 
 
 def pad_text(ids, what):
@@ -66,7 +66,7 @@ def pad_text(ids, what):
     return (torch.nn.functional.pad(ids, (0, S - L)) if S != L else ids).contiguous(), L
 
 
-def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag, valid=None):
+def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_grad, out, out_stride, out_b, out_b_stride, tag, valid=None, y_keep=None):
     """gather -> dropout -> conv3 -> relu -> dropout -> additive pooling for ids int64 [n_seq, S] on the GPU.
     Pooled vectors go to `out` (f32 rows of stride out_stride, may be None) and/or `out_b` (bf16 ctx rows).  valid (<= S): real text
     length when the ids were zero-padded (pad_text): padded positions are zero vectors for the convolution and outside the pooling."""
@@ -81,7 +81,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
     st.Wd2 = pack_conv_dgrad(conv_w) if (need_grad and ops._GEMM_HAND & 32) else None
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
-    st.WaT = ops.pack_additive_t(Wa) if need_grad else None
+    st.WaT = ops.pack_additive_t(Wa) if (need_grad and not ops._POOL_FLAT) else None
     st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
     xs_ptr = None
     st.xstore = None
@@ -96,12 +96,24 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd_v, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
           n_seq, S, valid, p, seed, tok_offset, _stream())
     st.aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+    # the pooled vectors in f32 are an operand of the backward (csrc/k_pool3.h): a private buffer when the caller only wants the bf16 copy;
+    # a caller-owned `out` is the autograd function's own output, referenced through y_keep (detached: no reference cycle)
+    st.y = None
+    if need_grad and ops._POOL_FLAT:
+        if out is None:
+            st.y = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+            out, out_stride = st.y.data_ptr(), NR_D
+        else:
+            if y_keep is None or y_keep.data_ptr() != out or y_keep.stride(0) != out_stride:
+                raise ValueError("text_fwd: y_keep must be the tensor view behind `out`")
+            st.y = y_keep.detach()
+    st.y_ptr, st.y_stride = out, out_stride
     _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_v, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
           out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, _stream())
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0, y_ptr=None, y_stride=NR_D):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
     Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.
     With ``dy`` (seqpad buffer of a conv text encoder whose activations ctx_b are) the gradient goes on through the relu / dropout stage
@@ -110,11 +122,18 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
-    nwg = lib.nr_additive_bwd_grid(n_seq, S)
-    dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-    dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-    dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
-    if dy is None:
+    if ops._POOL_FLAT:
+        if y_ptr is None:
+            raise ValueError("_pool_bwd: the flat pooling backward needs the forward's pooled vectors")
+        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, dy=dy, p_drop=p_drop)
+    else:
+        nwg = lib.nr_additive_bwd_grid(n_seq, S)
+        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+        dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
+    if ops._POOL_FLAT:
+        pass
+    elif dy is None:
         _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_ex, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), n_seq, S, _stream())
     else:
@@ -139,7 +158,8 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
-    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p)
+    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
+                                    y_ptr=st.y_ptr, y_stride=st.y_stride)
 
     def wgrad():
         if ops._GEMM_HAND & 2:
@@ -222,14 +242,14 @@ class _NamlNewsFn(torch.autograd.Function):
         _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(bc_), _ptr(Ws_), _ptr(bs_), _ptr(E), _stream())
         _call('nr_views_fill', lib.nr_views_fill, _ptr(cat), _ptr(sub), _ptr(E), ncat, _ptr(views), T, _stream())
         Wap, bap, qvp = pack_additive(Wa_f, ba_f, qv_f)
-        WaT = ops.pack_additive_t(Wa_f) if need_grad else None
+        WaT = ops.pack_additive_t(Wa_f) if (need_grad and not ops._POOL_FLAT) else None
         out = torch.empty(T, NR_D, dtype=torch.float32, device=dev)
         out_b = torch.empty(T, NR_KP, dtype=_BF16_AS_I16, device=dev)
         aw = torch.empty(T, 4, dtype=torch.float32, device=dev)
         _call('nr_additive_fwd[views]', lib.nr_additive_fwd_ex, _ptr(views), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, _ptr(out_b), NR_KP,
               _ptr(aw), T, 4, _stream())
         if need_grad:
-            ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT)
+            ctx.save_for_backward(title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT, out)
             ctx.st = (st_t, st_a)
             ctx.meta = (p, seed, Wa_f.shape[0])
             ctx.sorted = sort_tokens_async([title, abstract], table.shape[0]) if ctx.needs_input_grad[4] else None
@@ -240,14 +260,14 @@ class _NamlNewsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_b):
         lib = _lib()
-        title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT = ctx.saved_tensors
+        title, abstract, cat, sub, table, embf, Wc_, Ws_, E, views, aw, Wap, bap, qvp, WaT, y = ctx.saved_tensors
         st_t, st_a = ctx.st
         p, seed, qdim = ctx.meta
         dev = views.device
         T = title.shape[0]
         g_out = g_out.to(torch.float32).contiguous()
         # final attention over the 4 views
-        d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views', WaT)
+        d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views', WaT, y_ptr=_ptr(y), y_stride=y.stride(0))
         gv = _workspace('gviews', (4, T, NR_D), torch.float32, dev)               # view-major: 4 contiguous [T][D] blocks
         _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
         # element encoders: reduce per category row, then the tiny table backward
@@ -302,17 +322,17 @@ class _PoolFn(torch.autograd.Function):
         aw = torch.empty(n, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_v, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
               _ptr(aw), n, S, valid, _stream())
-        ctx.save_for_backward(x_b, aw, Wap, bap, qvp, ops.pack_additive_t(Wa))
+        ctx.save_for_backward(x_b, aw, Wap, bap, qvp, None if ops._POOL_FLAT else ops.pack_additive_t(Wa), out)
         ctx.qdim = Wa.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib()
-        x_b, aw, Wap, bap, qvp, WaT = ctx.saved_tensors
+        x_b, aw, Wap, bap, qvp, WaT, y = ctx.saved_tensors
         n, S = aw.shape
         g = g.to(torch.float32).contiguous()
-        d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}', WaT)
+        d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}', WaT, y_ptr=_ptr(y), y_stride=y.stride(0))
         dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
         _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
         return dx, None, d_Wa, d_ba, d_qv, None
@@ -357,7 +377,8 @@ class _LsturNewsFn(torch.autograd.Function):
         for j, ids in enumerate((cat, sub)):
             _call('nr_gather_rows_strided', lib.nr_gather_rows_strided, _ptr(ids), _ptr(ct), ct.shape[0], NR_D, None, out.data_ptr() + j * NR_D * 4,
                   3 * NR_D, T, _stream())
-        st = text_fwd(title, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr() + 2 * NR_D * 4, 3 * NR_D, None, 0, 'title', valid)
+        st = text_fwd(title, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr() + 2 * NR_D * 4, 3 * NR_D, None, 0, 'title', valid,
+                      y_keep=out[:, 2 * NR_D:])
         if need_grad:
             ctx.save_for_backward(title, cat, sub, table)
             ctx.st = st
@@ -401,7 +422,7 @@ class _TextFn(torch.autograd.Function):
     def forward(ctx, ids, table, cw, cb, Wa, ba, qv, p, seed, valid=None):
         need_grad = any(ctx.needs_input_grad)
         out = torch.empty(ids.shape[0], NR_D, dtype=torch.float32, device=table.device)
-        st = text_fwd(ids, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr(), NR_D, None, 0, 'text', valid)
+        st = text_fwd(ids, table, cw, cb, Wa, ba, qv, p, seed, 0, need_grad, out.data_ptr(), NR_D, None, 0, 'text', valid, y_keep=out)
         if need_grad:
             ctx.save_for_backward(ids, table)
             ctx.st = st

@@ -130,6 +130,7 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
                  (size_t)(smem), [&]() { kern(__VA_ARGS__); })
 
 #define NR_SCHED_BARRIER() ((void)0)
+#define NR_OPAQUE(x) ((void)0)
 #define NR_ONE_WAVE_PER_SIMD
 
 // emulation of global_load_lds_dwordx4: every lane copies its 16 B to lds_base + 16 * lane
@@ -308,6 +309,7 @@ template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }
 template <typename T> __forceinline__ void st_nt(T* p, T v) { *p = v; }
 
 inline int set_max_dynamic_lds(const void*, int) { return 0; }
+inline int device_cus() { return 3; }      // few "CUs": the persistent kernels run several iterations per wave even in small tests
 
 __forceinline__ uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 

@@ -155,3 +155,18 @@ def test_pool2_geometries(geom):
 
 def test_dropout_mask_statistics(be):
     kc.check_dropout_mask_statistics(be)
+
+
+# ---- flat pooling backward (csrc/k_pool3.h) -----------------------------------------------------------------------------
+from tests import kernel_checks_pool3 as k3  # noqa: E402
+
+
+def test_pool_flat_bad_args(be): k3.check_flat_bad_args(be)
+def test_pool_flat_s20(be): k3.check_flat(be, S=20, n_seq=6)                      # 120 tokens: sequences straddle the 48-row groups
+def test_pool_flat_s50(be): k3.check_flat(be, S=50, n_seq=5)
+def test_pool_flat_s4(be): k3.check_flat(be, S=4, n_seq=45, seed=3)
+def test_pool_flat_valid_and_strided_y(be): k3.check_flat(be, S=20, n_seq=7, valid=13, y_stride=3 * 300)
+def test_pool_flat_any_length_dpre_only(be): k3.check_flat(be, S=33, n_seq=4, with_dctx=False, seed=5)     # a length no forward kernel is instantiated for
+def test_pool_flat_act_s20(be): k3.check_flat_act(be, S=20, n_seq=7)
+def test_pool_flat_act_s50(be): k3.check_flat_act(be, S=50, n_seq=3)
+def test_pool_flat_persistent_loop(be): k3.check_flat(be, S=20, n_seq=130, seed=9); k3.check_flat_act(be, S=50, n_seq=60, seed=4)    # > 24 groups: several iterations per wave

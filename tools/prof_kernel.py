@@ -89,6 +89,23 @@ if name.startswith('conv'):
     act = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
     xs = torch.empty(Tn * (S + 1) + 1, NR_KP, dtype=torch.int16, device=dev)
     fns[name] = lambda: ck(lib.nr_conv3_fwd(idc.data_ptr(), table.data_ptr(), V, Wc.data_ptr(), bc.data_ptr(), act.data_ptr(), xs.data_ptr(), Tn, S, 0.2, 1, 0, st()))
+if name.startswith('pool_flat'):     # flat pooling backward (csrc/k_pool3.h): pool_flat / pool_flat_act (titles), pool_flat50 / pool_flat50_act (abstracts)
+    S = 50 if '50' in name else 20
+    Tn = B * 53
+    cx = torch.randn(Tn * S, NR_KP, generator=g).mul_(0.3)
+    if 'act' in name: cx = torch.relu(cx)
+    cx = cx.to(torch.bfloat16).view(torch.int16).to(dev)
+    y_ = torch.empty(Tn, NR_D, device=dev); aw_ = torch.empty(Tn, S, device=dev)
+    ck(lib.nr_additive_fwd(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), y_.data_ptr(), aw_.data_ptr(), Tn, S, st()))
+    go_ = torch.randn(Tn, NR_D, generator=g).to(dev)
+    dp_ = torch.empty(Tn * S, NR_QP, dtype=torch.int16, device=dev); dq_ = torch.empty(lib.nr_additive_bwd_flat_grid(Tn * S), NR_QP, device=dev)
+    tot_ = torch.empty(Tn, device=dev)
+    dc_ = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
+    dy_ = torch.zeros(Tn * (S + 1) + 1, NR_KP, dtype=torch.int16, device=dev)
+    act_ = 'act' in name
+    fns[name] = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
+                                                    tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
+                                                    0.2 if act_ else 0.0, Tn, S, st()))
 fn = fns[name]
 for _ in range(2): fn()
 torch.cuda.synchronize()
