@@ -13,32 +13,47 @@
 // boundaries, for any S.
 //
 // With no per-sequence phase left there is nothing to synchronise: the kernel is PERSISTENT (one workgroup of 8 waves per CU), Wa sits in
-// LDS for its whole life (208 rows x 656 B, loaded once) and serves BOTH products -- x Wa^T through plain 16-byte fragment reads, dpre @ Wa
+// LDS for its whole life (200 rows x 640 B, loaded once) and serves BOTH products -- x Wa^T through plain 16-byte fragment reads, dpre @ Wa
 // through the transposing read ds_read_b64_tr_b16 of the same rows (no Wa^T operand, no weight streaming, no barrier inside the loop).
-// A wave's 48 ctx rows live in registers as MFMA B fragments (as in k_pool2.h); the next group's rows are requested as soon as the
-// projection has consumed the current ones, so their latency hides behind the dctx product; the two waves of a SIMD drift apart and
-// overlap each other's load / MFMA / tanh / store phases.
+// A wave's 48 ctx rows live in registers as MFMA B fragments (as in k_pool2.h).
+//
+// Global memory is only touched LANE-CONTIGUOUSLY.  The MFMA layouts put consecutive lanes on consecutive TOKENS (rows 640 B apart): a fragment-
+// shaped load or an accumulator-shaped store is 64 separate requests to the texture addresser, and the first version of this kernel, like
+// k_pool2.h, spent two thirds of its time issuing them (phase switches: 428 us, 259 without the stores, 329 without the loads; the matrix
+// and vector pipes together busy 40 % of the time).  Now every vector-memory instruction moves 16 bytes per lane with four consecutive lanes
+// on one row -- 16 runs of 64 contiguous bytes -- and the change of layout happens in 3 KB of wave-private LDS: loaded pieces are written
+// there as they arrive and read back as fragments; accumulator tiles are written there two column tiles at a time and read back as row
+// pieces.  (Same wave on both sides: LDS operations of a wave execute in order, no barrier.)
 #pragma once
 #include "nr_common.h"
 #include "k_additive_fwd.h"
 
 namespace nr {
 
-template <int MT_>
-struct Pool3GeomT {
+struct Pool3Geom {
   static constexpr int NWAVE = 8, THREADS = NWAVE * 64;
-  static constexpr int MT = MT_, ROWS = MT * 16;   // token rows per wave and iteration
+  static constexpr int MT = 3, ROWS = MT * 16;   // token rows per wave and iteration
   static constexpr int NTQ = QP / 16;            // 13 n-tiles of the query dim
   static constexpr int KS2 = QKP / 32;           // 7 k-steps of the dctx product
   static constexpr int NTD = (D + 15) / 16;      // 19 feature tiles of dctx
-  static constexpr int WROW = XS * 2;            // 656 B per Wa row: conflict-free b128 fragment reads and transposing reads
-  static constexpr int W_BYTES = QP * WROW;      // 136,448
+  static constexpr int WROWS = 200;              // rows of Wa kept (query_vector_dim <= 200 real rows of the 208 packed ones); row WROWS = zeros
+  static constexpr int WROW = KP * 2;            // 640 B per row, 16-byte slots swizzled (w_swz): no padding
+  static constexpr int W_BYTES = (WROWS + 1) * WROW;               // 128,640
   static constexpr int BQ_BYTES = 2 * QP * 4;    // bias and query vector
   static constexpr int DQ_BYTES = NWAVE * QP * 4;
-  static constexpr int SMEM = W_BYTES + BQ_BYTES + DQ_BYTES;      // 144,768
-  static_assert(SMEM <= 163840, "LDS");
+  static constexpr int SC_WAVE = ROWS * 64;      // 3,072 B of layout-change scratch per wave: [48 rows][4 slots of 16 B], slots swizzled (sc_swz)
+  static constexpr int SMEM = W_BYTES + BQ_BYTES + DQ_BYTES + NWAVE * SC_WAVE;      // 161,536
+  static_assert(SMEM <= 163840 && QP - WROWS == 8, "LDS; the dropped rows are the upper half of the last n-tile");
 };
-using Pool3Geom = Pool3GeomT<3>;
+
+// Swizzle of the 16-byte slots of Wa row r (XOR into the slot index, inside aligned groups of 8 slots = 128 B = all 32 banks): the 8 rows a
+// b128 fragment read touches per clock (r & 7 = 0..7) land in 8 different slots, and so do the 4 rows x 2 slots of a transposing read
+// (r & 3 = 0..3 with equal r >> 2) -- the two access shapes of the two products.
+__device__ __forceinline__ int w_swz(int r) { return ((r & 3) << 1) | ((r >> 2) & 1); }
+// scratch rows are 64 B (4 slots): consecutive row pairs fill the 128 B of banks, the pair index picks the slot rotation
+__device__ __forceinline__ int sc_swz(int r) { return (r >> 1) & 3; }
+
+template <int V> struct IntTag { static constexpr int value = V; };
 
 struct Pool3Params {
   const u16* ctx;        // [n_tok][KP]  forward input of the additive layer
@@ -53,10 +68,12 @@ struct Pool3Params {
   u16* dctx;             // optional: bf16 [n_tok][KP] = dpre @ Wa (columns < D written)
   u16* dy_pad;           // optional, instead of dctx: bf16 seqpad rows (tok + seq + 1) = (dpre @ Wa + w (x) g_out) * [ctx != 0] * act_scale
   float act_scale;
+  int64_t n_seq;
   int64_t n_tok;         // n_seq * S < 2^31
   uint32_t S;            // >= 2
   uint32_t s_magic;      // floor(2^32 / S) + 1
-  int dbg;               // DBG instantiation only (NR_POOL_DEBUG, tools/pool_phases.sh): 1 no ctx loads, 2 no dw phase, 4 no projection MFMAs,
+  unsigned long long* stamps;   // DBG instantiation only (nr_debug_pool3_stamps): [4 workgroups][2 waves][8 iterations][8] cycle-counter stamps
+  int dbg;               // DBG instantiation only (NR_POOL_DEBUG, tools/pool3_phases.py): 1 no ctx loads, 2 no dw phase, 4 no projection MFMAs,
                          // 8 no tanh / dpre / dq arithmetic, 16 no dctx product, 32 no global stores, 128 no dq accumulation
 };
 
@@ -76,82 +93,129 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
   }
 }
 
-// the wave's 48 ctx rows as B-operand fragments: lane (li, g) holds features 32 ks + 8 g .. + 7 of token 16 m + li
-template <int MT>
-__device__ __forceinline__ void pool3_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t n_tok, u16x8 (&xf)[MT][KSTEPS]) {
-  const int l = lane_id(), g = l >> 4, li = l & 15;
+// The wave's 48 ctx rows as row pieces: xr[ks][t] = columns 32 ks + 8 (l & 3) .. + 7 of row 16 t + (l >> 2) -- per instruction 16 runs of 64
+// contiguous bytes.  pool3_to_fragments() turns them into B-operand fragments in place.
+__device__ __forceinline__ void pool3_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t n_tok, u16x8 (&xr)[KSTEPS][Pool3Geom::MT]) {
+  const int l = lane_id();
+  const int64_t left = n_tok - tok0;                                    // (<= 0: a phase switch of the debug build)
+  const int nrows = left < Pool3Geom::ROWS ? (left > 0 ? (int)left : 0) : Pool3Geom::ROWS;
+  const BufRsrc rx = make_buf(ctx + tok0 * KP, (uint32_t)(nrows * KP * 2));      // rows past the end read as zeros
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int64_t tok = tok0 + m * 16 + li;
-    const bool live = tok < n_tok;
-    const u16* row = ctx + (live ? tok : 0) * KP + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) xf[m][ks] = live ? *(const u16x8*)(row + ks * 32) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < Pool3Geom::MT; ++t) {
+    uint32_t off = (uint32_t)((t * 16 + (l >> 2)) * (KP * 2) + (l & 3) * 16);
+    NR_OPAQUE(off);                                                     // (one offset register per row tile, the k-step in the immediate)
+    xr[0][t] = buf_load16<0>(rx, off); xr[1][t] = buf_load16<64>(rx, off); xr[2][t] = buf_load16<128>(rx, off); xr[3][t] = buf_load16<192>(rx, off);
+    xr[4][t] = buf_load16<256>(rx, off); xr[5][t] = buf_load16<320>(rx, off); xr[6][t] = buf_load16<384>(rx, off); xr[7][t] = buf_load16<448>(rx, off);
+    xr[8][t] = buf_load16<512>(rx, off); xr[9][t] = buf_load16<576>(rx, off);
+    static_assert(KSTEPS == 10, "unrolled by hand: the immediate is a template argument");
   }
 }
 
-// ACT: the fused activation gradient (dy_pad) instead of dctx -- a compile-time form: its mask words and row scalars cost registers the plain
-// form does not have to carry through the projection
-template <bool ACT, int MT_ = 3, bool PF = true, bool DBG = false>
-__global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Pool3Params p) {
-  using Gm = Pool3GeomT<MT_>;
+// row pieces -> fragments through the wave's scratch, one k-step (48 rows x 64 B) at a time: afterwards xr[ks][m] holds features
+// 32 ks + 8 g .. + 7 of token 16 m + li (lane = 16 g + li)
+__device__ __forceinline__ void pool3_to_fragments(unsigned char* sc, u16x8 (&xr)[KSTEPS][Pool3Geom::MT]) {
+  const int l = lane_id(), g = l >> 4, li = l & 15;
+  unsigned char* wr = sc + (l >> 2) * 64 + (((l & 3) ^ sc_swz(l >> 2)) * 16);         // + t * 1024
+  const unsigned char* rd = sc + li * 64 + ((g ^ sc_swz(li)) * 16);                     // + m * 1024   (16 m does not move the swizzle)
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+    for (int t = 0; t < Pool3Geom::MT; ++t) *(u16x8*)(wr + t * 1024) = xr[ks][t];
+    wave_barrier();
+#pragma unroll
+    for (int m = 0; m < Pool3Geom::MT; ++m) xr[ks][m] = *(const u16x8*)(rd + m * 1024);
+    wave_barrier();
+  }
+}
+
+// ACT: the fused activation gradient (dy_pad) instead of dctx -- a compile-time form
+template <bool ACT, bool DBG = false>
+__global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Params p) {
+  using Gm = Pool3Geom;
   const int dbg = DBG ? p.dbg : 0;        // the production instantiation folds every switch away
   constexpr int MT = Gm::MT;
   NR_SMEM_DECL(smem);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
   float* bq = (float*)(smem + Gm::W_BYTES);              // [QP] bias, [QP] query vector
   float* dqp = bq + 2 * QP + w * QP;                     // this wave's dq accumulator row
+  unsigned char* sc = smem + Gm::W_BYTES + Gm::BQ_BYTES + Gm::DQ_BYTES + w * Gm::SC_WAVE;
   const u16x4 Z4 = u16x4{0, 0, 0, 0};
   const bool with_dctx = (ACT || p.dctx != nullptr) && !(dbg & 16);       // the stand-alone AdditiveAttention backward stops at dpre / dq
 
-  // ---- Wa rows -> LDS (once per workgroup): 16-byte pieces out of the tile-ordered operand -----------------------------------------------
-  for (int i = tid; i < QP * (KP / 8); i += Gm::THREADS) {
-    const int row = i / (KP / 8), s = i - row * (KP / 8);
-    *(u16x8*)(smem + row * Gm::WROW + s * 16) = *(const u16x8*)(p.Wap + tile_off(row, s * 8, KP));
+  // ---- Wa rows -> LDS (once per workgroup): the tile-ordered operand is read front to back (piece e = block (row tile, k-step), lane) ------------
+  for (int e = tid; e < Gm::NTQ * KSTEPS * 64; e += Gm::THREADS) {
+    const int blk = e >> 6, ln = e & 63;
+    const int row = (blk / KSTEPS) * 16 + (ln & 15), s = (blk % KSTEPS) * 4 + (ln >> 4);
+    if (row < Gm::WROWS) *(u16x8*)(smem + row * Gm::WROW + ((s ^ w_swz(row)) * 16)) = *(const u16x8*)(p.Wap + (size_t)e * 8);
   }
+  for (int i = tid; i < KP / 8; i += Gm::THREADS) *(u16x8*)(smem + Gm::WROWS * Gm::WROW + i * 16) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < QP; i += Gm::THREADS) { bq[i] = p.bap[i]; bq[QP + i] = p.qvp[i]; }
   for (int i = tid; i < Gm::NWAVE * QP; i += Gm::THREADS) bq[2 * QP + i] = 0.0f;
   __syncthreads();
 
   const int64_t n_groups = (p.n_tok + Gm::ROWS - 1) / Gm::ROWS, gstride = (int64_t)gridDim.x * Gm::NWAVE;
   int64_t grp = (int64_t)blockIdx.x * Gm::NWAVE + w;     // neighbouring groups run on one CU at the same time: their partial lines merge in its L2
-  u16x8 xf[MT][KSTEPS];
-  const int64_t n_load = (dbg & 1) ? 0 : p.n_tok;        // (rows past the end are zero fragments)
-  if (grp < n_groups) pool3_load_x(p.ctx, grp * Gm::ROWS, n_load, xf);
+  u16x8 xr[KSTEPS][MT];
+  const int64_t n_load = (dbg & 1) ? 0 : p.n_tok;
+  if (grp < n_groups) pool3_load_x(p.ctx, grp * Gm::ROWS, n_load, xr);
 
+  // lane constants of the scratch: accumulator-shaped writes (token li of tile m, 4 columns 4 g ..: half h of a column-tile pair) and row-piece
+  // reads (row 16 t + (l >> 2), slot l & 3 = columns 8 (l & 3) .. + 7 of the pair)
+  const int cw0 = li * 64 + ((((g >> 1) ^ sc_swz(li))) * 16) + (g & 1) * 8;           // + m * 1024, ^ 32 for the second tile of a pair
+  const int pr0 = (l >> 2) * 64 + (((l & 3) ^ sc_swz(l >> 2)) * 16);                  // + t * 1024
+
+  int it = 0;
+  auto stamp = [&](int k) {               // (timeline of the first iterations of a few waves: tools/pool3_phases.py --timeline)
+    if (DBG && p.stamps != nullptr && l == 0 && w < 2 && blockIdx.x < 4 && it < 8)
+      p.stamps[(((size_t)blockIdx.x * 2 + w) * 8 + it) * 8 + k] = __builtin_readcyclecounter();
+  };
   while (grp < n_groups) {
     const int64_t tok0 = grp * Gm::ROWS;
-    // ---- the lane's three rows (token tb + 16 m): ds = w (g . x - tot).  Sequence index and forward weight are dropped again after this
+    stamp(0);
+    pool3_to_fragments(sc, xr);
+    stamp(1);
+    // ---- the lane's three rows (row 16 m + li of the group): ds = w (g . x - tot).  Sequence index and forward weight are dropped again after this
     // phase (the ACT epilogue fetches them a second time) instead of living through the projection ------------------------------------------
-    const int64_t tb = tok0 + li;
-    auto row_seq = [&](int m) -> uint32_t {
-      const uint32_t tk = tb + m * 16 < p.n_tok ? (uint32_t)(tb + m * 16) : 0u;
+    const int nrows = p.n_tok - tok0 < Gm::ROWS ? (int)(p.n_tok - tok0) : Gm::ROWS;       // live rows of the group (wave-uniform)
+    const uint32_t t0u = (uint32_t)tok0;
+    auto seq_of = [&](int row) -> uint32_t {  // sequence of the group's row (rows past the end: of row 0)
+      const uint32_t tk = t0u + (row < nrows ? (uint32_t)row : 0u);
       uint32_t q = mulhi_u32(tk, p.s_magic);   // floor(tk / S) or one more (tk < 2^31)
       return q - ((q * p.S > tk) ? 1u : 0u);
     };
+    const int rowl = l >> 2;                   // + 16 t: the lane's row in the row-piece layout
+    // every global access of the group: a buffer resource on the group's rows (rows past the end: loads give 0, stores vanish) + 32-bit offsets
+    const BufRsrc r_aw = make_buf(p.attn_w + tok0, (uint32_t)(nrows * 4));
+    const BufRsrc r_g = make_buf(p.g_out, (uint32_t)(p.n_seq * (D * 4))), r_tot = make_buf(p.tot, (uint32_t)(p.n_seq * 4));
+    const BufRsrc r_dpre = make_buf(p.dpre + tok0 * QP, (uint32_t)(nrows * QP * 2));
     float ds[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const bool live = tb + m * 16 < p.n_tok;
-      const uint32_t sq = row_seq(m);
-      const float* go = p.g_out + (int64_t)sq * D + g * 8;
+      const uint32_t sq = seq_of(m * 16 + li);
+      uint32_t go = sq * (uint32_t)(D * 4) + (uint32_t)(g * 32);
+      NR_OPAQUE(go);
       float a = 0.0f;
-#pragma unroll
-      for (int ks = (dbg & 2) ? KSTEPS : 0; ks < KSTEPS; ++ks) {
-        const u16x8 x = xf[m][ks];
+      auto dot8 = [&](auto ks_tag) {
+        constexpr int ks = decltype(ks_tag)::value;
+        const u16x8 x = xr[ks][m];
         if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 4 <= D) {                   // (columns >= D: the bias column of ctx, zeros)
-          const f32x4 g0 = *(const f32x4*)(go + ks * 32);
+          const f32x4 g0 = buf_load16f<ks * 128>(r_g, go);
           a += g0[0] * bf2f(x[0]) + g0[1] * bf2f(x[1]) + g0[2] * bf2f(x[2]) + g0[3] * bf2f(x[3]);
         }
         if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 8 <= D) {
-          const f32x4 g1 = *(const f32x4*)(go + ks * 32 + 4);
+          const f32x4 g1 = buf_load16f<ks * 128 + 16>(r_g, go);
           a += g1[0] * bf2f(x[4]) + g1[1] * bf2f(x[5]) + g1[2] * bf2f(x[6]) + g1[3] * bf2f(x[7]);
         }
+      };
+      if (!(dbg & 2)) {
+        dot8(IntTag<0>{}); dot8(IntTag<1>{}); dot8(IntTag<2>{}); dot8(IntTag<3>{}); dot8(IntTag<4>{});
+        dot8(IntTag<5>{}); dot8(IntTag<6>{}); dot8(IntTag<7>{}); dot8(IntTag<8>{}); dot8(IntTag<9>{});
       }
       a = sum_rows4(a);
-      ds[m] = live ? p.attn_w[tb + m * 16] * (a - p.tot[sq]) : 0.0f;
+      ds[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4)) * (a - buf_load4f(r_tot, sq * 4u));      // (rows past the end: weight 0)
     }
 
+    stamp(2);
     // ---- t = tanh(x Wa^T + ba);  dpre = ds qv (1 - t^2) (kept packed in registers + stored);  dq += ds t ---------------------------------------
     u16x4 dpk[Gm::NTQ + 1][MT];               // +1: the zero partner of the last (odd) n-tile in the dctx product
 #pragma unroll
@@ -159,23 +223,25 @@ __global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Poo
 #pragma unroll
     for (int nt = 0; nt < Gm::NTQ; ++nt) {
       const int wrow = nt * 16 + 4 * g;
-      int bo = Gm::W_BYTES + 16 * g;          // (opaque for the same reason as `wo` below: else one hoisted address per n-tile and vector)
+      int bo = Gm::W_BYTES + 16 * g;          // (opaque: else one hoisted address per n-tile and vector, spilled around the whole loop)
       NR_OPAQUE(bo);
       const f32x4 b4 = *(const f32x4*)(smem + bo + nt * 64), q4 = *(const f32x4*)(smem + bo + QP * 4 + nt * 64);
       f32x4 acc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = b4;
-      // fragment (nt, ks) of Wa: one lane offset per SIX n-tiles + the instruction's 16-bit offset field.  (Left alone the compiler keeps one
-      // loop-invariant address per n-tile, 13 registers, and spills them around the whole loop.)
-      int wo = (li * Gm::WROW + g * 16) + (nt / 6) * (6 * 16 * Gm::WROW);
+      // fragment (nt, ks) of Wa: row 16 nt + li (rows >= 200: the zero row), slot (4 ks + g) ^ w_swz(row) = 4 (ks ^ b) + c with b, c lane constants
+      const int wr_ = nt * 16 + li < Gm::WROWS ? nt * 16 + li : Gm::WROWS;
+      const int wb = w_swz(li) >> 2, wc = (g ^ w_swz(li)) & 3;                      // (16 nt does not move the swizzle; the zero row is zero in every slot)
+      int wo = wr_ * Gm::WROW + wc * 16;
       NR_OPAQUE(wo);
-      const unsigned char* wp = smem + wo + (nt % 6) * (16 * Gm::WROW);
-      u16x8 a = *(const u16x8*)wp;
+      const unsigned char* wp = smem + wo;
+      auto frag = [&](int ks) -> u16x8 { return *(const u16x8*)(wp + ((ks ^ wb) * 64)); };
+      u16x8 a = frag(0);
 #pragma unroll
       for (int ks = (dbg & 4) ? KSTEPS : 0; ks < KSTEPS; ++ks) {
-        const u16x8 an = ks + 1 < KSTEPS ? *(const u16x8*)(wp + (ks + 1) * 64) : a;
+        const u16x8 an = ks + 1 < KSTEPS ? frag(ks + 1) : a;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, xf[m][ks], acc[m]);
+        for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, xr[ks][m], acc[m]);
         a = an;
       }
       f32x4 dq4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -188,9 +254,7 @@ __global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Poo
           dp[r] = (dbg & 8) ? t : ds[m] * q4[r] * (1.0f - t * t);
           dq4[r] += (dbg & 8) ? 0.0f : ds[m] * t;
         }
-        const u16x4 pk = pack4(dp);
-        dpk[nt][m] = pk;
-        if (tb + m * 16 < p.n_tok && !(dbg & 32)) *(u16x4*)(p.dpre + (tb + m * 16) * QP + wrow) = pk;
+        dpk[nt][m] = pack4(dp);
       }
       // dq: the tile's tokens live in the 16 lanes of a row -> DPP sum; the wave's own LDS row accumulates over all of its groups
 #pragma unroll
@@ -198,48 +262,97 @@ __global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Poo
         const float v = sum_row16(dq4[r]);
         if (li == 0) dqp[wrow + r] += v;
       }
+      // dpre rows leave two n-tiles at a time: 32 columns = 64 contiguous bytes of every row
+      if ((nt & 1) || nt == Gm::NTQ - 1) {
+        const int nt0 = nt & ~1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          *(u16x4*)(sc + m * 1024 + cw0) = dpk[nt0][m];
+          if (nt & 1) *(u16x4*)(sc + m * 1024 + (cw0 ^ 32)) = dpk[nt][m];
+        }
+        wave_barrier();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const u16x8 v = *(const u16x8*)(sc + t * 1024 + pr0);
+          uint32_t o = (uint32_t)((t * 16 + rowl) * (QP * 2) + (l & 3) * 16);
+          NR_OPAQUE(o);                       // (recomputed here: else 21 hoisted offsets, spilled)
+          if (((nt & 1) || (l & 3) < 2) && !(dbg & 32)) buf_store16(r_dpre, o, v, (uint32_t)(nt0 * 32));
+        }
+        wave_barrier();
+      }
+      if (nt == 5) stamp(3);
       NR_SCHED_BARRIER();                     // keep the n-tiles apart: interleaving them stretches the live ranges past the register file
     }
+    stamp(4);
 
-    // ---- the next group's rows: the fragments are free, their latency hides behind the dctx product ----------------------------------------
+    // ---- the next group's rows: the fragments are free, their latency hides behind the dctx product (ACT needs them for its mask: below) ----------
     const int64_t nxt = grp + gstride;
-    if (PF && !ACT && nxt < n_groups) pool3_load_x(p.ctx, nxt * Gm::ROWS, n_load, xf);
+    if (!ACT && nxt < n_groups) pool3_load_x(p.ctx, nxt * Gm::ROWS, n_load, xr);
+    stamp(5);
 
     // ---- dctx[tok][:] = dpre[tok][:] @ Wa: A = Wa^T rows of a feature tile by transposing reads of the SAME LDS rows (k-slot (g, j) of k-step ks
     // stands for query index 32 ks + 16 (j / 4) + 4 g + j % 4: the lane's packed dpre registers of tiles 2 ks, 2 ks + 1 are the B fragment) -----
     if (with_dctx) {
-      uint32_t seqm[MT];
-      float alpha[MT];
-      if (ACT) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          seqm[m] = row_seq(m);
-          alpha[m] = tb + m * 16 < p.n_tok ? p.attn_w[tb + m * 16] : 0.0f;
-        }
-      }
-      const u16* wq = (const u16*)(smem + (4 * g + (li >> 2)) * Gm::WROW) + 4 * (li & 3);
-      // one feature tile (columns 16 dt ..) of the product for the wave's rows
+      // piece P_{4 r + qq} of the lane's group: row 32 ks + 16 h + 4 g + r, columns 16 dt + 4 qq .. + 3 -> slot 2 dt + (qq >> 1), swizzled by
+      // w_swz(row) = 2 r + (g & 1): low bit of the slot ^ (g & 1), its next two bits = (dt & 3) ^ r
+      const int tr_r = li >> 2, tr_q = li & 3;
+      const int tr_lo = (((tr_q >> 1) ^ (g & 1)) * 16) + (tr_q & 1) * 8;
       auto product = [&](int dt, f32x4 (&acc)[MT]) {
+        const unsigned char* wq = smem + (4 * g + tr_r) * Gm::WROW + (dt >> 2) * 128 + ((((dt & 3) ^ tr_r)) * 32) + tr_lo;
+        const unsigned char* wz = smem + Gm::WROWS * Gm::WROW;        // rows >= 200 of the last k-step: the zero row
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < Gm::KS2; ++ks) {
-          const u16x4 lo = lds_tr16_b64(wq + (ks * 32) * XS + dt * 16);
-          const u16x4 hi = 2 * ks + 1 < Gm::NTQ ? lds_tr16_b64(wq + (ks * 32 + 16) * XS + dt * 16) : lo;     // (the partner of the last n-tile is zero on the dpre side)
+          const bool in0 = ks * 32 + 15 < Gm::WROWS || ks * 32 + 4 * g + tr_r < Gm::WROWS;
+          const u16x4 lo = lds_tr16_b64((const u16*)(in0 ? wq + (ks * 32) * Gm::WROW : wz));
+          const u16x4 hi = 2 * ks + 1 < Gm::NTQ ? lds_tr16_b64((const u16*)(wq + (ks * 32 + 16) * Gm::WROW)) : lo;     // (the partner of the last n-tile is zero on the dpre side)
           const u16x8 a = cat8(lo, hi);
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, cat8(dpk[2 * ks][m], dpk[2 * ks + 1][m]), acc[m]);
         }
       };
+      // two feature tiles (32 columns) of the wave's rows leave together: accumulator-shaped 8-byte writes into the scratch, 16-byte row pieces out
+      uint32_t seql[MT];                      // ACT: sequence of row 16 t + (l >> 2) (the seqpad row is tok + seq + 1)
+      if (ACT) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) seql[t] = seq_of(t * 16 + rowl);
+      }
+      // ACT: seqpad row of a token = tok + seq + 1; the resource starts at the seqpad row of the group's first token
+      const uint32_t sq0 = ACT ? (uint32_t)uniform((int)seq_of(0)) : 0u;
+      const int64_t out_rows = ACT ? (p.n_tok + p.n_seq) - (tok0 + sq0) : nrows;
+      const BufRsrc r_out = make_buf(ACT ? p.dy_pad + (tok0 + sq0 + 1) * KP : p.dctx + tok0 * KP,
+                                     (uint32_t)((out_rows < 3000000 ? out_rows : 3000000) * (KP * 2)));
+      auto flush = [&](int dt0, bool pair) {
+        wave_barrier();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const u16x8 v = *(const u16x8*)(sc + t * 1024 + pr0);
+          const int col = dt0 * 16 + (l & 3) * 8;
+          if ((!ACT || t * 16 + rowl < nrows) && (pair || (l & 3) < 2) && !(dbg & 32)) {
+            const uint32_t row = (uint32_t)(t * 16 + rowl) + (ACT ? seql[t] - sq0 : 0u);
+            uint32_t off = row * (uint32_t)(KP * 2) + (uint32_t)((l & 3) * 16);
+            NR_OPAQUE(off);
+            if (col + 8 <= D) buf_store16(r_out, off, v, (uint32_t)(dt0 * 32));
+            else if (col + 4 <= D) buf_store8(r_out, off, u16x4{v[0], v[1], v[2], v[3]}, (uint32_t)(dt0 * 32));
+          }
+        }
+        wave_barrier();
+      };
       if (!ACT) {
 #pragma nounroll
-        for (int dt = 0; dt < Gm::NTD; ++dt) {
+        for (int dt0 = 0; dt0 < Gm::NTD; dt0 += 2) {
           f32x4 acc[MT];
-          product(dt, acc);
-          const int col = dt * 16 + 4 * g;
+          product(dt0, acc);
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            if (tb + m * 16 < p.n_tok && col < D && !(dbg & 32)) *(u16x4*)(p.dctx + (tb + m * 16) * KP + col) = pack4(acc[m]);
+          for (int m = 0; m < MT; ++m) *(u16x4*)(sc + m * 1024 + cw0) = pack4(acc[m]);
+          const bool pair = dt0 + 1 < Gm::NTD;
+          if (pair) {
+            product(dt0 + 1, acc);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *(u16x4*)(sc + m * 1024 + (cw0 ^ 32)) = pack4(acc[m]);
+          }
+          flush(dt0, pair);
         }
       } else {
         // The relu / dropout mask of the conv stage is [activation != 0], and the activations are this wave's own B fragments -- in operand layout,
@@ -250,6 +363,13 @@ __global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Poo
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int j = 0; j < 8; ++j) eh[h][j] = (g == 2 * h + (li >> 3) && j == (li & 7)) ? BF16_ONE : (u16)0;
+        uint32_t seqm[MT];
+        float alpha[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          seqm[m] = seq_of(m * 16 + li);
+          alpha[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4));
+        }
 #pragma unroll
         for (int dt = 0; dt < Gm::NTD; ++dt) {
           f32x4 acc[MT];
@@ -257,22 +377,24 @@ __global__ __launch_bounds__(Pool3GeomT<MT_>::THREADS) void pool3_bwd_kernel(Poo
           const int col = dt * 16 + 4 * g;
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const f32x4 xv = mfma_16x16x32_bf16(eh[dt & 1], xf[m][dt >> 1], f32x4{0.f, 0.f, 0.f, 0.f});
-            if (tb + m * 16 < p.n_tok && col < D && !(dbg & 32)) {
-              // direct term from the g_out row and forward weight, straight into the seqpad row
-              const f32x4 go = *(const f32x4*)(p.g_out + (int64_t)seqm[m] * D + col);
-              f32x4 o;
+            const f32x4 xv = mfma_16x16x32_bf16(eh[dt & 1], xr[dt >> 1][m], f32x4{0.f, 0.f, 0.f, 0.f});
+            // direct term from the g_out row and forward weight (columns >= D: nothing to fetch, never stored)
+            const f32x4 go = col < D ? buf_load16f<0>(r_g, seqm[m] * (uint32_t)(D * 4) + (uint32_t)(col * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 o;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = xv[r] != 0.0f ? (acc[m][r] + alpha[m] * go[r]) * p.act_scale : 0.0f;
-              *(u16x4*)(p.dy_pad + (tb + m * 16 + seqm[m] + 1) * KP + col) = pack4(o);
-            }
+            for (int r = 0; r < 4; ++r) o[r] = xv[r] != 0.0f ? (acc[m][r] + alpha[m] * go[r]) * p.act_scale : 0.0f;
+            *(u16x4*)(sc + m * 1024 + ((dt & 1) ? (cw0 ^ 32) : cw0)) = pack4(o);
           }
+          if ((dt & 1) || dt == Gm::NTD - 1) flush(dt & ~1, (dt & 1) != 0);
           NR_SCHED_BARRIER();
         }
       }
     }
+    stamp(6);
     grp = nxt;
-    if ((!PF || ACT) && nxt < n_groups) pool3_load_x(p.ctx, nxt * Gm::ROWS, n_load, xf);
+    if (ACT && nxt < n_groups) pool3_load_x(p.ctx, nxt * Gm::ROWS, n_load, xr);
+    stamp(7);
+    ++it;
   }
   __syncthreads();
   for (int n = tid; n < QP; n += Gm::THREADS) {

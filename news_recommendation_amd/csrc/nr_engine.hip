@@ -777,6 +777,9 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
   return nr_conv_act_bwd(act, dctx_scratch, NR_KP, attn_w, g_out, NR_D, dy_pad, n_seq, S, p_drop, stream);
 }
 
+static unsigned long long* g_pool3_stamps = nullptr;
+void nr_debug_pool3_stamps(uint64_t* buf) { g_pool3_stamps = (unsigned long long*)buf; }
+
 int64_t nr_additive_bwd_flat_grid(int64_t n_tok) {
   if (n_tok <= 0) return 0;
   const int64_t wgs = ((n_tok + nr::Pool3Geom::ROWS - 1) / nr::Pool3Geom::ROWS + nr::Pool3Geom::NWAVE - 1) / nr::Pool3Geom::NWAVE;
@@ -791,20 +794,22 @@ int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
       y_stride < NR_D || (y_stride & 3))
     return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: dropout probability out of range");
-  if (S < 2 || n_seq * (int64_t)S >= (1LL << 31)) return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 2 and n_seq * S < 2^31");
+  if (S < 2 || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 2, n_seq * S < 2^31 and n_seq < 2^31 / 1200");
   if (n_seq == 0) return NR_OK;
   NR_LAUNCH(nr::rowdot_kernel, grid_for(n_seq, 4, 4096), 256, 0, (hipStream_t)stream, g_out, (int64_t)NR_D, y, y_stride, n_seq, NR_D, tot);
   nr::Pool3Params p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.tot = tot; p.dpre = dpre; p.dq_part = dq_part;
-  p.dctx = dctx; p.dy_pad = dy_pad; p.act_scale = 1.0f / (1.0f - p_drop); p.n_tok = n_seq * S; p.S = (uint32_t)S;
+  p.dctx = dctx; p.dy_pad = dy_pad; p.act_scale = 1.0f / (1.0f - p_drop); p.n_seq = n_seq; p.n_tok = n_seq * S; p.S = (uint32_t)S;
   p.s_magic = (uint32_t)((1ULL << 32) / (uint32_t)S) + 1u;
   const int64_t grid = nr_additive_bwd_flat_grid(p.n_tok);
   const char* d = getenv("NR_POOL_DEBUG");        // profiling: phase switches of the DBG instantiations (re-read per call; tools/pool_phases.sh)
   p.dbg = d ? atoi(d) : 0;
+  p.stamps = g_pool3_stamps;
 #define NR_POOL3_LAUNCH(ACT_, DBG_)                                                                                                       \
   do {                                                                                                                                    \
-    if (allow_smem(nr::pool3_bwd_kernel<ACT_, 3, true, DBG_>, nr::Pool3Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd_flat: cannot reserve LDS"); \
-    NR_LAUNCH((nr::pool3_bwd_kernel<ACT_, 3, true, DBG_>), grid, nr::Pool3Geom::THREADS, nr::Pool3Geom::SMEM, (hipStream_t)stream, p);      \
+    if (allow_smem(nr::pool3_bwd_kernel<ACT_, DBG_>, nr::Pool3Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd_flat: cannot reserve LDS"); \
+    NR_LAUNCH((nr::pool3_bwd_kernel<ACT_, DBG_>), grid, nr::Pool3Geom::THREADS, nr::Pool3Geom::SMEM, (hipStream_t)stream, p);      \
   } while (0)
   if (dy_pad) { if (p.dbg) NR_POOL3_LAUNCH(true, true); else NR_POOL3_LAUNCH(true, false); }
   else { if (p.dbg) NR_POOL3_LAUNCH(false, true); else NR_POOL3_LAUNCH(false, false); }

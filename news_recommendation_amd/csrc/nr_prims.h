@@ -150,6 +150,33 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // 64-bit mask of the lanes whose predicate is true
 __device__ __forceinline__ uint64_t ballot(bool pred) { return __ballot(pred); }
 
+// Raw buffer access: a 128-bit resource in SGPRs (base pointer, byte count) + ONE 32-bit byte offset per lane + an immediate -- no 64-bit
+// address pair per lane and no compare-and-branch around the access: an offset at or past the byte count reads zeros / stores nothing.
+// (Kernels whose lanes keep 64-bit addresses per row spill them; a spill reload sits in the same in-order counter as the stores before it
+// and waits for all of them.)  nbytes and off must be multiples of the access size.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_buf(const void* base, uint32_t nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nbytes, 0x00020000);
+}
+template <int IMM = 0> __device__ __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off) {
+  return __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + IMM, 0, 0));
+}
+template <int IMM = 0> __device__ __forceinline__ f32x4 buf_load16f(BufRsrc r, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + IMM, 0, 0));
+}
+__device__ __forceinline__ float buf_load4f(BufRsrc r, uint32_t off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+// soff: a wave-uniform byte offset (scalar operand of the instruction)
+template <int IMM = 0> __device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t off, u16x8 v, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, off + IMM, soff, 0);
+}
+template <int IMM = 0> __device__ __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, off + IMM, soff, 0);
+}
+
 template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }   // streaming store: not re-read soon
 

@@ -305,6 +305,31 @@ __forceinline__ uint64_t ballot(bool pred) {
   return m;
 }
 
+// raw buffer access (see csrc/nr_prims.h): offsets at or past the byte count read zeros / store nothing
+struct BufRsrc { unsigned char* base; uint32_t nbytes; };
+__forceinline__ BufRsrc make_buf(const void* base, uint32_t nbytes) { return BufRsrc{(unsigned char*)base, nbytes}; }
+template <int IMM = 0> __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off) {
+  u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if ((uint64_t)off + IMM + 16 <= r.nbytes) memcpy(&v, r.base + off + IMM, 16);
+  return v;
+}
+template <int IMM = 0> __forceinline__ f32x4 buf_load16f(BufRsrc r, uint32_t off) {
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if ((uint64_t)off + IMM + 16 <= r.nbytes) memcpy(&v, r.base + off + IMM, 16);
+  return v;
+}
+__forceinline__ float buf_load4f(BufRsrc r, uint32_t off) {
+  float v = 0.0f;
+  if ((uint64_t)off + 4 <= r.nbytes) memcpy(&v, r.base + off, 4);
+  return v;
+}
+template <int IMM = 0> __forceinline__ void buf_store16(BufRsrc r, uint32_t off, u16x8 v, uint32_t soff = 0) {
+  if ((uint64_t)off + IMM + soff + 16 <= r.nbytes) memcpy(r.base + off + IMM + soff, &v, 16);
+}
+template <int IMM = 0> __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
+  if ((uint64_t)off + IMM + soff + 8 <= r.nbytes) memcpy(r.base + off + IMM + soff, &v, 8);
+}
+
 template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }
 template <typename T> __forceinline__ void st_nt(T* p, T v) { *p = v; }
 

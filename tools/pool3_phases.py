@@ -8,7 +8,9 @@ import torch
 from news_recommendation_amd import _capi
 from news_recommendation_amd._capi import NR_D, NR_KP, NR_QP
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+TIMELINE = '--timeline' in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+B = int(args[0]) if args else 512
 dev = torch.device('cuda:0'); lib = _capi.load(); st = lambda: torch.cuda.current_stream().cuda_stream
 ck = lambda rc: _capi.check(lib, rc)
 g = torch.Generator().manual_seed(0)
@@ -41,6 +43,25 @@ for S, act, Tn in ((20, False, B * 53), (20, True, B * 55), (50, True, B * 55), 
     fn = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
                                              tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act else dc_.data_ptr(), dy_.data_ptr() if act else None,
                                              0.2 if act else 0.0, Tn, S, st()))
+    if TIMELINE:
+        # cycle-counter stamps of the first 8 iterations of waves 0-1 of workgroups 0-3 (debug build, nothing switched off): 0 top of the
+        # iteration, 1 rows are fragments, 2 ds known, 3 six n-tiles done, 4 projection done, 5 next rows requested, 6 dctx done, 7 end
+        import numpy as np
+        st_buf = torch.zeros(4 * 2 * 8 * 8, dtype=torch.int64, device=dev)
+        lib.nr_debug_pool3_stamps(st_buf.data_ptr())
+        os.environ['NR_POOL_DEBUG'] = '64'
+        fn(); torch.cuda.synchronize()
+        lib.nr_debug_pool3_stamps(None)
+        a = st_buf.cpu().numpy().reshape(4, 2, 8, 8)
+        print(f"timeline S={S} act={int(act)} (ticks; columns: to-fragments, dw, n-tiles 0-5, n-tiles 6-12, prefetch issue, dctx, tail | iteration total)")
+        for wg in range(2):
+            for wv in range(2):
+                for it in range(6):
+                    r = a[wg, wv, it]
+                    if r[0] == 0: continue
+                    d = [int(r[k + 1] - r[k]) for k in range(7)]
+                    nxt = int(a[wg, wv, it + 1][0] - r[0]) if it + 1 < 8 and a[wg, wv, it + 1][0] else -1
+                    print(f"  wg{wg} w{wv} it{it}: start {int(r[0] - a[0, 0, 0][0]):8d} | " + ' '.join(f'{x:6d}' for x in d) + f" | {nxt}")
     os.environ.pop('NR_POOL_DEBUG', None)
     line = [f"S={S} act={int(act)} n_seq={Tn} | production {timed(fn):.1f}"]
     for d in (64, 65, 66, 68, 72, 80, 96, 192, 48, 255):
