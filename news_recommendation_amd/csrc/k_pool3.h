@@ -42,7 +42,8 @@ struct Pool3Geom {
   static constexpr int BQ_BYTES = 2 * QP * 4;    // bias and query vector
   static constexpr int DQ_BYTES = NWAVE * QP * 4;
   static constexpr int SC_WAVE = ROWS * 64;      // 3,072 B of layout-change scratch per wave: [48 rows][4 slots of 16 B], slots swizzled (sc_swz)
-  static constexpr int SMEM = W_BYTES + BQ_BYTES + DQ_BYTES + NWAVE * SC_WAVE;      // 161,536
+  static constexpr int EH_BYTES = 2 * 64 * 16;   // the two selector fragments of the activation-gradient form (see there)
+  static constexpr int SMEM = W_BYTES + BQ_BYTES + DQ_BYTES + NWAVE * SC_WAVE + EH_BYTES;      // 163,584
   static_assert(SMEM <= 163840 && QP - WROWS == 8, "LDS; the dropped rows are the upper half of the last n-tile");
 };
 
@@ -95,20 +96,21 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
 
 // The wave's 48 ctx rows as row pieces: xr[ks][t] = columns 32 ks + 8 (l & 3) .. + 7 of row 16 t + (l >> 2) -- per instruction 16 runs of 64
 // contiguous bytes.  pool3_to_fragments() turns them into B-operand fragments in place.
-__device__ __forceinline__ void pool3_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t n_tok, u16x8 (&xr)[KSTEPS][Pool3Geom::MT]) {
-  const int l = lane_id();
-  const int64_t left = n_tok - tok0;                                    // (<= 0: a phase switch of the debug build)
+__device__ __forceinline__ BufRsrc pool3_x_rsrc(const u16* __restrict__ ctx, int64_t tok0, int64_t n_tok) {
+  const int64_t left = n_tok - tok0;                                    // (<= 0: past the last group, or a phase switch of the debug build)
   const int nrows = left < Pool3Geom::ROWS ? (left > 0 ? (int)left : 0) : Pool3Geom::ROWS;
-  const BufRsrc rx = make_buf(ctx + tok0 * KP, (uint32_t)(nrows * KP * 2));      // rows past the end read as zeros
+  return make_buf(ctx + (left > 0 ? tok0 : 0) * KP, (uint32_t)(nrows * KP * 2));      // rows past the end read as zeros
+}
+__device__ __forceinline__ void pool3_load_x_ks(BufRsrc rx, int ks, u16x8 (&x)[Pool3Geom::MT]) {
+  int lq = lane_id();
+  NR_OPAQUE(lq);                                                        // (offsets rebuilt from an opaque lane id: not worth three registers)
 #pragma unroll
-  for (int t = 0; t < Pool3Geom::MT; ++t) {
-    uint32_t off = (uint32_t)((t * 16 + (l >> 2)) * (KP * 2) + (l & 3) * 16);
-    NR_OPAQUE(off);                                                     // (one offset register per row tile, the k-step in the immediate)
-    xr[0][t] = buf_load16<0>(rx, off); xr[1][t] = buf_load16<64>(rx, off); xr[2][t] = buf_load16<128>(rx, off); xr[3][t] = buf_load16<192>(rx, off);
-    xr[4][t] = buf_load16<256>(rx, off); xr[5][t] = buf_load16<320>(rx, off); xr[6][t] = buf_load16<384>(rx, off); xr[7][t] = buf_load16<448>(rx, off);
-    xr[8][t] = buf_load16<512>(rx, off); xr[9][t] = buf_load16<576>(rx, off);
-    static_assert(KSTEPS == 10, "unrolled by hand: the immediate is a template argument");
-  }
+  for (int t = 0; t < Pool3Geom::MT; ++t) x[t] = buf_load16<0>(rx, (uint32_t)((t * 16 + (lq >> 2)) * (KP * 2) + (lq & 3) * 16), (uint32_t)(ks * 64));
+}
+__device__ __forceinline__ void pool3_load_x(const u16* __restrict__ ctx, int64_t tok0, int64_t n_tok, u16x8 (&xr)[KSTEPS][Pool3Geom::MT]) {
+  const BufRsrc rx = pool3_x_rsrc(ctx, tok0, n_tok);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) pool3_load_x_ks(rx, ks, xr[ks]);
 }
 
 // row pieces -> fragments through the wave's scratch, one k-step (48 rows x 64 B) at a time: afterwards xr[ks][m] holds features
@@ -151,6 +153,14 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
   for (int i = tid; i < KP / 8; i += Gm::THREADS) *(u16x8*)(smem + Gm::WROWS * Gm::WROW + i * 16) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < QP; i += Gm::THREADS) { bq[i] = p.bap[i]; bq[QP + i] = p.qvp[i]; }
   for (int i = tid; i < Gm::NWAVE * QP; i += Gm::THREADS) bq[2 * QP + i] = 0.0f;
+  unsigned char* eht = smem + Gm::SMEM - Gm::EH_BYTES;
+  if (ACT && tid < 128) {                 // E_h as an A fragment: lane (d = li, g) holds E_h[d][8 g + j] = [8 g + j == 16 h + d]
+    const int h = tid >> 6, ln = tid & 63;
+    u16x8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = ((ln >> 4) == 2 * h + ((ln >> 3) & 1) && j == (ln & 7)) ? BF16_ONE : (u16)0;
+    *(u16x8*)(eht + tid * 16) = e;
+  }
   __syncthreads();
 
   const int64_t n_groups = (p.n_tok + Gm::ROWS - 1) / Gm::ROWS, gstride = (int64_t)gridDim.x * Gm::NWAVE;
@@ -188,53 +198,66 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
     const BufRsrc r_aw = make_buf(p.attn_w + tok0, (uint32_t)(nrows * 4));
     const BufRsrc r_g = make_buf(p.g_out, (uint32_t)(p.n_seq * (D * 4))), r_tot = make_buf(p.tot, (uint32_t)(p.n_seq * 4));
     const BufRsrc r_dpre = make_buf(p.dpre + tok0 * QP, (uint32_t)(nrows * QP * 2));
+    // dw[tok] = g_out[seq(tok)] . x[tok] on the matrix core: the group's rows belong to at most 8 sequences (S >= 7), "slots" sq0 .. sq0 + 7.  A tile:
+    // row li = (slot li >> 1, part li & 1) of g_out split into two bf16 numbers (g = hi + lo to 2^-17: the products with the bf16 rows are exact,
+    // the accumulation fp32); B = the rows' own fragments.  A token then picks the two accumulator rows of ITS slot.  [As 3 x 80 multiply-adds per
+    // lane with 60 sixteen-byte loads of g_out in front of them this phase took a fifth of the kernel -- latency of six load batches per group.]
+    const uint32_t sq0 = (uint32_t)uniform((int)seq_of(0));
     float ds[MT];
+    {
+      f32x4 accg[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const uint32_t sq = seq_of(m * 16 + li);
-      uint32_t go = sq * (uint32_t)(D * 4) + (uint32_t)(g * 32);
+      for (int m = 0; m < MT; ++m) accg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint32_t go = (sq0 + (uint32_t)(li >> 1)) * (uint32_t)(D * 4) + (uint32_t)(g * 32);      // (slots past the last sequence: outside the buffer, zeros)
       NR_OPAQUE(go);
-      float a = 0.0f;
-      auto dot8 = [&](auto ks_tag) {
+      auto gstep = [&](auto ks_tag) {
         constexpr int ks = decltype(ks_tag)::value;
-        const u16x8 x = xr[ks][m];
-        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 4 <= D) {                   // (columns >= D: the bias column of ctx, zeros)
-          const f32x4 g0 = buf_load16f<ks * 128>(r_g, go);
-          a += g0[0] * bf2f(x[0]) + g0[1] * bf2f(x[1]) + g0[2] * bf2f(x[2]) + g0[3] * bf2f(x[3]);
+        f32x4 g0 = f32x4{0.f, 0.f, 0.f, 0.f}, g1 = g0;
+        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 4 <= D) g0 = buf_load16f<ks * 128>(r_g, go);            // (columns >= D: the bias column of ctx, zeros)
+        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 8 <= D) g1 = buf_load16f<ks * 128 + 16>(r_g, go);
+        u16x8 fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u16 h0 = f2bf(g0[j]), h1 = f2bf(g1[j]);
+          fr[j] = (li & 1) ? f2bf(g0[j] - bf2f(h0)) : h0;
+          fr[4 + j] = (li & 1) ? f2bf(g1[j] - bf2f(h1)) : h1;
         }
-        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 8 <= D) {
-          const f32x4 g1 = buf_load16f<ks * 128 + 16>(r_g, go);
-          a += g1[0] * bf2f(x[4]) + g1[1] * bf2f(x[5]) + g1[2] * bf2f(x[6]) + g1[3] * bf2f(x[7]);
-        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accg[m] = mfma_16x16x32_bf16(fr, xr[ks][m], accg[m]);
       };
       if (!(dbg & 2)) {
-        dot8(IntTag<0>{}); dot8(IntTag<1>{}); dot8(IntTag<2>{}); dot8(IntTag<3>{}); dot8(IntTag<4>{});
-        dot8(IntTag<5>{}); dot8(IntTag<6>{}); dot8(IntTag<7>{}); dot8(IntTag<8>{}); dot8(IntTag<9>{});
+        gstep(IntTag<0>{}); gstep(IntTag<1>{}); gstep(IntTag<2>{}); gstep(IntTag<3>{}); gstep(IntTag<4>{});
+        gstep(IntTag<5>{}); gstep(IntTag<6>{}); gstep(IntTag<7>{}); gstep(IntTag<8>{}); gstep(IntTag<9>{});
       }
-      a = sum_rows4(a);
-      ds[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4)) * (a - buf_load4f(r_tot, sq * 4u));      // (rows past the end: weight 0)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint32_t sq = seq_of(m * 16 + li), slot = sq - sq0;                 // accumulator rows 4 g + r = (slot 2 g + (r >> 1), part r & 1)
+        const float pair = (slot & 1) ? accg[m][2] + accg[m][3] : accg[m][0] + accg[m][1];
+        const float dw = sum_rows4((int)(slot >> 1) == g ? pair : 0.0f);
+        ds[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4)) * (dw - buf_load4f(r_tot, sq * 4u));      // (rows past the end: weight 0)
+      }
     }
 
     stamp(2);
     // ---- t = tanh(x Wa^T + ba);  dpre = ds qv (1 - t^2) (kept packed in registers + stored);  dq += ds t ---------------------------------------
-    u16x4 dpk[Gm::NTQ + 1][MT];               // +1: the zero partner of the last (odd) n-tile in the dctx product
-#pragma unroll
-    for (int m = 0; m < MT; ++m) dpk[Gm::NTQ][m] = Z4;
+    u16x4 dpk[Gm::NTQ][MT];
 #pragma unroll
     for (int nt = 0; nt < Gm::NTQ; ++nt) {
       const int wrow = nt * 16 + 4 * g;
-      int bo = Gm::W_BYTES + 16 * g;          // (opaque: else one hoisted address per n-tile and vector, spilled around the whole loop)
-      NR_OPAQUE(bo);
+      // (every lane-constant address below is rebuilt per n-tile from an opaque lane id, ~8 integer instructions: kept across the loop they are the
+      // first values the register allocator spills, and a spill reload sits in the in-order memory counter behind the dpre stores)
+      int lq = l;
+      NR_OPAQUE(lq);
+      const int lg = lq >> 4, lr = lq & 15;
+      const int bo = Gm::W_BYTES + 16 * lg;
       const f32x4 b4 = *(const f32x4*)(smem + bo + nt * 64), q4 = *(const f32x4*)(smem + bo + QP * 4 + nt * 64);
       f32x4 acc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = b4;
       // fragment (nt, ks) of Wa: row 16 nt + li (rows >= 200: the zero row), slot (4 ks + g) ^ w_swz(row) = 4 (ks ^ b) + c with b, c lane constants
-      const int wr_ = nt * 16 + li < Gm::WROWS ? nt * 16 + li : Gm::WROWS;
-      const int wb = w_swz(li) >> 2, wc = (g ^ w_swz(li)) & 3;                      // (16 nt does not move the swizzle; the zero row is zero in every slot)
-      int wo = wr_ * Gm::WROW + wc * 16;
-      NR_OPAQUE(wo);
-      const unsigned char* wp = smem + wo;
+      const int wr_ = nt * 16 + lr < Gm::WROWS ? nt * 16 + lr : Gm::WROWS;
+      const int wb = w_swz(lr) >> 2, wc = (lg ^ w_swz(lr)) & 3;                     // (16 nt does not move the swizzle; the zero row is zero in every slot)
+      const unsigned char* wp = smem + wr_ * Gm::WROW + wc * 16;
       auto frag = [&](int ks) -> u16x8 { return *(const u16x8*)(wp + ((ks ^ wb) * 64)); };
       u16x8 a = frag(0);
 #pragma unroll
@@ -274,8 +297,9 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const u16x8 v = *(const u16x8*)(sc + t * 1024 + pr0);
-          uint32_t o = (uint32_t)((t * 16 + rowl) * (QP * 2) + (l & 3) * 16);
-          NR_OPAQUE(o);                       // (recomputed here: else 21 hoisted offsets, spilled)
+          int lq = l;                         // (the offset is recomputed here from an opaque lane id: hoisted, the 3 of them -- 21 with the column --
+          NR_OPAQUE(lq);                      //  are spilled, and a spill reload in front of a store waits for every store before it)
+          const uint32_t o = (uint32_t)((t * 16 + (lq >> 2)) * (QP * 2) + (lq & 3) * 16);
           if (((nt & 1) || (l & 3) < 2) && !(dbg & 32)) buf_store16(r_dpre, o, v, (uint32_t)(nt0 * 32));
         }
         wave_barrier();
@@ -297,19 +321,24 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
       // w_swz(row) = 2 r + (g & 1): low bit of the slot ^ (g & 1), its next two bits = (dt & 3) ^ r
       const int tr_r = li >> 2, tr_q = li & 3;
       const int tr_lo = (((tr_q >> 1) ^ (g & 1)) * 16) + (tr_q & 1) * 8;
-      auto product = [&](int dt, f32x4 (&acc)[MT]) {
-        const unsigned char* wq = smem + (4 * g + tr_r) * Gm::WROW + (dt >> 2) * 128 + ((((dt & 3) ^ tr_r)) * 32) + tr_lo;
+      auto product = [&](int dt, f32x4 (&acc)[MT], bool zero) {
+        int lq = l;                           // (opaque lane id: with the tile loop unrolled, one hoisted address per feature tile otherwise)
+        NR_OPAQUE(lq);
+        const int r_ = (lq >> 2) & 3;
+        const unsigned char* wq = smem + (4 * (lq >> 4) + r_) * Gm::WROW + (dt >> 2) * 128 + ((((dt & 3) ^ r_)) * 32) + tr_lo;
         const unsigned char* wz = smem + Gm::WROWS * Gm::WROW;        // rows >= 200 of the last k-step: the zero row
+        if (zero) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < Gm::KS2; ++ks) {
-          const bool in0 = ks * 32 + 15 < Gm::WROWS || ks * 32 + 4 * g + tr_r < Gm::WROWS;
+          const bool in0 = ks * 32 + 15 < Gm::WROWS || ks * 32 + 4 * (lq >> 4) + r_ < Gm::WROWS;
           const u16x4 lo = lds_tr16_b64((const u16*)(in0 ? wq + (ks * 32) * Gm::WROW : wz));
           const u16x4 hi = 2 * ks + 1 < Gm::NTQ ? lds_tr16_b64((const u16*)(wq + (ks * 32 + 16) * Gm::WROW)) : lo;     // (the partner of the last n-tile is zero on the dpre side)
           const u16x8 a = cat8(lo, hi);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, cat8(dpk[2 * ks][m], dpk[2 * ks + 1][m]), acc[m]);
+          for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, cat8(dpk[2 * ks][m], 2 * ks + 1 < Gm::NTQ ? dpk[2 * ks + 1][m] : Z4), acc[m]);
         }
       };
       // two feature tiles (32 columns) of the wave's rows leave together: accumulator-shaped 8-byte writes into the scratch, 16-byte row pieces out
@@ -319,7 +348,6 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
         for (int t = 0; t < MT; ++t) seql[t] = seq_of(t * 16 + rowl);
       }
       // ACT: seqpad row of a token = tok + seq + 1; the resource starts at the seqpad row of the group's first token
-      const uint32_t sq0 = ACT ? (uint32_t)uniform((int)seq_of(0)) : 0u;
       const int64_t out_rows = ACT ? (p.n_tok + p.n_seq) - (tok0 + sq0) : nrows;
       const BufRsrc r_out = make_buf(ACT ? p.dy_pad + (tok0 + sq0 + 1) * KP : p.dctx + tok0 * KP,
                                      (uint32_t)((out_rows < 3000000 ? out_rows : 3000000) * (KP * 2)));
@@ -330,9 +358,10 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
           const u16x8 v = *(const u16x8*)(sc + t * 1024 + pr0);
           const int col = dt0 * 16 + (l & 3) * 8;
           if ((!ACT || t * 16 + rowl < nrows) && (pair || (l & 3) < 2) && !(dbg & 32)) {
-            const uint32_t row = (uint32_t)(t * 16 + rowl) + (ACT ? seql[t] - sq0 : 0u);
-            uint32_t off = row * (uint32_t)(KP * 2) + (uint32_t)((l & 3) * 16);
-            NR_OPAQUE(off);
+            int lq = l;
+            NR_OPAQUE(lq);
+            const uint32_t row = (uint32_t)(t * 16 + (lq >> 2)) + (ACT ? seql[t] - sq0 : 0u);
+            const uint32_t off = row * (uint32_t)(KP * 2) + (uint32_t)((lq & 3) * 16);
             if (col + 8 <= D) buf_store16(r_out, off, v, (uint32_t)(dt0 * 32));
             else if (col + 4 <= D) buf_store8(r_out, off, u16x4{v[0], v[1], v[2], v[3]}, (uint32_t)(dt0 * 32));
           }
@@ -343,12 +372,12 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
 #pragma nounroll
         for (int dt0 = 0; dt0 < Gm::NTD; dt0 += 2) {
           f32x4 acc[MT];
-          product(dt0, acc);
+          product(dt0, acc, true);
 #pragma unroll
           for (int m = 0; m < MT; ++m) *(u16x4*)(sc + m * 1024 + cw0) = pack4(acc[m]);
           const bool pair = dt0 + 1 < Gm::NTD;
           if (pair) {
-            product(dt0 + 1, acc);
+            product(dt0 + 1, acc, true);
 #pragma unroll
             for (int m = 0; m < MT; ++m) *(u16x4*)(sc + m * 1024 + (cw0 ^ 32)) = pack4(acc[m]);
           }
@@ -358,41 +387,54 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
         // The relu / dropout mask of the conv stage is [activation != 0], and the activations are this wave's own B fragments -- in operand layout,
         // where the epilogue needs accumulator layout.  The matrix core moves them: E_h (16 x 32, E[d][k] = [k == 16 h + d]) times the
         // fragment of k-step dt / 2 is the tile x[tok][16 dt + d] exactly (1.0 x bf16 in fp32), lane for lane where acc holds the same element.
-        u16x8 eh[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) eh[h][j] = (g == 2 * h + (li >> 3) && j == (li & 7)) ? BF16_ONE : (u16)0;
-        uint32_t seqm[MT];
-        float alpha[MT];
+        // The direct term w[tok] g_out[seq(tok)][d] enters the accumulators as one more k-step: A[d][8 s + j] = parts of g_out[sq0 + s][d] (the group's
+        // rows belong to at most 4 sequences: S >= 16), B[8 s + j][tok] = parts of w[tok] where s is the token's slot, else 0, both numbers split
+        // into two bf16: hi hi + lo hi + hi lo.  One 4-byte load per lane and feature tile (row sq0 + g, column 16 dt + li) instead of a
+        // 16-byte g_out piece per lane, tile AND row tile with its wait right behind the previous tile's stores.
+        u16x4 bd[MT];                          // k-slots 0..3 of the lane's eight (the other four are zero)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          seqm[m] = seq_of(m * 16 + li);
-          alpha[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4));
+          const float a_ = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4));
+          const u16 ah = f2bf(a_), al = f2bf(a_ - bf2f(ah));
+          const bool mine = (int)(seq_of(m * 16 + li) - sq0) == g;
+          bd[m] = u16x4{mine ? ah : (u16)0, mine ? ah : (u16)0, mine ? al : (u16)0, 0};
         }
+        uint32_t gq = (sq0 + (uint32_t)g) * (uint32_t)(D * 4) + (uint32_t)(li * 4);
+        NR_OPAQUE(gq);
+        auto gload = [&](int dt) -> float { return dt * 16 + li < D ? buf_load4f(r_g, gq + (uint32_t)(dt * 64)) : 0.0f; };
+        float gn = gload(0), gn2 = gload(1);      // two tiles ahead: the wait for a value then never covers the stores and row requests of the tile before
+                                                 // (the memory counter is in order: one tile ahead, every second wait was a wait for the HBM latency of the rows)
+        const BufRsrc rx_next = pool3_x_rsrc(p.ctx, (grp + gstride) * Gm::ROWS, n_load);        // (past the last group: an empty resource, zeros nobody reads)
 #pragma unroll
         for (int dt = 0; dt < Gm::NTD; ++dt) {
+          const float gv = gn;
+          gn = gn2;
+          if (dt + 2 < Gm::NTD) gn2 = gload(dt + 2);
+          const u16x8 eh = *(const u16x8*)(eht + (dt & 1) * 1024 + l * 16);
+          const u16 gh = f2bf(gv), gl = f2bf(gv - bf2f(gh));
+          const u16x8 ad = u16x8{gh, gl, gh, 0, 0, 0, 0, 0};
           f32x4 acc[MT];
-          product(dt, acc);
-          const int col = dt * 16 + 4 * g;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(ad, cat8(bd[m], Z4), f32x4{0.f, 0.f, 0.f, 0.f});
+          product(dt, acc, false);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const f32x4 xv = mfma_16x16x32_bf16(eh[dt & 1], xr[dt >> 1][m], f32x4{0.f, 0.f, 0.f, 0.f});
-            // direct term from the g_out row and forward weight (columns >= D: nothing to fetch, never stored)
-            const f32x4 go = col < D ? buf_load16f<0>(r_g, seqm[m] * (uint32_t)(D * 4) + (uint32_t)(col * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 xv = mfma_16x16x32_bf16(eh, xr[dt >> 1][m], f32x4{0.f, 0.f, 0.f, 0.f});
             f32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = xv[r] != 0.0f ? (acc[m][r] + alpha[m] * go[r]) * p.act_scale : 0.0f;
+            for (int r = 0; r < 4; ++r) o[r] = xv[r] != 0.0f ? acc[m][r] * p.act_scale : 0.0f;
             *(u16x4*)(sc + m * 1024 + ((dt & 1) ? (cw0 ^ 32) : cw0)) = pack4(o);
           }
-          if ((dt & 1) || dt == Gm::NTD - 1) flush(dt & ~1, (dt & 1) != 0);
+          if ((dt & 1) || dt == Gm::NTD - 1) {
+            flush(dt & ~1, (dt & 1) != 0);
+            pool3_load_x_ks(rx_next, dt >> 1, xr[dt >> 1]);     // this k-step's fragments have served their last tile: the next group's rows take their registers
+          }
           NR_SCHED_BARRIER();
         }
       }
     }
     stamp(6);
     grp = nxt;
-    if (ACT && nxt < n_groups) pool3_load_x(p.ctx, nxt * Gm::ROWS, n_load, xr);
     stamp(7);
     ++it;
   }

@@ -794,8 +794,9 @@ int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
       y_stride < NR_D || (y_stride & 3))
     return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: dropout probability out of range");
-  if (S < 2 || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
-    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 2, n_seq * S < 2^31 and n_seq < 2^31 / 1200");
+  // 48 consecutive tokens belong to 1 + ceil(47 / S) sequences: the kernel has 8 slots for them, 4 in the activation-gradient form
+  if (S < 7 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 7 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq < 2^31 / 1200");
   if (n_seq == 0) return NR_OK;
   NR_LAUNCH(nr::rowdot_kernel, grid_for(n_seq, 4, 4096), 256, 0, (hipStream_t)stream, g_out, (int64_t)NR_D, y, y_stride, n_seq, NR_D, tot);
   nr::Pool3Params p;

@@ -160,8 +160,8 @@ typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_buf(const void* base, uint32_t nbytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nbytes, 0x00020000);
 }
-template <int IMM = 0> __device__ __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off) {
-  return __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + IMM, 0, 0));
+template <int IMM = 0> __device__ __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off, uint32_t soff = 0) {
+  return __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + IMM, soff, 0));
 }
 template <int IMM = 0> __device__ __forceinline__ f32x4 buf_load16f(BufRsrc r, uint32_t off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + IMM, 0, 0));

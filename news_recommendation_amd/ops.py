@@ -470,6 +470,15 @@ def _wgrad(a, b, name):
 # NR_POOL_FLAT: 1 (default) = the pooling backward over the flat token stream (csrc/k_pool3.h: persistent kernel, Wa resident in LDS, any
 # sequence length); 0 = the sequence-shaped kernels of rounds 1-3 (A/B only)
 _POOL_FLAT = os.environ.get('NR_POOL_FLAT', '1') == '1'
+_POOL_FLAT_MIN_TOK = int(os.environ.get('NR_POOL_FLAT_MIN_TOK', '98304'))
+
+
+def pool_flat_ok(S, act, n_seq=None):
+    """Whether the flat kernel takes a pooling level of S-token sequences (act: with the fused activation gradient): 48 consecutive tokens must
+    belong to at most 8 sequences (4 with act) -- the final attention over NAML's 4 views stays on the sequence-shaped kernel -- and the
+    batch must be worth a persistent launch (one workgroup per CU loads the projection matrix once: 512 click histories are faster on the
+    sequence-shaped kernel, 36 vs 47 us)."""
+    return _POOL_FLAT and S >= (16 if act else 7) and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK)
 
 
 def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, want_dctx=True, dy=None, p_drop=0.0):
@@ -650,7 +659,7 @@ class _EncoderFn(torch.autograd.Function):
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
-        WaT = pack_additive_t(Wa) if (need_grad and not _POOL_FLAT) else None
+        WaT = pack_additive_t(Wa) if (need_grad and not pool_flat_ok(S, False, n_seq)) else None
         WpT = None
         pooled = False
         if need_grad:
@@ -716,7 +725,7 @@ class _EncoderFn(torch.autograd.Function):
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
         # ---- additive attention backward: dpre (kernel), then two plain GEMMs ---------------------------------
-        if _POOL_FLAT:
+        if pool_flat_ok(S, False, n_seq):
             dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, f'S={S}')
             nwg = dq_part.shape[0]
         else:
@@ -973,7 +982,7 @@ class _AdditiveFn(torch.autograd.Function):
               valid, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp, out)
         ctx.qdim = Wa.shape[0]
-        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not _POOL_FLAT) else None
+        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not pool_flat_ok(S, False, n_seq)) else None
         return out
 
     @staticmethod
@@ -985,12 +994,13 @@ class _AdditiveFn(torch.autograd.Function):
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
         qdim = ctx.qdim
-        if not _POOL_FLAT:
+        flat = pool_flat_ok(S, False, n_seq)
+        if not flat:
             nwg = lib.nr_additive_bwd_grid(n_seq, S)
             dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
             dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
         if _GEMM_HAND:          # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
-            if _POOL_FLAT:
+            if flat:
                 dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense')
             else:
                 dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
@@ -1000,7 +1010,7 @@ class _AdditiveFn(torch.autograd.Function):
             _call('nr_additive_dx', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dx), n_seq, S, 0, _stream())
             dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
         else:
-            if _POOL_FLAT:
+            if flat:
                 dpre, dq_part, _ = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense', want_dctx=False)
             else:
                 _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())

@@ -308,9 +308,9 @@ __forceinline__ uint64_t ballot(bool pred) {
 // raw buffer access (see csrc/nr_prims.h): offsets at or past the byte count read zeros / store nothing
 struct BufRsrc { unsigned char* base; uint32_t nbytes; };
 __forceinline__ BufRsrc make_buf(const void* base, uint32_t nbytes) { return BufRsrc{(unsigned char*)base, nbytes}; }
-template <int IMM = 0> __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off) {
+template <int IMM = 0> __forceinline__ u16x8 buf_load16(BufRsrc r, uint32_t off, uint32_t soff = 0) {
   u16x8 v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  if ((uint64_t)off + IMM + 16 <= r.nbytes) memcpy(&v, r.base + off + IMM, 16);
+  if ((uint64_t)off + IMM + soff + 16 <= r.nbytes) memcpy(&v, r.base + off + IMM + soff, 16);
   return v;
 }
 template <int IMM = 0> __forceinline__ f32x4 buf_load16f(BufRsrc r, uint32_t off) {

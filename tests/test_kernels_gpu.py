@@ -173,10 +173,10 @@ from tests import kernel_checks_pool3 as k3  # noqa: E402
 
 
 def test_pool_flat_bad_args(be): k3.check_flat_bad_args(be)
-def test_pool_flat_small(be): k3.check_flat(be, S=20, n_seq=6); k3.check_flat(be, S=50, n_seq=5); k3.check_flat(be, S=4, n_seq=45, seed=3)
+def test_pool_flat_small(be): k3.check_flat(be, S=20, n_seq=6); k3.check_flat(be, S=50, n_seq=5); k3.check_flat(be, S=7, n_seq=30, seed=3)
 def test_pool_flat_valid_strided_any_length(be):
     k3.check_flat(be, S=20, n_seq=1027, valid=13, y_stride=3 * 300); k3.check_flat(be, S=50, n_seq=131, valid=37)
     k3.check_flat(be, S=33, n_seq=517, with_dctx=False, seed=5)
-def test_pool_flat_act(be): k3.check_flat_act(be, S=20, n_seq=1027); k3.check_flat_act(be, S=50, n_seq=2051)
+def test_pool_flat_act(be): k3.check_flat_act(be, S=20, n_seq=1027); k3.check_flat_act(be, S=50, n_seq=2051); k3.check_flat_act(be, S=16, n_seq=333, seed=8)
 def test_pool_flat_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3)
 def test_pool_flat_act_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136, act=True); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3, act=True)

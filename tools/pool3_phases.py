@@ -29,7 +29,7 @@ def timed(fn, n=5):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for S, act, Tn in ((20, False, B * 53), (20, True, B * 55), (50, True, B * 55), (50, False, 512), (4, False, B * 55)):
+for S, act, Tn in ((20, False, B * 53), (20, True, B * 55), (50, True, B * 55), (50, False, 512), (50, False, B * 55 // 2)):
     cx = torch.randn(Tn * S, NR_KP, generator=g).mul_(0.3)
     if act: cx = torch.relu(cx)
     cx = cx.to(torch.bfloat16).view(torch.int16).to(dev)
