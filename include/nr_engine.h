@@ -288,7 +288,7 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
 int64_t nr_additive_bwd_flat_grid(int64_t n_tok);
 /* Profiling aid (tools/pool3_phases.py): with NR_POOL_DEBUG set, the debug instantiation of the flat kernel writes cycle-counter stamps of the
  * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64); NULL switches it off. */
-void nr_debug_pool3_stamps(uint64_t* buf);
+int nr_debug_pool3_stamps(uint64_t* buf);
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
                          float p_drop, int64_t n_seq, int S, void* stream);

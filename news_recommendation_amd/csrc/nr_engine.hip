@@ -778,7 +778,7 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
 }
 
 static unsigned long long* g_pool3_stamps = nullptr;
-void nr_debug_pool3_stamps(uint64_t* buf) { g_pool3_stamps = (unsigned long long*)buf; }
+int nr_debug_pool3_stamps(uint64_t* buf) { g_pool3_stamps = (unsigned long long*)buf; return NR_OK; }
 
 int64_t nr_additive_bwd_flat_grid(int64_t n_tok) {
   if (n_tok <= 0) return 0;

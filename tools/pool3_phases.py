@@ -9,6 +9,7 @@ from news_recommendation_amd import _capi
 from news_recommendation_amd._capi import NR_D, NR_KP, NR_QP
 
 TIMELINE = '--timeline' in sys.argv
+PROD_ONLY = '--prod-only' in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 B = int(args[0]) if args else 512
 dev = torch.device('cuda:0'); lib = _capi.load(); st = lambda: torch.cuda.current_stream().cuda_stream
@@ -64,7 +65,7 @@ for S, act, Tn in ((20, False, B * 53), (20, True, B * 55), (50, True, B * 55), 
                     print(f"  wg{wg} w{wv} it{it}: start {int(r[0] - a[0, 0, 0][0]):8d} | " + ' '.join(f'{x:6d}' for x in d) + f" | {nxt}")
     os.environ.pop('NR_POOL_DEBUG', None)
     line = [f"S={S} act={int(act)} n_seq={Tn} | production {timed(fn):.1f}"]
-    for d in (64, 65, 66, 68, 72, 80, 96, 192, 48, 255):
+    for d in (() if PROD_ONLY else (64, 65, 66, 68, 72, 80, 96, 192, 48, 255)):
         os.environ['NR_POOL_DEBUG'] = str(d)
         line.append(f"{d}: {timed(fn):.1f}")
     print(' | '.join(line), flush=True)
