@@ -23,11 +23,10 @@
 
 namespace nr {
 
-// TPW titles per wave x NWAVE waves = 16 titles per workgroup in both instantiations: <4, 4> (one wave per SIMD, 5 token tiles, every LDS
-// weight fragment feeds 5 MFMAs) and <2, 8> (two waves per SIMD on 3 token tiles = 48 rows for 40 tokens: 17 % padding, but one wave's
-// loads / tanh / reductions overlap the other's MFMAs)
-// <50, 1, 4> (backward only): one 50-token sequence (NAML abstracts, the NRMS click history) per wave on 4 token tiles, 4 sequences per
-// workgroup -- the LDS-tile kernel gives a whole workgroup ONE such sequence and re-reads Wa / Wa^T (266 KB) from L2 for it.
+// TPW titles per wave x NWAVE waves per workgroup.  Instantiations: <20, 2, 8> -- two waves per SIMD on 3 token tiles = 48 rows for 40 tokens (17 %
+// padding, but one wave's loads / tanh / reductions overlap the other's MFMAs; the one-wave-per-SIMD form <20, 4, 4> lost in rounds 2 and 3 and is
+// gone) -- and <50, 1, 4>: one 50-token sequence (NAML abstracts, the NRMS click history) per wave on 4 token tiles, 4 sequences per workgroup.
+// Both are the SHORT-launch kernels since round 4: large launches run the flat kernel of k_pool3.h.
 template <int S_, int TPW_, int NWAVE_>
 struct Pool2Geom {
   static constexpr int S = S_;

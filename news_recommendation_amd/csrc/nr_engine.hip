@@ -70,14 +70,6 @@ int grid_for(int64_t work, int per_block, int cap) {
   return (int)b;
 }
 
-// tuning knob NR_ADD_VARIANT for the S = 20 pooling kernels: 4 (default) = register-resident kernels of k_pool2.h (one wave = 4 titles,
-// weights streamed through LDS); LDS-tile kernels: 0 = forward 4 waves on 2 titles, backward 4 waves on 4 titles; 1 = 8 waves on 8 titles
-// (both); 2 = 4 waves on 2 titles (both); 3 = 4 waves on 4 titles (both)
-int add_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NR_ADD_VARIANT"); v = e ? atoi(e) : 4; }
-  return v;
-}
 // 50-token sequences (NAML abstracts, click histories): the register-resident backward of k_pool2.h (<50, 1, 4>: 4 sequences per
 // workgroup) from 2048 sequences up -- measured on MI355X: 27,136 abstracts 1.31 -> 1.03 ms, but 512 histories 36 -> 45 us (128 workgroups
 // leave half of the CUs idle), so short batches keep the LDS-tile kernel (one sequence per workgroup).  NR_POOL2_S50=0: always the
@@ -85,7 +77,7 @@ int add_variant() {
 bool pool2_s50(int64_t n_seq) {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NR_POOL2_S50"); v = e ? atoi(e) : 1; }
-  return add_variant() == 4 && (v == 2 || (v == 1 && n_seq >= 2048));
+  return v == 2 || (v == 1 && n_seq >= 2048);
 }
 
 template <typename K>
@@ -247,18 +239,8 @@ int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap
   nr::AdditiveParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b;
   p.out_b_stride = out_b_stride; p.attn_w = attn_w; p.n_seq = n_seq; p.valid = valid;
-  if (S == 20 && add_variant() == 1) {
-    constexpr int NSEQ = 8, NW = 8;
-    using G = nr::AddGeom<20, NSEQ, NW>;
-    if (allow_smem(nr::additive_fwd_kernel<20, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
-  } else if (S == 20 && add_variant() != 3) {      // LDS-tile default: 2 titles per workgroup (5 workgroups per CU hide the per-tile latency chain: -14 %)
-    constexpr int NSEQ = 2;
-    using G = nr::AddGeom<20, NSEQ>;
-    if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
-  } else if (S == 20) {
-    constexpr int NSEQ = 4;
+  if (S == 20) {                      // 2 titles per workgroup (5 workgroups per CU hide the per-tile latency chain: -14 % against 4; 8 waves on 8 titles lost too:
+    constexpr int NSEQ = 2;           //  profiles/r02_ab_switches.txt -- those variants are gone)
     using G = nr::AddGeom<20, NSEQ>;
     if (allow_smem(nr::additive_fwd_kernel<20, NSEQ>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd: cannot reserve LDS");
     NR_LAUNCH((nr::additive_fwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::SMEM, (hipStream_t)stream, p);
@@ -546,7 +528,7 @@ int nr_attn_pool_fwd(const uint16_t* qkv, uint16_t* ctx, const int32_t* key_len,
 }
 
 int64_t nr_additive_bwd_grid(int64_t n_seq, int S) {
-  if (S == 20) return add_variant() == 4 ? (n_seq + 15) / 16 : add_variant() == 1 ? (n_seq + 7) / 8 : add_variant() == 2 ? (n_seq + 1) / 2 : (n_seq + 3) / 4;
+  if (S == 20) return (n_seq + 15) / 16;
   if (S == 50) return pool2_s50(n_seq) ? (n_seq + 3) / 4 : n_seq;
   if (S == 4) return (n_seq + 19) / 20;
   return -1;
@@ -577,23 +559,8 @@ int nr_additive_bwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
   nr::AdditiveBwdParams p;
   p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre;
   p.dq_part = dq_part; p.WaT = WaT; p.dctx = dctx; p.n_seq = n_seq; p.dy_pad = nullptr; p.act_scale = 1.0f;
-  if (S == 20 && add_variant() == 4) {
+  if (S == 20) {                      // (the LDS-tile backward kernels for titles -- 2, 4 and 8 titles per workgroup -- lost to this one in rounds 2 and 3 and are gone)
     if (nr::launch_pool2_bwd(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
-  } else if (S == 20 && add_variant() == 1) {
-    constexpr int NSEQ = 8, NW = 8;
-    using G = nr::AddGeom<20, NSEQ, NW>;
-    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ, NW>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ, NW>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::BWD_SMEM, (hipStream_t)stream, p);
-  } else if (S == 20 && add_variant() == 2) {
-    constexpr int NSEQ = 2;
-    using G = nr::AddGeom<20, NSEQ>;
-    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
-  } else if (S == 20) {
-    constexpr int NSEQ = 4;
-    using G = nr::AddGeom<20, NSEQ>;
-    if (allow_smem(nr::additive_bwd_kernel<20, NSEQ>, G::BWD_SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::additive_bwd_kernel<20, NSEQ>), (n_seq + NSEQ - 1) / NSEQ, nr::WG, G::BWD_SMEM, (hipStream_t)stream, p);
   } else if (S == 50 && pool2_s50(n_seq)) {
     if (nr::launch_pool2_bwd50(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_additive_bwd: cannot reserve LDS");
   } else if (S == 50) {
@@ -763,7 +730,7 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
   if (n_seq == 0) return NR_OK;
   static int fuse = -1;       // NR_POOL_ACT_FUSE=0: always the two-kernel form (A/B knob)
   if (fuse < 0) { const char* e = getenv("NR_POOL_ACT_FUSE"); fuse = e ? atoi(e) : 1; }
-  const bool reg = (S == 20 && add_variant() == 4) || (S == 50 && pool2_s50(n_seq));
+  const bool reg = S == 20 || (S == 50 && pool2_s50(n_seq));
   if (fuse == 1 && reg) {
     nr::AdditiveBwdParams p;
     p.ctx = act; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre; p.dq_part = dq_part; p.WaT = WaT;

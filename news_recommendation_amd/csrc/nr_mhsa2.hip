@@ -22,15 +22,9 @@ int launch_mhsa_fwd2(const MhsaParams& p, hipStream_t stream) {
   return 0;
 }
 
-// register-resident pooling kernels for titles (k_pool2.h): 16 titles per workgroup, as 8 waves x 2 titles (28: two waves per SIMD) or
-// 4 waves x 4 titles (44: one wave per SIMD).  Measured at B = 512, A/B on one box (gpurun_out/r02i): backward 368 us (28) vs 415 us (44).
-// NR_POOL2_GEOM overrides the default.
-static int pool2_geom(int dflt) {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("NR_POOL2_GEOM"); v = e ? atoi(e) : -1; }
-  return v > 0 ? v : dflt;
-}
-
+// register-resident pooling backward for titles (k_pool2.h): 16 titles per workgroup as 8 waves x 2 titles, two waves per SIMD (4 waves x 4 titles at
+// one wave per SIMD measured 415 - 426 us against 362 - 368 in rounds 2 and 3 and is gone).  The default of large launches is the flat kernel
+// of k_pool3.h; this one serves short launches and NR_POOL_FLAT=0.
 template <typename G>
 static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
   const char* d = getenv("NR_POOL_DEBUG");         // profiling: phase switches of pool2_bwd_kernel (re-read per call)
@@ -45,7 +39,7 @@ static int launch_pool2_bwd_t(const AdditiveBwdParams& p, hipStream_t stream) {
 }
 
 int launch_pool2_bwd(const AdditiveBwdParams& p, hipStream_t stream) {
-  return pool2_geom(28) == 28 ? launch_pool2_bwd_t<Pool2Geom<20, 2, 8>>(p, stream) : launch_pool2_bwd_t<Pool2Geom<20, 4, 4>>(p, stream);
+  return launch_pool2_bwd_t<Pool2Geom<20, 2, 8>>(p, stream);
 }
 
 // 50-token sequences: 4 per workgroup (one per wave, one wave per SIMD)

@@ -137,22 +137,6 @@ def test_gru_lds_variant():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize('geom', ['28', '44'])
-def test_pool2_geometries(geom):
-    """Both instantiations of the pooling backward of csrc/k_pool2.h: 8 waves x 2 titles (48-row token tiles for 40 tokens; the default
-    backward) and 4 waves x 4 titles (one wave per SIMD)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, NR_POOL2_GEOM=geom)
-    code = ("from tests.backends import EmuBackend as B; from tests import kernel_checks as k, kernel_checks_conv as kc; be = B(); "
-            "k.check_additive(be, S=20, n_seq=6); k.check_additive_valid(be, S=20, n_seq=5, valid=7); kc.check_additive_ex(be, S=20, n_seq=5); "
-            "k.check_additive_bwd(be, S=20, n_seq=6); k.check_additive_bwd(be, S=20, n_seq=17)")
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-
-
 def test_dropout_mask_statistics(be):
     kc.check_dropout_mask_statistics(be)
 
