@@ -30,4 +30,3 @@ timeout 900 python bench.py --model NAML --no-train-parity > $O/bench_line_NAML_
 timeout 1200 python bench.py --model LSTUR --shape large --no-train-parity > $O/bench_line_LSTUR_large.json 2> $O/bench_line_LSTUR_large.err; q $O/bench_line_LSTUR_large.json
 timeout 900 python bench.py --model LSTUR --no-train-parity --no-parity > $O/bench_line_LSTUR_small.json 2> $O/bench_line_LSTUR_small.err; q $O/bench_line_LSTUR_small.json
 timeout 900 python bench.py --shape large --no-train-parity --no-parity > $O/bench_line_NRMS_large.json 2> $O/bench_line_NRMS_large.err; q $O/bench_line_NRMS_large.json
-bash tools/gpu_two_ranks_one_gpu.sh > $O/two_ranks.log 2>&1; grep "^rc\[" $O/two_ranks.log; cp gpurun_out/two_ranks_NRMS.log gpurun_out/two_ranks_LSTUR.log $O/ 2>/dev/null

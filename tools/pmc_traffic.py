@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import bench
 out = sys.argv[1]
 tags = {'proj_train': ('nr_qkv_proj_fwd[S=20]', 'qkv_proj'), 'attn_fwd': ('nr_attn_fwd[S=20]', 'attn_fwd_kernel'), 'attn_pool_fwd': ('nr_attn_pool_fwd[S=20]', 'attn_fwd_kernel'), 'attn_bwd_hm': ('nr_attn_bwd[S=20]', 'attn_bwd'),
-        'additive_bwd': ('nr_additive_bwd[S=20]', 'pool2_bwd'), 'mhsa_infer': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2')}
+        'additive_bwd': ('nr_additive_bwd[S=20] (sequence-shaped)', 'pool2_bwd'), 'pool_flat': ('nr_additive_bwd[S=20]', 'pool3_bwd'), 'mhsa_infer': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2')}
 SRC = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r03_pmc_traffic.txt'
 
 
