@@ -211,3 +211,18 @@ def test_launcher_shards_training_rows_per_rank_and_gates_checkpoints(tmp_path):
     assert files0 == files1 and 'news_parsed.tsv' in files0 and val0 and val1
     assert ck0 == ck1 == os.path.realpath(os.path.join(root, 'checkpoint'))
     assert os.listdir(os.path.join(root, 'checkpoint', 'NRMS')) == ['ckpt-10.pth']          # rank 1's torch.save was gated
+
+
+def test_pool_flat_dispatch_by_shape(monkeypatch):
+    """Which pooling levels take the flat backward kernel (ops.pool_flat_ok): sequences long enough that 48 consecutive tokens span at most
+    8 of them (4 with the activation gradient), launches worth a persistent kernel; NR_POOL_FLAT=0 switches it off everywhere."""
+    from news_recommendation_amd import ops
+    monkeypatch.setattr(ops, '_POOL_FLAT', True)
+    monkeypatch.setattr(ops, '_POOL_FLAT_MIN_TOK', 98304)
+    assert ops.pool_flat_ok(20, False, 27136) and ops.pool_flat_ok(50, True, 28160) and ops.pool_flat_ok(20, True, 28160)
+    assert not ops.pool_flat_ok(4, False, 28160)                 # the four views of a NAML news item: 13 sequences in 48 tokens
+    assert ops.pool_flat_ok(7, False, 20000) and not ops.pool_flat_ok(15, True, 20000) and ops.pool_flat_ok(16, True, 20000)
+    assert not ops.pool_flat_ok(50, False, 512)                  # 512 click histories: the sequence-shaped kernel is faster
+    assert ops.pool_flat_ok(50, False)                           # shape-only question (operands packed before the batch is known)
+    monkeypatch.setattr(ops, '_POOL_FLAT', False)
+    assert not ops.pool_flat_ok(20, False, 27136)
