@@ -278,7 +278,8 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
                         int64_t n_seq, int S, void* stream);
 
 /* The pooling backward over a FLAT token stream (csrc/k_pool3.h; autograd of additive.py:27-53): every output of nr_additive_bwd_ex /
- * nr_additive_bwd_act for ANY sequence length S >= 2 from one persistent kernel.  The sum inside the softmax backward,
+ * nr_additive_bwd_act for any sequence length S >= 7 (S >= 16 with dy_pad: 48 consecutive tokens must belong to at most 8 / 4 sequences;
+ * shorter ones return NR_ERR_UNSUPPORTED and stay with the sequence-shaped entries) from one persistent kernel.  The sum inside the softmax backward,
  * sum_s w[s] (g_out . x[s]), equals g_out[seq] . y[seq] with y the pooled vector of the FORWARD (nr_additive_fwd*'s `out`: f32 rows of stride
  * y_stride), so token rows are independent and are dealt to waves 48 at a time regardless of sequence boundaries.  tot: f32 [n_seq]
  * scratch (receives g_out . y).  dq_part: f32 [nr_additive_bwd_flat_grid(n_seq * S)][NR_QP] partial rows.  Exactly one of, or neither of,
@@ -286,12 +287,13 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
  * 1 / (1 - p_drop)) may be given; with neither the call stops at dpre / dq.  Needs no Wa^T operand: the kernel reads Wa through LDS
  * transposing reads. */
 int64_t nr_additive_bwd_flat_grid(int64_t n_tok);
-/* Profiling aid (tools/pool3_phases.py): with NR_POOL_DEBUG set, the debug instantiation of the flat kernel writes cycle-counter stamps of the
- * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64); NULL switches it off. */
-int nr_debug_pool3_stamps(uint64_t* buf);
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
                          float p_drop, int64_t n_seq, int S, void* stream);
+/* Profiling aid (tools/pool3_phases.py): with NR_POOL_DEBUG set, the debug instantiation of the flat kernel writes cycle-counter stamps of the
+ * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64, owned by the caller until it passes NULL
+ * again, which switches the stamps off). */
+int nr_debug_pool3_stamps(uint64_t* buf);
 
 /* nr_additive_fwd with strided outputs: out f32 rows of stride out_stride (may be NULL) and/or out_b, a bf16 copy in the
  * ctx layout (row i at out_b + i*out_b_stride: cols 0..D-1, col D = 1.0, rest 0) that can feed another pooling level

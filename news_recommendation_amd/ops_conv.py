@@ -56,7 +56,7 @@ def _seqpad_alloc(n_seq, S):
 
 class _TextState:
     """What one text encoder keeps between forward and backward."""
-    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset', 'y', 'y_ptr', 'y_stride')
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset', 'y', 'y_ptr', 'y_stride', 'y_version')
 
 
 def pad_text(ids, what):
@@ -99,6 +99,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     # the pooled vectors in f32 are an operand of the backward (csrc/k_pool3.h): a private buffer when the caller only wants the bf16 copy;
     # a caller-owned `out` is the autograd function's own output, referenced through y_keep (detached: no reference cycle)
     st.y = None
+    st.y_version = None
     if need_grad and ops.pool_flat_ok(S, True, n_seq):
         if out is None:
             st.y = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
@@ -107,6 +108,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
             if y_keep is None or y_keep.data_ptr() != out or y_keep.stride(0) != out_stride:
                 raise ValueError("text_fwd: y_keep must be the tensor view behind `out`")
             st.y = y_keep.detach()
+            st.y_version = y_keep._version          # (the buffer is the autograd function's own output: an in-place edit before the backward would go unnoticed)
     st.y_ptr, st.y_stride = out, out_stride
     _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_v, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
           out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, _stream())
@@ -157,6 +159,8 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
+    if getattr(st, 'y_version', None) is not None and st.y._version != st.y_version:
+        raise RuntimeError("text_bwd: the pooled vectors were modified in place after the forward; the pooling backward needs them unchanged")
     d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
                                     y_ptr=st.y_ptr, y_stride=st.y_stride)
 
