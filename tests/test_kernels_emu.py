@@ -154,3 +154,8 @@ def test_pool_flat_any_length_dpre_only(be): k3.check_flat(be, S=33, n_seq=4, wi
 def test_pool_flat_act_s20(be): k3.check_flat_act(be, S=20, n_seq=7)
 def test_pool_flat_act_s50(be): k3.check_flat_act(be, S=50, n_seq=3); k3.check_flat_act(be, S=16, n_seq=10, seed=8)      # 16: four sequences in 48 tokens
 def test_pool_flat_persistent_loop(be): k3.check_flat(be, S=20, n_seq=130, seed=9); k3.check_flat_act(be, S=50, n_seq=60, seed=4)    # > 24 groups: several iterations per wave
+def test_pool_flat_group_boundaries(be):
+    """Row counts around the 48-row group: one full group, one row more, fewer rows than a tile; sequences longer than a group."""
+    k3.check_flat(be, S=48, n_seq=1, seed=1); k3.check_flat(be, S=49, n_seq=1, seed=2); k3.check_flat(be, S=7, n_seq=1, seed=3)
+    k3.check_flat(be, S=200, n_seq=2, seed=4)
+def test_pool_flat_act_lengths(be): k3.check_flat_act(be, S=16, n_seq=3, seed=5); k3.check_flat_act(be, S=17, n_seq=20, seed=6); k3.check_flat_act(be, S=128, n_seq=2, seed=7)
