@@ -294,6 +294,9 @@ int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
  * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64, owned by the caller until it passes NULL
  * again, which switches the stamps off). */
 int nr_debug_pool3_stamps(uint64_t* buf);
+/* The same for nr_attn_bwd_hm (tools/attnb_timeline.py; NR_ATTNB_DEBUG=8 selects the debug instantiation with nothing switched off):
+ * [2 workgroups][4 waves][4 sequences][4 rounds][12] stamps. */
+int nr_debug_attnb_stamps(uint64_t* buf);
 
 /* nr_additive_fwd with strided outputs: out f32 rows of stride out_stride (may be NULL) and/or out_b, a bf16 copy in the
  * ctx layout (row i at out_b + i*out_b_stride: cols 0..D-1, col D = 1.0, rest 0) that can feed another pooling level

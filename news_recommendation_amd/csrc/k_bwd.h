@@ -64,7 +64,8 @@ struct AttnBwdParams {
   const int32_t* key_len;  // optional [n_seq]: the forward's key lengths (MhsaParams::key_len); null: S
   DropCfg dc;            // dropout site 2 (applied to ctx in the forward)
   int xcd_major;         // workgroup -> pair order (xcd_major_block); 0 = plain blockIdx order (A/B knob NR_ATTN_XCD=0)
-  int debug;             // profiling only (NR_ATTNB_DEBUG, DBG instantiation): 1 skip the global loads, 4 skip the dqkv stores
+  int debug;             // profiling only (NR_ATTNB_DEBUG, DBG instantiation): 1 skip the global loads, 4 skip the dqkv stores, 16 skip the arithmetic (8: nothing off)
+  unsigned long long* stamps;   // DBG instantiation only (nr_debug_attnb_stamps): [2 workgroups][4 waves][4 sequences][4 rounds][12] cycle-counter stamps
   int hm;                // 1: q_save is the head-major [n_seq][H][3][S][DK] buffer of qkv_proj_kernel (k_proj.h; S = 20): Q, K, V of a pair, each
                          // [token][d] row-major, are 2,400 contiguous bytes (k_save / vt_save unused)
 };
@@ -248,6 +249,11 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
   // TILE iteration state: (sequence, round); every wave of the workgroup runs the same iterations and meets the same barriers
   int64_t seq_t = blockIdx.x;
   int rnd = 0;
+  int it_t = 0;                             // (timeline of the first sequences of a few workgroups: tools/attnb_timeline.py)
+  auto stamp = [&](int k) {
+    if (DBG && TILE && p.stamps != nullptr && l == 0 && blockIdx.x < 2 && it_t < 4)
+      p.stamps[((((size_t)blockIdx.x * WPB + w) * 4 + it_t) * Gm::ROUNDS + rnd) * 12 + k] = __builtin_readcyclecounter();
+  };
   if (TILE) {
     if (staged && seq_t < p.n_seq) stage_dctx(seq_t);
     __syncthreads();
@@ -259,7 +265,9 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
     const int hd = TILE ? w + rnd * WPB : (int)(pair - seq * H);
     const int64_t tok0 = seq * S;
     const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
+    stamp(0);
     if (act) store_lds(seq, hd);
+    stamp(1);
     if (TILE && staged && rnd == Gm::ROUNDS - 1) {          // every wave has taken its last pieces of this sequence's dctx rows
       __syncthreads();
       if (seq_t + gridDim.x < p.n_seq) stage_dctx(seq_t + gridDim.x);
@@ -272,7 +280,9 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       else load_regs(next / H, (int)(next % H));
     }
     wave_barrier();
+    stamp(2);
 
+    if (!(dbg & 16)) {     // (debug bit 16: the I/O skeleton alone -- loads, LDS staging, barriers and the write-out, no arithmetic)
     // ---- operand preparation ----------------------------------------------------------------------------------------
     u16x8 kf[Gm::QT], qf[Gm::QT], cperm[Gm::QT];
     u16x4 kcl[Gm::QT][Gm::DTL], qcl[Gm::QT][Gm::DTL], ccl[Gm::QT][Gm::DTL];   // CL(K), CL(Q), CL(dC) tiles [token tile][d tile]
@@ -326,6 +336,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       va[kt] = cat8(part[0], Gm::DTL > 1 ? part[Gm::DTL - 1] : Z4);
     }
 
+    stamp(3);
     u16x4 dsT[Gm::QT][Gm::QT];    // CL(dS^T)  [key tile][query tile]
     u16x4 dsN[Gm::QT][Gm::QT];    // CL(dS)    [query tile][key tile]
     u16x4 pN[Gm::QT][Gm::QT];     // CL(P)     [query tile][key tile]
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       }
       NR_SCHED_BARRIER();
     }
+    stamp(4);
     {
       u16x4 tp[Gm::QT][Gm::QT];
 #pragma unroll
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
       NR_SCHED_BARRIER();
     }
 
+    stamp(5);
     // ---- output products: every A/B operand below is a packed CL tile already in registers --------------------------
     // dQ^T[d][q]   = sum_key K^T[d][key] dS^T[key][q] : A = CL(K)  (k = key), B = CL(dS^T) (k = key)
     // dK^T[d][key] = sum_q   Q^T[d][q]   dS[q][key]   : A = CL(Q)  (k = q),   B = CL(dS)   (k = q)
@@ -427,10 +440,14 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
         }
       }
     }
+    }                      // !(dbg & 16)
     wave_barrier();        // all LDS reads of this pair done before the next pair's stores
+    stamp(6);
     }                      // act
     if (TILE && rnd == Gm::ROUNDS - 1) {         // the sequence is complete in every wave after this barrier: S x 1,920 contiguous bytes leave
+      stamp(7);
       __syncthreads();
+      stamp(8);
       if (!(dbg & 4)) {
         u16* dst = p.dqkv + tok0 * LDG;
 #pragma unroll
@@ -440,10 +457,12 @@ __global__ __launch_bounds__(WPB * 64, NR_ATTN_OCC) void attn_bwd_kernel(AttnBwd
           if (idx < S * (LDG / 8)) *(u16x8*)(dst + idx * 8) = *(const u16x8*)(tile + r * Gm::TROW + pc * 16);
         }
       }
+      stamp(9);
       __syncthreads();
+      stamp(10);
     }
     if (TILE) {
-      if (++rnd == Gm::ROUNDS) { rnd = 0; seq_t += gridDim.x; }
+      if (++rnd == Gm::ROUNDS) { rnd = 0; seq_t += gridDim.x; ++it_t; }
     } else {
       pair = next;
     }

@@ -276,6 +276,9 @@ int nr_attn_bwd(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* 
   return nr_attn_bwd_len(q_save, k_save, vt_save, dctx_gemm, ldc, attn_w, g_out, dqkv, nullptr, n_seq, S, p_drop, seed, stream);
 }
 
+static unsigned long long* g_attnb_stamps = nullptr;
+int nr_debug_attnb_stamps(uint64_t* buf) { g_attnb_stamps = (unsigned long long*)buf; return NR_OK; }
+
 static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const uint16_t* vt_save, int hm, const uint16_t* dctx_gemm, int ldc,
                            const float* attn_w, const float* g_out, uint16_t* dqkv, const int32_t* key_len, int64_t n_seq, int S, float p_drop,
                            uint64_t seed, void* stream) {
@@ -287,6 +290,7 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   nr::AttnBwdParams p;
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.dctx_gemm = dctx_gemm; p.ldc = ldc; p.attn_w = attn_w;
   p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm; p.debug = 0;
+  p.stamps = g_attnb_stamps;
   // head-major saves: a pair's operands are contiguous, nothing is shared between the heads of a token row except the dqkv row that is written
   { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
   const int64_t pairs = n_seq * NR_HEADS;
