@@ -34,8 +34,11 @@ def timed(n=10):
 
 os.environ.pop('NR_ATTNB_DEBUG', None)
 print(f"production {timed():.1f} us")
+for d, what in ((8, 'nothing off'), (9, 'no global loads'), (12, 'no dqkv stores'), (13, 'no loads, no stores'), (24, 'no arithmetic (I/O skeleton)'),
+                (25, 'no arithmetic, no loads'), (28, 'no arithmetic, no stores'), (29, 'barriers and LDS staging only')):
+    os.environ['NR_ATTNB_DEBUG'] = str(d)
+    print(f"debug build {d:2d} {what:32s} {timed():.1f} us", flush=True)
 os.environ['NR_ATTNB_DEBUG'] = '8'
-print(f"debug build, nothing off, no stamps {timed():.1f} us")
 NW, NS, NR, NK = 4, 4, 4, 12
 buf = torch.zeros(2 * NW * NS * NR * NK, dtype=torch.int64, device=dev)
 lib.nr_debug_attnb_stamps(buf.data_ptr())
