@@ -127,6 +127,14 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
   return o;
 }
 
+// ORs a 32-bit pattern into elements 4 | 5 (dword 2) of an operand fragment: one v_or_b32
+__device__ __forceinline__ u16x8 or_dword2(u16x8 f, uint32_t v) {
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v x = __builtin_bit_cast(u32x4v, f);
+  x[2] |= v;
+  return __builtin_bit_cast(u16x8, x);
+}
+
 __device__ __forceinline__ u16x8 cat8(u16x4 lo, u16x4 hi) {
   u16x8 o;
   o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];

@@ -5,6 +5,7 @@
 #include "k_additive_fwd.h"
 #include "k_bwd.h"
 #include "k_proj.h"
+#include "k_attn_bwd2.h"
 #include "k_gemm.h"
 #include "k_conv.h"
 #include "k_pool3.h"
@@ -298,6 +299,34 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   // grid (used by the tests to force many pairs per wave on small inputs).
   const char* capenv = getenv("NR_ATTN_BWD_MAX_WGS");      // (re-read per call: the tests flip it inside one process)
   const int capdiv = capenv ? atoi(capenv) : 0;
+  // head-major saves, contiguous 16-byte aligned operands: the DMA form (csrc/k_attn_bwd2.h).  NR_ATTNB2=0: the round-4 TILE kernel (A/B only)
+  // (2: required -- the call fails instead of falling back; re-read per call: the tests flip it inside one process)
+  const char* v2env = getenv("NR_ATTNB2");
+  const int v2 = v2env ? atoi(v2env) : 1;
+  const bool v2ok = hm && S == 20 && ldc == NR_KP &&
+      ((((uintptr_t)q_save) | ((uintptr_t)dctx_gemm) | ((uintptr_t)attn_w) | ((uintptr_t)g_out) | ((uintptr_t)dqkv)) & 15) == 0;
+  if (v2 == 2 && !v2ok) return fail(NR_ERR_UNSUPPORTED, "nr_attn_bwd: NR_ATTNB2=2 needs head-major saves, ldc == 320 and 16-byte aligned operands");
+  if (v2 && v2ok) {
+    nr::AttnBwd2Params q;
+    q.qkv = q_save; q.dctx = dctx_gemm; q.attn_w = attn_w; q.g_out = g_out; q.dqkv = dqkv; q.n_seq = n_seq; q.key_len = key_len; q.dc = p.dc;
+    q.debug = 0; q.stamps = g_attnb_stamps;
+    const int64_t cap = capdiv > 0 ? capdiv : 2 * (int64_t)nr::device_cus();        // persistent: two workgroups per CU walk the titles
+    const int grid = (int)(n_seq < cap ? n_seq : cap);
+    const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches of the DBG instantiation, re-read per call
+    const char* nwe = getenv("NR_ATTNB2_NW");       // A/B: waves per workgroup (5: three rounds of five heads; 4: four rounds)
+    const int nw = nwe ? atoi(nwe) : 5;
+    q.debug = d ? atoi(d) : 0;
+#define NR_AB2_LAUNCH(NW_, DBG_)                                                                                                  \
+    do {                                                                                                                          \
+      using G2 = nr::AttnBwd2Geom<NW_>;                                                                                           \
+      if (allow_smem(nr::attn_bwd2_kernel<NW_, DBG_>, G2::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");  \
+      NR_LAUNCH((nr::attn_bwd2_kernel<NW_, DBG_>), grid, G2::NT, G2::SMEM, (hipStream_t)stream, q);                              \
+    } while (0)
+    if (nw == 4) { if (q.debug) NR_AB2_LAUNCH(4, true); else NR_AB2_LAUNCH(4, false); }
+    else { if (q.debug) NR_AB2_LAUNCH(5, true); else NR_AB2_LAUNCH(5, false); }
+#undef NR_AB2_LAUNCH
+    return check_launch("nr_attn_bwd");
+  }
   if (S == 20) {
     constexpr int WPB = 4;
     using G = nr::AttnBwdGeom<20, WPB>;

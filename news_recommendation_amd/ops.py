@@ -473,15 +473,20 @@ _POOL_FLAT = os.environ.get('NR_POOL_FLAT', '1') == '1'
 _POOL_FLAT_MIN_TOK = int(os.environ.get('NR_POOL_FLAT_MIN_TOK', '98304'))
 
 
-def pool_flat_ok(S, act, n_seq=None):
+NR_POOL_FLAT_QMAX = 200      # rows of Wa the flat kernel keeps in LDS (Pool3Geom::WROWS, csrc/k_pool3.h)
+
+
+def pool_flat_ok(S, act, n_seq=None, *, qdim):
     """Whether the flat kernel takes a pooling level of S-token sequences (act: with the fused activation gradient): 48 consecutive tokens must
     belong to at most 8 sequences (4 with act) -- the final attention over NAML's 4 views stays on the sequence-shaped kernel -- and the
     batch must be worth a persistent launch (one workgroup per CU loads the projection matrix once: 512 click histories are faster on the
-    sequence-shaped kernel, 36 vs 47 us)."""
-    return _POOL_FLAT and S >= (16 if act else 7) and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK)
+    sequence-shaped kernel, 36 vs 47 us).  qdim (query_vector_dim, keyword-only so that no call site can forget it): the flat kernel holds
+    200 rows of the projection matrix in LDS; 201 .. 208 stay on the sequence-shaped kernels, which keep all 208 packed rows."""
+    return (_POOL_FLAT and qdim <= NR_POOL_FLAT_QMAX and S >= (16 if act else 7)
+            and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK))
 
 
-def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, want_dctx=True, dy=None, p_drop=0.0):
+def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0):
     """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
     y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused
     activation gradient goes there instead of dgemm."""
@@ -494,7 +499,7 @@ def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, w
     tot = _workspace('pool_tot', (n_seq,), torch.float32, dev)
     dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev) if (want_dctx and dy is None) else None
     _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), y_ptr, y_stride,
-          _ptr(tot), _ptr(dpre), _ptr(dq_part), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
+          _ptr(tot), _ptr(dpre), _ptr(dq_part), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, qdim, _stream())
     return dpre, dq_part, dgemm
 
 
@@ -659,7 +664,7 @@ class _EncoderFn(torch.autograd.Function):
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
         sp4 = (S + 3) // 4 * 4
-        WaT = pack_additive_t(Wa) if (need_grad and not pool_flat_ok(S, False, n_seq)) else None
+        WaT = pack_additive_t(Wa) if (need_grad and not pool_flat_ok(S, False, n_seq, qdim=Wa.shape[0])) else None
         WpT = None
         pooled = False
         if need_grad:
@@ -725,8 +730,8 @@ class _EncoderFn(torch.autograd.Function):
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
         # ---- additive attention backward: dpre (kernel), then two plain GEMMs ---------------------------------
-        if pool_flat_ok(S, False, n_seq):
-            dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, f'S={S}')
+        if pool_flat_ok(S, False, n_seq, qdim=qdim):
+            dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, f'S={S}')
             nwg = dq_part.shape[0]
         else:
             nwg = lib.nr_additive_bwd_grid(n_seq, S)
@@ -982,7 +987,7 @@ class _AdditiveFn(torch.autograd.Function):
               valid, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp, out)
         ctx.qdim = Wa.shape[0]
-        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not pool_flat_ok(S, False, n_seq)) else None
+        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not pool_flat_ok(S, False, n_seq, qdim=Wa.shape[0])) else None
         return out
 
     @staticmethod
@@ -994,14 +999,14 @@ class _AdditiveFn(torch.autograd.Function):
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
         qdim = ctx.qdim
-        flat = pool_flat_ok(S, False, n_seq)
+        flat = pool_flat_ok(S, False, n_seq, qdim=qdim)
         if not flat:
             nwg = lib.nr_additive_bwd_grid(n_seq, S)
             dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
             dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
         if _GEMM_HAND:          # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
             if flat:
-                dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense')
+                dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, 'dense')
             else:
                 dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
                 _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
@@ -1011,7 +1016,7 @@ class _AdditiveFn(torch.autograd.Function):
             dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
         else:
             if flat:
-                dpre, dq_part, _ = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, 'dense', want_dctx=False)
+                dpre, dq_part, _ = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, 'dense', want_dctx=False)
             else:
                 _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
             dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))

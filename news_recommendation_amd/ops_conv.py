@@ -81,7 +81,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
     st.Wd2 = pack_conv_dgrad(conv_w) if (need_grad and ops._GEMM_HAND & 32) else None
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
-    st.WaT = ops.pack_additive_t(Wa) if (need_grad and not ops.pool_flat_ok(S, True, n_seq)) else None
+    st.WaT = ops.pack_additive_t(Wa) if (need_grad and not ops.pool_flat_ok(S, True, n_seq, qdim=st.qdim)) else None
     st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
     xs_ptr = None
     st.xstore = None
@@ -100,7 +100,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     # a caller-owned `out` is the autograd function's own output, referenced through y_keep (detached: no reference cycle)
     st.y = None
     st.y_version = None
-    if need_grad and ops.pool_flat_ok(S, True, n_seq):
+    if need_grad and ops.pool_flat_ok(S, True, n_seq, qdim=st.qdim):
         if out is None:
             st.y = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
             out, out_stride = st.y.data_ptr(), NR_D
@@ -124,9 +124,9 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
-    flat = ops.pool_flat_ok(S, dy is not None, n_seq) and y_ptr is not None
+    flat = ops.pool_flat_ok(S, dy is not None, n_seq, qdim=qdim) and y_ptr is not None
     if flat:
-        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, tag, dy=dy, p_drop=p_drop)
+        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop)
     else:
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
@@ -245,7 +245,7 @@ class _NamlNewsFn(torch.autograd.Function):
         _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(bc_), _ptr(Ws_), _ptr(bs_), _ptr(E), _stream())
         _call('nr_views_fill', lib.nr_views_fill, _ptr(cat), _ptr(sub), _ptr(E), ncat, _ptr(views), T, _stream())
         Wap, bap, qvp = pack_additive(Wa_f, ba_f, qv_f)
-        WaT = ops.pack_additive_t(Wa_f) if (need_grad and not ops.pool_flat_ok(4, False)) else None
+        WaT = ops.pack_additive_t(Wa_f) if (need_grad and not ops.pool_flat_ok(4, False, qdim=Wa_f.shape[0])) else None
         out = torch.empty(T, NR_D, dtype=torch.float32, device=dev)
         out_b = torch.empty(T, NR_KP, dtype=_BF16_AS_I16, device=dev)
         aw = torch.empty(T, 4, dtype=torch.float32, device=dev)
@@ -325,7 +325,7 @@ class _PoolFn(torch.autograd.Function):
         aw = torch.empty(n, S, dtype=torch.float32, device=dev)
         _call(f'nr_additive_fwd[user S={S}]', lib.nr_additive_fwd_v, _ptr(x_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(out), NR_D, None, 0,
               _ptr(aw), n, S, valid, _stream())
-        ctx.save_for_backward(x_b, aw, Wap, bap, qvp, None if ops.pool_flat_ok(S, False, n) else ops.pack_additive_t(Wa), out)
+        ctx.save_for_backward(x_b, aw, Wap, bap, qvp, None if ops.pool_flat_ok(S, False, n, qdim=Wa.shape[0]) else ops.pack_additive_t(Wa), out)
         ctx.qdim = Wa.shape[0]
         return out
 

@@ -105,3 +105,24 @@ for k in res:
     if k.startswith('proj'):
         out.setdefault('proj_TFLOPs', {})[k] = flop_proj / res[k] / 1e6
 print(json.dumps(out))
+
+# KB_SWEEP=1: phase decomposition of the two forward kernels in this process (the debug switches are re-read by every call)
+if os.environ.get('KB_SWEEP'):
+    def _t(fn, n=10):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    print('qkv_proj phases (NR_PROJ_DEBUG: 1 no table loads, 2 no MFMAs, 4 no Q/K/V stores, 8 no x_save stores, 16 no weight copies; 32 = debug build, nothing off)')
+    for d in (32, 33, 34, 36, 40, 48, 44, 45, 47, 63):
+        os.environ['NR_PROJ_DEBUG'] = str(d)
+        print(f'  NR_PROJ_DEBUG={d:2d}: {_t(kern["proj_train(x_save,drop)"]):8.1f} us', flush=True)
+    os.environ.pop('NR_PROJ_DEBUG')
+    print('attn_pool_fwd phases (NR_ATTNF_DEBUG: 1 no operand loads, 2 no exp / normalisation, 4 no ctx stores; 8 = debug build, nothing off)')
+    for d in (8, 9, 10, 12, 13, 15):
+        os.environ['NR_ATTNF_DEBUG'] = str(d)
+        print(f'  NR_ATTNF_DEBUG={d:2d}: pooled {_t(kern["attn_pool_fwd(drop)"]):8.1f} us   plain {_t(kern["attn_fwd(drop)"]):8.1f} us', flush=True)
+    os.environ.pop('NR_ATTNF_DEBUG')
