@@ -518,6 +518,93 @@ def gather_source_hash():
     return hashlib.sha256(src[a:src.index('\n}\n', a)].encode()).hexdigest()[:16]
 
 
+def build_step_graph(wl, model, opt, crit, target, batches, device):
+    """The training step of workload wl as ONE HIP graph (forward + backward + Adam; news_recommendation_amd/graph.py).  Returns (graph, flat):
+    flat(batch) is the graph's argument list for a batch."""
+    from news_recommendation_amd.graph import StepGraph
+    name = wl.name
+    if name == 'LSTUR':          # the captured step keeps user ids and history lengths on the device (graph.py)
+        for b in batches:
+            b['length_dev'] = b['length'].to(device)
+    flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if name == 'LSTUR' else [])
+
+    def step_fn(*xs):
+        n = len(wl.attrs)
+        cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
+        if name == 'LSTUR':
+            lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
+        else:
+            lg_ = model.forward_ids(cand['title'], click['title']) if name == 'NRMS' else model.forward_ids(cand, click)
+        l_ = crit(lg_, target)
+        l_.backward()
+        opt.step()
+        return l_
+    return StepGraph(step_fn, flat(batches[0]), opt, warmup=1), flat
+
+
+def other_workload(name, shape, vocab, B, device, steps=10):
+    """A short graph-replay leg of another BASELINE workload on this GPU, for the driver's own record (the default line is NRMS): the same
+    protocol as the headline -- one HIP graph per step, `steps` replays between synchronisations -- plus the dominant hand-written kernel of two
+    profiled eager steps, priced against its roofline like the headline's."""
+    from news_recommendation_amd import ops
+    cfg = make_cfg(name, shape, vocab)
+    wl = Workload(name, cfg)
+    model = wl.make_model().to(device).train()
+    opt = wl.make_optimizer(model)
+    crit = torch.nn.CrossEntropyLoss()
+    batches = wl.batches(0, 4, B, device)
+    target = torch.zeros(B, dtype=torch.long, device=device)
+
+    def step(i):
+        loss = crit(wl.forward(model, batches[i % len(batches)]), target)
+        loss.backward()
+        opt.step()
+        return loss
+    for i in range(3):
+        step(i)
+    with ops.profile() as rec:
+        for i in range(2):
+            step(i)
+    prof = rec.summary()
+    hand = {k: v for k, v in prof.items() if k.startswith('nr_') and not k.startswith(('nr_pack', 'nr_sort', 'nr_adam', 'nr_row_adam'))}
+    dominant = max(hand, key=lambda k: hand[k][2])
+    sg, flat = build_step_graph(wl, model, opt, crit, target, batches, device)
+    for i in range(3):
+        sg(*flat(batches[i % len(batches)]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = sg(*flat(batches[i % len(batches)]))
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lossv = float(loss.item())
+    sg.close()
+    flops, hbm = wl.flops(B), wl.hbm_bytes(B)
+    dom = prof[dominant]                    # (launches, avg us, total us) over the two profiled eager steps (HIP events on the launch stream)
+    per_call = ops.seq_launches.get({'nr_gru_fwd_step': 'nr_gru_fwd_seq', 'nr_gru_bwd_step': 'nr_gru_bwd_seq'}.get(dominant, ''), 1)
+    if dominant in hbm:
+        ach = hbm[dominant] / (dom[1] * 1e-6) / 1e9
+        roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "avg_us": dom[1], "bytes_per_launch": hbm[dominant]}
+    elif dominant in flops:
+        ach = flops[dominant] / (dom[1] * 1e-6) / 1e12
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF,
+                "avg_us": dom[1], "flop_per_launch": flops[dominant]}
+    else:
+        roof = {"kernel": dominant, "avg_us": dom[1], "note": "no algorithmic figure tabulated for this kernel"}
+    roof["launches_per_step"] = dom[0] // 2
+    del per_call
+    tag = {('NAML', 'small'): "BASELINE.json configs[2]", ('LSTUR', 'large'): "single-GPU shard of BASELINE.json configs[4]",
+           ('NRMS', 'large'): "single-GPU shard of BASELINE.json configs[3]"}.get((name, shape), "")
+    out = {"workload": f"{name} bf16, MIND-{shape}-shaped synthetic, batch {B} ({tag})", "value": B * steps / dt, "unit": "impressions/s",
+           "ms_per_step": dt / steps * 1e3, "host_enqueue_ms_per_step": t_enq / steps * 1e3, "steps": steps, "loss": lossv, "roofline": roof,
+           "kernel_breakdown_us_per_step": {k: round(v[2] / 2, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][2])[:12]}}
+    del sg, opt, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -532,6 +619,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-train-parity', action='store_true', help='skip the 200-step engine-vs-oracle training leg (~1 min of host time)')
     ap.add_argument('--parity-seeds', type=int, default=8, help='independent n = 1000 evaluation sets per weight state of the parity leg')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip the NAML / LSTUR graph-replay legs of the default line (~30 s)')
     ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
     ap.add_argument('--no-graph', action='store_true',
                     help='issue the step kernel by kernel (default on 1 GPU: one HIP graph of forward + backward + Adam, replayed)')
@@ -585,24 +673,7 @@ def main():
     use_graph = world == 1 and not args.no_graph
     sg = None
     if use_graph:
-        from news_recommendation_amd.graph import StepGraph
-        if args.model == 'LSTUR':          # the captured step keeps user ids and history lengths on the device (graph.py)
-            for b in batches:
-                b['length_dev'] = b['length'].to(device)
-        flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if args.model == 'LSTUR' else [])
-
-        def step_fn(*xs):
-            n = len(wl.attrs)
-            cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
-            if args.model == 'LSTUR':
-                lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
-            else:
-                lg_ = model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click)
-            l_ = crit(lg_, target)
-            l_.backward()
-            opt.step()
-            return l_
-        sg = StepGraph(step_fn, flat(batches[0]), opt, warmup=1)
+        sg, flat = build_step_graph(wl, model, opt, crit, target, batches, device)
         for i in range(2):
             sg(*flat(batches[i % len(batches)]))
 
@@ -628,11 +699,20 @@ def main():
                 l_.backward()
                 return l_
             seg = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=1)
-            for i in range(2):
-                seg(*flat(batches[i % len(batches)]))
         except Exception as e:               # noqa: BLE001 -- the measured line matters more than the issue mode
             seg, seg_note = None, f"segmented graphs unavailable ({e!r}): kernel-by-kernel step"
+        # the ranks must agree on the issue mode (two graphs + exchange_all vs step() with overlap are DIFFERENT collective sequences): one
+        # rank that failed to build its graphs (capture error, row capacity, memory) takes every rank to the kernel-by-kernel step
+        ok = torch.tensor([1 if seg is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if seg is not None:
+                seg.close()
+                seg, seg_note = None, "segmented graphs unavailable on another rank: kernel-by-kernel step"
             opt.overlap = True
+        else:
+            for i in range(2):
+                seg(*flat(batches[i % len(batches)]))
 
     barrier()
     t0 = time.perf_counter()
@@ -819,6 +899,9 @@ def main():
             extras["score_impressions_per_s_fwd_only"] = 10 * B / (time.perf_counter() - ts)
         model.train()
         extras["score_eval"] = score_eval(wl, model, device)
+        # ---- the other BASELINE workloads in the driver's own record: 10-step graph replays (north_star names NAML; configs[2], configs[4]) ----
+        if world == 1 and args.model == 'NRMS' and shape == 'small' and not args.no_other_workloads:
+            extras["other_workloads"] = {f"{m}_{sh}": other_workload(m, sh, 0, B, device) for m, sh in (('NAML', 'small'), ('LSTUR', 'large'))}
 
     wname = {'NRMS': "NRMS", 'NAML': "NAML (title+abstract+category+subcategory views, Conv1d k=3)",
              'LSTUR': "LSTUR (GRU user encoder 'ini' + per-user embedding row)"}[args.model]

@@ -285,11 +285,12 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
  * scratch (receives g_out . y).  dq_part: f32 [nr_additive_bwd_flat_grid(n_seq * S)][NR_QP] partial rows.  Exactly one of, or neither of,
  * dctx (bf16 [n_seq*S][NR_KP] = dpre @ Wa, columns < D written) and dy_pad (the fused activation gradient of nr_additive_bwd_act, scaled by
  * 1 / (1 - p_drop)) may be given; with neither the call stops at dpre / dq.  Needs no Wa^T operand: the kernel reads Wa through LDS
- * transposing reads. */
+ * transposing reads.  qdim = query_vector_dim of the packed operands: the kernel keeps 200 rows of Wa in LDS -- 201 .. NR_QP return
+ * NR_ERR_UNSUPPORTED (the sequence-shaped entries above handle all NR_QP packed rows). */
 int64_t nr_additive_bwd_flat_grid(int64_t n_tok);
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
-                         float p_drop, int64_t n_seq, int S, void* stream);
+                         float p_drop, int64_t n_seq, int S, int qdim, void* stream);
 /* Profiling aid (tools/pool3_phases.py): with NR_POOL_DEBUG set, the debug instantiation of the flat kernel writes cycle-counter stamps of the
  * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64, owned by the caller until it passes NULL
  * again, which switches the stamps off). */

@@ -13,7 +13,7 @@
 //        N = 3 * 320 whose G tile is fetched once for all taps.
 //   NT3  (MODE 2) the data gradient of the 3-tap convolution (k_conv.h) as a GEMM: C^T[d][row] = sum_{tap, f} Wd2[d][tap * 320 + f] dY[row + tap][f] --
 //        A = the flipped / transposed filter bank, row-major [320][960]; B = the VIRTUAL row [dy[i], dy[i + 1], dy[i + 2]] of the seqpad gradient
-//        buffer (chunk c of the contraction reads columns 32 (c % 10) of row i + c / 10); the result leaves as bf16 rows in plain token layout
+//        buffer (chunk c of the contraction reads columns 32 (c / 3) of row i + c % 3: tap-inner); the result leaves as bf16 rows in plain token layout
 //        (separator rows dropped), staged through LDS so that every store is a 16-byte piece of a contiguous 640-byte row.
 // Three tile shapes (8 waves as WR x WC, a wave owns TM x TN 32 x 32 accumulator tiles): 256 x 256 (4 x 2 waves of 2 x 4 tiles), 320 x 256
 // (2 x 4 waves of 5 x 2 tiles: the conv tap gradients have M = 320 rows) and 256 x 320 (4 x 2 waves of 2 x 5 tiles: N = 320 columns).
@@ -142,9 +142,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     if (TN) {
       const u16* cb = isA ? baseA + (int64_t)c * 32 * p.lda : baseB + (int64_t)c * 32 * p.ldb;      // wave-uniform
       s_ = (off[i] >= 0 && c * 32 + trow[i] < ntok) ? cb + off[i] : p.zeros;
-    } else if (MODE == 2 && !isA) {
-      constexpr int CPT = KP / 32;                                // chunks per tap: chunk c = columns 32 (c % CPT) of the row c / CPT below
-      s_ = baseB + (int64_t)(c / CPT) * p.ldb + (c % CPT) * 32 + off[i];
+    } else if (MODE == 2) {
+      // TAP-INNER order of the contraction: chunk c = tap c % 3, columns 32 (c / 3): the three chunks that read the 64-byte pieces of rows
+      // i, i + 1, i + 2 at one column block follow each other, so two of the three fetches of every piece hit the L2 line the first one brought
+      // in (tap-outer -- chunk c = tap c / 10 -- re-read each tile's rows 10 and 20 chunks later, through a 4 MB L2 shared by 64 such tiles:
+      // 3.82 GB fetched for 1.22 GB of rows, profiles/r04_pmc_step_traffic_NAML.txt)
+      const int tap = c % 3, cb = c / 3;
+      s_ = isA ? baseA + tap * KP + cb * 32 + off[i] : baseB + (int64_t)tap * p.ldb + cb * 32 + off[i];
     } else {
       s_ = (isA ? baseA : baseB) + c * 32 + off[i];
     }

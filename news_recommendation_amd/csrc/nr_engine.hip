@@ -789,11 +789,14 @@ int64_t nr_additive_bwd_flat_grid(int64_t n_tok) {
 
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
-                         float p_drop, int64_t n_seq, int S, void* stream) {
+                         float p_drop, int64_t n_seq, int S, int qdim, void* stream) {
   if (!ctx || !Wap || !bap || !qvp || !attn_w || !g_out || !y || !tot || !dpre || !dq_part || n_seq < 0 || (dctx && dy_pad) ||
       y_stride < NR_D || (y_stride & 3))
     return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: dropout probability out of range");
+  if (qdim < 1 || qdim > NR_QP) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: query_vector_dim out of range");
+  if (qdim > nr::Pool3Geom::WROWS)
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: the flat kernel keeps 200 rows of Wa in LDS (query_vector_dim <= 200); use nr_additive_bwd_ex / _act");
   // 48 consecutive tokens belong to 1 + ceil(47 / S) sequences: the kernel has 8 slots for them, 4 in the activation-gradient form
   if (S < 7 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
     return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 7 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq < 2^31 / 1200");

@@ -355,76 +355,12 @@ def _bf16(t_i16):
     return t_i16.view(torch.bfloat16)
 
 
-_HAS_OUT_DTYPE = None
-
-
-def _mm_f32(a, b, name='gemm_f32'):
-    """bf16 x bf16 GEMM with fp32 result (hipBLASLt accumulates in fp32)."""
-    global _HAS_OUT_DTYPE
-    if _HAS_OUT_DTYPE is None:
-        try:
-            t = torch.zeros(16, 16, dtype=torch.bfloat16, device=a.device)
-            torch.mm(t, t, out_dtype=torch.float32)
-            _HAS_OUT_DTYPE = True
-        except (TypeError, RuntimeError):
-            _HAS_OUT_DTYPE = False
-    if _HAS_OUT_DTYPE:
-        return _timed(name, lambda: torch.mm(a, b, out_dtype=torch.float32))
-    return _timed(name, lambda: torch.mm(a, b).float())     # older torch: round to bf16 at the end
-
-
-def _mm(a, b, name='gemm'):
-    return _timed(name, lambda: torch.mm(a, b))
-
-
-
-
-def _wgrad_chunks(n, M, N):
-    """Number of token chunks for a^T @ b ([n, M]^T x [n, N]): hipBLASLt does not split K for this tall-skinny shape, so the token
-    dim is cut into nc independent products.  Measured on MI355X (n = 542,720): the best nc puts ~300 output tiles of ~192 x 256
-    in flight -- M=960,N=320: nc=32 (422 us vs 727 us at nc=256); M=208,N=320: nc=64 (154 us vs 210 us)."""
-    tiles = ((M + 191) // 192) * ((N + 255) // 256)
-    want = max(1, 320 // tiles)
-    best = 1
-    for c in (2, 4, 8, 16, 32, 64, 128, 256):
-        if n % c == 0 and n // c >= 512 and c <= want:
-            best = c
-    return best
-
-
-def _wgrad_parts(a, b, name):
-    """a^T @ b for tall-skinny bf16 a [n, M], b [n, N] (n = tokens, up to ~1.4e6; M, N <= 2752) as fp32 partial products over token
-    chunks: f32 [nc, M, N] (a batched GEMM; nc = 1 when the shape needs no split).  The sum over dim 0 is the weight gradient."""
-    n = a.shape[0]
-    nc = _wgrad_chunks(n, a.shape[1], b.shape[1])
-    if nc == 1:
-        return _mm_f32(a.t(), b, name).unsqueeze(0)
-
-    def run():
-        av, bv = a.view(nc, n // nc, a.shape[1]).transpose(1, 2), b.view(nc, n // nc, b.shape[1])
-        if _HAS_OUT_DTYPE is not False:
-            try:
-                return torch.bmm(av, bv, out_dtype=torch.float32)
-            except (TypeError, RuntimeError):
-                pass
-        return torch.bmm(av, bv).float()
-    return _timed(name, run)
-
-
 _zeros16 = {}
 
 
-# NR_GEMM_HAND: which of the former library GEMMs run in the general hand-written ring kernels of csrc/k_gemm.h (bit mask; default all):
-#   1  LSTUR's GRU products: x W_ih^T (forward), dGi W_ih, dGi^T X, dGh^T H (backward)        [ops_gru.py]
-#   2  the three tap gradients of the conv text encoders as ONE 3-tap GEMM                      [ops_conv.py]
-#   4  the projection weight gradients dqkv^T [X | 1] of the NRMS encoders (256 x 320 tiles)
-#   8  the recurrent product h W_hh^T of LSTUR's batched evaluation sweep
-#  16  the pooling layers' weight gradients dpre^T [ctx | 1] (208 x 320: one 256 x 320 tile per token partition)
-#  32  the data gradient of the conv text encoders as ONE GEMM over virtual 3-tap rows (nr_conv3_dgrad_gemm) instead of the LDS-tile conv kernel
-# Measured against hipBLASLt inside the training steps on one MI355X (profiles/r04_ab_gemm.txt): conv taps 603 vs 1,254 us (abstracts), 264 vs 590 us
-# (titles); projection gradients 290 vs 358 us; GRU x W_ih^T 188 vs 230, dW_hh 176 vs 197, dW_ih 170 vs 196, dX 165 vs 163 us (fp32 result, no
-# conversion pass).  0 = the library calls (A/B).
-_GEMM_HAND = int(os.environ.get('NR_GEMM_HAND', '63'))
+# Every weight / input / recurrent product of the backward and recurrent paths runs in the engine's own ring GEMMs (csrc/k_gemm.h, csrc/k_proj.h).
+# The hipBLASLt routes they replaced (round 3: chunked batched GEMMs through torch) were kept behind NR_GEMM_HAND=0 for one round of A/B
+# (profiles/r04_ab_gemm.txt: conv taps 603 vs 1,254 us, projection gradients 290 vs 358 us, GRU products 165-188 vs 163-230 us) and are gone.
 
 
 def gemm_nt(A, B, M, N, K, name, out=None, ldc=None):
@@ -459,12 +395,6 @@ def sum_parts(parts, name='nr_sum_parts'):
     out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
     _call(name, _lib().nr_sum_parts, _ptr(parts), P, n, _ptr(out), 0, _stream())
     return out
-
-
-def _wgrad(a, b, name):
-    """a^T @ b with fp32 result (chunk partials summed in fp32)."""
-    parts = _wgrad_parts(a, b, name)
-    return parts[0] if parts.shape[0] == 1 else parts.sum(dim=0)
 
 
 # NR_POOL_FLAT: 1 (default) = the pooling backward over the flat token stream (csrc/k_pool3.h: persistent kernel, Wa resident in LDS, any
@@ -741,12 +671,8 @@ class _EncoderFn(torch.autograd.Function):
             _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                   _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
         # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1]: split-K ring kernel (csrc/k_gemm.h), partials [P, QP, KP]; column D =
-        # bias gradient (ctx[:, D] == 1).  NR_GEMM_HAND bits off: the same products as chunked hipBLASLt batched GEMMs (A/B only)
-        dpre_b, ctx_b = _bf16(dpre), _bf16(cbuf)
-        if _GEMM_HAND & 16:
-            dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')
-        else:
-            dWa_parts = _wgrad_parts(dpre_b, ctx_b, f'gemm_dWa[S={S}]')
+        # bias gradient (ctx[:, D] == 1)
+        dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
         if split:
@@ -755,13 +681,8 @@ class _EncoderFn(torch.autograd.Function):
         else:
             _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                   _ptr(key_len), n_seq, S, p_drop, seed, _stream())
-        dqkv_b = _bf16(dqkv)
         # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1]: 256 x 320 tiles of the ring kernel, partials [P, 960, KP]
-        Xb_b = _bf16(Xb)
-        if _GEMM_HAND & 4:
-            dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')
-        else:
-            dW_parts = _wgrad_parts(dqkv_b, Xb_b, f'gemm_dWqkv[S={S}]')
+        dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] (nr_dx_gemm), then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
         dX = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
@@ -912,7 +833,7 @@ class _MhsaFn(torch.autograd.Function):
                             _ptr(key_len), n_seq, S, 0.0, 0, _stream())
         if need_grad:
             ctx.save_for_backward(xd, qs, ks, vts, Wp, key_len)
-            ctx.WdX = pack_qkv_dx(Wq, Wk, Wv) if _GEMM_HAND else None
+            ctx.WdX = pack_qkv_dx(Wq, Wk, Wv)
         return _bf16(cbuf)[:, :NR_D].float().view(n_seq, S, NR_D)
 
     @staticmethod
@@ -928,17 +849,13 @@ class _MhsaFn(torch.autograd.Function):
         dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)
         _call('nr_attn_bwd', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx), NR_D, _ptr(zw), _ptr(zg), _ptr(dqkv), _ptr(key_len),
               n_seq, S, 0.0, 0, _stream())
-        dqkv_b = _bf16(dqkv)
         Xb = _workspace('Xb', (ntok, NR_KP), _BF16_AS_I16, dev)
         _call('nr_gather_bf16', lib.nr_gather_bf16, None, None, 0, _ptr(xd), _ptr(Xb), ntok, 0.0, 0, _stream())
-        if _GEMM_HAND:          # the engine's own GEMMs: split-K TN kernel for dW = dqkv^T [X | 1], nr_dx_gemm for dX = dqkv [Wq; Wk; Wv]
-            dW_ext = sum_parts(gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, 'nr_gemm_tn_dWqkv'))
-            dXb = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
-            _call('nr_dx_gemm', lib.nr_dx_gemm, _ptr(dqkv), _ptr(ctx.WdX), _ptr(dXb), ntok, _stream())
-            dX = dXb[:, :NR_D].float().view(n_seq, S, NR_D)
-        else:
-            dW_ext = _mm_f32(dqkv_b.t(), _bf16(Xb))
-            dX = torch.mm(dqkv_b, _bf16(untile(Wp, 3 * NR_NP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D)
+        # the engine's own GEMMs: split-K TN kernel for dW = dqkv^T [X | 1], nr_dx_gemm for dX = dqkv [Wq; Wk; Wv]
+        dW_ext = sum_parts(gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, 'nr_gemm_tn_dWqkv'))
+        dXb = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
+        _call('nr_dx_gemm', lib.nr_dx_gemm, _ptr(dqkv), _ptr(ctx.WdX), _ptr(dXb), ntok, _stream())
+        dX = dXb[:, :NR_D].float().view(n_seq, S, NR_D)
         gW = [dW_ext[i * NR_KP:i * NR_KP + NR_D, :NR_D] for i in range(3)]
         gb = [dW_ext[i * NR_KP:i * NR_KP + NR_D, NR_D] for i in range(3)]
         return dX, gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], None
@@ -987,7 +904,7 @@ class _AdditiveFn(torch.autograd.Function):
               valid, _stream())
         ctx.save_for_backward(cbuf, aw, Wap, bap, qvp, out)
         ctx.qdim = Wa.shape[0]
-        ctx.WaT = pack_additive_t(Wa) if (_GEMM_HAND and not pool_flat_ok(S, False, n_seq, qdim=Wa.shape[0])) else None
+        ctx.WaT = None if pool_flat_ok(S, False, n_seq, qdim=Wa.shape[0]) else pack_additive_t(Wa)
         return out
 
     @staticmethod
@@ -1004,23 +921,16 @@ class _AdditiveFn(torch.autograd.Function):
             nwg = lib.nr_additive_bwd_grid(n_seq, S)
             dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
             dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
-        if _GEMM_HAND:          # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
-            if flat:
-                dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, 'dense')
-            else:
-                dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
-                _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
-                      _ptr(ctx.WaT), _ptr(dgemm), n_seq, S, _stream())
-            dx = torch.empty(n_seq, S, NR_D, dtype=torch.float32, device=dev)
-            _call('nr_additive_dx', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dx), n_seq, S, 0, _stream())
-            dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
+        # the fused backward (dctx = dpre @ Wa inside the kernel), the direct term added by nr_additive_dx, dWa by the TN kernel
+        if flat:
+            dpre, dq_part, dgemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, 'dense')
         else:
-            if flat:
-                dpre, dq_part, _ = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, 'dense', want_dctx=False)
-            else:
-                _call('nr_additive_bwd', lib.nr_additive_bwd, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part), n_seq, S, _stream())
-            dWa_ext = _mm_f32(_bf16(dpre).t(), _bf16(cbuf))
-            dx = torch.mm(_bf16(dpre), _bf16(untile(Wap, NR_QP, NR_KP))[:, :NR_D]).float().view(n_seq, S, NR_D) + aw.unsqueeze(-1) * g_out.unsqueeze(1)
+            dgemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)
+            _call('nr_additive_bwd', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre), _ptr(dq_part),
+                  _ptr(ctx.WaT), _ptr(dgemm), n_seq, S, _stream())
+        dx = torch.empty(n_seq, S, NR_D, dtype=torch.float32, device=dev)
+        _call('nr_additive_dx', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dx), n_seq, S, 0, _stream())
+        dWa_ext = sum_parts(gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, 'nr_gemm_tn_dWa'))
         return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim], None
 
 

@@ -7,7 +7,7 @@ No CPU path.
 import torch
 
 from . import ops
-from .ops import (_lib, _stream, _call, _ptr, _f32c, _bf16, _mm, _timed, _workspace, _require_cuda, pack_additive,
+from .ops import (_lib, _stream, _call, _ptr, _f32c, _bf16, _workspace, _require_cuda, pack_additive,
                   _BF16_AS_I16, NR_D, NR_KP, NR_QP)
 
 WGRAD_CHUNKS = 64     # batched-GEMM chunks of the conv weight gradient ([320 x rows]^T x [rows x 320] per tap: ~4 output tiles each)
@@ -79,7 +79,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     st = _TextState()
     st.S, st.n_seq, st.tok_offset, st.qdim = S, n_seq, tok_offset, Wa.shape[0]
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
-    st.Wd2 = pack_conv_dgrad(conv_w) if (need_grad and ops._GEMM_HAND & 32) else None
+    st.Wd2 = pack_conv_dgrad(conv_w) if need_grad else None       # operand of the data gradient as ONE GEMM over virtual 3-tap rows (csrc/k_gemm.h, NT3 form)
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
     st.WaT = ops.pack_additive_t(Wa) if (need_grad and not ops.pool_flat_ok(S, True, n_seq, qdim=st.qdim)) else None
     st.act = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)
@@ -141,10 +141,8 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
         _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_act, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
     d_qv = dq_part.sum(dim=0)[:qdim]
-    if ops._GEMM_HAND & 16:                        # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
-        dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
-    else:                                          # A/B only: chunked hipBLASLt
-        dWa_ext = ops._wgrad(_bf16(dpre), _bf16(ctx_b), f'gemm_dWa[{tag}]')
+    # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
+    dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
     return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
 
 
@@ -164,27 +162,12 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
                                     y_ptr=st.y_ptr, y_stride=st.y_stride)
 
-    def wgrad():
-        if ops._GEMM_HAND & 2:
-            # ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap shift is a row offset
-            # of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three taps
-            both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, st.xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
-            return [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
-        taps = []                   # A/B only: three chunked hipBLASLt batched GEMMs on shifted views
-        dy_b = _bf16(dy).view(nc, ra // nc, NR_KP).transpose(1, 2)
-        xs_b = _bf16(st.xstore)
-        for w in range(3):          # dW[:, w, :] = dY^T @ X[row + w - 1]: the tap shift is a row offset into the seqpad store
-            xw = xs_b[w:w + ra].view(nc, ra // nc, NR_KP)
-            try:
-                taps.append(torch.bmm(dy_b, xw, out_dtype=torch.float32).sum(dim=0))
-            except (TypeError, RuntimeError):
-                taps.append(torch.bmm(dy_b, xw).float().sum(dim=0))
-        return taps
-    taps = _timed(f'gemm_dWconv[{tag}]', wgrad)
-    if st.Wd2 is not None:       # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
-        _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
-    else:
-        _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad, _ptr(dy), _ptr(st.Wd), dx_out, n_seq, S, _stream())
+    # the three tap gradients as ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap shift
+    # is a row offset of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three taps
+    both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, st.xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
+    taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
+    # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
+    _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
     d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
     d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
     return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import ops
-from .ops import _lib, _stream, _call, _ptr, _f32c, _bf16, _mm, _mm_f32, _workspace, _require_cuda, _BF16_AS_I16
+from .ops import _lib, _stream, _call, _ptr, _f32c, _workspace, _require_cuda, _BF16_AS_I16
 
 
 def gru_dims(Hd):
@@ -68,20 +68,15 @@ def user_rows(ids, table, row_scale=None):
     return _UserRowsFn.apply(ids.contiguous(), table, row_scale)
 
 
-_wih_t_cache = {}
-
-
 def _wih_t(Wih_p, Hg, Ip, Kp):
     """W_ih^T as the K-contiguous B operand of dX = dGi W_ih: bf16 [Ip][Kp] (rows = input features, columns = the 3 Hg gate rows, K padding
-    zero), re-packed when the packed W_ih it derives from changes (ops._packed builds a new tensor per parameter state)."""
-    key = (Wih_p.data_ptr(), Wih_p._version, str(Wih_p.device))
-    hit = _wih_t_cache.get('t')
-    if hit is not None and hit[0] == key and hit[1] is Wih_p:
-        return hit[2]
-    WihT = torch.zeros(Ip, Kp, dtype=_BF16_AS_I16, device=Wih_p.device)
-    _call('nr_transpose_bf16', _lib().nr_transpose_bf16, _ptr(Wih_p), 3 * Hg, Ip, Ip, _ptr(WihT), Kp, _stream())
-    _wih_t_cache['t'] = (key, Wih_p, WihT)
-    return WihT
+    zero).  Cached like every other packed operand (ops._packed, keyed on the packed W_ih it derives from -- a new tensor per parameter state --
+    per device and parameter, dropped by ops.invalidate_packed())."""
+    def build():
+        WihT = torch.zeros(Ip, Kp, dtype=_BF16_AS_I16, device=Wih_p.device)
+        _call('nr_transpose_bf16', _lib().nr_transpose_bf16, _ptr(Wih_p), 3 * Hg, Ip, Ip, _ptr(WihT), Kp, _stream())
+        return WihT
+    return ops._packed('gru_wih_t', (Wih_p,), build)
 
 
 class _GruFn(torch.autograd.Function):
@@ -108,10 +103,8 @@ class _GruFn(torch.autograd.Function):
         bi, bh = _f32c(b_ih), _f32c(b_hh)
         xf = _f32c(x).view(B * N, I)
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
-        if ops._GEMM_HAND & 1:       # hoisted input projection, hand-written NT kernel (csrc/k_gemm.h): K = Ip (column I of Xb is 1.0, of W_ih the padding 0)
-            gi = ops.gemm_nt(Xb, Wih_p, B * N, 3 * Hg, Ip, 'nr_gemm_nt_gru_gi')
-        else:
-            gi = _mm_f32(_bf16(Xb), _bf16(Wih_p).t(), 'gemm_gru_gi')                         # [B*N][3*Hg] f32 (hoisted input projection)
+        # hoisted input projection [B*N][3*Hg] f32, hand-written NT kernel (csrc/k_gemm.h): K = Ip (column I of Xb is 1.0, of W_ih the padding 0)
+        gi = ops.gemm_nt(Xb, Wih_p, B * N, 3 * Hg, Ip, 'nr_gemm_nt_gru_gi')
         H_all = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
         hf = torch.zeros(2, B, Hp, dtype=torch.float32, device=dev)
         if h0 is not None:
@@ -166,21 +159,15 @@ class _GruFn(torch.autograd.Function):
                   _ptr(lens_dev), _ptr(dgi) if t >= 0 else None, _ptr(dgh[t]) if t >= 0 else None, _ptr(dght[i % 2]) if t >= 0 else None,
                   _ptr(carry[i % 2]), B, N, Hd, t, first, _stream())
         d_h0 = carry[T % 2][:, :Hd].contiguous() if has_h0 else None
-        dgi_b = _bf16(dgi)
-        if ops._GEMM_HAND & 1:
-            # the three time-independent products of the backward in the hand-written ring kernels (csrc/k_gemm.h): dX = dGi W_ih as an NT product
-            # against W_ih^T (re-packed once per optimiser step, K padding zero), fp32 result in place of a bf16 one + conversion pass; the two
-            # weight gradients as split-K TN products over the (sample, step) rows, partials summed in a fixed order
-            d_x = None
-            if ctx.needs_input_grad[0]:
-                WihT = _wih_t(Wih_p, Hg, Ip, Kp)
-                d_x = ops.gemm_nt(dgi, WihT, B * N, I, Kp, 'nr_gemm_nt_gru_dx').view(B, N, I)
-            dWi = ops.sum_parts(ops.gemm_tn_parts(dgi, Kp, Xb, Ip, 'nr_gemm_tn_gru_dWih'))
-            dWh = ops.sum_parts(ops.gemm_tn_parts(dgh.view(T * B, Kp), Kp, H_all.view((T + 1) * B, Hp), Hp, 'nr_gemm_tn_gru_dWhh', n_tok=T * B))
-        else:
-            d_x = _mm(dgi_b[:, :3 * Hg], _bf16(Wih_p)[:, :I], 'gemm_gru_dx').float().view(B, N, I) if ctx.needs_input_grad[0] else None
-            dWi = ops._wgrad(dgi_b, _bf16(Xb), 'gemm_gru_dWih')                               # [Kp][Ip]; col I = bias gradient
-            dWh = ops._wgrad(_bf16(dgh).view(T * B, Kp), _bf16(H_all)[:T].reshape(T * B, Hp), 'gemm_gru_dWhh')     # [Kp][Hp]; col Hd = bias gradient
+        # the three time-independent products of the backward in the hand-written ring kernels (csrc/k_gemm.h): dX = dGi W_ih as an NT product
+        # against W_ih^T (re-packed once per optimiser step, K padding zero), fp32 result in place of a bf16 one + conversion pass; the two
+        # weight gradients as split-K TN products over the (sample, step) rows, partials summed in a fixed order
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            WihT = _wih_t(Wih_p, Hg, Ip, Kp)
+            d_x = ops.gemm_nt(dgi, WihT, B * N, I, Kp, 'nr_gemm_nt_gru_dx').view(B, N, I)
+        dWi = ops.sum_parts(ops.gemm_tn_parts(dgi, Kp, Xb, Ip, 'nr_gemm_tn_gru_dWih'))                      # [Kp][Ip]; col I = bias gradient
+        dWh = ops.sum_parts(ops.gemm_tn_parts(dgh.view(T * B, Kp), Kp, H_all.view((T + 1) * B, Hp), Hp, 'nr_gemm_tn_gru_dWhh', n_tok=T * B))      # [Kp][Hp]; col Hd = bias gradient
         unpad = lambda m, ncol: torch.cat([m[q * Hg:q * Hg + Hd, :ncol] for q in range(3)], dim=0)
         return (d_x, d_h0, None, None, unpad(dWi, I), unpad(dWh, Hd), unpad(dWi, I + 1)[:, I].contiguous(), unpad(dWh, Hd + 1)[:, Hd].contiguous())
 
@@ -235,10 +222,7 @@ def gru_last_state_rows(table, rows, h0, lengths, gru):
     Wih_p, Whh_p, _ = ops._packed('gru', (W_ih, W_hh), build)
     bi, bh = _f32c(gru.bias_ih_l0), _f32c(gru.bias_hh_l0)
     Xb = rows_to_bf16(_f32c(table), I, Ip)
-    if ops._GEMM_HAND & 1:
-        gi = ops.gemm_nt(Xb, Wih_p, Xb.shape[0], 3 * Hg, Ip, 'nr_gemm_nt_gru_gi[table]')     # [R][3*Hg] f32, hand-written NT kernel
-    else:
-        gi = _mm_f32(_bf16(Xb), _bf16(Wih_p).t(), 'gemm_gru_gi[table]')                      # [R][3*Hg] f32
+    gi = ops.gemm_nt(Xb, Wih_p, Xb.shape[0], 3 * Hg, Ip, 'nr_gemm_nt_gru_gi[table]')         # [R][3*Hg] f32, hand-written NT kernel
     lens = np.clip(np.asarray(lengths, dtype=np.int64), 1, N)
     order = np.argsort(-lens, kind='stable')                                                 # longest first
     T = int(lens[order[0]])
@@ -253,24 +237,19 @@ def gru_last_state_rows(table, rows, h0, lengths, gru):
     hb = torch.empty(B, Hp, dtype=_BF16_AS_I16, device=dev)
     _call('nr_rows_to_bf16', lib.nr_rows_to_bf16, _ptr(hf), Hp, Hd, _ptr(hb), Hp, B, _stream())
     if B >= _GEMM_STEP_MIN_B:
-        # large batches: the recurrent product as a library GEMM per step + the gate kernel (csrc/k_gru.h gru_gate_rows_kernel): the fused
+        # large batches: the recurrent product as one NT GEMM per step (nr_gemm_nt) + the gate kernel (csrc/k_gru.h gru_gate_rows_kernel): the fused
         # step kernel's 16-unit workgroups would each re-read the state rows (57 x per step)
         def build_rm():
             Whh_rm = torch.empty(3 * Hg, Hp, dtype=_BF16_AS_I16, device=dev)
             _call('nr_pack_gru', lib.nr_pack_gru, _ptr(_f32c(W_hh)), Hd, Hd, Hp, _ptr(Whh_rm), None, 0, _stream())
             return (Whh_rm,)
         (Whh_rm,) = ops._packed('gru_rm', (W_hh,), build_rm)
-        WT = _bf16(Whh_rm).t()
         gh = torch.empty(B, 3 * Hg, dtype=torch.float32, device=dev)
-        hb_b = _bf16(hb)
         for t in range(T):
             Bt = int(active[t])
             if Bt == 0:
                 break
-            if ops._GEMM_HAND & 8:
-                ops.gemm_nt(hb, Whh_rm, Bt, 3 * Hg, Hp, 'nr_gemm_nt_gru_gh', out=gh, ldc=3 * Hg)      # hand-written NT kernel, fp32 result
-            else:
-                torch.mm(hb_b[:Bt], WT, out_dtype=torch.float32, out=gh[:Bt])      # hipBLASLt, fp32 accumulation and result
+            ops.gemm_nt(hb, Whh_rm, Bt, 3 * Hg, Hp, 'nr_gemm_nt_gru_gh', out=gh, ldc=3 * Hg)          # hand-written NT kernel, fp32 result
             _call('nr_gru_gate_rows', lib.nr_gru_gate_rows, _ptr(gi), _ptr(rows_s), _ptr(gh), _ptr(bi), _ptr(bh), _ptr(lens_s), _ptr(hf), _ptr(hb),
                   Bt, N, Hd, t, _stream())
     else:

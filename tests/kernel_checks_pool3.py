@@ -69,7 +69,7 @@ def check_flat(be, S=20, n_seq=6, valid=None, seed=15, y_stride=NR_D, with_dctx=
     tot = be.poison((n_seq,), np.float32)
     dctx = be.poison((n_seq * S, NR_KP), np.uint16) if with_dctx else None
     ck(be, be.lib.nr_additive_bwd_flat(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)), be.ptr(out), y_stride,
-                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), be.ptr(dctx) if with_dctx else None, None, 0.0, n_seq, S, be.stream))
+                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), be.ptr(dctx) if with_dctx else None, None, 0.0, n_seq, S, 200, be.stream))
     be.sync()
     W, w, dpre_ref, dq_ref = _reference(params, ctx_u, go, S, n_seq, V_)
     # the per-sequence scalar: g . y == sum_s w[s] (g . x[s])
@@ -102,7 +102,7 @@ def check_flat_act(be, S=20, n_seq=7, p_drop=0.2, seed=22):
     tot = be.poison((n_seq,), np.float32)
     dy = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16)
     ck(be, be.lib.nr_additive_bwd_flat(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo), be.ptr(out), NR_D,
-                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), None, be.ptr(dy), p_drop, n_seq, S, be.stream))
+                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), None, be.ptr(dy), p_drop, n_seq, S, 200, be.stream))
     be.sync()
     W, w, dpre_ref, dq_ref = _reference(params, ctx_u, go, S, n_seq, S)
     got = bf16_to_f32(be.np(dpre))
@@ -122,13 +122,15 @@ def check_flat_act(be, S=20, n_seq=7, p_drop=0.2, seed=22):
 def check_flat_bad_args(be):
     pa = be.ptr(be.empty((64,), np.float32))
     lib = be.lib
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, None, NR_D, pa, pa, pa, None, None, 0.0, 4, 20, be.stream) != 0 and b'nr_additive_bwd_flat' in lib.nr_last_error()
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, pa, pa, 0.0, 4, 20, be.stream) != 0          # dctx AND dy_pad
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D - 4, pa, pa, pa, None, None, 0.0, 4, 20, be.stream) != 0   # y stride
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 1.0, 4, 20, be.stream) != 0       # p_drop
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 6, be.stream) != 0         # S < 7: more than 8 sequences in 48 tokens
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, pa, 0.0, 4, 15, be.stream) != 0       # S < 16 with dy_pad: more than 4
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 0, 20, be.stream) == 0        # nothing to do
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, None, NR_D, pa, pa, pa, None, None, 0.0, 4, 20, 200, be.stream) != 0 and b'nr_additive_bwd_flat' in lib.nr_last_error()
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, pa, pa, 0.0, 4, 20, 200, be.stream) != 0          # dctx AND dy_pad
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D - 4, pa, pa, pa, None, None, 0.0, 4, 20, 200, be.stream) != 0   # y stride
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 1.0, 4, 20, 200, be.stream) != 0       # p_drop
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 6, 200, be.stream) != 0         # S < 7: more than 8 sequences in 48 tokens
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, pa, 0.0, 4, 15, 200, be.stream) != 0       # S < 16 with dy_pad: more than 4
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 0, 20, 200, be.stream) == 0        # nothing to do
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 20, 201, be.stream) != 0 and b'200 rows' in lib.nr_last_error()      # query_vector_dim 201 .. 208: the sequence-shaped kernels
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 20, 0, be.stream) != 0
     assert lib.nr_additive_bwd_flat_grid(0) == 0 and lib.nr_additive_bwd_flat_grid(1) == 1
 
 
@@ -144,7 +146,7 @@ def check_flat_scale(be, S=20, n_seq=27136, chunk=2048, act=False, p_drop=0.2):
     dy = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16) if act else None
     ck(be, be.lib.nr_additive_bwd_flat(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)), be.ptr(out), NR_D,
                                        be.ptr(tot), be.ptr(dpre), be.ptr(dqp), None if act else be.ptr(dctx), be.ptr(dy) if act else None,
-                                       p_drop if act else 0.0, n_seq, S, be.stream))
+                                       p_drop if act else 0.0, n_seq, S, 200, be.stream))
     be.sync()
     dpre_n, aw_n = be.np(dpre), be.np(aw)
     dctx_n = None if act else be.np(dctx)

@@ -219,10 +219,15 @@ def test_pool_flat_dispatch_by_shape(monkeypatch):
     from news_recommendation_amd import ops
     monkeypatch.setattr(ops, '_POOL_FLAT', True)
     monkeypatch.setattr(ops, '_POOL_FLAT_MIN_TOK', 98304)
-    assert ops.pool_flat_ok(20, False, 27136) and ops.pool_flat_ok(50, True, 28160) and ops.pool_flat_ok(20, True, 28160)
-    assert not ops.pool_flat_ok(4, False, 28160)                 # the four views of a NAML news item: 13 sequences in 48 tokens
-    assert ops.pool_flat_ok(7, False, 20000) and not ops.pool_flat_ok(15, True, 20000) and ops.pool_flat_ok(16, True, 20000)
-    assert not ops.pool_flat_ok(50, False, 512)                  # 512 click histories: the sequence-shaped kernel is faster
-    assert ops.pool_flat_ok(50, False)                           # shape-only question (operands packed before the batch is known)
+    q = dict(qdim=200)
+    assert ops.pool_flat_ok(20, False, 27136, **q) and ops.pool_flat_ok(50, True, 28160, **q) and ops.pool_flat_ok(20, True, 28160, **q)
+    assert not ops.pool_flat_ok(4, False, 28160, **q)            # the four views of a NAML news item: 13 sequences in 48 tokens
+    assert ops.pool_flat_ok(7, False, 20000, **q) and not ops.pool_flat_ok(15, True, 20000, **q) and ops.pool_flat_ok(16, True, 20000, **q)
+    assert not ops.pool_flat_ok(50, False, 512, **q)             # 512 click histories: the sequence-shaped kernel is faster
+    assert ops.pool_flat_ok(50, False, **q)                      # shape-only question (operands packed before the batch is known)
+    # the flat kernel keeps 200 rows of the projection matrix in LDS: query_vector_dim 201 .. 208 stays on the sequence-shaped kernels
+    assert ops.pool_flat_ok(20, False, 27136, qdim=1) and not ops.pool_flat_ok(20, False, 27136, qdim=201) and not ops.pool_flat_ok(50, True, 28160, qdim=208)
+    with pytest.raises(TypeError):
+        ops.pool_flat_ok(20, False, 27136)                       # qdim is keyword-only and required: no call site can forget it
     monkeypatch.setattr(ops, '_POOL_FLAT', False)
-    assert not ops.pool_flat_ok(20, False, 27136)
+    assert not ops.pool_flat_ok(20, False, 27136, **q)

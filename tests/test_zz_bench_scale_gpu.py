@@ -1,0 +1,128 @@
+"""Whole-model backward parity of NAML and LSTUR at the launch sizes of BASELINE configs[2] / the 1-GPU shard of configs[4] (B = 512: 27,136 news,
+542,720 title tokens, 1,356,800 abstract tokens; src/train.py:183-233), dropout off: logits and EVERY parameter gradient of the drop-in models
+against the CPU fp32 torch oracle (oracle/naml_torch.py, oracle/lstur_torch.py) -- the composition of the ring GEMMs (3-tap TN, NT3), the flat
+pooling backward with the fused activation gradient, the GRU step kernels and the sorted scatters at the sizes the bench runs, where the
+kernel-by-kernel checks stop at tens of thousands of rows.  The oracle's forward + backward takes 1-2 minutes of host time per model: the file
+sorts last so that `pytest -x` reaches it after everything cheaper (NRMS at this size: tests/test_model_gpu.py).
+
+Bounds are ~3x the values measured on MI355X (written beside each); the measured figures of a run go to gpurun_out/bench_scale_backward_*.json."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle.make_golden_naml_lstur import as_lists, synth_batch
+from tests.test_model_gpu import rel_err, grad_floor
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+MIND = dict(V=70976, d=300, ncat=275, dcat=100, F=300, window=3, Q=200, C=3, N=50, L=20, La=50)
+B = 512
+
+
+def table_rows(ge, gr, used, V):
+    """The word-embedding gradient row by row (see tests/test_model_gpu.py): exactly the rows that receive a gradient in the oracle receive one
+    here (LSTUR: clicked news behind a user's history length are never consumed by the packed GRU, user_encoder.py:30-37, so their tokens get
+    none in either), no row outside the batch's tokens is written, and the per-row relative error of rows whose reference gradient is not
+    rounding-sized."""
+    ge, gr = ge.astype(np.float64), gr.astype(np.float64)
+    used = used[used != 0]
+    assert not ge[0].any() and not gr[0].any()                              # padding_idx
+    hit_ref, hit = np.linalg.norm(gr, axis=1) > 0, np.linalg.norm(ge, axis=1) > 0
+    assert np.array_equal(hit_ref, hit), f'{(hit_ref & ~hit).sum()} rows lost their gradient, {(hit & ~hit_ref).sum()} rows gained one'
+    untouched = np.ones(V, dtype=bool)
+    untouched[used] = False
+    assert not ge[untouched].any(), 'gradient written to rows no token of the batch refers to'
+    used = np.flatnonzero(hit_ref)
+    nr = np.linalg.norm(gr[used], axis=1)
+    ne = np.linalg.norm(ge[used] - gr[used], axis=1)
+    big = nr > 0.05 * np.median(nr)
+    ratio = ne[big] / nr[big]
+    return {"rows": int(big.sum()), "row_err_median": float(np.median(ratio)), "row_err_p999": float(np.quantile(ratio, 0.999)),
+            "row_err_max": float(ratio.max())}
+
+
+def record(name, stats):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f'bench_scale_backward_{name}.json'), 'w') as f:
+            json.dump(stats, f, indent=1)
+
+
+def test_naml_bench_scale_backward_vs_torch_oracle():
+    from oracle.naml_torch import OracleNAML, random_naml_params
+    from tests.test_naml_gpu import build, oracle_with_engine_operands
+    c = dict(MIND, B=B, seed=61)
+    params = random_naml_params(61, c['V'], c['d'], c['ncat'], c['dcat'], c['F'], c['window'], c['Q'], emb_std=0.3)
+    cand, click, _ = synth_batch(np.random.default_rng(61), c, True)
+    cl, hl = as_lists(cand, click)
+    m = build(c, params).eval()
+    lg = m(cl, hl)
+    torch.nn.CrossEntropyLoss()(lg, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
+    plain = OracleNAML(c['V'], c['d'], c['ncat'], c['dcat'], c['F'], c['window'], c['Q'], 0.2)
+    plain.load_state_dict(params)
+    with torch.no_grad():
+        l_plain = plain.eval()(cl, hl)
+    del plain
+    ref = oracle_with_engine_operands(c, params)
+    lr = ref(cl, hl)
+    torch.nn.CrossEntropyLoss()(lr, torch.zeros(B, dtype=torch.long)).backward()
+    e_logit = rel_err(lg.detach().cpu().numpy(), l_plain.numpy())
+    rg = {k: p.grad.numpy() for k, p in ref.named_parameters()}
+    fl = grad_floor(rg)
+    errs = {k: float(rel_err(p.grad.cpu().numpy(), rg[k], fl)) for k, p in m.named_parameters()}
+    we = 'news_encoder.text_encoders.title.word_embedding.weight'
+    used = np.unique(np.concatenate([cand['title'].reshape(-1), click['title'].reshape(-1), cand['abstract'].reshape(-1), click['abstract'].reshape(-1)]))
+    rows = table_rows(dict(m.named_parameters())[we].grad.cpu().numpy(), rg[we], used, c['V'])
+    stats = {"logit_rel_err": float(e_logit), "tensor_rel_err": errs, "table": rows}
+    record('NAML', stats)
+    assert e_logit < NAML_LOGIT, stats
+    assert max(v for k, v in errs.items() if not k.endswith('bias')) < NAML_GRAD and max(v for k, v in errs.items() if k.endswith('bias')) < NAML_GRAD_BIAS, stats
+    assert rows["row_err_median"] < NAML_ROW_MEDIAN and rows["row_err_max"] < NAML_ROW_MAX, stats
+    assert torch.all(m.news_encoder.element_encoders['category'].embedding.weight.grad[0] == 0)
+
+
+def test_lstur_bench_scale_backward_vs_torch_oracle():
+    from oracle.lstur_torch import random_lstur_params
+    from tests.test_lstur_gpu import build, oracle
+    c = dict(MIND, nusers=50001, B=B, seed=71, method='ini')
+    params = random_lstur_params(71, c['V'], c['d'], c['ncat'], c['nusers'], c['F'], c['window'], c['Q'], 'ini', emb_std=0.3)
+    rng = np.random.default_rng(71)
+    cand, click, hist = synth_batch(rng, c, False)
+    user = torch.from_numpy(rng.integers(0, c['nusers'], size=B).astype(np.int64))
+    length = torch.from_numpy(hist)
+    cl, hl = as_lists(cand, click)
+    m = build(c, params).eval()
+    lg = m(user, length.clone(), cl, hl)
+    torch.nn.CrossEntropyLoss()(lg, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
+    with torch.no_grad():
+        l_plain = oracle(c, params, q_operands=False)(user, length.clone(), cl, hl)
+    ref = oracle(c, params)
+    lr = ref(user, length.clone(), cl, hl)
+    torch.nn.CrossEntropyLoss()(lr, torch.zeros(B, dtype=torch.long)).backward()
+    e_logit = rel_err(lg.detach().cpu().numpy(), l_plain.numpy())
+    rg = {k: p.grad.numpy() for k, p in ref.named_parameters()}
+    fl = grad_floor(rg)
+    errs = {k: float(rel_err(p.grad.cpu().numpy(), rg[k], fl)) for k, p in m.named_parameters()}
+    we = 'news_encoder.word_embedding.weight'
+    used = np.unique(np.concatenate([cand['title'].reshape(-1), click['title'].reshape(-1)]))
+    rows = table_rows(dict(m.named_parameters())[we].grad.cpu().numpy(), rg[we], used, c['V'])
+    # the per-user rows: exactly the batch's users receive a gradient (nn.Embedding(padding_idx=0): user 0 none)
+    gu = m.user_embedding.weight.grad.cpu().numpy()
+    hit = np.zeros(c['nusers'], dtype=bool)
+    hit[user.numpy()] = True
+    hit[0] = False
+    assert not gu[~hit].any(), 'gradient written to user rows outside the batch'
+    stats = {"logit_rel_err": float(e_logit), "tensor_rel_err": errs, "table": rows}
+    record('LSTUR', stats)
+    assert e_logit < LSTUR_LOGIT, stats
+    assert max(v for k, v in errs.items() if not k.endswith('bias')) < LSTUR_GRAD and max(v for k, v in errs.items() if k.endswith('bias')) < LSTUR_GRAD_BIAS, stats
+    assert rows["row_err_median"] < LSTUR_ROW_MEDIAN and rows["row_err_max"] < LSTUR_ROW_MAX, stats
+
+
+# bounds: ~3x the MI355X measurements (gpurun_out/bench_scale_backward_*.json of the run that set them, copied to profiles/)
+# NAML measured (profiles/r05_bench_scale_backward_NAML.json): logits 2.9e-4, weight tensors <= 3.2e-3, bias tensors <= 2.3e-2 (the pooling layers'
+# linear.bias: small sums of bf16 dpre rows over a floor of 2e-2 of the largest bias gradient), table rows median 0.30 %, worst row 0.65 %
+NAML_LOGIT, NAML_GRAD, NAML_GRAD_BIAS, NAML_ROW_MEDIAN, NAML_ROW_MAX = 1e-3, 1e-2, 7e-2, 0.01, 0.02
+LSTUR_LOGIT, LSTUR_GRAD, LSTUR_GRAD_BIAS, LSTUR_ROW_MEDIAN, LSTUR_ROW_MAX = 2e-2, 5e-2, 5e-2, 0.02, 0.15

@@ -43,7 +43,7 @@ for S, act, Tn in ((20, False, B * 53), (20, True, B * 55), (50, True, B * 55), 
     dy_ = torch.zeros(Tn * (S + 1) + 1, NR_KP, dtype=torch.int16, device=dev)
     fn = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
                                              tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act else dc_.data_ptr(), dy_.data_ptr() if act else None,
-                                             0.2 if act else 0.0, Tn, S, st()))
+                                             0.2 if act else 0.0, Tn, S, 200, st()))
     if TIMELINE:
         # cycle-counter stamps of the first 8 iterations of waves 0-1 of workgroups 0-3 (debug build, nothing switched off): 0 top of the
         # iteration, 1 rows are fragments, 2 ds known, 3 six n-tiles done, 4 projection done, 5 next rows requested, 6 dctx done, 7 end
