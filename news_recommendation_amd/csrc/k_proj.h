@@ -58,18 +58,24 @@ __global__ __launch_bounds__(256) void pack_qkv32_kernel(const float* __restrict
     const int row = i / KW, k = i - row * KW;
     const int which = row / NP, n = packed_row_feature(row - which * NP);
     const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
-    const float v = (n >= 0 && k < D) ? W[n * D + k] : 0.0f;
+    const float* b = which == 0 ? bq : (which == 1 ? bk : bv);
+    // columns D, D + 1 carry the bias as two bf16 numbers (hi + lo: 16 mantissa bits) against the two 1.0 columns of the token rows: the bias
+    // rides the contraction -- no bias loads between a chunk's weight copies and its stores, nothing in the chunk loop waits on vmcnt for data
+    float v = (n >= 0 && k < D) ? W[n * D + k] : 0.0f;
+    if (n >= 0 && k == D) v = bf2f(f2bf(b[n]));
+    if (n >= 0 && k == D + 1) v = b[n] - bf2f(f2bf(b[n]));
     Wp32[tile32_off(row, k)] = f2bf(v);
-    if (k == 0) {
-      const float* b = which == 0 ? bq : (which == 1 ? bk : bv);
-      bp[row] = n >= 0 ? b[n] : 0.0f;
-    }
+    if (k == 0) bp[row] = n >= 0 ? b[n] : 0.0f;
   }
 }
 
+#ifndef NR_PROJ_NWAVE
+#define NR_PROJ_NWAVE 8    // waves per workgroup (tuning knob of the build): 8 = 256 tokens, two workgroups per CU, four waves per SIMD (default: 502 vs
+                           // 572 us for 4 = 128 tokens, three per CU, A/B on one MI355X: half the weight-chunk copies and barriers per token); 16 = 512 tokens, one per CU
+#endif
 struct ProjGeom {
   static constexpr int S = 20;
-  static constexpr int NWAVE = 4;
+  static constexpr int NWAVE = NR_PROJ_NWAVE;
   static constexpr int TOKW = 32;                    // tokens per wave: one 32-row MFMA tile
   static constexpr int TOK_WG = NWAVE * TOKW;        // 128
   static constexpr int CH_BYTES = K16 * 1024;        // 19,456 B: one 32-column chunk of W = 19 fragment blocks
@@ -78,13 +84,13 @@ struct ProjGeom {
   static constexpr int XROW = 656;                   // bytes per staged token row: 320 bf16 + 16 (rows shift by 4 banks, 16-byte aligned)
   static constexpr int STAGE_BYTES = PG_HEADS * TOKW * DK * 2;      // 3,840 B per wave: the projection epilogue's [3 heads][32 tokens][20]; the gather
                                                      // passes use the first RP * XROW = 2,624 B
-  static constexpr int SMEM = 2 * CH_BYTES + NWAVE * STAGE_BYTES;   // 54,272 B: three workgroups per CU (163,840 B)
+  static constexpr int SMEM = 2 * CH_BYTES + NWAVE * STAGE_BYTES;   // 69,632 B (8 waves): two workgroups per CU (163,840 B)
   static constexpr int NCHUNK = 3 * NT32;            // 30
   static constexpr int QPR = D / 4;                  // 75 float4 quads per table row
   static constexpr int LD_IT = (RP * QPR + 63) / 64; // 10 row pieces per lane and pass
   static constexpr int WO_PC = TOKW * DK * 2 / 16;   // 80 sixteen-byte pieces per head of a column group
   static constexpr int WO_IT = (PG_HEADS * WO_PC + 63) / 64;            // 4 sixteen-byte pieces per lane and column group
-  static_assert(STAGE_BYTES >= RP * XROW && 3 * SMEM <= 163840, "the gather tile fits the epilogue staging; three workgroups per CU");
+  static_assert(STAGE_BYTES >= RP * XROW && (NWAVE == 4 ? 3 : (NWAVE == 8 ? 2 : 1)) * SMEM <= 163840, "the gather tile fits the epilogue staging; three / two / one workgroups per CU");
 };
 
 struct ProjParams {
@@ -102,11 +108,19 @@ struct ProjParams {
 };
 
 #ifndef NR_PROJ_OCC
-#define NR_PROJ_OCC 3      // waves per SIMD the register allocation must allow
+#define NR_PROJ_OCC (NR_PROJ_NWAVE == 4 ? 3 : 4)      // waves per SIMD the register allocation must allow
 #endif
 // KSPLIT = 2: even / odd k-steps accumulate into two independent accumulators (no MFMA waits on the previous one's result)
+//
+// Round 5: nothing in the kernel waits for a STORE any more.  Its phase decomposition (profiles/r05_proj_phases.txt) had every phase additive --
+// table loads 119 us, MFMAs 125, Q / K / V stores 175, x_save stores 85, weight copies 111 of 618 -- because each phase ended in a wait that
+// covered the stores issued before it (one in-order memory counter per wave): __syncthreads() drains vmcnt to 0 while a global -> LDS copy is in
+// flight, i.e. also the Q / K / V stores issued a moment earlier; the bias loads at the top of a chunk sat behind the previous chunk's stores; a
+// gather pass waited for its table rows behind the x_save stores of the pass before.  Now: the bias rides the contraction (two bf16 columns
+// against the token rows' two 1.0 columns: no loads in the chunk loop), the chunk barrier is a raw s_barrier behind a COUNTED wait that leaves
+// the chunk's own stores in flight, and the table rows of pass p + 1 are requested before the x_save stores of pass p are issued.
 template <int KSPLIT, bool DBG>
-__global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p) {
+__global__ __launch_bounds__(ProjGeom::NWAVE * 64, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p) {
   using Gm = ProjGeom;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
   unsigned char* const stage = smem + 2 * Gm::CH_BYTES + w * Gm::STAGE_BYTES;      // wave-private
 
   // chunk c = 32 consecutive rows of the packed matrix: global -> LDS directly; the image is fragment-major already (tile32 order), so
-  // block ks is read back as ONE conflict-free ds_read_b128 at block + 16 lane
+  // block ks is read back as ONE conflict-free ds_read_b128 at block + 16 lane.  Blocks w, w + 4, ...: waves 0 - 2 issue five copies, wave 3 four
   auto chunk_fetch = [&](int c, int buf) {
     if (dbg & 16) return;
     const u16* src = p.Wp32 + (size_t)c * K16 * 512 + l * 8;
@@ -128,7 +142,8 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
 
   // ---- gather: 8 passes of 4 token rows.  Row pieces (float4 = one dropout quad) are read lane-linear along the rows, masked, rounded and
   // written to the wave's LDS tile; the tile leaves as 4 x 640 contiguous bytes of x_save, and the 8 lanes that own these 4 tokens take
-  // their 19 operand fragments (features 16 ks + 8 h .. + 7 of token li) from it -----------------------------------------------------------
+  // their 19 operand fragments (features 16 ks + 8 h .. + 7 of token li) from it.  The rows of pass p + 1 are requested as soon as pass p's rows
+  // are in LDS, BEFORE its x_save stores are issued: their wait then never covers those stores (the memory counter returns in issue order) ----
   u16x8 xf[K16];
   int myrow = 0;                                                  // table row of token li (lanes li and li + 32 hold the same)
   if (tile_tok0 + li < p.n_tok) {
@@ -136,56 +151,80 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
     id = id < 0 ? 0 : (id >= p.num_rows ? p.num_rows - 1 : id);
     myrow = (int)id;
   }
-  if (l < Gm::RP * 5) {                                           // K padding of the staged rows: col D = 1.0, D + 1 .. KP - 1 = 0 (not rewritten per pass)
+  if (l < Gm::RP * 5) {                                           // K padding of the staged rows: cols D, D + 1 = 1.0 (bias hi / lo parts), D + 2 .. KP - 1 = 0 (not rewritten per pass)
     const int r = l / 5, cq = l - r * 5;
-    *(u16x4*)(stage + r * Gm::XROW + (D + cq * 4) * 2) = u16x4{(u16)(cq == 0 ? BF16_ONE : 0), 0, 0, 0};
+    *(u16x4*)(stage + r * Gm::XROW + (D + cq * 4) * 2) = u16x4{(u16)(cq == 0 ? BF16_ONE : 0), (u16)(cq == 0 ? BF16_ONE : 0), 0, 0};
   }
-#pragma unroll 1
-  for (int ps = 0; ps < Gm::NPASS; ++ps) {
-    f32x4 raw[Gm::LD_IT];
+  const BufRsrc r_xs = make_buf(p.x_save != nullptr ? p.x_save + tile_tok0 * KP : nullptr,
+                                (p.x_save != nullptr && !(dbg & 8) && tile_tok0 < p.n_tok)
+                                    ? (uint32_t)((p.n_tok - tile_tok0 < Gm::TOKW ? p.n_tok - tile_tok0 : Gm::TOKW) * KP * 2) : 0u);      // rows past the end: stores vanish
+  // table rows through a buffer resource: one 32-bit byte offset per piece (row * 1,200 + quad * 16) instead of a 64-bit address pair -- the
+  // address pairs of a pass were what the register allocator spilled; a piece with nothing to read (past the pass / the last token) gets an
+  // offset behind the resource and reads zeros
+  const BufRsrc r_tab = make_buf(p.table, (dbg & 1) ? 0u : (uint32_t)((uint64_t)p.num_rows * (D * 4) < 0xFFFFFFFFull ? (uint64_t)p.num_rows * (D * 4) : 0xFFFFFFFFull));
+  auto load_pass = [&](int ps, f32x4 (&raw)[Gm::LD_IT]) {
+    int lq = l;
+    NR_OPAQUE(lq);
 #pragma unroll
     for (int i = 0; i < Gm::LD_IT; ++i) {
-      const int idx = l + 64 * i;
+      const int idx = lq + 64 * i;
       const int r = idx / Gm::QPR, qd = idx - r * Gm::QPR;
       const int rid = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, myrow), ps * Gm::RP + (r < Gm::RP ? r : 0)));
-      const bool ok = idx < Gm::RP * Gm::QPR && tile_tok0 + ps * Gm::RP + r < p.n_tok && !(dbg & 1);
-      raw[i] = ok ? *(const f32x4*)(p.table + (size_t)rid * D + qd * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = idx < Gm::RP * Gm::QPR && tile_tok0 + ps * Gm::RP + r < p.n_tok;
+      raw[i] = buf_load16f<0>(r_tab, ok ? (uint32_t)rid * (uint32_t)(D * 4) + (uint32_t)(qd * 16) : 0xFFFFFFF0u);
     }
+  };
+  {
+    const uint64_t qbase = (uint64_t)tile_tok0 * D4;              // dropout quad index of the wave's first element: scalar; the lane adds 32 bits
+    f32x4 raw[Gm::LD_IT];
+    load_pass(0, raw);
+#pragma unroll 1
+    for (int ps = 0; ps < Gm::NPASS; ++ps) {
 #pragma unroll
-    for (int i = 0; i < Gm::LD_IT; ++i) {
-      const int idx = l + 64 * i;
-      const int r = idx / Gm::QPR, qd = idx - r * Gm::QPR;
-      if (idx < Gm::RP * Gm::QPR) {
-        f32x4 a = raw[i];
-        if (p.dc.enabled) a = a * drop_mul4(p.dc, 1u, (uint64_t)(tile_tok0 + ps * Gm::RP + r) * D4 + qd);
-        *(u16x4*)(stage + r * Gm::XROW + qd * 8) = pack4(a);
-      }
-    }
-    wave_barrier();
-    if (p.x_save != nullptr && !(dbg & 8)) {
-      u16* dst = p.x_save + (tile_tok0 + ps * Gm::RP) * KP;       // the pass's rows are RP x 640 contiguous bytes
-#pragma unroll
-      for (int i = 0; i < (Gm::RP * (KP / 8) + 63) / 64; ++i) {
+      for (int i = 0; i < Gm::LD_IT; ++i) {
         const int idx = l + 64 * i;
-        const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
-        if (idx < Gm::RP * (KP / 8) && tile_tok0 + ps * Gm::RP + r < p.n_tok)
-          *(u16x8*)(dst + idx * 8) = *(const u16x8*)(stage + r * Gm::XROW + pc * 16);
+        const int r = idx / Gm::QPR, qd = idx - r * Gm::QPR;
+        if (idx < Gm::RP * Gm::QPR) {
+          f32x4 a = raw[i];
+          if (p.dc.enabled) a = a * drop_mul4(p.dc, 1u, qbase + (uint32_t)((ps * Gm::RP + r) * D4 + qd));
+          *(u16x4*)(stage + r * Gm::XROW + qd * 8) = pack4(a);
+        }
       }
-    }
-    if (li / Gm::RP == ps) {
-      const unsigned char* src = stage + (li % Gm::RP) * Gm::XROW + h * 16;
+      NR_SCHED_BARRIER();
+      if (ps + 1 < Gm::NPASS) load_pass(ps + 1, raw);             // requested BEFORE this pass's x_save stores are issued (same registers: the rows above are in LDS)
+      NR_SCHED_BARRIER();
+      wave_barrier();
+      {                                                           // the pass's rows are RP x 640 contiguous bytes of x_save
+        int lq = l;
+        NR_OPAQUE(lq);
 #pragma unroll
-      for (int ks = 0; ks < K16; ++ks) xf[ks] = *(const u16x8*)(src + ks * 32);
+        for (int i = 0; i < (Gm::RP * (KP / 8) + 63) / 64; ++i) {
+          const int idx = lq + 64 * i;
+          const int r = idx / (KP / 8), pc = idx - r * (KP / 8);
+          if (idx < Gm::RP * (KP / 8)) buf_store16<0>(r_xs, (uint32_t)(idx * 16), *(const u16x8*)(stage + r * Gm::XROW + pc * 16), (uint32_t)(ps * Gm::RP * KP * 2));
+        }
+      }
+      if (li / Gm::RP == ps) {
+        const unsigned char* src = stage + (li % Gm::RP) * Gm::XROW + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < K16; ++ks) xf[ks] = *(const u16x8*)(src + ks * 32);
+      }
+      wave_barrier();
     }
-    wave_barrier();
   }
   __syncthreads();
 
   // write-out geometry of a column group (fixed per lane): 16-byte piece idx = l + 64 i of [3 heads][32 tokens x 40 B].  A wave's 32 tokens
   // start at an even position of their title (32 k mod 20 is even) and title fragments hold an even number of tokens, so every fragment
-  // starts on a 16-byte boundary of its head-major block and is a whole number of pieces: a piece may span two token rows, never two titles
-  int wo_off[Gm::WO_IT];           // element offset inside qkv relative to the wave's first title, -1: nothing to write
+  // starts on a 16-byte boundary of its head-major block and is a whole number of pieces: a piece may span two token rows, never two titles.
+  // Through a buffer resource on the wave's titles: a lane with nothing to write (the tail of the last tile, idx >= 240) gets an offset past
+  // the resource -- the store instruction is ALWAYS issued (its count is what the chunk barrier's wait relies on) and writes nothing
   const int64_t seq_base = tile_tok0 / S;
+  const int64_t seq_end = (tile_tok0 + Gm::TOKW - 1) / S + 1;          // titles the wave's tokens touch
+  const int64_t nseq_all = p.n_tok / S;
+  const uint32_t wave_bytes = (dbg & 4) || tile_tok0 >= p.n_tok ? 0u : (uint32_t)(((seq_end < nseq_all ? seq_end : nseq_all) - seq_base) * (H * HM_PAIR * 2));
+  const BufRsrc r_qkv = make_buf(p.qkv + seq_base * (H * HM_PAIR), wave_bytes);
+  uint32_t wo_off[Gm::WO_IT];      // byte offset inside the wave's titles, 0xFFFFFFFF: nothing to write
 #pragma unroll
   for (int i = 0; i < Gm::WO_IT; ++i) {
     const int idx = l + 64 * i;
@@ -193,28 +232,21 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
     const int t = (2 * pc) / 5, e = 8 * pc - DK * t;            // first token the piece touches, element offset inside its row
     const int64_t tok = tile_tok0 + t;
     const int sq = (int)(tok / S - seq_base), tis = (int)(tok % S);
-    wo_off[i] = (idx < PG_HEADS * Gm::WO_PC && tok < p.n_tok) ? (sq * H + hh) * HM_PAIR + tis * DK + e : -1;
+    wo_off[i] = (idx < PG_HEADS * Gm::WO_PC && tok < p.n_tok) ? (uint32_t)(((sq * H + hh) * HM_PAIR + tis * DK + e) * 2) : 0xFFFFFFF0u;
   }
-  u16* const qkv_wave = p.qkv + seq_base * (H * HM_PAIR);
 
   // one chunk: prefetch the next, 19 MFMAs of the transposed product (A = weights: the lane ends up with 4 x 4 consecutive features of ITS
   // token), accumulators -> staging tile; after the second chunk of a 64-column group the three heads leave as contiguous runs
   auto run_chunk = [&](int which, int j, int s, int c) {
     if (c + 1 < Gm::NCHUNK) chunk_fetch(c + 1, (c + 1) & 1);
     const u16* wp = (const u16*)(smem + (c & 1) * Gm::CH_BYTES) + l * 8;
-    // the bias is requested now and added after the MFMAs: as the accumulators' initial value its L2 round trip sat in front of every chunk
-    const float* bsrc = p.bp + which * NP + j * PG_COLS + s * 32 + 4 * h;
-    f32x4 b4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4*)(bsrc + 8 * q);
     f32x16 acc[KSPLIT];
 #pragma unroll
     for (int k = 0; k < KSPLIT; ++k)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-    // weight fragments are requested PF k-steps ahead of their MFMA (the compiler's own schedule: two reads, wait, two MFMAs); the bias
-    // request above is pinned in front of them (left alone, the scheduler sank it to the end of the chain and waited for it there)
-    constexpr int PF = KSPLIT > 1 ? 4 : 6;
+    // weight fragments are requested PF k-steps ahead of their MFMA (the compiler's own schedule: two reads, wait, two MFMAs)
+    constexpr int PF = (KSPLIT > 1 || ProjGeom::NWAVE >= 8) ? 4 : 6;
     u16x8 wf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) wf[i] = *(const u16x8*)(wp + i * 512);
@@ -234,20 +266,21 @@ __global__ __launch_bounds__(256, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p
       const int r = s * 32 + 8 * q + 4 * h;                     // column inside the group: head r / 20, feature r % 20 (a quad never straddles heads)
       if (r < PG_HEADS * DK) {
         const int hh = r / DK, d = r - hh * DK;
-        *(u16x4*)(stage + ((hh * Gm::TOKW + li) * DK + d) * 2) =
-            pack4(f32x4{acc[0][4 * q] + b4[q][0], acc[0][4 * q + 1] + b4[q][1], acc[0][4 * q + 2] + b4[q][2], acc[0][4 * q + 3] + b4[q][3]});
+        *(u16x4*)(stage + ((hh * Gm::TOKW + li) * DK + d) * 2) = pack4(f32x4{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]});
       }
     }
     if (s == 1) {
       wave_barrier();
-      if (!(dbg & 4)) {
-        u16* dst = qkv_wave + (j * PG_HEADS * 3 + which) * HM_BLK;
+      const uint32_t soff = (uint32_t)((j * PG_HEADS * 3 + which) * HM_BLK * 2);
 #pragma unroll
-        for (int i = 0; i < Gm::WO_IT; ++i)
-          if (wo_off[i] >= 0) *(u16x8*)(dst + wo_off[i]) = *(const u16x8*)(stage + (l + 64 * i) * 16);
-      }
+      for (int i = 0; i < Gm::WO_IT; ++i) buf_store16<0>(r_qkv, wo_off[i], *(const u16x8*)(stage + (l + 64 * i) * 16), soff);
     }
-    __syncthreads();       // drains the in-flight global->LDS copies of chunk c + 1; everybody is done reading chunk c's buffer (and its staging tile)
+    // this wave's copies of chunk c + 1 have landed once at most the stores issued after them are outstanding (exactly WO_IT when s == 1);
+    // the LDS reads of chunk c's buffer and of the staging tile have returned; then everybody meets: chunk c + 1 is complete and visible,
+    // chunk c's buffer may take the copies of chunk c + 2.  No fence: the stores stay in flight
+    if (s == 1) NR_WAIT_VMCNT(Gm::WO_IT); else NR_WAIT_VMCNT(0);
+    NR_WAIT_LGKMCNT(0);
+    NR_BARRIER_RAW();
   };
   int c = 0;
   for (int which = 0; which < 3; ++which)

@@ -389,20 +389,24 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
   if (!ids || !table || num_rows <= 0 || !Wp32 || !bp || !qkv || n_seq < 0) return fail(NR_ERR_BADARG, "nr_qkv_proj_fwd: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_qkv_proj_fwd: dropout probability out of range");
   if (S != 20) return fail(NR_ERR_UNSUPPORTED, "nr_qkv_proj_fwd: instantiated for 20-token sequences");
+  if ((uint64_t)num_rows * (NR_D * 4) >= 0xFFFFFFF0ull || (uint64_t)n_seq * (NR_QKV_HM_SEQ * 2) >= (1ull << 40))
+    return fail(NR_ERR_UNSUPPORTED, "nr_qkv_proj_fwd: the table is addressed with 32-bit byte offsets (at most 3,579,139 rows)");
   if (n_seq == 0) return NR_OK;
   nr::ProjParams p;
   p.ids = ids; p.table = table; p.num_rows = num_rows; p.Wp32 = Wp32; p.bp = bp; p.qkv = qkv; p.x_save = x_save; p.n_tok = n_seq * S;
   p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::ProjGeom;
   const int64_t grid = (p.n_tok + G::TOK_WG - 1) / G::TOK_WG;
-  static int ksplit = -1;                           // A/B knob NR_PROJ_KSPLIT: 1 = one accumulator chain per chunk, 2 (default) = two
-  if (ksplit < 0) { const char* e = getenv("NR_PROJ_KSPLIT"); ksplit = e ? atoi(e) : 2; }
+  static int ksplit = -1;                           // A/B knob NR_PROJ_KSPLIT: 1 = one accumulator chain per chunk (default at four waves per SIMD: the
+  if (ksplit < 0) { const char* e = getenv("NR_PROJ_KSPLIT"); ksplit = e ? atoi(e) : (G::NWAVE >= 8 ? 1 : 2); }       // second chain's 16 registers spill under the 128 cap), 2 = two
   const char* d = getenv("NR_PROJ_DEBUG");          // profiling: phase switches (ProjParams::debug), re-read per call
+  if (allow_smem(nr::qkv_proj_kernel<1, true>, G::SMEM) || allow_smem(nr::qkv_proj_kernel<1, false>, G::SMEM) || allow_smem(nr::qkv_proj_kernel<2, false>, G::SMEM))
+    return fail(NR_ERR_LAUNCH, "nr_qkv_proj_fwd: cannot reserve LDS");
   if (d != nullptr && atoi(d) != 0) {
     p.debug = atoi(d);
-    NR_LAUNCH((nr::qkv_proj_kernel<2, true>), grid, 256, G::SMEM, (hipStream_t)stream, p);
-  } else if (ksplit == 1) NR_LAUNCH((nr::qkv_proj_kernel<1, false>), grid, 256, G::SMEM, (hipStream_t)stream, p);
-  else NR_LAUNCH((nr::qkv_proj_kernel<2, false>), grid, 256, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::qkv_proj_kernel<1, true>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
+  } else if (ksplit == 1) NR_LAUNCH((nr::qkv_proj_kernel<1, false>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
+  else NR_LAUNCH((nr::qkv_proj_kernel<2, false>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
   return check_launch("nr_qkv_proj_fwd");
 }
 

@@ -86,7 +86,8 @@ inline void dma_land(size_t keep) {
   Fiber& f = cur_fiber();
   if (f.dma.size() <= keep) return;
   const size_t n = f.dma.size() - keep;
-  for (size_t i = 0; i < n; ++i) memcpy(f.dma[i].dst, f.dma[i].src, 16);
+  for (size_t i = 0; i < n; ++i)
+    if (f.dma[i].src != nullptr) memcpy(f.dma[i].dst, f.dma[i].src, 16);        // (nullptr: a buffer STORE -- it only occupies a slot of the in-order counter)
   f.dma.erase(f.dma.begin(), f.dma.begin() + n);
 }
 inline void dma_issue(const void* src, void* dst) { cur_fiber().dma.push_back(PendingCopy{src, dst}); }
@@ -323,11 +324,15 @@ __forceinline__ float buf_load4f(BufRsrc r, uint32_t off) {
   if ((uint64_t)off + 4 <= r.nbytes) memcpy(&v, r.base + off, 4);
   return v;
 }
+// A buffer store is one more entry of the wave's in-order memory counter (gfx950: vmcnt counts stores too): kernels that leave stores in flight
+// across a COUNTED wait for their LDS-DMA copies (qkv_proj_kernel) count on that, so the emulator counts them as well
 template <int IMM = 0> __forceinline__ void buf_store16(BufRsrc r, uint32_t off, u16x8 v, uint32_t soff = 0) {
   if ((uint64_t)off + IMM + soff + 16 <= r.nbytes) memcpy(r.base + off + IMM + soff, &v, 16);
+  nr_emu::dma_issue(nullptr, nullptr);
 }
 template <int IMM = 0> __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
   if ((uint64_t)off + IMM + soff + 8 <= r.nbytes) memcpy(r.base + off + IMM + soff, &v, 8);
+  nr_emu::dma_issue(nullptr, nullptr);
 }
 
 template <typename T> __forceinline__ T ld_nt(const T* p) { return *p; }

@@ -44,9 +44,14 @@ def check_pack32(be):
     for i, n in enumerate(('W_Q', 'W_K', 'W_V')):
         blk = W[i * NR_NP:(i + 1) * NR_NP]
         assert np.array_equal(blk[real][:, :NR_D], f32_to_bf16(params[m + n + '.weight'])[feat[real]])
-        assert not blk[~real].any() and not blk[:, NR_D:].any()
+        assert not blk[~real].any() and not blk[:, NR_D + 2:].any()
         b = be.np(bp)[i * NR_NP:(i + 1) * NR_NP]
         assert np.array_equal(b[real], params[m + n + '.bias'][feat[real]]) and not b[~real].any()
+        # columns D, D + 1: the bias as two bf16 numbers (hi + lo) -- it rides the contraction against the token rows' two 1.0 columns
+        bias = params[m + n + '.bias'][feat[real]]
+        hi = f32_to_bf16(bias)
+        lo = f32_to_bf16(bias - bf16_to_f32(hi))
+        assert np.array_equal(blk[real][:, NR_D], hi) and np.array_equal(blk[real][:, NR_D + 1], lo)
 
 
 def hm_split(qkv_u16, n_seq):
@@ -96,7 +101,9 @@ def check_qkv_proj(be, n_seq=13, V=300, p_drop=0.0, seed=4321):
     xq = bf16_round(x.astype(np.float32))
     got_x = be.np(xs)
     assert np.array_equal(bf16_to_f32(got_x[:, :NR_D]), xq.reshape(-1, NR_D)), 'x_save differs from the masked bf16 token matrix'
-    assert (got_x[:, NR_D] == 0x3F80).all() and not got_x[:, NR_D + 1:].any(), 'x_save K padding wrong'
+    # K padding: columns D and D + 1 are 1.0 (the projection's bias parts multiply them; the weight-gradient GEMM reads its bias gradient from
+    # column D and ignores the duplicate), the rest zero
+    assert (got_x[:, NR_D] == 0x3F80).all() and (got_x[:, NR_D + 1] == 0x3F80).all() and not got_x[:, NR_D + 2:].any(), 'x_save K padding wrong'
     q, k, v = hm_split(be.np(qkv), n_seq)
     m = 'news_encoder.multihead_self_attention.'
     rels = []
