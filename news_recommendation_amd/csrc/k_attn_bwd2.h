@@ -25,28 +25,30 @@ namespace nr {
 template <int NW_>
 struct AttnBwd2Geom {
   static constexpr int S = 20;
-  static constexpr int NW = NW_;                        // waves per workgroup = heads per round (5: three full rounds; 4: four rounds, the last with three heads)
+  static constexpr int NW = NW_;                        // waves per workgroup = heads per round (8: two rounds, 8 + 7 heads, four waves per SIMD; 5: three full rounds)
   static constexpr int NT = NW * 64;
   static constexpr int ROUNDS = (H + NW - 1) / NW;
-  static constexpr int WROWS = S / NW;                  // rows each wave writes out
-  static_assert(S % NW == 0 && S == 20 && DK == 20, "whole rows per wave in the write-out; fragment offsets are written for 20 x 20 blocks");
+  static_assert(S == 20 && DK == 20, "fragment offsets are written for 20 x 20 blocks");
   static constexpr int BLK = HM_BLK * 2;                // 800 B: one [20][20] bf16 block, row stride 40 B
   static constexpr int OPER = 3 * BLK;                  // 2,400 B: Q | K | V of a pair
   static constexpr int OPER_STRIDE = OPER + 32;         // transposing reads of rows 16 .. 19 with d-tile 1 run 22 B past a block
-  static constexpr int DCTX_BYTES = S * KP * 2;         // 12,800
   static constexpr int GO_BYTES = D * 4;                // 1,200
   static constexpr int WT_BYTES = S * 4;                // 80
-  static constexpr int RAW_BYTES = DCTX_BYTES + GO_BYTES + WT_BYTES;     // 14,080 = 880 sixteen-byte pieces
-  static constexpr int RAW_PIECES = RAW_BYTES / 16;
+  static constexpr int GW_BYTES = GO_BYTES + WT_BYTES;  // 1,280 = 80 sixteen-byte pieces: the title's pooled-vector gradient and pooling weights
+  static constexpr int GW_PIECES = GW_BYTES / 16;
+  static constexpr int TOUCH_BYTES = 512;               // landing area of the 4-byte copies that pull the next title's dctx lines into the cache (never read)
+  static constexpr int DCTX_LINES = S * KP * 2 / 128;   // 100 cache lines
   static constexpr int DCH_BYTES = (H + 1) * BLK;       // head-major dC tile + a dummy block (the dC pass writes its padding quad there; zeroed once: slack of the transposing reads)
   static constexpr int LDG = 3 * KP;                    // 960 columns of a dqkv row (dQ | dK | dV blocks of KP)
   static constexpr int TROW = LDG * 2 + 16;             // 1,936 B per staged dqkv row
   static constexpr int TILE_BYTES = S * TROW;           // 38,720
   static constexpr int ZERO_BYTES = 2 * BLK + 16;       // lanes without a k-slot read zeros at block offsets 0, 800 and 1,600
-  static constexpr int SMEM = NW * OPER_STRIDE + RAW_BYTES + DCH_BYTES + TILE_BYTES + ZERO_BYTES;    // 78,624 B: two workgroups per CU
-  static_assert(2 * SMEM <= 163840 && OPER_STRIDE % 16 == 0 && RAW_BYTES % 16 == 0 && DCH_BYTES % 16 == 0 && TILE_BYTES % 16 == 0, "LDS budget / alignment");
+  static constexpr int SMEM = NW * OPER_STRIDE + GW_BYTES + DCH_BYTES + TILE_BYTES + ZERO_BYTES + TOUCH_BYTES;    // 74,384 B at eight waves: two workgroups per CU
+  static_assert(2 * SMEM <= 163840 && OPER_STRIDE % 16 == 0 && GW_BYTES % 16 == 0 && DCH_BYTES % 16 == 0 && TILE_BYTES % 16 == 0, "LDS budget / alignment");
   static constexpr int CPR = (D + 7) / 8;               // 38 sixteen-byte pieces cover the 300 real columns of a dctx row
-  static_assert(LDG / 8 > 64 && LDG / 8 <= 128, "write-out: two store instructions per row");
+  static constexpr int ASM_IT = (S * CPR + NT - 1) / NT;          // dctx pieces per thread in the dC pass (2 at eight waves)
+  static constexpr int WO_PIECES = S * (LDG / 8);       // 2,400 sixteen-byte pieces of the title's dqkv rows (contiguous in global memory)
+  static constexpr int WO_IT = (WO_PIECES + NT - 1) / NT;         // per thread (5 at eight waves)
 };
 
 struct AttnBwd2Params {
@@ -63,7 +65,7 @@ struct AttnBwd2Params {
 };
 
 template <int NW, bool DBG>
-__global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bwd2_kernel(AttnBwd2Params p) {
+__global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 8 ? 4 : (NW == 5 ? 3 : 2)) void attn_bwd2_kernel(AttnBwd2Params p) {
   using Gm = AttnBwd2Geom<NW>;
   constexpr int S = Gm::S;
   const int dbg = DBG ? p.debug : 0;
@@ -71,10 +73,11 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15, tid = (int)threadIdx.x;
   unsigned char* const oper = smem + w * Gm::OPER_STRIDE;             // wave-private: Q | K | V of the current pair
-  unsigned char* const raw = smem + Gm::NW * Gm::OPER_STRIDE;         // dctx rows | g_out row | pooling weights of the NEXT title to be assembled
-  unsigned char* const dch = raw + Gm::RAW_BYTES;                     // dC of the current title, head-major
+  unsigned char* const gw = smem + Gm::NW * Gm::OPER_STRIDE;          // g_out row | pooling weights of the NEXT title to be assembled
+  unsigned char* const dch = gw + Gm::GW_BYTES;                       // dC of the current title, head-major
   unsigned char* const tile = dch + Gm::DCH_BYTES;                    // dqkv rows of the current title
   unsigned char* const zero = tile + Gm::TILE_BYTES;
+  unsigned char* const touch = zero + Gm::ZERO_BYTES;
 
   // ---- one-time LDS state: zero block, slack behind the operand / dC blocks (finite), K padding of the staged rows ---------------------------
   for (int i = tid; i < Gm::ZERO_BYTES / 8; i += Gm::NT) *(u16x4*)(zero + i * 8) = u16x4{0, 0, 0, 0};
@@ -91,21 +94,46 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
   // ---- copies ---------------------------------------------------------------------------------------------------------------------------------
   auto fetch_pair = [&](int64_t seq, int hd) {            // 150 sixteen-byte pieces: lanes 0 .. 63, 0 .. 63, 0 .. 21
     if (dbg & 1) return;
-    const u16* src = p.qkv + (seq * H + hd) * HM_PAIR + l * 8;
-    NR_GLDS16(src, oper);
-    NR_GLDS16(src + 512, oper + 1024);
-    if (l < Gm::OPER / 16 - 128) NR_GLDS16(src + 1024, oper + 2048);
+    // (wave-uniform 64-bit base + unsigned 32-bit lane offset: the copy takes the base in scalar registers; per-lane 64-bit addresses of the
+    //  three copy streams were what the register allocator spilled under the 128-register cap)
+    const unsigned char* base = (const unsigned char*)(p.qkv + (seq * H + hd) * HM_PAIR);
+    const unsigned lo = (unsigned)l * 16u;
+    NR_GLDS16_S(base, lo, oper);
+    NR_GLDS16_S(base, lo + 1024u, oper + 1024);
+    if (l < Gm::OPER / 16 - 128) NR_GLDS16_S(base, lo + 2048u, oper + 2048);
   };
-  auto fetch_raw = [&](int64_t seq) {                     // 880 pieces over the five waves: dctx rows (800), g_out row (75), pooling weights (5)
-    if (dbg & 1) return;
-    const unsigned char* s_dctx = (const unsigned char*)(p.dctx + seq * S * KP);
+  auto fetch_gw = [&](int64_t seq) {                      // 75 + 5 pieces, wave 0: lanes 0 .. 63, 0 .. 15
+    if ((dbg & 1) || w != 0) return;
     const unsigned char* s_go = (const unsigned char*)(p.g_out + seq * D);
     const unsigned char* s_wt = (const unsigned char*)(p.attn_w + seq * S);
-    for (int b = w; b * 64 < Gm::RAW_PIECES; b += Gm::NW) {
-      const int pc = b * 64 + l;
-      constexpr int P0 = Gm::DCTX_BYTES / 16, P1 = P0 + Gm::GO_BYTES / 16;
-      const unsigned char* src = pc < P0 ? s_dctx + pc * 16 : (pc < P1 ? s_go + (pc - P0) * 16 : s_wt + (pc - P1) * 16);
-      if (pc < Gm::RAW_PIECES) NR_GLDS16(src, raw + b * 1024);
+    constexpr int P1 = Gm::GO_BYTES / 16;                   // 75: lanes 0 .. 10 of the second copy finish the g_out row, lanes 11 .. 15 take the weights
+    const unsigned lo = (unsigned)l * 16u;
+    NR_GLDS16_S(s_go, lo, gw);
+    if (l < P1 - 64) NR_GLDS16_S(s_go, lo + 1024u, gw + 1024);
+    else if (l < Gm::GW_PIECES - 64) NR_GLDS16_S(s_wt, lo - (unsigned)(P1 - 64) * 16u, gw + 1024);
+  };
+  // The title's dctx rows for the dC pass: ASM_IT sixteen-byte pieces per thread, straight into registers at the top of the pass (through LDS
+  // like the operands they cost 12.8 KB per workgroup -- the difference between five and eight waves per title; held in registers across
+  // the pairs they do not fit under the 128-register cap of four waves per SIMD).  Their HBM latency is taken a title earlier: in round 0 one
+  // wave TOUCHES the next title's 100 cache lines with 4-byte global -> LDS copies into a landing area nobody reads, so the loads of the pass
+  // hit the L2 (the copies are asynchronous like every other: nothing waits for them but the title barrier).
+  auto touch_dctx = [&](int64_t seq) {
+    if ((dbg & 1) || w != 1 % Gm::NW) return;
+    const unsigned char* base = (const unsigned char*)(p.dctx + seq * S * KP);
+    const unsigned lo = (unsigned)l * 128u;
+    NR_GLDS4_S(base, lo, touch);
+    if (l < Gm::DCTX_LINES - 64) NR_GLDS4_S(base, lo + 64u * 128u, touch + 256);
+  };
+  u16x8 dgp[Gm::ASM_IT];
+  auto prefetch_dctx = [&](int64_t seq) {
+    const BufRsrc rd = make_buf(p.dctx + seq * S * KP, (dbg & 1) ? 0u : (uint32_t)(S * KP * 2));
+    int tq = tid;
+    NR_OPAQUE(tq);
+#pragma unroll
+    for (int i = 0; i < Gm::ASM_IT; ++i) {
+      const int idx = tq + i * Gm::NT;
+      const int r = (idx * 1725) >> 16, pc = idx - r * Gm::CPR;                     // idx / 38 for idx < 760 (larger: past the resource, zeros)
+      dgp[i] = buf_load16<0>(rd, idx < S * Gm::CPR ? (uint32_t)((r * KP + pc * 8) * 2) : 0xFFFFFFF0u);
     }
   };
 
@@ -148,25 +176,29 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
       p.stamps[((((size_t)blockIdx.x * Gm::NW + w) * 4 + it_t) * Gm::ROUNDS + rnd) * 12 + k] = __builtin_readcyclecounter();
   };
 
-  constexpr int ASM_IT = (S * Gm::CPR + Gm::NT - 1) / Gm::NT;
-  // ---- the dC pass: raw dctx rows + attn_w (x) g_out, dropout 2, -> head-major bf16 tile --------------------------------------------------------
+  // ---- the dC pass: dctx rows (registers) + attn_w (x) g_out, dropout 2, -> head-major bf16 tile --------------------------------------------------
   auto assemble = [&](int64_t seq) {
-    const float* go = (const float*)(raw + Gm::DCTX_BYTES);
-    const float* wt = (const float*)(raw + Gm::DCTX_BYTES + Gm::GO_BYTES);
+    const float* go = (const float*)gw;
+    const float* wt = (const float*)(gw + Gm::GO_BYTES);
     const uint64_t qbase = (uint64_t)(seq * S) * D4;       // dropout quad index of the title's first element: scalar; the lane adds 32 bits
+    // every wave waits for ALL of its dctx pieces here (a counted wait: the write-out's stores, issued behind them, stay in flight) -- also the
+    // waves that skip the second piece below: a load still pending on some path makes the compiler drain the whole counter, stores included,
+    // in front of the first instruction that reuses its destination registers (it did: in front of the first pair's fragment reads)
 #pragma unroll
-    for (int i = 0; i < ASM_IT; ++i) {
+    for (int i = 0; i < Gm::ASM_IT; ++i) asm volatile("" : "+v"(dgp[i]));
+#pragma unroll
+    for (int i = 0; i < Gm::ASM_IT; ++i) {
       int idx = tid + i * Gm::NT;
       NR_OPAQUE(idx);                                      // (row / piece / addresses recomputed here: hoisted out of the title loop they cost ~20 registers)
       if (idx < S * Gm::CPR) {
         const int r = (idx * 1725) >> 16, pc = idx - r * Gm::CPR, c = pc * 8;      // idx / 38 for idx < 760
-        const u16x8 dg = *(const u16x8*)(raw + (r * KP + c) * 2);
+        const u16x8 dg = dgp[i];
         const float wr = wt[r];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int cc = c + 4 * hf;                       // a quad never straddles heads (20 % 4 == 0) and is one dropout quad
           // the quad of columns 300 .. 303 (last piece of a row) is computed like the others -- its g_out values are the pooling weights that
-          // follow in the raw block -- and lands in the dummy block behind the 15 heads: no branch
+          // follow in the LDS block -- and lands in the dummy block behind the 15 heads: no branch
           const f32x4 g4 = *(const f32x4*)(go + cc);
           f32x4 v;
 #pragma unroll
@@ -178,33 +210,32 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
       }
     }
   };
-  // wave w writes rows WROWS w .. WROWS w + WROWS - 1 of the title: per row 120 sixteen-byte pieces = lanes 0 .. 63 + lanes 0 .. 55.  One LDS address and one
-  // buffer offset per lane, everything else in immediates / scalar offsets
-  const unsigned char* const wo_src = tile + (Gm::WROWS * w) * Gm::TROW + l * 16;
+  // the title's rows are 38,400 contiguous bytes of dqkv: piece idx = tid + NT i goes to byte 16 idx, from tile row idx / 120
   auto writeout = [&](int64_t seq) {
     if (dbg & 4) return;
-    const BufRsrc rs = make_buf(p.dqkv + (seq * S + Gm::WROWS * w) * Gm::LDG, Gm::WROWS * Gm::LDG * 2);
+    const BufRsrc rs = make_buf(p.dqkv + seq * S * Gm::LDG, S * Gm::LDG * 2);
+    int tq = tid;
+    NR_OPAQUE(tq);
 #pragma unroll
-    for (int j = 0; j < Gm::WROWS; ++j) {
-      buf_store16<0>(rs, l * 16, *(const u16x8*)(wo_src + j * Gm::TROW), j * Gm::LDG * 2);
-      if (l < Gm::LDG / 8 - 64) buf_store16<1024>(rs, l * 16, *(const u16x8*)(wo_src + j * Gm::TROW + 1024), j * Gm::LDG * 2);
+    for (int i = 0; i < Gm::WO_IT; ++i) {
+      const int idx = tq + i * Gm::NT;
+      const int r = (idx * 2185) >> 18;                     // idx / 120 for idx < 2,600
+      buf_store16<0>(rs, idx < Gm::WO_PIECES ? (uint32_t)(tq * 16) : 0xFFFFFFF0u, *(const u16x8*)(tile + idx * 16 + r * 16), (uint32_t)(i * Gm::NT * 16));
     }
   };
 
   int64_t seq = blockIdx.x;
   if (seq >= p.n_seq) return;
-  fetch_raw(seq);
+  fetch_gw(seq);
   fetch_pair(seq, w);
-  __syncthreads();                                        // the first title's raw rows have landed (every wave drains its own copies, then meets)
-  int64_t prev = -1;
-  while (seq < p.n_seq) {
+  prefetch_dctx(seq);
+  NR_WAIT_VMCNT(0);                                       // (the copies are asm: the barrier's own fence does not know them)
+  __syncthreads();                                        // the first title's g_out row / weights have landed (every wave drains its own copies, then meets)
+  assemble(seq);
+  while (true) {
     rnd = 0;
-    stamp(0);
-    if (prev >= 0) writeout(prev);
-    stamp(1);
-    assemble(seq);
     stamp(2);
-    __syncthreads();                                      // dC tile complete; raw rows consumed; the previous title's rows have been read out of the tile
+    __syncthreads();                                      // dC tile complete; g_out row consumed; the previous title's rows have been read out of the tile
     const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
     const uint32_t kmask[2] = {(g == 2 && li >= klen) ? (uint32_t)BF16_NEG_BIG : 0u, (g == 2 && 16 + li >= klen) ? (uint32_t)BF16_NEG_BIG : 0u};
     const int64_t nseq = seq + gridDim.x;
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
       NR_SCHED_BARRIER();
       if (hd + Gm::NW < H) fetch_pair(seq, hd + Gm::NW);
       else if (nseq < p.n_seq) fetch_pair(nseq, w);
-      if (rnd == 0 && nseq < p.n_seq) fetch_raw(nseq);     // (the raw rows of this title were consumed before the barrier above)
+      if (rnd == 0 && nseq < p.n_seq) { fetch_gw(nseq); touch_dctx(nseq); }      // (this title's g_out row was consumed before the barrier above)
       stamp(4);
 
       if (!(dbg & 16)) {
@@ -334,13 +365,22 @@ __global__ __launch_bounds__(AttnBwd2Geom<NW>::NT, NW == 5 ? 3 : 2) void attn_bw
     }
     rnd = Gm::ROUNDS - 1;
     stamp(8);
-    __syncthreads();                                      // the title's rows are complete in the tile; the next title's raw rows have landed
+    NR_WAIT_VMCNT(0);                                     // this wave's copies for the next title (first pair, g_out row, line touches) have landed
+    __syncthreads();                                      // the title's rows are complete in the tile; the next title's g_out row has landed
     stamp(9);
-    prev = seq;
-    seq = nseq;
     ++it_t;
+    if (nseq >= p.n_seq) break;
+    rnd = 0;
+    stamp(0);
+    // the next title's dctx pieces are requested BEFORE the write-out (they are L2 hits after the touches and fly behind its LDS reads), the
+    // stores are issued behind them: the dC pass then waits for the loads only
+    prefetch_dctx(nseq);
+    writeout(seq);
+    stamp(1);
+    assemble(nseq);
+    seq = nseq;
   }
-  writeout(prev);
+  writeout(seq);
 }
 
 }  // namespace nr

@@ -313,8 +313,8 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
     const int64_t cap = capdiv > 0 ? capdiv : 2 * (int64_t)nr::device_cus();        // persistent: two workgroups per CU walk the titles
     const int grid = (int)(n_seq < cap ? n_seq : cap);
     const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches of the DBG instantiation, re-read per call
-    const char* nwe = getenv("NR_ATTNB2_NW");       // A/B: waves per workgroup (5: three rounds of five heads; 4: four rounds)
-    const int nw = nwe ? atoi(nwe) : 5;
+    const char* nwe = getenv("NR_ATTNB2_NW");       // A/B: waves per workgroup (8, default: two rounds, four waves per SIMD; 5: three rounds of five heads)
+    const int nw = nwe ? atoi(nwe) : 8;
     q.debug = d ? atoi(d) : 0;
 #define NR_AB2_LAUNCH(NW_, DBG_)                                                                                                  \
     do {                                                                                                                          \
@@ -322,8 +322,8 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
       if (allow_smem(nr::attn_bwd2_kernel<NW_, DBG_>, G2::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");  \
       NR_LAUNCH((nr::attn_bwd2_kernel<NW_, DBG_>), grid, G2::NT, G2::SMEM, (hipStream_t)stream, q);                              \
     } while (0)
-    if (nw == 4) { if (q.debug) NR_AB2_LAUNCH(4, true); else NR_AB2_LAUNCH(4, false); }
-    else { if (q.debug) NR_AB2_LAUNCH(5, true); else NR_AB2_LAUNCH(5, false); }
+    if (nw == 5) { if (q.debug) NR_AB2_LAUNCH(5, true); else NR_AB2_LAUNCH(5, false); }
+    else { if (q.debug) NR_AB2_LAUNCH(8, true); else NR_AB2_LAUNCH(8, false); }
 #undef NR_AB2_LAUNCH
     return check_launch("nr_attn_bwd");
   }

@@ -24,6 +24,30 @@
 #define NR_GLDS16(gptr, lds_base) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
 
+// the 4-byte form (lane i's dword lands at lds_base + 4 i): used to TOUCH cache lines -- an asynchronous prefetch into the L2 whose landing area
+// nobody reads
+#define NR_GLDS4(gptr, lds_base) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_base), 4, 0, 0)
+
+// The same copies with the source as (wave-uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): written in asm because the builtin
+// takes one flat pointer and the compiler then keeps a 64-bit VGPR address pair per copy stream alive across the loop.  Invisible to the
+// compiler's waitcnt bookkeeping: the caller waits (NR_WAIT_VMCNT) before it reads the landing area AND before any barrier that is to publish
+// it -- __syncthreads() does not drain copies it cannot see.  M0 (the LDS destination) is saved and restored; s_nop 4 covers a base freshly
+// written by a v_readfirstlane.
+__device__ __forceinline__ void glds16_sbase(const void* base, uint32_t voff, void* lds_dst) {
+  uint32_t keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_dst)) : "memory");      // (low 32 bits of a generic LDS pointer = the LDS byte address)
+}
+__device__ __forceinline__ void glds4_sbase(const void* base, uint32_t voff, void* lds_dst) {
+  uint32_t keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_dst)) : "memory");      // (low 32 bits of a generic LDS pointer = the LDS byte address)
+}
+
+#define NR_GLDS16_S(base, voff, lds_dst) glds16_sbase((base), (voff), (lds_dst))
+#define NR_GLDS4_S(base, voff, lds_dst) glds4_sbase((base), (voff), (lds_dst))
+
 // Counted wait for a RING of such copies: returns when at most n of this wave's vector-memory loads (LDS-DMA included; they complete in
 // issue order) are still in flight.  s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; the other two
 // counters are left unconstrained.  NR_BARRIER_RAW is s_barrier WITHOUT the fence __syncthreads() implies (that fence drains vmcnt to 0,

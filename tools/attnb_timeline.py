@@ -73,7 +73,7 @@ def timeline(NW, NR, names, title_cols):
 # ---- interleaved A/B of the production builds (the first timed launches of a process run at a lower clock: warm up first) ---------------------
 for _ in range(40): fn()
 torch.cuda.synchronize()
-variants = {'TILE (r04)': {'NR_ATTNB2': '0'}, 'DMA NW=5': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '5'}, 'DMA NW=4': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '4'}}
+variants = {'TILE (r04)': {'NR_ATTNB2': '0'}, 'DMA NW=5': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '5'}, 'DMA NW=8': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '8'}}
 res = {k: [] for k in variants}
 for rnd_ in range(5):
     for k, env in variants.items():
@@ -89,7 +89,7 @@ os.environ['NR_ATTNB2'] = '1'
 phases('DMA form')
 # stamps of the DMA form: 0 title top, 1 write-out issued, 2 dC pass done, (barrier), 3 pair top, 4 fragments read + copies issued, 5 P / dP / dS,
 # 6 transposes, 7 outputs in the tile, 8 in front of the title barrier (round 2), 9 behind it
-timeline(5, 3, ['writeout', 'dC pass', 'barrier B', 'frags+dma', 'softmax', 'transp', 'outputs', '(next)', 'barrier C'], None)
+timeline(8, 2, ['writeout', 'dC pass', 'barrier B', 'frags+dma', 'softmax', 'transp', 'outputs', '(next)', 'barrier C'], None)
 os.environ['NR_ATTNB2'] = '0'
 phases('TILE form')
 timeline(4, 4, ['store_lds', 'prefetch', 'operands', 'softmax', 'transp', 'outputs', '(gap)', 'barrier1', 'writeout', 'barrier2'], None)
