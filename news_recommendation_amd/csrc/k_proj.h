@@ -310,7 +310,8 @@ struct AttnFwdGeom {
   static constexpr int CROW = 656;                    // bytes per staged ctx row (320 bf16 + 16)
   static constexpr int TILE_BYTES = S * CROW;         // 13,120 B per title
   static constexpr int OPER_BYTES = HM_PAIR * 2;      // 2,400 B per wave: Q, K, V of one pair
-  static constexpr int SMEM = TPB * TILE_BYTES + WPB * OPER_BYTES;   // 71,680 B: two workgroups per CU = 4 waves per SIMD
+  static constexpr int ZERO_BYTES = 2 * 800 + 16;     // lanes without a k-slot read zeros at block offsets 0 and 800 (Q, K row fragments)
+  static constexpr int SMEM = TPB * TILE_BYTES + WPB * OPER_BYTES + 1664;   // 73,344 B: two workgroups per CU = 4 waves per SIMD
   static constexpr int OP_IT = (OPER_BYTES / 16 + 63) / 64;      // 3 sixteen-byte pieces per lane and pair
   static constexpr int WO_ROWS = S / 2;               // rows each of the title's two waves writes out
   static constexpr int WO_IT = (WO_ROWS * (KP / 8) + 63) / 64;   // 7 sixteen-byte pieces per lane
@@ -334,9 +335,10 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
   if (!POOL && !have) return;                                     // (both waves of a title leave together; exited waves do not hold up the barrier)
   unsigned char* const tile = smem + (w >> 1) * Gm::TILE_BYTES;   // ctx rows of the title, shared by its two waves (disjoint columns)
   unsigned char* const oper = smem + Gm::TPB * Gm::TILE_BYTES + w * Gm::OPER_BYTES;      // operands of this wave's current pair
-  const u16x4 Z4 = u16x4{0, 0, 0, 0};
+  unsigned char* const zero = smem + Gm::TPB * Gm::TILE_BYTES + Gm::WPB * Gm::OPER_BYTES;      // lanes without a k-slot read zeros here
   const int hd0 = half * Gm::HSPLIT, hd1 = half ? H : Gm::HSPLIT;
 
+  for (int i = l; i * 8 < Gm::ZERO_BYTES; i += 64) *(u16x4*)(zero + i * 8) = u16x4{0, 0, 0, 0};      // (every wave writes the same zeros: no barrier needed before its own reads)
   if (have) {                                                     // (a pooled workgroup keeps the waves of missing titles for the pooling)
   // K padding of the staged ctx rows: col D = 1.0 (bias-gradient column), cols D + 1 .. KP - 1 = 0
   if (half == 0)
@@ -344,57 +346,62 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
       const int r = i / 5, cq = i - r * 5;
       *(u16x4*)(tile + r * Gm::CROW + (D + cq * 4) * 2) = u16x4{(u16)(cq == 0 ? BF16_ONE : 0), 0, 0, 0};
     }
-  const u16* const qkv_seq = p.qkv + seq * (H * HM_PAIR);
-  u16x8 nxt[Gm::OP_IT];
+  // a pair's Q | K | V block (2,400 contiguous bytes) goes global -> LDS directly (round 5, as in k_attn_bwd2.h): three copies with a scalar
+  // base, issued as soon as the previous pair's fragments are in registers -- no staging registers, no LDS stores
+  const unsigned char* const qkv_seq = (const unsigned char*)(p.qkv + seq * (H * HM_PAIR));
   auto fetch = [&](int hd) {
-#pragma unroll
-    for (int i = 0; i < Gm::OP_IT; ++i) {
-      const int idx = l + 64 * i;
-      nxt[i] = (idx < Gm::OPER_BYTES / 16 && !(dbg & 1)) ? *(const u16x8*)(qkv_seq + hd * HM_PAIR + idx * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    if (dbg & 1) return;
+    const unsigned char* base = qkv_seq + hd * (HM_PAIR * 2);
+    const unsigned lo = (unsigned)l * 16u;
+    NR_GLDS16_S(base, lo, oper);
+    NR_GLDS16_S(base, lo + 1024u, oper + 1024);
+    if (l < Gm::OPER_BYTES / 16 - 128) NR_GLDS16_S(base, lo + 2048u, oper + 2048);
   };
   fetch(hd0);
 
   const int klen = p.key_len != nullptr ? uniform(clamp_len(p.key_len[seq], S)) : S;
   const float c2 = LOG2E / sqrtf((float)DK), clamp2 = EXP_CLAMP * LOG2E;
-  // identity B operands (natural k-slots 8 g + j): CL(V) = AL(V) x identity puts V^T into A-operand form on the matrix core
-  u16x8 ident[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ident[t][j] = (8 * g + j == 16 * t + li) ? BF16_ONE : (u16)0;
-
   // Fragment shapes (v_mfma_f32_16x16x32_bf16, lane = (li, g)):
-  //   K / Q tile t as A / B operand of S^T = K Q^T: row 16 t + li, k-slots d = 8 g .. 8 g + 7 (d < 20); slot d = 20 carries the key mask
-  //   (q = 1, k = 0 for a live key, -29952 for a padded one: exp2 of it underflows to exactly 0, no select per element);
+  //   K / Q tile t as A / B operand of S^T = K Q^T: row 16 t + li (clamped to 19: duplicates that are masked as keys / never stored as
+  //   queries), k-slots d = 8 g .. 8 g + 7; halves with d >= 20 read the zero block; slot d = 20 carries the key mask (q = 1, k = 0 for a
+  //   live key, -29952 for a padded one: exp2 of it underflows to exactly 0, no select per element);
   //   the packed P^T tiles are the B operand of ctx^T = V^T P^T with k-slot (g, j < 4) = key 4 g + j and (g, j >= 4) = key 16 + 4 g + j - 4:
-  //   exactly the slots of the two packed CL(V) tiles (rows = keys) used as the A operand.
-  for (int hd = hd0; hd < hd1; ++hd) {
+  //   V^T as the A operand in exactly those slots comes from the TRANSPOSING LDS read of the row-major V block (rows = keys): lane (li, g)
+  //   supplies the piece &V[16 t + 4 g + (li >> 2)][16 dt + 4 (li & 3)] and receives V[16 t + 4 g + 0 .. 3][16 dt + li] (round 4: four
+  //   identity MFMAs + eight conversions per pair)
+  const int zoff = (int)(zero - oper);
+  int lo_off[2], hi_off[2], tr_off[2];
 #pragma unroll
-    for (int i = 0; i < Gm::OP_IT; ++i)
-      if (l + 64 * i < Gm::OPER_BYTES / 16) *(u16x8*)(oper + (l + 64 * i) * 16) = nxt[i];
-    if (hd + 1 < hd1) fetch(hd + 1);
+  for (int t = 0; t < 2; ++t) {
+    const int row = 16 * t + li < S ? 16 * t + li : S - 1;
+    lo_off[t] = g < 3 ? row * 40 + 16 * g : zoff;
+    hi_off[t] = g < 2 ? row * 40 + 16 * g + 8 : zoff;
+    const int trow = 16 * t + 4 * g + (li >> 2) < S ? 16 * t + 4 * g + (li >> 2) : S - 1;
+    tr_off[t] = trow * 40 + 8 * (li & 3);
+  }
+  const uint32_t qone = g == 2 ? (uint32_t)BF16_ONE : 0u;
+  const uint32_t kmask[2] = {(g == 2 && li >= klen) ? (uint32_t)BF16_NEG_BIG : 0u, (g == 2 && 16 + li >= klen) ? (uint32_t)BF16_NEG_BIG : 0u};
+  constexpr int BLK = HM_BLK * 2;
+
+  for (int hd = hd0; hd < hd1; ++hd) {
+    NR_WAIT_VMCNT(0);                                // this pair's copy has landed (the copies are asm: nothing else waits for them)
     wave_barrier();
-    u16x8 kf[2], qf[2], vf[2];
+    u16x8 kf[2], qf[2];
+    u16x4 vt[2][2];                                  // V^T fragments [key tile][dv tile]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int rw = 16 * t + li;
-      const bool rok = rw < S;
-      const unsigned char* q_ = oper + (rw * DK + 8 * g) * 2;
-      const u16x4 qlo = (rok && g < 3) ? *(const u16x4*)q_ : Z4, qhi = (rok && g < 2) ? *(const u16x4*)(q_ + 8) : Z4;
-      const u16x4 klo = (rok && g < 3) ? *(const u16x4*)(q_ + HM_BLK * 2) : Z4, khi = (rok && g < 2) ? *(const u16x4*)(q_ + HM_BLK * 2 + 8) : Z4;
-      const u16x4 vlo = (rok && g < 3) ? *(const u16x4*)(q_ + HM_BLK * 4) : Z4, vhi = (rok && g < 2) ? *(const u16x4*)(q_ + HM_BLK * 4 + 8) : Z4;
-      kf[t] = cat8(klo, khi);
-      qf[t] = cat8(qlo, qhi);
-      vf[t] = cat8(vlo, vhi);
-      if (g == 2) { kf[t][4] = (rw < klen) ? (u16)0 : BF16_NEG_BIG; qf[t][4] = BF16_ONE; }
+      qf[t] = cat8(*(const u16x4*)(oper + lo_off[t]), *(const u16x4*)(oper + hi_off[t]));
+      kf[t] = cat8(*(const u16x4*)(oper + BLK + lo_off[t]), *(const u16x4*)(oper + BLK + hi_off[t]));
+      const u16* trv = (const u16*)(oper + tr_off[t]);
+      vt[t][0] = lds_tr16_b64_async<2 * BLK>(trv);
+      vt[t][1] = lds_tr16_b64_async<2 * BLK + 32>(trv);
+      qf[t] = or_dword2(qf[t], qone);
+      kf[t] = or_dword2(kf[t], kmask[t]);
     }
-    wave_barrier();                                  // the operand buffer may be overwritten (next iteration) once every lane has read it
-    u16x8 va[2];                                     // V^T as A operand per dv tile
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-      va[dt] = cat8(pack4(mfma_16x16x32_bf16(vf[0], ident[dt], f32x4{0.f, 0.f, 0.f, 0.f})),
-                    pack4(mfma_16x16x32_bf16(vf[1], ident[dt], f32x4{0.f, 0.f, 0.f, 0.f})));
+    NR_WAIT_LGKMCNT(0);                              // the fragments are in registers: the operand buffer may take the next pair
+    wave_barrier();
+    NR_SCHED_BARRIER();
+    if (hd + 1 < hd1) fetch(hd + 1);
     u16x4 pt[2][2];                                  // P^T [key tile][query tile]
 #pragma unroll
     for (int qj = 0; qj < 2; ++qj) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int qj = 0; qj < 2; ++qj) {
-        f32x4 acc = mfma_16x16x32_bf16(va[t], cat8(pt[0][qj], pt[1][qj]), f32x4{0.f, 0.f, 0.f, 0.f});
+        f32x4 acc = mfma_16x16x32_bf16(cat8(vt[0][t], vt[1][t]), cat8(pt[0][qj], pt[1][qj]), f32x4{0.f, 0.f, 0.f, 0.f});
         const int tokl = 16 * qj + li, dv = 16 * t + 4 * g;
         if (tokl < S && dv < DK) {
           const int col = hd * DK + dv;
