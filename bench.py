@@ -320,7 +320,7 @@ def parity_seeds(wl, states, device, seeds=8, n_news=2000, n_impr=1000):
     return out
 
 
-def train_parity(device, steps=200, B=16, lr=1e-3, engine_seeds=(0, 1), oracle=True):
+def train_parity(device, steps=200, B=16, lr=1e-3, engine_seeds=(0, 1), oracle=True, oracle_seeds=(0, 1)):
     """Statistical training parity: the engine and the CPU oracle train NRMS for `steps` steps with dropout ON from
     the same initial weights on the same teacher-labelled batches (oracle/train_parity.py: the reference's loop, src/train.py:202-233, with
     torch.optim.Adam and torch's dropout; the engine with EngineAdam and its own counter-based dropout), then both trained models rank the
@@ -363,16 +363,24 @@ def train_parity(device, steps=200, B=16, lr=1e-3, engine_seeds=(0, 1), oracle=T
     ops.invalidate_packed()
     if oracle:
         init_m = tp.eval_metrics(task, tp.oracle_eval_scores(task, st0))
-        trained, losses = tp.train_oracle(task, st0, lr=lr, p_drop=cfg.dropout_probability)
-        om = tp.eval_metrics(task, tp.oracle_eval_scores(task, trained))
         out["auc_init"] = float(init_m[0])
-        out["oracle"] = {"auc": float(om[0]), "ndcg10": float(om[3]), "last10_loss": float(np.mean(losses[-10:]))}
+        # the oracle on TWO dropout streams as well: its own seed-to-seed spread is the yardstick of the comparison, and it is in the record
+        oruns = []
+        for os_ in oracle_seeds:
+            trained, losses = tp.train_oracle(task, st0, lr=lr, p_drop=cfg.dropout_probability, torch_seed=os_)
+            om = tp.eval_metrics(task, tp.oracle_eval_scores(task, trained))
+            oruns.append({"auc": float(om[0]), "ndcg10": float(om[3]), "last10_loss": float(np.mean(losses[-10:])), "torch_seed": os_})
+        out["oracle_runs"] = oruns
+        out["oracle"] = {k: float(np.mean([r[k] for r in oruns])) for k in ("auc", "ndcg10", "last10_loss")}
+        out["oracle_seed_spread_auc"] = float(max(r["auc"] for r in oruns) - min(r["auc"] for r in oruns))
+        out["oracle_seed_spread_ndcg10"] = float(max(r["ndcg10"] for r in oruns) - min(r["ndcg10"] for r in oruns))
         ea = float(np.mean([r["auc"] for r in out["engine"]]))
         en = float(np.mean([r["ndcg10"] for r in out["engine"]]))
         out["abs_diff_auc"] = abs(ea - out["oracle"]["auc"])
         out["abs_diff_ndcg10"] = abs(en - out["oracle"]["ndcg10"])
-        # two trainings with different dropout streams differ by the seed-to-seed spread (oracle vs oracle: 3e-3 AUC at 100 steps on the build host)
-        out["tolerance_auc"] = 1.5e-2
+        # two trainings with different dropout streams differ by the seed-to-seed spread: the means of two runs each may differ by about the
+        # larger of the two recorded spreads (floor 5e-3: two draws under-estimate a spread)
+        out["tolerance_auc"] = float(max(5e-3, 1.5 * max(out["engine_seed_spread_auc"], out["oracle_seed_spread_auc"])))
         out["within_noise"] = bool(out["abs_diff_auc"] < out["tolerance_auc"] and ea > out["auc_init"] + 0.1)
     out["seconds"] = time.perf_counter() - t0
     return out

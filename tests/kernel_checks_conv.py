@@ -188,6 +188,42 @@ def check_conv_dgrad_gemm(be, S=20, n_seq=5):
     assert be.lib.nr_conv3_dgrad_gemm(None, be.ptr(Wd2), be.ptr(dx), n_seq, S, be.stream) != 0 and b'nr_conv3_dgrad_gemm' in be.lib.nr_last_error()
 
 
+def check_conv_dgrad_gemm_scale(be, S=50, n_seq=27136, chunk=1024):
+    """nr_conv3_dgrad_gemm at the bench's launch size (NAML abstracts: 27,136 x 50 tokens, 5,300+ output tiles) against the float64 convolution
+    evaluated over chunks of sequences: every token row, padding columns exact zeros."""
+    W, b = conv_params(5)
+    rng = np.random.default_rng(16)
+    dyu = np.zeros((n_seq * S, NR_KP), dtype=np.uint16)
+    dy = rng.normal(0, 0.3, size=(n_seq * S, NR_D)).astype(np.float32)
+    dy[rng.random(size=dy.shape) < 0.4] = 0.0
+    dyu[:, :NR_D] = f32_to_bf16(dy)
+    del dy
+    dy_pad = to_seqpad(dyu, n_seq, S)
+    Wd2 = be.poison((NR_KP, 3 * NR_KP), np.uint16)
+    ck(be, be.lib.nr_pack_conv_dgrad(be.ptr(be.dev(W)), W.shape[0], W.shape[3], be.ptr(Wd2), be.stream))
+    dx = be.poison((n_seq * S, NR_KP), np.uint16)
+    ck(be, be.lib.nr_conv3_dgrad_gemm(be.ptr(be.dev(dy_pad)), be.ptr(Wd2), be.ptr(dx), n_seq, S, be.stream))
+    be.sync()
+    out = be.np(dx)
+    assert not out[:, NR_D:].any(), 'padding columns of dx must be exact zeros'
+    Wq = bf16_round(W).astype(np.float64)
+    worst = 0.0
+    for lo in range(0, n_seq, chunk):
+        hi = min(lo + chunk, n_seq)
+        n = hi - lo
+        dyp = np.zeros((n, S + 2, NR_D))
+        dyp[:, 1:S + 1] = bf16_to_f32(dyu[lo * S:hi * S, :NR_D]).astype(np.float64).reshape(n, S, NR_D)
+        ref = np.zeros((n, S, NR_D))
+        for w in range(3):
+            ref += dyp[:, 2 - w:2 - w + S] @ Wq[:, 0, w, :]
+        got = bf16_to_f32(out[lo * S:hi * S, :NR_D]).astype(np.float64).reshape(ref.shape)
+        err = np.abs(got - ref)
+        bound = 2.0 ** -7 * np.abs(ref) + 2e-4 * np.abs(ref).max()
+        assert (err <= bound).all(), f'conv dgrad (GEMM form) S={S} sequences {lo}..{hi}: max err {err.max():.3g}'
+        worst = max(worst, float((err / bound).max()))
+    return worst
+
+
 def check_conv_act_bwd(be, S=20, n_seq=7, p_drop=0.2):
     rng = np.random.default_rng(7)
     act = np.maximum(rng.normal(size=(n_seq * S, NR_D)), 0).astype(np.float32)

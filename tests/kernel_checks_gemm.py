@@ -69,6 +69,37 @@ def check_gemm_tn(be, n_tok=300, M=290, ldg=None, ncol=200, ldx=None, taps=1, se
     assert be.lib.nr_gemm_tn(be.ptr(zeros), ldg, M, be.ptr(zeros), ldx, ncol, taps, be.ptr(zeros), be.ptr(out), N, n_tok, 12, be.stream) != 0      # P % 8
 
 
+def check_gemm_tn_scale(be, n_tok=1356803, M=320, ncol=320, taps=3, seed=12, chunk=65536):
+    """nr_gemm_tn at the launch size of the bench (NAML's abstracts: 1,356,800 seqpad rows per step, three taps: src/model/NAML/news_encoder.py:21-37
+    through autograd) against the float64 product accumulated over chunks of tokens; the sum over the partitions AND every single partition."""
+    rng = np.random.default_rng(seed)
+    G = f32_to_bf16(rng.normal(0, 0.5, size=(n_tok, M)).astype(np.float32))
+    X = f32_to_bf16(rng.normal(0, 0.5, size=(n_tok + taps - 1, ncol)).astype(np.float32))
+    N = taps * ncol
+    P = be.lib.nr_gemm_tn_parts(M, N, n_tok)
+    out = be.poison((P, M, N), np.float32)
+    zeros = be.empty((64,), np.uint16)
+    kc.ck(be, be.lib.nr_gemm_tn(be.ptr(be.dev(G)), M, M, be.ptr(be.dev(X)), ncol, ncol, taps, be.ptr(zeros), be.ptr(out), N, n_tok, P, be.stream))
+    be.sync()
+    got = be.np(out).astype(np.float64)
+    assert np.isfinite(got).all()
+    tpp = ((n_tok + P - 1) // P + 31) // 32 * 32                   # tokens per partition (the launcher's split)
+    worst = 0.0
+    for p_ in range(P):
+        lo, hi = p_ * tpp, min((p_ + 1) * tpp, n_tok)
+        ref = np.zeros((M, N))
+        for c0 in range(lo, hi, chunk):
+            c1 = min(c0 + chunk, hi)
+            Gf = bf16_to_f32(G[c0:c1]).astype(np.float64)
+            for t in range(taps):
+                ref[:, t * ncol:(t + 1) * ncol] += Gf.T @ bf16_to_f32(X[c0 + t:c1 + t]).astype(np.float64)
+        tol = 2e-5 * np.sqrt(max(hi - lo, 1)) + 1e-6
+        err = np.abs(got[p_] - ref).max()
+        assert err <= tol, f'partition {p_} (tokens {lo}..{hi}): max err {err:.3g} > {tol:.3g}'
+        worst = max(worst, err / tol)
+    return worst
+
+
 def check_transpose(be, R=70, C=45, lds=48, ldd=72):
     rng = np.random.default_rng(3)
     src = rng.integers(0, 65536, size=(R, lds)).astype(np.uint16)

@@ -2,7 +2,7 @@
 EngineAdam) vs the CPU oracle (the reference's fp32 loop: torch dropout, torch.optim.Adam; oracle/train_parity.py), same initial weights, same
 teacher-labelled batches -- the two TRAINED models must rank a held-out impression set equally well.  The comparison is statistical: the two
 runs draw different dropout masks, so their AUCs differ like two seeds of one trainer do (measured on the build host, oracle vs oracle,
-100 steps: 3e-3); the bound is 1.5e-2 on an AUC that training moves by > 0.2."""
+100 steps: 3e-3).  Both sides run TWO dropout seeds; the bound on the difference of the means is 1.5 x the larger recorded spread."""
 import os
 import sys
 
@@ -28,7 +28,9 @@ def test_engine_and_oracle_train_to_the_same_auc():
     assert r["auc_init"] < 0.56, r                                  # the task starts at chance ...
     assert r["oracle"]["auc"] > r["auc_init"] + 0.15, r             # ... the reference's loop learns it ...
     assert all(e["auc"] > r["auc_init"] + 0.15 for e in r["engine"]), r      # ... and so does the engine, on both dropout seeds
-    assert r["abs_diff_auc"] < r["tolerance_auc"], r
-    assert r["abs_diff_ndcg10"] < 2.5e-2, r
-    assert r["engine_seed_spread_auc"] < 1.5e-2, r
+    # the means of two engine seeds and two oracle seeds: within 1.5 x the larger of the two RECORDED seed-to-seed spreads (floor 5e-3); r04 measured
+    # |diff| 1.8e-3 with an engine spread of 3.6e-3
+    assert len(r["oracle_runs"]) == 2 and r["abs_diff_auc"] < r["tolerance_auc"] <= 1.5e-2, r
+    assert r["abs_diff_ndcg10"] < max(6e-3, 2.0 * max(r["oracle_seed_spread_ndcg10"], 3e-3)), r
+    assert r["engine_seed_spread_auc"] < 1.5e-2 and r["oracle_seed_spread_auc"] < 1.5e-2, r
     assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.08, r

@@ -121,6 +121,20 @@ def test_lstur_bench_scale_backward_vs_torch_oracle():
     assert rows["row_err_median"] < LSTUR_ROW_MEDIAN and rows["row_err_max"] < LSTUR_ROW_MAX, stats
 
 
+def test_gemm_tn_three_taps_at_bench_scale():
+    """The conv encoders' 3-tap weight gradient at 1,356,803 token rows (NAML's abstracts per step), every partition against float64."""
+    from tests.backends import GpuBackend
+    from tests import kernel_checks_gemm as kg
+    assert kg.check_gemm_tn_scale(GpuBackend()) <= 1.0
+
+
+def test_conv_dgrad_gemm_at_bench_scale():
+    """The conv data gradient (NT3 GEMM, tap-inner contraction order) at 27,136 abstracts of 50 tokens."""
+    from tests.backends import GpuBackend
+    from tests import kernel_checks_conv as kcc
+    assert kcc.check_conv_dgrad_gemm_scale(GpuBackend()) <= 1.0
+
+
 # bounds: ~3x the MI355X measurements (gpurun_out/bench_scale_backward_*.json of the run that set them, copied to profiles/)
 # NAML measured (profiles/r05_bench_scale_backward_NAML.json): logits 2.9e-4, weight tensors <= 3.2e-3, bias tensors <= 2.3e-2 (the pooling layers'
 # linear.bias: small sums of bf16 dpre rows over a floor of 2e-2 of the largest bias gradient), table rows median 0.30 %, worst row 0.65 %
