@@ -84,7 +84,7 @@ def test_golden_base_forward_and_grads(golden_dir):
         assert rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 1.5e-2
         cv = torch.stack([m.get_news_vector(x) for x in as_lists(g['click_ids'])], dim=1)
         uv = m.get_user_vector(cv)
-        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 1.5e-2
+        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 1e-2                    # measured 3.2e-3 (news vectors above: 4.4e-3)
         pr = m.get_prediction(nv[:C], uv[0])
         assert pr.shape == (C,) and len(pr.tolist()) == C
         assert np.abs(pr.cpu().numpy() - g['f32_pred0']).max() < 1.5e-2 * np.abs(g['f32_logits']).max()
@@ -118,7 +118,7 @@ def test_mind_shape_vs_torch_oracle():
     m = build(V, 300, 15, 200, 50, 20, params).eval()
     lg = m(as_lists(cand), as_lists(click))
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(24, dtype=torch.long, device=DEV)).backward()
-    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1.5e-2
+    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1.2e-2          # measured 3.6e-3 (gradients below: worst tensor 1.8e-2 at B = 24)
     gref = dict(ref.named_parameters())
     fl = grad_floor({k: v.grad.numpy() for k, v in gref.items()})
     for k, p in m.named_parameters():
@@ -145,13 +145,13 @@ def test_bench_scale_backward_vs_torch_oracle():
     m = build(V, 300, 15, 200, 50, 20, params).eval()
     lg = m(as_lists(cand), as_lists(click))
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
-    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1.5e-2
+    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1e-2            # measured 3.4e-3 (profiles/r05_measured_rel_err.txt)
     gref = dict(ref.named_parameters())
     fl = grad_floor({k: v.grad.numpy() for k, v in gref.items()})
     errs = {}
     for k, p in m.named_parameters():
         errs[k] = rel_err(p.grad.cpu().numpy(), gref[k].grad.numpy(), fl)
-        assert errs[k] < 5e-2, (k, errs[k])
+        assert errs[k] < 1.5e-2, (k, errs[k])                                         # measured: worst tensor 5.0e-3
     # (1) + (2): the table gradient row by row
     ge = m.news_encoder.word_embedding.weight.grad.cpu().numpy().astype(np.float64)
     gr = gref['news_encoder.word_embedding.weight'].grad.numpy().astype(np.float64)
@@ -175,7 +175,7 @@ def test_bench_scale_backward_vs_torch_oracle():
         import json
         with open(os.path.join(out_dir, 'bench_scale_backward.json'), 'w') as f:
             json.dump(stats, f, indent=1)
-    assert np.median(ratio) < 0.02 and ratio.max() < 0.15, stats                # measured on MI355X (r04a): median 0.56 %, worst row 5.4 %
+    assert np.median(ratio) < 0.015 and ratio.max() < 0.12, stats               # measured on MI355X (r04a, r05): median 0.56 %, worst row 5.4 %
 
 
 def test_training_mode_dropout_matches_oracle_with_exported_masks():
@@ -206,7 +206,7 @@ def test_training_mode_dropout_matches_oracle_with_exported_masks():
     masks = dict(cand1=m1[:B * C], cand2=m2[:B * C], click1=m1[B * C:], click2=m2[B * C:])
     p64 = {k: v.astype(np.float64) for k, v in params.items()}
     ref, cache = onp.nrms_forward(cand, click, p64, 15, p_drop=np.float32(0.2), masks={k: v.astype(np.float64) for k, v in masks.items()})
-    assert rel_err(l1.detach().cpu().numpy(), ref) < 1.5e-2
+    assert rel_err(l1.detach().cpu().numpy(), ref) < 6e-3                            # measured 1.7e-3
     loss = torch.nn.CrossEntropyLoss()(l1, torch.zeros(B, dtype=torch.long, device=DEV))
     m.zero_grad()
     loss.backward()
@@ -215,7 +215,7 @@ def test_training_mode_dropout_matches_oracle_with_exported_masks():
     fl = grad_floor(grads)
     for k, p in m.named_parameters():
         e = rel_err(p.grad.cpu().numpy(), grads[k], fl)
-        assert e < 5e-2, (k, e)
+        assert e < 2e-2, (k, e)                                                       # measured: worst tensor 6.2e-3
 
 
 def test_state_dict_roundtrip_and_optimizer_step():
@@ -257,14 +257,14 @@ def test_standalone_primitives_match_oracle():
     xg = x.clone().to(DEV).requires_grad_(True)
     xr = x.clone().requires_grad_(True)
     yg, yr = ad(mh(xg)), ra(rm(xr))
-    assert rel_err(yg.detach().cpu().numpy(), yr.detach().numpy()) < 1.5e-2
+    assert rel_err(yg.detach().cpu().numpy(), yr.detach().numpy()) < 1.2e-2          # measured 3.5e-3
     w = torch.randn(9, 300)
     (yg * w.to(DEV)).sum().backward(); (yr * w).sum().backward()
-    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 5e-2
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1.5e-2                  # measured 4.9e-3
     refp = list(rm.named_parameters()) + list(ra.named_parameters())
     fl = grad_floor({k: q.grad.numpy() for k, q in refp})
     for (k, p), (_, q) in zip(list(mh.named_parameters()) + list(ad.named_parameters()), refp):
-        assert rel_err(p.grad.cpu().numpy(), q.grad.numpy(), fl) < 5e-2, k
+        assert rel_err(p.grad.cpu().numpy(), q.grad.numpy(), fl) < 1e-2, k           # measured: worst tensor 2.5e-3
     cp = DotProductClickPredictor()
     c, u = torch.randn(5, 7, 300), torch.randn(5, 300)
     np.testing.assert_allclose(cp(c.to(DEV), u.to(DEV)).cpu().numpy(), torch.bmm(c, u.unsqueeze(-1)).squeeze(-1).numpy(), rtol=1e-4, atol=1e-4)
