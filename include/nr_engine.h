@@ -134,6 +134,14 @@ int nr_attn_bwd_len(const uint16_t* q_save, const uint16_t* k_save, const uint16
  * output feature 60*(c/64) + c%64 when c%64 < 60 (groups of 3 heads), zeros otherwise; bp f32[3*NR_NP] in the same row order. */
 int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                   uint16_t* Wp32, float* bp, void* stream);
+/* Every operand packing of ONE encoder in one launch (pack_encoder_kernel, csrc/k_proj.h): any subset of nr_pack_qkv (Wp, bp),
+ * nr_pack_qkv32 (Wp32, bp32), nr_pack_qkv_dx (WdX), nr_pack_additive (Wap, bap, qvp), nr_pack_additive_t (WaT) -- null outputs are skipped;
+ * same layouts, same bits as the single entry points.  The parameters are the nn.Linear weights / biases of MultiHeadSelfAttention
+ * (multihead_self.py:38-40) and AdditiveAttention (additive.py:18-25) of one encoder. */
+int nr_pack_encoder(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv, const float* Wa,
+                    const float* ba, const float* qv, int qdim, uint16_t* Wp, float* bp, uint16_t* Wp32, float* bp32, uint16_t* WdX,
+                    uint16_t* Wap, float* bap, float* qvp, uint16_t* WaT, void* stream);
+
 /* x = F.dropout(table[ids]) (src/model/NRMS/news_encoder.py:38-40), then Q, K, V = x W^T + b (multihead_self.py:53-55), S = 20.
  * ids int64[n_seq*S]; qkv: head-major (above); x_save (optional) bf16[n_seq*S][NR_KP]: the dropout-masked token matrix, column D = 1.0,
  * other padding 0 -- the operand of the weight-gradient GEMM dW = dqkv^T @ [X | 1]. */

@@ -22,6 +22,7 @@ SIGNATURES = {
     'nr_mhsa_fwd_len': ([_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_attn_bwd_len': ([_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_pack_qkv32': ([_P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    'nr_pack_encoder': ([_P] * 9 + [c_int] + [_P] * 9 + [_P], c_int),
     'nr_qkv_proj_fwd': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_pack_qkv_dx': ([_P, _P, _P, _P, _P], c_int),
     'nr_dx_gemm': ([_P, _P, _P, c_int64, _P], c_int),

@@ -22,12 +22,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
 }
 
 // ---- weight packing: fp32 nn.Linear parameters -> zero-padded bf16 MFMA operand layout -----------------------
-__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ Wq, const float* __restrict__ bq,
-                                                       const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                       u16* __restrict__ Wp, float* __restrict__ bp) {
+// (each packing loop is a __device__ body over (block index, block count) shared by its own kernel and by pack_encoder_kernel, which runs all
+//  operand packings of one encoder in ONE launch: nr_engine.hip)
+__device__ __forceinline__ void pack_qkv_body(const float* __restrict__ Wq, const float* __restrict__ bq,
+                                              const float* __restrict__ Wk, const float* __restrict__ bk,
+                                              const float* __restrict__ Wv, const float* __restrict__ bv,
+                                              u16* __restrict__ Wp, float* __restrict__ bp, int bid, int nb) {
   int total = 3 * NP * KP;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     int row = i / KP, k = i - row * KP;
     int which = row / NP, n = row - which * NP;
     const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
@@ -39,12 +41,18 @@ __global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__
     }
   }
 }
+__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                       const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                       u16* __restrict__ Wp, float* __restrict__ bp) {
+  pack_qkv_body(Wq, bq, Wk, bk, Wv, bv, Wp, bp, blockIdx.x, gridDim.x);
+}
 
-__global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                            const float* __restrict__ qv, int qdim, u16* __restrict__ Wap,
-                                                            float* __restrict__ bap, float* __restrict__ qvp) {
+__device__ __forceinline__ void pack_additive_body(const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                   const float* __restrict__ qv, int qdim, u16* __restrict__ Wap,
+                                                   float* __restrict__ bap, float* __restrict__ qvp, int bid, int nb) {
   int total = QP * KP;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     int n = i / KP, k = i - n * KP;
     float v = (n < qdim && k < D) ? Wa[n * D + k] : 0.0f;
     Wap[tile_off(n, k, KP)] = f2bf(v);
@@ -54,20 +62,28 @@ __global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restr
     }
   }
 }
+__global__ __launch_bounds__(256) void pack_additive_kernel(const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                            const float* __restrict__ qv, int qdim, u16* __restrict__ Wap,
+                                                            float* __restrict__ bap, float* __restrict__ qvp) {
+  pack_additive_body(Wa, ba, qv, qdim, Wap, bap, qvp, blockIdx.x, gridDim.x);
+}
 
 // AdditiveAttention.linear weight transposed for the fused input-gradient product dctx = dpre @ Wa of the pooling backward kernels:
 // WaT bf16 [KP][QKP] in tile order (QKP = QP rounded up to the MFMA k-step of 32), zero padded, with a PAIR-PERMUTED contraction
 // index: slot kappa = 32 ks + 8 g + j of row d holds Wa[q][d] with q = 16 (2 ks + j / 4) + 4 g + j % 4.  The transposed projection
 // product leaves a lane with rows 4g..4g+3 of each 16-row query tile; in this order the B fragment of k-step ks is just the lane's
 // registers of tiles 2 ks and 2 ks + 1 back to back (k_pool2.h), or two 8-byte LDS reads (additive_bwd_kernel).
-__global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __restrict__ Wa, int qdim, u16* __restrict__ WaT) {
+__device__ __forceinline__ void pack_additive_t_body(const float* __restrict__ Wa, int qdim, u16* __restrict__ WaT, int bid, int nb) {
   const int total = KP * QKP;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     const int d = i / QKP, kap = i - d * QKP;
     const int ks = kap >> 5, g = (kap & 31) >> 3, j = kap & 7;
     const int q = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
     WaT[tile_off(d, kap, QKP)] = f2bf((d < D && q < qdim) ? Wa[q * D + d] : 0.0f);
   }
+}
+__global__ __launch_bounds__(256) void pack_additive_t_kernel(const float* __restrict__ Wa, int qdim, u16* __restrict__ WaT) {
+  pack_additive_t_body(Wa, qdim, WaT, blockIdx.x, gridDim.x);
 }
 
 // ---- weight gradients of one NRMS encoder: chunk partials -> the parameters' gradient buffers, one launch --------------------------

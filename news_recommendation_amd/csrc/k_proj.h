@@ -48,13 +48,13 @@ __device__ __host__ __forceinline__ int packed_row_feature(int c) {
   return r < PG_HEADS * DK ? (c / PG_COLS) * (PG_HEADS * DK) + r : -1;
 }
 
-__global__ __launch_bounds__(256) void pack_qkv32_kernel(const float* __restrict__ Wq, const float* __restrict__ bq,
-                                                         const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                         const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                         u16* __restrict__ Wp32, float* __restrict__ bp) {
+__device__ __forceinline__ void pack_qkv32_body(const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                u16* __restrict__ Wp32, float* __restrict__ bp, int bid, int nb) {
   constexpr int KW = K16 * 16;
   const int total = 3 * NP * KW;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     const int row = i / KW, k = i - row * KW;
     const int which = row / NP, n = packed_row_feature(row - which * NP);
     const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) void pack_qkv32_kernel(const float* __restrict
     Wp32[tile32_off(row, k)] = f2bf(v);
     if (k == 0) bp[row] = n >= 0 ? b[n] : 0.0f;
   }
+}
+__global__ __launch_bounds__(256) void pack_qkv32_kernel(const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                         const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                         const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                         u16* __restrict__ Wp32, float* __restrict__ bp) {
+  pack_qkv32_body(Wq, bq, Wk, bk, Wv, bv, Wp32, bp, blockIdx.x, gridDim.x);
 }
 
 #ifndef NR_PROJ_NWAVE
@@ -469,16 +475,43 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
 constexpr int DXK = 3 * KP;                 // 960 contraction columns
 // packed operand of dx_gemm_ring_kernel: WdX bf16 [60 k-steps][10 n-tiles][64 lanes][8]: lane l of block (ks, nt) holds
 // Wall[k = 16 ks + 8 (l >> 5) + j][n = 32 nt + (l & 31)], j = 0..7, Wall[which * KP + f][n] = W_which[f][n] (zero for f, n >= D)
-__global__ __launch_bounds__(256) void pack_qkv_dx_kernel(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                                          u16* __restrict__ WdX) {
+__device__ __forceinline__ void pack_qkv_dx_body(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                 u16* __restrict__ WdX, int bid, int nb) {
   const int total = DXK * KP;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     const int k = i / KP, n = i - k * KP;
     const int which = k / KP, f = k - which * KP;
     const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
     const float v = (f < D && n < D) ? W[f * D + n] : 0.0f;
     const int ks = k >> 4, h = (k & 15) >> 3, j = k & 7, nt = n >> 5;
     WdX[((size_t)(ks * NT32 + nt) * 64 + h * 32 + (n & 31)) * 8 + j] = f2bf(v);
+  }
+}
+__global__ __launch_bounds__(256) void pack_qkv_dx_kernel(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                          u16* __restrict__ WdX) {
+  pack_qkv_dx_body(Wq, Wk, Wv, WdX, blockIdx.x, gridDim.x);
+}
+
+// Every operand packing of ONE encoder (projection operands of the inference / training forward and of the input-gradient GEMM, the pooling
+// layer's operand and its transpose) in one launch: blockIdx.y picks the packing, null outputs are skipped.  The training step re-packs after
+// every optimiser step: five launches of ~8 us each per encoder (launch + latency of a 300 K-element scatter) were 60 us of the NRMS step.
+struct PackEncoderParams {
+  const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *Wa, *ba, *qv;
+  int qdim;
+  u16* Wp; float* bp;          // pack_qkv (register-resident forward, S = 50 encoder)
+  u16* Wp32; float* bp32;      // pack_qkv32 (qkv_proj_kernel)
+  u16* WdX;                    // pack_qkv_dx (dx_gemm_ring_kernel)
+  u16* Wap; float* bap; float* qvp;     // pack_additive
+  u16* WaT;                    // pack_additive_t
+};
+__global__ __launch_bounds__(256) void pack_encoder_kernel(PackEncoderParams p) {
+  const int bid = blockIdx.x, nb = gridDim.x;
+  switch (blockIdx.y) {
+    case 0: if (p.Wp) pack_qkv_body(p.Wq, p.bq, p.Wk, p.bk, p.Wv, p.bv, p.Wp, p.bp, bid, nb); break;
+    case 1: if (p.Wp32) pack_qkv32_body(p.Wq, p.bq, p.Wk, p.bk, p.Wv, p.bv, p.Wp32, p.bp32, bid, nb); break;
+    case 2: if (p.WdX) pack_qkv_dx_body(p.Wq, p.Wk, p.Wv, p.WdX, bid, nb); break;
+    case 3: if (p.Wap) pack_additive_body(p.Wa, p.ba, p.qv, p.qdim, p.Wap, p.bap, p.qvp, bid, nb); break;
+    default: if (p.WaT) pack_additive_t_body(p.Wa, p.qdim, p.WaT, bid, nb); break;
   }
 }
 

@@ -384,6 +384,17 @@ int nr_pack_qkv32(const float* Wq, const float* bq, const float* Wk, const float
   return check_launch("nr_pack_qkv32");
 }
 
+int nr_pack_encoder(const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv, const float* Wa,
+                    const float* ba, const float* qv, int qdim, uint16_t* Wp, float* bp, uint16_t* Wp32, float* bp32, uint16_t* WdX,
+                    uint16_t* Wap, float* bap, float* qvp, uint16_t* WaT, void* stream) {
+  if (!Wq || !bq || !Wk || !bk || !Wv || !bv || !Wa || !ba || !qv) return fail(NR_ERR_BADARG, "nr_pack_encoder: null parameter");
+  if ((Wp && !bp) || (Wp32 && !bp32) || (Wap && (!bap || !qvp))) return fail(NR_ERR_BADARG, "nr_pack_encoder: an operand without its bias / query vector");
+  if (qdim <= 0 || qdim > NR_QP) return fail(NR_ERR_UNSUPPORTED, "nr_pack_encoder: query_vector_dim must be in [1,208]");
+  nr::PackEncoderParams p{Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, qdim, Wp, bp, Wp32, bp32, WdX, Wap, bap, qvp, WaT};
+  NR_LAUNCH2(nr::pack_encoder_kernel, 128, 5, 256, 0, (hipStream_t)stream, p);
+  return check_launch("nr_pack_encoder");
+}
+
 int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wp32, const float* bp, uint16_t* qkv,
                     uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream) {
   if (!ids || !table || num_rows <= 0 || !Wp32 || !bp || !qkv || n_seq < 0) return fail(NR_ERR_BADARG, "nr_qkv_proj_fwd: bad argument");

@@ -295,6 +295,53 @@ def _packed(kind, tensors, build):
     return out
 
 
+def _packed_fresh(kind, tensors):
+    """Whether the cache holds a current entry for (kind, tensors) -- same test as _packed."""
+    hit = _pack_cache.get((kind,) + tuple(id(t) for t in tensors))
+    if hit is None:
+        return False
+    refs, st, epoch, _ = hit
+    return epoch == _pack_epoch and st == tuple((t.data_ptr(), t._version) for t in tensors) and all(r() is t for r, t in zip(refs, tensors))
+
+
+def _packed_put(kind, tensors, out):
+    _pack_cache[(kind,) + tuple(id(t) for t in tensors)] = (tuple(weakref.ref(t) for t in tensors), tuple((t.data_ptr(), t._version) for t in tensors),
+                                                            _pack_epoch, out)
+    _pack_cache.move_to_end((kind,) + tuple(id(t) for t in tensors))
+    while len(_pack_cache) > _PACK_CACHE_MAX:
+        _pack_cache.popitem(last=False)
+
+
+def prepack_encoder(Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, kinds):
+    """All stale packed operands of ONE encoder in ONE launch (nr_pack_encoder): kinds is a subset of ('qkv', 'qkv32', 'qkv_dx', 'additive',
+    'additive_t').  After an optimiser step every operand of the encoder is stale, and packing them one by one costs five ~8 us launches per
+    encoder and step; the single pack_* functions below then find their entries in the cache.  Nothing to do when everything asked for is
+    current."""
+    keys = {'qkv': (Wq, bq, Wk, bk, Wv, bv), 'qkv32': (Wq, bq, Wk, bk, Wv, bv), 'qkv_dx': (Wq, Wk, Wv), 'additive': (Wa, ba, qv), 'additive_t': (Wa,)}
+    stale = [k for k in kinds if not _packed_fresh(k, keys[k])]
+    if len(stale) < 2:
+        return
+    dev = Wq.device
+    i16, f32 = _BF16_AS_I16, torch.float32
+    o = {}
+    if 'qkv' in stale:
+        o['qkv'] = (torch.empty(3 * NR_NP, NR_KP, dtype=i16, device=dev), torch.empty(3 * NR_NP, dtype=f32, device=dev))
+    if 'qkv32' in stale:
+        o['qkv32'] = (torch.empty(3 * NR_NP * NR_K16 * 16, dtype=i16, device=dev), torch.empty(3 * NR_NP, dtype=f32, device=dev))
+    if 'qkv_dx' in stale:
+        o['qkv_dx'] = torch.empty(60 * 10 * 64 * 8, dtype=i16, device=dev)
+    if 'additive' in stale:
+        o['additive'] = (torch.empty(NR_QP, NR_KP, dtype=i16, device=dev), torch.empty(NR_QP, dtype=f32, device=dev), torch.empty(NR_QP, dtype=f32, device=dev))
+    if 'additive_t' in stale:
+        o['additive_t'] = torch.empty(NR_KP, 224, dtype=i16, device=dev)
+    a = [_f32c(t) for t in (Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv)]
+    g = lambda k, i=None: None if k not in o else _ptr(o[k] if i is None else o[k][i])
+    _call('nr_pack_encoder', _lib().nr_pack_encoder, *[_ptr(t) for t in a], Wa.shape[0], g('qkv', 0), g('qkv', 1), g('qkv32', 0), g('qkv32', 1),
+          g('qkv_dx'), g('additive', 0), g('additive', 1), g('additive', 2), g('additive_t'), _stream())
+    for k in stale:
+        _packed_put(k, keys[k], o[k])
+
+
 def pack_qkv(Wq, bq, Wk, bk, Wv, bv):
     def build():
         dev = Wq.device
@@ -590,6 +637,9 @@ class _EncoderFn(torch.autograd.Function):
         # training form of the title encoder: gather-fused projection GEMM + stand-alone attention kernel on head-major saves (csrc/k_proj.h);
         # the register-resident kernel stays the inference form (_FWD_SPLIT = 2 uses the split form there too)
         split = gather and S == 20 and (_FWD_SPLIT == 2 or (_FWD_SPLIT == 1 and need_grad))
+        flat_bwd = pool_flat_ok(S, False, n_seq, qdim=Wa.shape[0])
+        prepack_encoder(Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, (['qkv32'] if split else ['qkv']) + ['additive'] + (['qkv_dx'] if need_grad else [])
+                        + (['additive_t'] if (need_grad and not flat_bwd) else []))
         Wp, bp = (None, None) if split else pack_qkv(Wq, bq, Wk, bk, Wv, bv)
         Wap, bap, qvp = pack_additive(Wa, ba, qv)
         cbuf = torch.empty(n_seq * S, NR_KP, dtype=_BF16_AS_I16, device=dev)

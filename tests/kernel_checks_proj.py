@@ -54,6 +54,46 @@ def check_pack32(be):
         assert np.array_equal(blk[real][:, NR_D], hi) and np.array_equal(blk[real][:, NR_D + 1], lo)
 
 
+def check_pack_encoder(be):
+    """nr_pack_encoder (every operand packing of one encoder in one launch) == the single entry points, bit for bit; null outputs are skipped."""
+    from news_recommendation_amd._capi import NR_QP
+    lib = be.lib
+    params = kc.make_params(3)
+    m, a = 'news_encoder.multihead_self_attention.', 'news_encoder.additive_attention.'
+    W = [be.dev(params[m + n + '.weight']) for n in ('W_Q', 'W_K', 'W_V')]
+    b = [be.dev(params[m + n + '.bias']) for n in ('W_Q', 'W_K', 'W_V')]
+    Wa, ba, qv = be.dev(params[a + 'linear.weight']), be.dev(params[a + 'linear.bias']), be.dev(params[a + 'attention_query_vector'])
+    qdim = params[a + 'linear.weight'].shape[0]
+    args = [be.ptr(x) for x in (W[0], b[0], W[1], b[1], W[2], b[2])]
+    pool = [be.ptr(Wa), be.ptr(ba), be.ptr(qv), qdim]
+    names = ('Wp', 'bp', 'Wp32', 'bp32', 'WdX', 'Wap', 'bap', 'qvp', 'WaT')
+
+    def bufs():
+        return dict(Wp=be.poison((3 * NR_NP, NR_KP), np.uint16), bp=be.poison((3 * NR_NP,), np.float32),
+                    Wp32=be.poison((3 * NR_NP * NR_K16 * 16,), np.uint16), bp32=be.poison((3 * NR_NP,), np.float32),
+                    WdX=be.poison((60 * 10 * 64 * 8,), np.uint16), Wap=be.poison((NR_QP, NR_KP), np.uint16), bap=be.poison((NR_QP,), np.float32),
+                    qvp=be.poison((NR_QP,), np.float32), WaT=be.poison((NR_KP, 224), np.uint16))
+    A, B, C = bufs(), bufs(), bufs()
+    kc.ck(be, lib.nr_pack_qkv(*args, be.ptr(A['Wp']), be.ptr(A['bp']), be.stream))
+    kc.ck(be, lib.nr_pack_qkv32(*args, be.ptr(A['Wp32']), be.ptr(A['bp32']), be.stream))
+    kc.ck(be, lib.nr_pack_qkv_dx(be.ptr(W[0]), be.ptr(W[1]), be.ptr(W[2]), be.ptr(A['WdX']), be.stream))
+    kc.ck(be, lib.nr_pack_additive(*pool, be.ptr(A['Wap']), be.ptr(A['bap']), be.ptr(A['qvp']), be.stream))
+    kc.ck(be, lib.nr_pack_additive_t(be.ptr(Wa), qdim, be.ptr(A['WaT']), be.stream))
+    kc.ck(be, lib.nr_pack_encoder(*args, *pool, *[be.ptr(B[k]) for k in names], be.stream))
+    be.sync()
+    for k in names:
+        assert np.array_equal(be.np(A[k]).view(np.uint8), be.np(B[k]).view(np.uint8)), k
+    only = ('Wp32', 'bp32', 'Wap', 'bap', 'qvp')
+    before = {k: be.np(C[k]).copy() for k in names}
+    kc.ck(be, lib.nr_pack_encoder(*args, *pool, *[be.ptr(C[k]) if k in only else None for k in names], be.stream))
+    be.sync()
+    for k in names:
+        want = be.np(A[k]) if k in only else before[k]
+        assert np.array_equal(be.np(C[k]).view(np.uint8), want.view(np.uint8)), k
+    assert lib.nr_pack_encoder(None, *args[1:], *pool, *[be.ptr(C[k]) for k in names], be.stream) != 0 and b'nr_pack_encoder' in lib.nr_last_error()
+    assert lib.nr_pack_encoder(*args, *pool[:3], 300, *[be.ptr(C[k]) for k in names], be.stream) != 0           # query_vector_dim > 208
+
+
 def hm_split(qkv_u16, n_seq):
     """head-major buffer -> float64 Q, K, V as [n_seq, H, S, dk]."""
     a = bf16_to_f32(np.asarray(qkv_u16).reshape(n_seq, H, 3, S * DK)).astype(np.float64)

@@ -11,6 +11,7 @@ def be():
 
 
 def test_pack32(be): kp.check_pack32(be)
+def test_pack_encoder_one_launch(be): kp.check_pack_encoder(be)
 def test_qkv_proj(be): kp.check_qkv_proj(be, n_seq=13)          # 260 tokens: two full workgroups + a partly filled one
 def test_qkv_proj_dropout(be): kp.check_qkv_proj(be, n_seq=7, p_drop=0.2)
 def test_qkv_proj_single_accumulator():

@@ -21,6 +21,11 @@ def test_pack32(be):
     kp.check_pack32(be)
 
 
+def test_pack_encoder_one_launch(be):
+    from tests import kernel_checks_proj as kp
+    kp.check_pack_encoder(be)
+
+
 def test_qkv_proj(be):
     from tests import kernel_checks_proj as kp
     kp.check_qkv_proj(be, n_seq=13)
