@@ -303,6 +303,15 @@ int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
  * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64, owned by the caller until it passes NULL
  * again, which switches the stamps off). */
 int nr_debug_pool3_stamps(uint64_t* buf);
+/* Probe of the XCD-local phase barrier (csrc/k_xcd.h; tools/xcd_probe.py): 256 workgroups, `phases` write / barrier / read-back rounds.
+ * sync_words: 32 uint32 (zeroed by the call); rec: 8 * 32 * 512 uint32; out: 768 uint32 (stale words per workgroup, XCC ids, slots). */
+int nr_debug_xcd_probe(uint32_t* sync_words, uint32_t* rec, uint32_t* out, int phases, void* stream);
+/* Error words of the last persistent GRU sweeps (csrc/k_gru_persist.h; nr_gru_fwd_seq / nr_gru_bwd_seq take that form on a 256-CU device for
+ * Hd = 900 / 450 and B <= 512 unless NR_GRU_PERSIST=0): 0 clean, 1 a workgroup found its XCD's team full, 2 a bounded wait gave up -- the
+ * sweep's outputs are then invalid.  SYNCHRONISES the device (not for use inside a stream capture). */
+int nr_gru_persist_status(int32_t* fwd, int32_t* bwd);
+/* debug: constant-clock (100 MHz) stamps of the persistent forward sweep, [256 workgroups][T][8 waves][8] int64 (null = off) */
+int nr_debug_gru_stamps(int64_t* buf);
 /* The same for nr_attn_bwd_hm (tools/attnb_timeline.py; NR_ATTNB_DEBUG=8 selects the debug instantiation with nothing switched off):
  * [2 workgroups][4 waves][4 sequences][4 rounds][12] stamps. */
 int nr_debug_attnb_stamps(uint64_t* buf);

@@ -11,6 +11,10 @@
 #include "k_pool3.h"
 #include "k_naml.h"
 #include "k_gru.h"
+#ifndef NR_EMU      // inter-workgroup waits: nothing the emulator (one workgroup after the other) can run
+#include "k_xcd.h"
+#include "k_gru_persist.h"
+#endif
 #include "k_eval.h"
 #include "k_optim.h"
 #include "k_sort.h"
@@ -997,6 +1001,85 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
   return check_launch("nr_gru_bwd_step");
 }
 
+#ifndef NR_EMU
+int nr_debug_xcd_probe(uint32_t* sync_words, uint32_t* rec, uint32_t* out, int phases, void* stream) {
+  if (!sync_words || !rec || !out || phases < 1 || phases > 1000) return fail(NR_ERR_BADARG, "nr_debug_xcd_probe: bad argument");
+  if (hipMemsetAsync(sync_words, 0, 32 * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_debug_xcd_probe: memset");
+  nr::XcdSync s{sync_words};
+  NR_LAUNCH(nr::xcd_probe_kernel, nr::NR_XCDS * nr::NR_XCD_TEAM, 512, 0, (hipStream_t)stream, s, rec, out, phases);
+  return check_launch("nr_debug_xcd_probe");
+}
+
+// ---- persistent sweeps (csrc/k_gru_persist.h): one launch per sweep, state exchanged inside each XCD ---------------------------------------
+// The team words of the two sweeps (forward / backward) live in the module: at most ONE forward and ONE backward sweep of a process may be in
+// flight at a time (they are stream-ordered in every caller of this library).
+__device__ unsigned int g_xcd_words[2][32];
+static unsigned int* xcd_words(int which) {
+  static unsigned int* base = nullptr;
+  if (base == nullptr && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_xcd_words)) != hipSuccess) base = nullptr;
+  return base ? base + which * 32 : nullptr;
+}
+static long long* g_gru_stamps = nullptr;
+int nr_debug_gru_stamps(int64_t* buf) { g_gru_stamps = (long long*)buf; return NR_OK; }
+static int gru_persist_knob() {
+  const char* e = std::getenv("NR_GRU_PERSIST");
+  return e ? std::atoi(e) : 1;
+}
+// the persistent form needs the MI355X shape it was built for: 256 CUs (8 XCDs x 32), the reference's hidden sizes, B <= 512 (64 samples per XCD)
+static bool gru_persist_ok(int B, int Hd, int T) {
+  const int Hp = ceil_to(Hd + 1, 32);
+  return gru_persist_knob() != 0 && T >= 2 && B >= 1 && B <= 512 && (Hp == 29 * 32 || Hp == 15 * 32) && nr::device_cus() == nr::NR_XCDS * nr::NR_XCD_TEAM;
+}
+
+static int gru_fwd_persist_launch(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2,
+                                  uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream) {
+  if (!gi || !Whh || !b_ih || !b_hh || !len) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
+  unsigned int* words = xcd_words(0);
+  if (words == nullptr) return NR_ERR_UNSUPPORTED;
+  nr::GruSeqFwdParams p;
+  p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_t2 = h_t2; p.H_all = H_all; p.h_f2 = h_f2; p.gates = gates;
+  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.T = T; p.sync = nr::XcdSync{words}; p.stamps = g_gru_stamps;
+  if (hipMemsetAsync(words, 0, 32 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: memset");
+  const int grid = nr::NR_XCDS * nr::NR_XCD_TEAM;
+  if (p.Hp == 29 * 32) {
+    using G = nr::GruPersistGeom<29>;
+    if (allow_smem(nr::gru_fwd_persist_kernel<29>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot reserve LDS");
+    NR_LAUNCH2(nr::gru_fwd_persist_kernel<29>, grid, 1, G::NT, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    using G = nr::GruPersistGeom<15>;
+    if (allow_smem(nr::gru_fwd_persist_kernel<15>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: cannot reserve LDS");
+    NR_LAUNCH2(nr::gru_fwd_persist_kernel<15>, grid, 1, G::NT, G::SMEM, (hipStream_t)stream, p);
+  }
+  return check_launch("nr_gru_fwd_seq");
+}
+
+// error word of the last persistent sweeps (0 = clean; 1 = a workgroup found its XCD's team full; 2 = a wait gave up): SYNCHRONISES the device.
+// A non-zero word means the sweep's outputs are garbage: callers re-run with NR_GRU_PERSIST=0 (bench.py and the tests check it after every run).
+int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
+  unsigned int* w0 = xcd_words(0);
+  unsigned int h[2] = {0, 0};
+  if (w0 != nullptr) {
+    if (hipDeviceSynchronize() != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_persist_status: device error");
+    if (hipMemcpy(&h[0], w0 + 16, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&h[1], w0 + 32 + 16, 4, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(NR_ERR_LAUNCH, "nr_gru_persist_status: copy");
+  }
+  if (fwd) *fwd = (int32_t)h[0];
+  if (bwd) *bwd = (int32_t)h[1];
+  return NR_OK;
+}
+#else       // emulator build: the step-per-launch form only
+int nr_debug_xcd_probe(uint32_t*, uint32_t*, uint32_t*, int, void*) { return fail(NR_ERR_UNSUPPORTED, "nr_debug_xcd_probe: not in the emulator build"); }
+int nr_debug_gru_stamps(int64_t*) { return NR_OK; }
+static bool gru_persist_ok(int, int, int) { return false; }
+static int gru_fwd_persist_launch(const float*, const uint16_t*, const float*, const float*, const int32_t*, uint16_t*, uint16_t*, float*, uint16_t*, int, int, int,
+                                  int, void*) { return NR_ERR_UNSUPPORTED; }
+int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
+  if (fwd) *fwd = 0;
+  if (bwd) *bwd = 0;
+  return NR_OK;
+}
+#endif
+
 int nr_gru_seq_buffers(int B, int Hd, int T) { (void)B; (void)Hd; (void)T; return 2; }      // a ping-pong pair (the per-step buffers of the removed persistent form are gone)
 
 int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, const float* b_hh, const int32_t* len, uint16_t* h_t2, int n_buf,
@@ -1014,6 +1097,10 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
   if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0 || n_buf < 2) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
   const size_t ht = (size_t)ceil_to(B, 16) * Hp, hf = (size_t)B * Hp;
+  if (gru_persist_ok(B, Hd, T)) {
+    const int rc = gru_fwd_persist_launch(gi, Whh, b_ih, b_hh, len, h_t2, H_all, h_f2, gates, B, N, Hd, T, stream);
+    if (rc != NR_ERR_UNSUPPORTED) return rc;
+  }
   for (int t = 0; t < T; ++t) {
     const int rc = nr_gru_fwd_step(gi, Whh, b_ih, b_hh, len, h_t2 + (t & 1) * ht, H_all ? H_all + (size_t)(t + 1) * hf : nullptr,
                                    h_t2 + ((t + 1) & 1) * ht, h_f2 + (t & 1) * hf, h_f2 + ((t + 1) & 1) * hf,
