@@ -588,6 +588,9 @@ def other_workload(name, shape, vocab, B, device, steps=10):
     dt = time.perf_counter() - t0
     lossv = float(loss.item())
     sg.close()
+    if name == 'LSTUR':
+        from news_recommendation_amd import ops_gru
+        ops_gru.persist_check()             # the persistent GRU sweeps of the replays above came out clean
     flops, hbm = wl.flops(B), wl.hbm_bytes(B)
     dom = prof[dominant]                    # (launches, avg us, total us) over the two profiled eager steps (HIP events on the launch stream)
     per_call = ops.seq_launches.get({'nr_gru_fwd_step': 'nr_gru_fwd_seq', 'nr_gru_bwd_step': 'nr_gru_bwd_seq'}.get(dominant, ''), 1)
@@ -752,6 +755,9 @@ def main():
         barrier()
         eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
         sg.close()
+    if args.model == 'LSTUR':
+        from news_recommendation_amd import ops_gru
+        ops_gru.persist_check()             # (after the timed region: the check synchronises) every persistent GRU sweep came out clean
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

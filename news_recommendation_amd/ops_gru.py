@@ -172,6 +172,23 @@ class _GruFn(torch.autograd.Function):
         return (d_x, d_h0, None, None, unpad(dWi, I), unpad(dWh, Hd), unpad(dWi, I + 1)[:, I].contiguous(), unpad(dWh, Hd + 1)[:, Hd].contiguous())
 
 
+def persist_status():
+    """(forward, backward) error words of the last persistent GRU sweeps (csrc/k_gru_persist.h; nr_gru_persist_status): 0 = clean.  SYNCHRONISES
+    the device -- call it where the host waits anyway (end of a timed region, an epoch, a test), never inside a stream capture."""
+    f, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    _call('nr_gru_persist_status', _lib().nr_gru_persist_status, ctypes.byref(f), ctypes.byref(b))
+    return f.value, b.value
+
+
+def persist_check():
+    """Raises when a persistent sweep since the last check gave up a wait or found its XCD team wrong: its outputs (and everything computed
+    from them) are invalid.  The step-per-launch form (NR_GRU_PERSIST=0) has no such failure mode."""
+    st = persist_status()
+    if st != (0, 0):
+        raise RuntimeError(f'persistent GRU sweep failed (error words forward / backward = {st}): results since the last check are invalid; '
+                           'run with NR_GRU_PERSIST=0')
+
+
 def gru_last_state(x, h0, clicked_news_length, gru):
     """x f32 [B, N, I] on the GPU, h0 f32 [B, Hd] or None (zeros), clicked_news_length: CPU (or device) integer tensor, already >= 1."""
     _require_cuda(x, "clicked_news_vector")

@@ -144,6 +144,9 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
         recent[(i - 1) % 256] = ld
         seen += per_rank_batch * world
         if i % config.num_batches_show_loss == 0 or i == n_iter:
+            if model_name == 'LSTUR':             # (the loss read below synchronises anyway) the persistent GRU sweeps since the last check were clean
+                from . import ops_gru
+                ops_gru.persist_check()
             if rank == 0:        # same three numbers as train.py:241-244: current, mean over all steps, mean over the latest 256
                 log(f"Time {time.strftime('%H:%M:%S', time.gmtime(time.time() - t0))}, batches {i}, current loss {float(ld):.4f}, "
                     f"average loss: {float(loss_sum) / i:.4f}, latest average loss: {float(recent[:min(i, 256)].mean()):.4f}, "

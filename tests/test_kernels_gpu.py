@@ -121,6 +121,27 @@ def test_gru_full_grid_batch_512(be):
     kcg.check_gru(be, B=512, N=9, Hd=450, I=900, seed=7, lens=[1 + (7 * i) % 9 for i in range(512)])
 
 
+def test_gru_persistent_forward_and_step_form(be):
+    """The forward sweep entry points take the persistent XCD-local form (csrc/k_gru_persist.h) on a 256-CU device; check_gru compares them bit for
+    bit with the step launches.  Both forms of the sweep (the knob is read per call), the error words clean afterwards, and a batch that leaves
+    some XCDs without samples (B = 40: three sample tiles for eight XCDs)."""
+    import os
+    from news_recommendation_amd import ops_gru
+    old = os.environ.get('NR_GRU_PERSIST')
+    try:
+        for knob in ('1', '0'):
+            os.environ['NR_GRU_PERSIST'] = knob
+            kcg.check_gru(be, B=512, N=7, Hd=900, I=900, seed=8, lens=[1 + (5 * i) % 7 for i in range(512)])
+            kcg.check_gru(be, B=40, N=5, Hd=900, I=900, seed=9)
+            kcg.check_gru(be, B=129, N=4, Hd=450, I=900, seed=10)
+            assert ops_gru.persist_status() == (0, 0)
+    finally:
+        if old is None:
+            os.environ.pop('NR_GRU_PERSIST', None)
+        else:
+            os.environ['NR_GRU_PERSIST'] = old
+
+
 def test_gru_register_only_variant():
     """NR_GRU_LDS=0 (the round-1 default: operands straight from L2 into registers) stays selectable; knobs are read once per process,
     hence the subprocess."""
