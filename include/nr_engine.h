@@ -312,6 +312,8 @@ int nr_debug_xcd_probe(uint32_t* sync_words, uint32_t* rec, uint32_t* out, int p
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd);
 /* debug: constant-clock (100 MHz) stamps of the persistent forward sweep, [256 workgroups][T][8 waves][8] int64 (null = off) */
 int nr_debug_gru_stamps(int64_t* buf);
+/* likewise for the backward sweep: [256 workgroups][T + 1 calls][8 waves][8] */
+int nr_debug_gru_stamps_bwd(int64_t* buf);
 /* The same for nr_attn_bwd_hm (tools/attnb_timeline.py; NR_ATTNB_DEBUG=8 selects the debug instantiation with nothing switched off):
  * [2 workgroups][4 waves][4 sequences][4 rounds][12] stamps. */
 int nr_debug_attnb_stamps(uint64_t* buf);

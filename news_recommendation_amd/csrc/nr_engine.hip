@@ -1020,10 +1020,12 @@ static unsigned int* xcd_words(int which) {
   return base ? base + which * 32 : nullptr;
 }
 static long long* g_gru_stamps = nullptr;
+static long long* g_gru_stamps_bwd = nullptr;
 int nr_debug_gru_stamps(int64_t* buf) { g_gru_stamps = (long long*)buf; return NR_OK; }
+int nr_debug_gru_stamps_bwd(int64_t* buf) { g_gru_stamps_bwd = (long long*)buf; return NR_OK; }
 static int gru_persist_knob() {
-  const char* e = std::getenv("NR_GRU_PERSIST");
-  return e ? std::atoi(e) : 1;
+  const char* e = std::getenv("NR_GRU_PERSIST");      // bit 0: forward sweep, bit 1: backward sweep (read per call)
+  return e ? std::atoi(e) : 3;
 }
 // the persistent form needs the MI355X shape it was built for: 256 CUs (8 XCDs x 32), the reference's hidden sizes, B <= 512 (64 samples per XCD)
 static bool gru_persist_ok(int B, int Hd, int T) {
@@ -1053,6 +1055,30 @@ static int gru_fwd_persist_launch(const float* gi, const uint16_t* Whh, const fl
   return check_launch("nr_gru_fwd_seq");
 }
 
+static int gru_bwd_persist_launch(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
+                                  uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream) {
+  if (!WhhT || !len) return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
+  unsigned int* words = xcd_words(1);
+  if (words == nullptr) return NR_ERR_UNSUPPORTED;
+  nr::GruSeqBwdParams p;
+  p.g_last = g_last; p.WhhT = WhhT; p.gates = gates; p.H_all = H_all; p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t2 = dgh_t2; p.carry2 = carry2;
+  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.Kp = ceil_to(3 * p.Hg, 32); p.T = T; p.sync = nr::XcdSync{words}; p.stamps = g_gru_stamps_bwd;
+  if (hipMemsetAsync(words, 0, 32 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: memset");
+  const int grid = nr::NR_XCDS * nr::NR_XCD_TEAM;
+  if (p.Kp == 86 * 32) {
+    using G = nr::GruBwdPersistGeom<86>;
+    if (allow_smem(nr::gru_bwd_persist_kernel<86>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot reserve LDS");
+    NR_LAUNCH2(nr::gru_bwd_persist_kernel<86>, grid, 1, G::NT, G::SMEM, (hipStream_t)stream, p);
+  } else if (p.Kp == 44 * 32) {
+    using G = nr::GruBwdPersistGeom<44>;
+    if (allow_smem(nr::gru_bwd_persist_kernel<44>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: cannot reserve LDS");
+    NR_LAUNCH2(nr::gru_bwd_persist_kernel<44>, grid, 1, G::NT, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    return NR_ERR_UNSUPPORTED;
+  }
+  return check_launch("nr_gru_bwd_seq");
+}
+
 // error word of the last persistent sweeps (0 = clean; 1 = a workgroup found its XCD's team full; 2 = a wait gave up): SYNCHRONISES the device.
 // A non-zero word means the sweep's outputs are garbage: callers re-run with NR_GRU_PERSIST=0 (bench.py and the tests check it after every run).
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
@@ -1070,9 +1096,12 @@ int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
 #else       // emulator build: the step-per-launch form only
 int nr_debug_xcd_probe(uint32_t*, uint32_t*, uint32_t*, int, void*) { return fail(NR_ERR_UNSUPPORTED, "nr_debug_xcd_probe: not in the emulator build"); }
 int nr_debug_gru_stamps(int64_t*) { return NR_OK; }
+int nr_debug_gru_stamps_bwd(int64_t*) { return NR_OK; }
 static bool gru_persist_ok(int, int, int) { return false; }
 static int gru_fwd_persist_launch(const float*, const uint16_t*, const float*, const float*, const int32_t*, uint16_t*, uint16_t*, float*, uint16_t*, int, int, int,
                                   int, void*) { return NR_ERR_UNSUPPORTED; }
+static int gru_bwd_persist_launch(const float*, const uint16_t*, const uint16_t*, const uint16_t*, const int32_t*, uint16_t*, uint16_t*, uint16_t*, float*, int,
+                                  int, int, int, void*) { return NR_ERR_UNSUPPORTED; }
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
   if (fwd) *fwd = 0;
   if (bwd) *bwd = 0;
@@ -1097,7 +1126,7 @@ int nr_gru_fwd_seq_n(const float* gi, const uint16_t* Whh, const float* b_ih, co
   if (!h_t2 || !h_f2 || T < 0 || T > N || B < 0 || Hd <= 0 || n_buf < 2) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32);
   const size_t ht = (size_t)ceil_to(B, 16) * Hp, hf = (size_t)B * Hp;
-  if (gru_persist_ok(B, Hd, T)) {
+  if (gru_persist_ok(B, Hd, T) && (gru_persist_knob() & 1)) {
     const int rc = gru_fwd_persist_launch(gi, Whh, b_ih, b_hh, len, h_t2, H_all, h_f2, gates, B, N, Hd, T, stream);
     if (rc != NR_ERR_UNSUPPORTED) return rc;
   }
@@ -1153,6 +1182,10 @@ int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* 
     return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
   const int Hg = ceil_to(Hd, 16), Hp = ceil_to(Hd + 1, 32), Kp = ceil_to(3 * Hg, 32);
   const size_t dt = (size_t)ceil_to(B, 16) * Kp, cf = (size_t)B * Hp, hb = (size_t)B * Hp, gb = (size_t)B * 4 * Hg, db = (size_t)B * Kp;
+  if (gru_persist_ok(B, Hd, T + 1) && (gru_persist_knob() & 2)) {
+    const int rc = gru_bwd_persist_launch(g_last, WhhT, gates, H_all, len, dgi, dgh, dgh_t2, carry2, B, N, Hd, T, stream);
+    if (rc != NR_ERR_UNSUPPORTED) return rc;
+  }
   int i = 0;
   for (int t = T - 1; t >= -1; --t, ++i) {
     const int first = i == 0;

@@ -121,15 +121,16 @@ def test_gru_full_grid_batch_512(be):
     kcg.check_gru(be, B=512, N=9, Hd=450, I=900, seed=7, lens=[1 + (7 * i) % 9 for i in range(512)])
 
 
-def test_gru_persistent_forward_and_step_form(be):
-    """The forward sweep entry points take the persistent XCD-local form (csrc/k_gru_persist.h) on a 256-CU device; check_gru compares them bit for
-    bit with the step launches.  Both forms of the sweep (the knob is read per call), the error words clean afterwards, and a batch that leaves
-    some XCDs without samples (B = 40: three sample tiles for eight XCDs)."""
+def test_gru_persistent_sweeps_and_step_form(be):
+    """The sweep entry points take the persistent XCD-local form (csrc/k_gru_persist.h) on a 256-CU device; check_gru compares the forward sweep bit
+    for bit with the step launches and the backward sweep (another summation order) to rounding, and both with the float64 oracle.  Every
+    setting of the knob (read per call: 3 both sweeps, 1 forward only, 2 backward only, 0 step launches), the error words clean afterwards, and
+    batches that leave some XCDs without samples (B = 40: three sample tiles for eight XCDs) or with an odd number of sample tiles."""
     import os
     from news_recommendation_amd import ops_gru
     old = os.environ.get('NR_GRU_PERSIST')
     try:
-        for knob in ('1', '0'):
+        for knob in ('3', '1', '2', '0'):
             os.environ['NR_GRU_PERSIST'] = knob
             kcg.check_gru(be, B=512, N=7, Hd=900, I=900, seed=8, lens=[1 + (5 * i) % 7 for i in range(512)])
             kcg.check_gru(be, B=40, N=5, Hd=900, I=900, seed=9)

@@ -64,7 +64,7 @@ for _ in range(10): fwd(); bwd()
 torch.cuda.synchronize()
 res = {}
 for rnd in range(4):
-    for name, env in (('steps', '0'), ('persistent', '1')):
+    for name, env in (('steps', '0'), ('persistent', '3')):
         os.environ['NR_GRU_PERSIST'] = env
         res.setdefault(name + ' fwd', []).append(timed(fwd))
         res.setdefault(name + ' bwd', []).append(timed(bwd))
@@ -73,7 +73,7 @@ for k, v in res.items():
 print('status', status())
 
 if '--timeline' in sys.argv:
-    os.environ['NR_GRU_PERSIST'] = '1'
+    os.environ['NR_GRU_PERSIST'] = '3'
     buf = torch.zeros(256 * N * 8 * 8, dtype=torch.int64, device=dev)
     lib.nr_debug_gru_stamps(buf.data_ptr())
     fwd(); torch.cuda.synchronize()
@@ -103,3 +103,27 @@ if '--timeline' in sys.argv:
         d_late, d_med = dur(ph), np.median(dur(med), axis=0)
         print(f't{t:2d}: spread {int(arr[:, t].max() - arr[:, t].min()):6d}  late-median {int(arr[:, t].max() - np.median(arr[:, t])):6d}  step {int(top[:, t + 1].min() - top[:, t].min()):6d}'
               f'  latest = slot-wg {late:2d}; its phases {" ".join(f"{int(x):5d}" for x in d_late)} | median {" ".join(f"{int(x):5d}" for x in d_med)}')
+
+if '--timeline-bwd' in sys.argv:
+    os.environ['NR_GRU_PERSIST'] = '3'
+    NC = N + 1
+    buf = torch.zeros(256 * NC * 8 * 8, dtype=torch.int64, device=dev)
+    fwd(); lib.nr_debug_gru_stamps_bwd(buf.data_ptr())
+    bwd(); torch.cuda.synchronize()
+    buf.zero_(); bwd(); torch.cuda.synchronize()
+    lib.nr_debug_gru_stamps_bwd(None)
+    a = buf.cpu().numpy().reshape(256, NC, 8, 8).astype(np.int64)
+    a = (a - a[a > 0].min()) * 10
+    names = ['loads+mfma', 'exch', 'sync', 'epilogue', 'drain', 'barrier']
+    print('backward sweep, ns; workgroup 0; columns: call start | ' + ' '.join(f'{n:>10s}' for n in names))
+    for i in (10, 30):
+        for w in range(8):
+            r = a[0][i][w]
+            d = [int(r[k + 1] - r[k]) for k in range(5)] + [int(a[0][i + 1][w][0] - r[5])]
+            print(f'i{i} w{w}: {int(r[0] - a[0][10][0][0]):7d} | ' + ' '.join(f'{x:10d}' for x in d))
+        print()
+    wg = np.arange(0, 256, 8)
+    top = a[wg][:, :, :, 0].min(axis=2)
+    arr = a[wg][:, :, :, 5].max(axis=2)
+    for i in range(5, N - 1, 8):
+        print(f'call {i:2d}: length {int(top[:, i + 1].min() - top[:, i].min()):6d} ns, arrival spread {int(arr[:, i].max() - arr[:, i].min()):6d}, latest - median {int(arr[:, i].max() - np.median(arr[:, i])):6d}')
