@@ -116,7 +116,8 @@ struct ProjParams {
 #ifndef NR_PROJ_OCC
 #define NR_PROJ_OCC (NR_PROJ_NWAVE == 4 ? 3 : 4)      // waves per SIMD the register allocation must allow
 #endif
-// KSPLIT = 2: even / odd k-steps accumulate into two independent accumulators (no MFMA waits on the previous one's result)
+// One accumulator chain per chunk (a second one for the odd k-steps spills 13 registers under the 128-register cap of four waves per SIMD:
+// 648 vs 489 us, profiles/r05_ab_notes.txt).
 //
 // Round 5: nothing in the kernel waits for a STORE any more.  Its phase decomposition (profiles/r05_proj_phases.txt) had every phase additive --
 // table loads 119 us, MFMAs 125, Q / K / V stores 175, x_save stores 85, weight copies 111 of 618 -- because each phase ended in a wait that
@@ -125,7 +126,7 @@ struct ProjParams {
 // gather pass waited for its table rows behind the x_save stores of the pass before.  Now: the bias rides the contraction (two bf16 columns
 // against the token rows' two 1.0 columns: no loads in the chunk loop), the chunk barrier is a raw s_barrier behind a COUNTED wait that leaves
 // the chunk's own stores in flight, and the table rows of pass p + 1 are requested before the x_save stores of pass p are issued.
-template <int KSPLIT, bool DBG>
+template <bool DBG>
 __global__ __launch_bounds__(ProjGeom::NWAVE * 64, NR_PROJ_OCC) void qkv_proj_kernel(ProjParams p) {
   using Gm = ProjGeom;
   constexpr int S = Gm::S;
@@ -246,26 +247,19 @@ __global__ __launch_bounds__(ProjGeom::NWAVE * 64, NR_PROJ_OCC) void qkv_proj_ke
   auto run_chunk = [&](int which, int j, int s, int c) {
     if (c + 1 < Gm::NCHUNK) chunk_fetch(c + 1, (c + 1) & 1);
     const u16* wp = (const u16*)(smem + (c & 1) * Gm::CH_BYTES) + l * 8;
-    f32x16 acc[KSPLIT];
+    f32x16 acc[1];
 #pragma unroll
-    for (int k = 0; k < KSPLIT; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
     // weight fragments are requested PF k-steps ahead of their MFMA (the compiler's own schedule: two reads, wait, two MFMAs)
-    constexpr int PF = (KSPLIT > 1 || ProjGeom::NWAVE >= 8) ? 4 : 6;
+    constexpr int PF = ProjGeom::NWAVE >= 8 ? 4 : 6;
     u16x8 wf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) wf[i] = *(const u16x8*)(wp + i * 512);
     NR_SCHED_BARRIER();
 #pragma unroll
     for (int ks = (dbg & 2) ? K16 : 0; ks < K16; ++ks) {
-      f32x16& a = acc[ks % KSPLIT];
-      a = mfma_32x32x16_bf16(wf[ks % PF], xf[ks], a);
+      acc[0] = mfma_32x32x16_bf16(wf[ks % PF], xf[ks], acc[0]);
       if (ks + PF < K16) wf[ks % PF] = *(const u16x8*)(wp + (ks + PF) * 512);
-    }
-    if (KSPLIT > 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] += acc[KSPLIT - 1][r];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -188,28 +188,9 @@ int nr_mhsa_fwd_len(const int64_t* ids, const float* table, int64_t num_rows, co
   p.q_save = q_save; p.k_save = k_save; p.vt_save = vt_save; p.x_save = nullptr;
   bool x_done = false;
   if (S == 20) {
-    constexpr int NSEQ = 4;
-    static int v = -1;                               // tuning knob NR_MHSA_VARIANT, read once: 2 = register-resident kernel (default);
-    if (v < 0) { const char* var = getenv("NR_MHSA_VARIANT"); v = var ? atoi(var) : 2; }     // LDS-tile kernels: 42, 81, 82
-    if (v == 2) {
-      p.x_save = x_save; x_done = true;
-      if (nr::launch_mhsa_fwd2(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-    } else if (v == 42) {
-      constexpr int NW = 4, GS = 2;
-      using G = nr::MhsaGeom<20, NSEQ, NW>;
-      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
-    } else if (v == 82) {
-      constexpr int NW = 8, GS = 2;
-      using G = nr::MhsaGeom<20, NSEQ, NW>;
-      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
-    } else {
-      constexpr int NW = 8, GS = 1;      // 8 waves: 4 waves per SIMD with two workgroups per CU -> latency hiding
-      using G = nr::MhsaGeom<20, NSEQ, NW>;
-      if (allow_smem(nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
-      NR_LAUNCH((nr::mhsa_fwd_kernel<20, NSEQ, NW, GS>), (n_seq + NSEQ - 1) / NSEQ, G::THREADS, G::SMEM, (hipStream_t)stream, p);
-    }
+    // the register-resident kernel (csrc/nr_mhsa2.hip); the LDS-tile kernel remains for 50-token sequences below
+    p.x_save = x_save; x_done = true;
+    if (nr::launch_mhsa_fwd2(p, (hipStream_t)stream)) return fail(NR_ERR_LAUNCH, "nr_mhsa_fwd: cannot reserve LDS");
   } else if (S == 50) {
     constexpr int NSEQ = 1, NW = 4, GS = 2;
     using G = nr::MhsaGeom<50, NSEQ, NW>;
@@ -297,7 +278,7 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
   p.g_out = g_out; p.dqkv = dqkv; p.n_seq = n_seq; p.key_len = key_len; p.dc = make_drop(p_drop, seed); p.hm = hm; p.debug = 0;
   p.stamps = g_attnb_stamps;
   // head-major saves: a pair's operands are contiguous, nothing is shared between the heads of a token row except the dqkv row that is written
-  { static int xm = -1; if (xm < 0) { const char* e = getenv("NR_ATTN_XCD"); xm = e ? atoi(e) != 0 : 1; } p.xcd_major = xm; }
+  p.xcd_major = 1;
   const int64_t pairs = n_seq * NR_HEADS;
   // persistent grid: each wave walks pairs with a stride and prefetches the next one.  NR_ATTN_BWD_MAX_WGS caps the
   // grid (used by the tests to force many pairs per wave on small inputs).
@@ -317,8 +298,6 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
     const int64_t cap = capdiv > 0 ? capdiv : 2 * (int64_t)nr::device_cus();        // persistent: two workgroups per CU walk the titles
     const int grid = (int)(n_seq < cap ? n_seq : cap);
     const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches of the DBG instantiation, re-read per call
-    const char* nwe = getenv("NR_ATTNB2_NW");       // A/B: waves per workgroup (8, default: two rounds, four waves per SIMD; 5: three rounds of five heads)
-    const int nw = nwe ? atoi(nwe) : 8;
     q.debug = d ? atoi(d) : 0;
 #define NR_AB2_LAUNCH(NW_, DBG_)                                                                                                  \
     do {                                                                                                                          \
@@ -326,39 +305,25 @@ static int attn_bwd_launch(const uint16_t* q_save, const uint16_t* k_save, const
       if (allow_smem(nr::attn_bwd2_kernel<NW_, DBG_>, G2::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");  \
       NR_LAUNCH((nr::attn_bwd2_kernel<NW_, DBG_>), grid, G2::NT, G2::SMEM, (hipStream_t)stream, q);                              \
     } while (0)
-    if (nw == 5) { if (q.debug) NR_AB2_LAUNCH(5, true); else NR_AB2_LAUNCH(5, false); }
-    else { if (q.debug) NR_AB2_LAUNCH(8, true); else NR_AB2_LAUNCH(8, false); }
+    // eight waves: two rounds of heads, four waves per SIMD (five waves / three rounds measured 523 - 540 us against 487: profiles/r05_ab_notes.txt)
+    if (q.debug) NR_AB2_LAUNCH(8, true); else NR_AB2_LAUNCH(8, false);
 #undef NR_AB2_LAUNCH
     return check_launch("nr_attn_bwd");
   }
   if (S == 20) {
-    constexpr int WPB = 4;
-    using G = nr::AttnBwdGeom<20, WPB>;
-    static int tilev = -1;                          // A/B knob NR_ATTN_TILE: 1 (default) = one workgroup per sequence, dqkv rows staged in LDS
-    if (tilev < 0) { const char* e = getenv("NR_ATTN_TILE"); tilev = e ? atoi(e) : 1; }
+    // row-major saves (and NR_ATTNB2=0): one workgroup per sequence, dqkv rows staged in LDS (the round-4 TILE kernel, csrc/k_bwd.h)
     const char* d = getenv("NR_ATTNB_DEBUG");       // profiling: phase switches (AttnBwdParams::debug), re-read per call
-    if (tilev) {
-      constexpr int TW = 4;                         // 15 heads = 4 rounds of 4 waves (the last round: 3): two workgroups per CU at 2 waves per SIMD
-      using GT = nr::AttnBwdGeom<20, TW>;
-      const int grid = (int)(n_seq < (capdiv > 0 ? capdiv : 256 * 8) ? n_seq : (capdiv > 0 ? capdiv : 256 * 8));
-      if (d != nullptr && atoi(d) != 0) {
-        p.debug = atoi(d);
-        if (allow_smem(nr::attn_bwd_kernel<20, TW, true, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-        NR_LAUNCH((nr::attn_bwd_kernel<20, TW, true, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
-      } else {
-        if (allow_smem(nr::attn_bwd_kernel<20, TW, false, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-        NR_LAUNCH((nr::attn_bwd_kernel<20, TW, false, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
-      }
-      return check_launch("nr_attn_bwd");
-    }
+    constexpr int TW = 4;                           // 15 heads = 4 rounds of 4 waves (the last round: 3): two workgroups per CU at 2 waves per SIMD
+    using GT = nr::AttnBwdGeom<20, TW>;
+    const int grid = (int)(n_seq < (capdiv > 0 ? capdiv : 256 * 8) ? n_seq : (capdiv > 0 ? capdiv : 256 * 8));
     if (d != nullptr && atoi(d) != 0) {
       p.debug = atoi(d);
-      if (allow_smem(nr::attn_bwd_kernel<20, WPB, true>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-      NR_LAUNCH((nr::attn_bwd_kernel<20, WPB, true>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 24), WPB * 64, G::SMEM, (hipStream_t)stream, p);
-      return check_launch("nr_attn_bwd");
+      if (allow_smem(nr::attn_bwd_kernel<20, TW, true, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+      NR_LAUNCH((nr::attn_bwd_kernel<20, TW, true, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
+    } else {
+      if (allow_smem(nr::attn_bwd_kernel<20, TW, false, true>, GT::SMEM_TILE)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
+      NR_LAUNCH((nr::attn_bwd_kernel<20, TW, false, true>), grid, TW * 64, GT::SMEM_TILE, (hipStream_t)stream, p);
     }
-    if (allow_smem(nr::attn_bwd_kernel<20, WPB>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_attn_bwd: cannot reserve LDS");
-    NR_LAUNCH((nr::attn_bwd_kernel<20, WPB>), grid_for(pairs, WPB, capdiv > 0 ? capdiv : 256 * 24), WPB * 64, G::SMEM, (hipStream_t)stream, p);
   } else if (S == 50) {
     constexpr int WPB = 2;
     using G = nr::AttnBwdGeom<50, WPB>;
@@ -412,16 +377,15 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
   p.dc = make_drop(p_drop, seed); p.debug = 0;
   using G = nr::ProjGeom;
   const int64_t grid = (p.n_tok + G::TOK_WG - 1) / G::TOK_WG;
-  static int ksplit = -1;                           // A/B knob NR_PROJ_KSPLIT: 1 = one accumulator chain per chunk (default at four waves per SIMD: the
-  if (ksplit < 0) { const char* e = getenv("NR_PROJ_KSPLIT"); ksplit = e ? atoi(e) : (G::NWAVE >= 8 ? 1 : 2); }       // second chain's 16 registers spill under the 128 cap), 2 = two
   const char* d = getenv("NR_PROJ_DEBUG");          // profiling: phase switches (ProjParams::debug), re-read per call
-  if (allow_smem(nr::qkv_proj_kernel<1, true>, G::SMEM) || allow_smem(nr::qkv_proj_kernel<1, false>, G::SMEM) || allow_smem(nr::qkv_proj_kernel<2, false>, G::SMEM))
+  if (allow_smem(nr::qkv_proj_kernel<true>, G::SMEM) || allow_smem(nr::qkv_proj_kernel<false>, G::SMEM))
     return fail(NR_ERR_LAUNCH, "nr_qkv_proj_fwd: cannot reserve LDS");
   if (d != nullptr && atoi(d) != 0) {
     p.debug = atoi(d);
-    NR_LAUNCH((nr::qkv_proj_kernel<1, true>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
-  } else if (ksplit == 1) NR_LAUNCH((nr::qkv_proj_kernel<1, false>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
-  else NR_LAUNCH((nr::qkv_proj_kernel<2, false>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
+    NR_LAUNCH((nr::qkv_proj_kernel<true>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
+  } else {
+    NR_LAUNCH((nr::qkv_proj_kernel<false>), grid, G::NWAVE * 64, G::SMEM, (hipStream_t)stream, p);
+  }
   return check_launch("nr_qkv_proj_fwd");
 }
 
@@ -716,16 +680,14 @@ int nr_pack_conv(const float* W, const float* b, int F, int D, uint16_t* Wc, uin
 
 static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what) {
   { static int dbg = -1; if (dbg < 0) { const char* d = getenv("NR_CONV_DEBUG"); dbg = d ? atoi(d) : 0; } p.debug = dbg; }
-  // tuning knob NR_CONV_VARIANT: 0 = 4 waves on 4 titles / 2 abstracts (two workgroups per CU); 1 (default) = 8 waves on 8 titles /
-  // 4 abstracts (one workgroup per CU, the filter bank is re-read from L2 half as often: ~10 % faster at B = 512)
-  static int v = -1;
-  if (v < 0) { const char* var = getenv("NR_CONV_VARIANT"); v = var ? atoi(var) : 1; }
+  // 8 waves on 8 titles / 4 abstracts: one workgroup per CU, the filter bank is re-read from L2 half as often as with 4 waves on 4 / 2
+  // (~10 % at B = 512, profiles/r02_ab_switches.txt; the 4-wave instantiations are gone)
   int rc;
   if (S == 20) {
-    rc = v == 1 ? launch_conv_t<20, 8, 8>(p, stream) : v == 2 ? launch_conv_t<20, 4, 8>(p, stream) : launch_conv_t<20, 4, 4>(p, stream);
+    rc = launch_conv_t<20, 8, 8>(p, stream);
     if (rc) return rc;
   } else if (S == 50) {
-    rc = v == 1 ? launch_conv_t<50, 4, 8>(p, stream) : v == 2 ? launch_conv_t<50, 2, 8>(p, stream) : launch_conv_t<50, 2, 4>(p, stream);
+    rc = launch_conv_t<50, 4, 8>(p, stream);
     if (rc) return rc;
   } else {
     return fail(NR_ERR_UNSUPPORTED, "conv3: sequence length not instantiated (20, 50)");
@@ -780,10 +742,8 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
     return fail(NR_ERR_BADARG, "nr_additive_bwd_act: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_act: dropout probability out of range");
   if (n_seq == 0) return NR_OK;
-  static int fuse = -1;       // NR_POOL_ACT_FUSE=0: always the two-kernel form (A/B knob)
-  if (fuse < 0) { const char* e = getenv("NR_POOL_ACT_FUSE"); fuse = e ? atoi(e) : 1; }
-  const bool reg = S == 20 || (S == 50 && pool2_s50(n_seq));
-  if (fuse == 1 && reg) {
+  const bool reg = S == 20 || (S == 50 && pool2_s50(n_seq));      // the register-resident kernels fuse the activation gradient
+  if (reg) {
     nr::AdditiveBwdParams p;
     p.ctx = act; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.dpre = dpre; p.dq_part = dq_part; p.WaT = WaT;
     p.dctx = nullptr; p.n_seq = n_seq; p.dy_pad = dy_pad; p.act_scale = 1.0f / (1.0f - p_drop);
@@ -1098,6 +1058,7 @@ int nr_debug_xcd_probe(uint32_t*, uint32_t*, uint32_t*, int, void*) { return fai
 int nr_debug_gru_stamps(int64_t*) { return NR_OK; }
 int nr_debug_gru_stamps_bwd(int64_t*) { return NR_OK; }
 static bool gru_persist_ok(int, int, int) { return false; }
+static int gru_persist_knob() { return 0; }
 static int gru_fwd_persist_launch(const float*, const uint16_t*, const float*, const float*, const int32_t*, uint16_t*, uint16_t*, float*, uint16_t*, int, int, int,
                                   int, void*) { return NR_ERR_UNSUPPORTED; }
 static int gru_bwd_persist_launch(const float*, const uint16_t*, const uint16_t*, const uint16_t*, const int32_t*, uint16_t*, uint16_t*, uint16_t*, float*, int,

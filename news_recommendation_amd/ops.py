@@ -502,9 +502,6 @@ def inplace_grads(params):
 # NR_FWD_SPLIT: 1 (default) = title encoders that need gradients run nr_qkv_proj_fwd + nr_attn_fwd (csrc/k_proj.h) instead of the
 # register-resident nr_mhsa_fwd kernel; 2 = inference too; 0 = never (A/B)
 _FWD_SPLIT = int(os.environ.get('NR_FWD_SPLIT', '1'))
-# NR_FWD_POOL: 1 = the split form pools the titles inside the attention kernel (nr_attn_pool_fwd: the ctx tile is pooled from LDS instead of
-# being read back by nr_additive_fwd); 0 = two launches.  Same results bit for bit.
-_FWD_POOL = int(os.environ.get('NR_FWD_POOL', '1'))
 
 _ws = {}
 _side = {}
@@ -667,14 +664,13 @@ class _EncoderFn(torch.autograd.Function):
             Wp32, bp32 = pack_qkv32(Wq, bq, Wk, bk, Wv, bv)
             _call(f'nr_qkv_proj_fwd[S={S}]', lib.nr_qkv_proj_fwd, _ptr(ids_c), _ptr(tab), tab.shape[0], _ptr(Wp32), _ptr(bp32), _ptr(qs), _ptr(xb),
                   n_seq, S, p_drop, seed, _stream())
-            if _FWD_POOL:
-                out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
-                aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
-                _call(f'nr_attn_pool_fwd[S={S}]', lib.nr_attn_pool_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), _ptr(Wap), _ptr(bap), _ptr(qvp),
-                      _ptr(out), NR_D, _ptr(aw), n_seq, S, valid, p_drop, seed, _stream())
-                pooled = True
-            else:
-                _call(f'nr_attn_fwd[S={S}]', lib.nr_attn_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), n_seq, S, p_drop, seed, _stream())
+            # the titles are pooled inside the attention kernel (the ctx tile is pooled from LDS instead of being read back by nr_additive_fwd;
+            # bit for bit the two-launch form nr_attn_fwd + nr_additive_fwd, which tests/kernel_checks_proj.py holds it against)
+            out = torch.empty(n_seq, NR_D, dtype=torch.float32, device=dev)
+            aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
+            _call(f'nr_attn_pool_fwd[S={S}]', lib.nr_attn_pool_fwd, _ptr(qs), _ptr(cbuf), _ptr(key_len), _ptr(Wap), _ptr(bap), _ptr(qvp),
+                  _ptr(out), NR_D, _ptr(aw), n_seq, S, valid, p_drop, seed, _stream())
+            pooled = True
             xd = None
         elif gather:
             ids_c = ids.contiguous()

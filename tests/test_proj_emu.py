@@ -14,12 +14,6 @@ def test_pack32(be): kp.check_pack32(be)
 def test_pack_encoder_one_launch(be): kp.check_pack_encoder(be)
 def test_qkv_proj(be): kp.check_qkv_proj(be, n_seq=13)          # 260 tokens: two full workgroups + a partly filled one
 def test_qkv_proj_dropout(be): kp.check_qkv_proj(be, n_seq=7, p_drop=0.2)
-def test_qkv_proj_single_accumulator():
-    import subprocess, sys, os
-    env = dict(os.environ, NR_PROJ_KSPLIT='1')
-    code = "from tests.backends import EmuBackend; from tests import kernel_checks_proj as k; k.check_qkv_proj(EmuBackend(), n_seq=5)"
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
 def test_proj_attn(be): kp.check_proj_attn(be, n_seq=9)
 def test_proj_attn_dropout(be): kp.check_proj_attn(be, n_seq=6, p_drop=0.2)
 def test_proj_attn_key_len(be): kp.check_proj_attn(be, n_seq=7, with_key_len=True)

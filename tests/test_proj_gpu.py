@@ -83,13 +83,6 @@ def test_proj_bad_args(be):
     kp.check_proj_bad_args(be)
 
 
-def test_qkv_proj_single_accumulator():
-    env = dict(os.environ, NR_PROJ_KSPLIT='1')
-    code = "from tests.backends import GpuBackend; from tests import kernel_checks_proj as k; k.check_qkv_proj(GpuBackend(), n_seq=300, V=2000)"
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-
-
 def _encoder_run(split, seed=3):
     """loss + every gradient of one title-encoder call through ops.encode_titles in a child process (NR_FWD_SPLIT is read at import)."""
     code = f'''

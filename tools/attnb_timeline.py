@@ -1,4 +1,4 @@
-"""Phase switches and per-wave timelines of nr_attn_bwd_hm, both forms in one process: the DMA form (csrc/k_attn_bwd2.h, NR_ATTNB2=1, default) and
+"""Phase switches and per-wave timelines of nr_attn_bwd_hm, both forms in one process: the DMA form (csrc/k_attn_bwd2.h, NR_ATTNB2=1, default; its five-wave variant of the round's A/B is no longer instantiated) and
 the round-4 TILE form (csrc/k_bwd.h, NR_ATTNB2=0).  Cycle-counter stamps of the first titles of workgroups 0-1, every wave and round.
 Usage: python tools/attnb_timeline.py [B]"""
 import os, sys
@@ -73,7 +73,7 @@ def timeline(NW, NR, names, title_cols):
 # ---- interleaved A/B of the production builds (the first timed launches of a process run at a lower clock: warm up first) ---------------------
 for _ in range(40): fn()
 torch.cuda.synchronize()
-variants = {'TILE (r04)': {'NR_ATTNB2': '0'}, 'DMA NW=5': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '5'}, 'DMA NW=8': {'NR_ATTNB2': '1', 'NR_ATTNB2_NW': '8'}}
+variants = {'TILE (r04)': {'NR_ATTNB2': '0'}, 'DMA (8 waves)': {'NR_ATTNB2': '1'}}
 res = {k: [] for k in variants}
 for rnd_ in range(5):
     for k, env in variants.items():
@@ -81,7 +81,6 @@ for rnd_ in range(5):
         res[k].append(timed(10))
 for k, v in res.items():
     print(f"A/B {k:12s} median {sorted(v)[len(v) // 2]:7.1f} us   min {min(v):7.1f}   all {' '.join(f'{x:.0f}' for x in v)}", flush=True)
-os.environ.pop('NR_ATTNB2_NW', None)
 if '--ab-only' in sys.argv:
     sys.exit(0)
 
