@@ -449,6 +449,11 @@ int nr_adam_flat(float* p, float* g, float* m, float* v, int64_t n, const float*
  * nr_row_adam_flush always uses its by-value argument. */
 int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
                         int64_t upto, double beta1, double beta2, double eps, void* stream);
+/* The same with an explicit choice: by_value != 0 takes `upto` from the argument even while a device step counter is attached -- for a forward
+ * issued OUTSIDE a step (validation between graph replays): the counter is bumped at the START of a step, so between steps it equals the number
+ * of completed steps and counter - 1 would leave the rows one step stale. */
+int nr_row_adam_catchup_ex(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
+                           int64_t upto, int by_value, double beta1, double beta2, double eps, void* stream);
 int nr_row_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched, int64_t upto, double beta1,
                       double beta2, double eps, void* stream);
 int nr_row_adam_step(const int64_t* ids_sorted, const int64_t* perm, int64_t n, const float* rows, int64_t ld, float* p, float* m, float* v,

@@ -85,6 +85,7 @@ SIGNATURES = {
     'nr_impression_metrics': ([_P, _P, _P, _P, c_int64, _P], c_int),
     'nr_adam_flat': ([_P, _P, _P, _P, c_int64, _P, c_int64, c_double, c_double, c_double, c_float, c_int, _P], c_int),
     'nr_row_adam_catchup': ([_P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double, _P], c_int),
+    'nr_row_adam_catchup_ex': ([_P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_int, c_double, c_double, c_double, _P], c_int),
     'nr_row_adam_flush': ([_P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double, _P], c_int),
     'nr_row_adam_step': ([_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double,
                           c_float, c_int, _P], c_int),

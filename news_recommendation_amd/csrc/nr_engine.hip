@@ -1197,15 +1197,21 @@ int nr_step_counter_add(uint32_t* ctr, uint32_t inc, void* stream) {
   return check_launch("nr_step_counter_add");
 }
 
-int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
-                        int64_t upto, double beta1, double beta2, double eps, void* stream) {
+int nr_row_adam_catchup_ex(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
+                           int64_t upto, int by_value, double beta1, double beta2, double eps, void* stream) {
   if (!ids || !p || !m || !v || !last || !sched || n < 0 || num_rows <= 0 || d <= 0 || d > 64 * nr::ROW_EPL || upto < 0 || bad_betas(beta1, beta2, eps))
     return fail(NR_ERR_BADARG, "nr_row_adam_catchup: bad argument");
-  if (n == 0 || (upto == 0 && g_step_ctr == nullptr)) return NR_OK;
+  const bool counter = g_step_ctr != nullptr && !by_value;
+  if (n == 0 || (upto == 0 && !counter)) return NR_OK;
   nr::AdamCfg cfg = make_adam(sched, beta1, beta2, eps);
-  cfg.t_dev = g_step_ctr;                  // device step counter attached: `upto` is read from it (counter - 1) by the kernel
+  cfg.t_dev = counter ? g_step_ctr : nullptr;      // inside a step with a device counter attached: `upto` is read from it (counter - 1) by the kernel
   NR_LAUNCH(nr::row_adam_catchup_kernel, (n + 3) / 4, 256, 0, (hipStream_t)stream, ids, n, p, m, v, (int*)last, num_rows, d, upto, cfg);
   return check_launch("nr_row_adam_catchup");
+}
+
+int nr_row_adam_catchup(const int64_t* ids, int64_t n, float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched,
+                        int64_t upto, double beta1, double beta2, double eps, void* stream) {
+  return nr_row_adam_catchup_ex(ids, n, p, m, v, last, num_rows, d, sched, upto, 0, beta1, beta2, eps, stream);
 }
 
 int nr_row_adam_flush(float* p, float* m, float* v, int32_t* last, int64_t num_rows, int d, const float* sched, int64_t upto, double beta1,

@@ -27,6 +27,21 @@ from . import _capi, ops
 _attached = []        # counter tensors the library currently points at (at most one: the counter is process-global)
 
 
+class _CounterStep:
+    """Marks the optimiser as inside a counter-driven step for the duration of a step function (optim.EngineAdam._make_sync: the row-sparse
+    catch-up then takes its step index from the device counter; outside, by value)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+
+    def __enter__(self):
+        self.prev = getattr(self.opt, 'counter_step', False)
+        self.opt.counter_step = True
+
+    def __exit__(self, *exc):
+        self.opt.counter_step = self.prev
+
+
 class StepGraph:
     """``g = StepGraph(step_fn, example_inputs, optimizer)``; ``loss = g(*inputs)`` runs one training step.
 
@@ -66,7 +81,8 @@ class StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
-            self.loss = step_fn(*self.static)
+            with _CounterStep(self.opt):
+                self.loss = step_fn(*self.static)
         # the capture ran the Python side of one step (optimizer.t advanced) without executing a kernel: take it back
         self.opt.t -= 1
         ops.invalidate_packed()                 # (operands cached during the capture were recorded, not computed)
@@ -74,7 +90,8 @@ class StepGraph:
     def eager_step(self, *inputs):
         """The same step without the graph, on the same counter protocol (used for warm-up and as the reference in tests)."""
         _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
-        return self.step_fn(*inputs)
+        with _CounterStep(self.opt):
+            return self.step_fn(*inputs)
 
     def __call__(self, *inputs):
         if self.opt.t + 1 > self.max_t:
@@ -93,13 +110,12 @@ class StepGraph:
         memory (the holder keeps the counter tensor alive until then)."""
         if getattr(self, '_closed', True):
             return
+        # closed -- and the counter tensor released -- only once the library no longer points at it: if the synchronisation or the detach
+        # raises, the holder keeps the tensor alive and a later close() can retry
+        torch.cuda.synchronize(self.opt.device)             # no replay in flight still reads the counter
+        _capi.check(self.lib, self.lib.nr_set_step_counter(None))
         self._closed = True
-        try:
-            torch.cuda.synchronize(self.opt.device)             # no replay in flight still reads the counter
-            _capi.check(self.lib, self.lib.nr_set_step_counter(None))
-        finally:
-            if any(c is self.ctr for c in _attached):
-                _attached[:] = [c for c in _attached if c is not self.ctr]
+        _attached[:] = [c for c in _attached if c is not self.ctr]
 
     def __enter__(self):
         return self
@@ -159,7 +175,8 @@ class SegmentedStep:
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
-            self.loss = fwd_bwd_fn(*self.static)
+            with _CounterStep(optimizer):
+                self.loss = fwd_bwd_fn(*self.static)
             optimizer.stage_rows()
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
@@ -170,7 +187,8 @@ class SegmentedStep:
 
     def eager_step(self, *inputs):
         _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
-        loss = self.fn(*inputs)
+        with _CounterStep(self.opt):
+            loss = self.fn(*inputs)
         self.opt.step()
         return loss
 

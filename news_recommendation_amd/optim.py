@@ -119,6 +119,7 @@ class EngineAdam:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("EngineAdam: all parameters must be fp32 on one device")
         self.t = 0
+        self.counter_step = False                # True while a StepGraph / SegmentedStep runs its step function on the device step counter
         self._row_cap = {}
         self.table_rs = (os.environ.get('NR_TABLE_RS', '0') == '1') if table_rs is None else bool(table_rs)
         self.force_dist = bool(force_dist)
@@ -225,12 +226,16 @@ class EngineAdam:
 
     def _make_sync(self, st):
         def sync(ids):
-            """Called by the forward before it gathers rows `ids`: replay the idle steps those rows missed."""
-            if self.t > 0:
+            """Called by the forward before it gathers rows `ids`: replay the idle steps those rows missed.  Inside a counter-driven step
+            (StepGraph / SegmentedStep capture, warm-up and eager_step set ``counter_step``) the launch is ALWAYS recorded and the kernel takes
+            the step index from the device counter (its `upto <= 0` early-out covers a fresh optimiser); anywhere else -- a validation forward
+            between replays -- the index is passed by value, so the rows come up to every completed step."""
+            in_step = self.counter_step
+            if in_step or self.t > 0:
                 p = st.param.data
-                self._ck(self.lib.nr_row_adam_catchup(ids.data_ptr(), ids.numel(), p.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
-                                                      st.last.data_ptr(), p.shape[0], p.shape[1], self.sched.table.data_ptr(), self.t,
-                                                      self.betas[0], self.betas[1], self.eps, self._stream_fn()))
+                self._ck(self.lib.nr_row_adam_catchup_ex(ids.data_ptr(), ids.numel(), p.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+                                                         st.last.data_ptr(), p.shape[0], p.shape[1], self.sched.table.data_ptr(), self.t,
+                                                         0 if in_step else 1, self.betas[0], self.betas[1], self.eps, self._stream_fn()))
         return sync
 
     def _ck(self, rc):

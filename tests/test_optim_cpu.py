@@ -127,6 +127,14 @@ def _row_lazy_body(emu, rng, ctr, with_counter):
                                     pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d, sched.ctypes.data, tv,
                                     0.9, 0.999, 1e-8, 0.5, 0, None) == 0
     assert not np.array_equal(pl, pd)                                 # lazy table is stale somewhere before the flush ...
+    # a forward OUTSIDE a step (validation between replays): the counter equals the number of completed steps there, so counter - 1 would
+    # leave the rows one step behind -- nr_row_adam_catchup_ex(by_value = 1) takes the index from the argument, counter attached or not
+    stale = np.flatnonzero((last > 0) & (last < T))
+    if len(stale):
+        read = stale[:3].astype(np.int64)
+        assert lib.nr_row_adam_catchup_ex(read.ctypes.data, len(read), pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d,
+                                          sched.ctypes.data, T, 1, 0.9, 0.999, 1e-8, None) == 0
+        assert np.array_equal(pl[read], pd[read]) and (last[read] == T).all()
     assert lib.nr_row_adam_flush(pl.ctypes.data, ml.ctypes.data, vl.ctypes.data, last.ctypes.data, R, d, sched.ctypes.data, T,
                                  0.9, 0.999, 1e-8, None) == 0
     assert np.array_equal(pl, pd) and np.array_equal(ml, md) and np.array_equal(vl, vd)      # ... and bit-identical after it
