@@ -64,21 +64,21 @@ def test_golden_base_forward_and_grads(golden_dir):
     logits = m(user, ln, cl, hl)
     assert (ln >= 1).all() and (ln[length == 0] == 1).all()                    # lengths clamped in place like the reference
     # bf16 operands through up to 50 recurrent steps: 2e-2 of the logit scale
-    assert rel_err(logits.detach().cpu().numpy(), g['f32_logits']) < 2e-2
+    assert rel_err(logits.detach().cpu().numpy(), g['f32_logits']) < 1.2e-2          # measured 3.9e-3
     torch.nn.CrossEntropyLoss()(logits, torch.zeros(c['B'], dtype=torch.long, device=DEV)).backward()
     ref = oracle(c, params)
     lr = ref(user, length.clone(), cl, hl)
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(c['B'], dtype=torch.long)).backward()
     np.testing.assert_allclose(lr.detach().numpy(), g['f32_logits'], rtol=0, atol=1e-2 * np.abs(g['f32_logits']).max())
-    check_grads(m, ref, 6e-2)
+    check_grads(m, ref, 2e-2)             # measured <= 6.2e-3
     assert torch.all(m.user_embedding.weight.grad[0] == 0) and torch.all(m.news_encoder.category_embedding.weight.grad[0] == 0)
     with torch.no_grad():
         flat = {k: torch.from_numpy(v.reshape(-1, *v.shape[2:])) for k, v in cand.items()}
         nv = m.get_news_vector(flat)
-        assert nv.shape == (c['B'] * c['C'], 3 * c['F']) and rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 1.5e-2
+        assert nv.shape == (c['B'] * c['C'], 3 * c['F']) and rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 1.5e-3          # measured 4.0e-4
         cv = torch.stack([m.get_news_vector(x) for x in hl], dim=1)
         uv = m.get_user_vector(user, length.clone(), cv)
-        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 2e-2
+        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 4e-3          # measured 1.3e-3
 
 
 @pytest.mark.parametrize('method', ['ini', 'con'])
@@ -98,8 +98,8 @@ def test_mind_shape_vs_torch_oracle(method):
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(c['B'], dtype=torch.long, device=DEV)).backward()
     with torch.no_grad():
         l_plain = oracle(c, params, q_operands=False)(user, length.clone(), cl, hl)
-    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 2e-2
-    check_grads(m, ref, 5e-2)
+    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 5e-3          # measured 1.6e-3 (ini), 9.7e-4 (con)
+    check_grads(m, ref, 2.4e-2)           # measured <= 8.0e-3
 
 
 def test_training_mode_masks_match_oracle():
@@ -131,11 +131,11 @@ def test_training_mode_masks_match_oracle():
         keeps.append({'title1': torch.from_numpy(t1[idx]), 'title2': torch.from_numpy(t2[idx])})
     ref = oracle(c, params, train=True)
     lr = ref(user, length.clone(), cl, hl, keeps, keep_u)
-    assert rel_err(l1.detach().cpu().numpy(), lr.detach().numpy()) < 2e-2
+    assert rel_err(l1.detach().cpu().numpy(), lr.detach().numpy()) < 3e-3          # measured 9.3e-4
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(B, dtype=torch.long)).backward()
     m.zero_grad()
     torch.nn.CrossEntropyLoss()(l1, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
-    check_grads(m, ref, 5e-2)
+    check_grads(m, ref, 1.2e-2)           # measured <= 3.9e-3
     # masked users' rows get no gradient; row 0 (padding_idx) never does
     ug = m.user_embedding.weight.grad
     for b in range(B):
@@ -182,13 +182,13 @@ def test_tiny_ragged_batches(model_name, B):
         m = build_nrms(c['V'], 300, 15, 200, 50, 20, p).eval()
         lr, lg = ref(cl, hl), m(cl, hl)
     assert lg.shape == (B, 3)
-    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 2e-2
+    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 2e-2          # measured <= 7.1e-3 (one LSTUR impression)
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(B, dtype=torch.long)).backward()
     rg = {k: q.grad.numpy() for k, q in ref.named_parameters()}
     fl = grad_floor(rg)
     worst = max(rel_err(q.grad.cpu().numpy(), rg[k], fl) for k, q in m.named_parameters())
-    assert worst < 8e-2, worst        # one impression: a handful of tokens carries the whole gradient (bf16 operand level)
+    assert worst < 8e-2, worst        # measured <= 2.6e-2; one impression: a handful of tokens carries the whole gradient (bf16 operand level)
 
 
 @pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])

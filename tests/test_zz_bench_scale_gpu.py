@@ -139,4 +139,6 @@ def test_conv_dgrad_gemm_at_bench_scale():
 # NAML measured (profiles/r05_bench_scale_backward_NAML.json): logits 2.9e-4, weight tensors <= 3.2e-3, bias tensors <= 2.3e-2 (the pooling layers'
 # linear.bias: small sums of bf16 dpre rows over a floor of 2e-2 of the largest bias gradient), table rows median 0.30 %, worst row 0.65 %
 NAML_LOGIT, NAML_GRAD, NAML_GRAD_BIAS, NAML_ROW_MEDIAN, NAML_ROW_MAX = 1e-3, 1e-2, 7e-2, 0.01, 0.02
-LSTUR_LOGIT, LSTUR_GRAD, LSTUR_GRAD_BIAS, LSTUR_ROW_MEDIAN, LSTUR_ROW_MAX = 2e-2, 5e-2, 5e-2, 0.02, 0.15
+# LSTUR measured (profiles/r05_bench_scale_backward_LSTUR.json): logits 1.6e-3, weight tensors <= 3.4e-3, bias tensors <= 2.3e-3, table rows median
+# 0.41 %, worst row 0.78 %
+LSTUR_LOGIT, LSTUR_GRAD, LSTUR_GRAD_BIAS, LSTUR_ROW_MEDIAN, LSTUR_ROW_MAX = 5e-3, 1.1e-2, 1e-2, 0.013, 0.025
