@@ -386,6 +386,64 @@ def train_parity(device, steps=200, B=16, lr=1e-3, engine_seeds=(0, 1), oracle=T
     return out
 
 
+def train_parity_naml(device, steps=100, B=16, lr=1e-3, engine_seeds=(0, 1), oracle_seeds=(0,)):
+    """The NAML leg of the statistical training parity (see train_parity): conv text encoders over titles and abstracts, the category views,
+    three levels of additive attention -- engine (bf16 operands, counter dropout, EngineAdam) vs OracleNAML (torch dropout, torch.optim.Adam)
+    from the same initial weights on the same teacher-labelled impressions, compared by the AUC / nDCG@10 of the two trained models on held-out
+    impressions.  Unlike the NRMS task this one does not start at chance (two random NAML models already agree on which candidates share a
+    category with the history: AUC_init ~0.7), so what is asserted is the gain over AUC_init and the agreement of the trained models."""
+    from news_recommendation_amd import ops
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle import train_parity as tp
+    t0 = time.perf_counter()
+    task = tp.make_task_naml(steps=steps, B=B)
+    st0 = tp.init_state_naml(task["num_words"], task["num_categories"])
+    cfg = make_cfg('NAML', 'small', vocab=task["num_words"])
+    cfg.num_categories = task["num_categories"]
+    wl = Workload('NAML', cfg)
+    crit = torch.nn.CrossEntropyLoss()
+    target = torch.zeros(B, dtype=torch.long, device=device)
+    to_dev = lambda d: {k: torch.from_numpy(v).to(device) for k, v in d.items()}
+    batches = [tuple(to_dev(x) for x in tp.naml_batch(task, i)) for i in range(steps)]
+    es = (task["news"], task["eval_hist"], task["eval_cands"], task["eval_ptr"], None)
+
+    def engine_run(seed):
+        m = wl.make_model().to(device)
+        m.load_state_dict(st0)
+        m.train()
+        opt = EngineAdam(m, lr=lr)
+        torch.manual_seed(1000 + seed)
+        losses = []
+        for cand, click in batches:
+            loss = crit(m.forward_ids(cand, click), target)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        return tp.eval_metrics(task, engine_scores(wl, m, device, es)), float(torch.stack(losses[-10:]).mean())
+    out = {"model": "NAML", "steps": steps, "batch": B, "lr": lr, "dropout": cfg.dropout_probability, "vocab": task["num_words"],
+           "eval_impressions": len(task["eval_ptr"]) - 1, "auc_teacher": float(tp.eval_metrics(task, task["teacher_scores"])[0]),
+           "auc_init": float(tp.eval_metrics(task, tp.oracle_eval_scores_naml(task, st0))[0])}
+    runs = [engine_run(s_) for s_ in engine_seeds]
+    out["engine"] = [{"auc": float(r[0][0]), "ndcg10": float(r[0][3]), "last10_loss": r[1]} for r in runs]
+    out["engine_seed_spread_auc"] = float(max(r["auc"] for r in out["engine"]) - min(r["auc"] for r in out["engine"]))
+    ops.invalidate_packed()
+    oruns = []
+    for os_ in oracle_seeds:
+        trained, losses = tp.train_oracle_naml(task, st0, lr=lr, p_drop=cfg.dropout_probability, torch_seed=os_)
+        om = tp.eval_metrics(task, tp.oracle_eval_scores_naml(task, trained))
+        oruns.append({"auc": float(om[0]), "ndcg10": float(om[3]), "last10_loss": float(np.mean(losses[-10:])), "torch_seed": os_})
+    out["oracle_runs"] = oruns
+    out["oracle"] = {k: float(np.mean([r[k] for r in oruns])) for k in ("auc", "ndcg10", "last10_loss")}
+    ea = float(np.mean([r["auc"] for r in out["engine"]]))
+    out["abs_diff_auc"] = abs(ea - out["oracle"]["auc"])
+    out["abs_diff_ndcg10"] = abs(float(np.mean([r["ndcg10"] for r in out["engine"]])) - out["oracle"]["ndcg10"])
+    # one oracle stream only (a CPU NAML training costs minutes of GPU-box time): the yardstick is the engine's own seed-to-seed spread, floor 1e-2
+    out["tolerance_auc"] = float(max(1e-2, 2.0 * out["engine_seed_spread_auc"]))
+    out["within_noise"] = bool(out["abs_diff_auc"] < out["tolerance_auc"])
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def score_eval(wl, model, device, n_impr_cap=100000):
     """Eval-shaped scoring throughput: phases A (encode every news once), B (one user vector per impression history), C
     (ragged candidate scoring + per-impression AUC / MRR / nDCG on the device) of src/evaluate.py:185-272 via evaluate_fast.run_plan,

@@ -34,3 +34,21 @@ def test_engine_and_oracle_train_to_the_same_auc():
     assert r["abs_diff_ndcg10"] < max(6e-3, 2.0 * max(r["oracle_seed_spread_ndcg10"], 3e-3)), r
     assert r["engine_seed_spread_auc"] < 1.5e-2 and r["oracle_seed_spread_auc"] < 1.5e-2, r
     assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.08, r
+
+
+def test_naml_engine_and_oracle_train_to_the_same_auc():
+    """The NAML leg: 100 steps with dropout on from the same initial weights (oracle/train_parity.py make_task_naml / train_oracle_naml)."""
+    import bench
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    r = bench.train_parity_naml(dev, steps=100, B=16)
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, 'train_parity_naml.json'), 'w') as f:
+            json.dump(r, f, indent=1)
+    gain = r["oracle"]["auc"] - r["auc_init"]
+    assert gain > 0.03, r                                               # the reference's loop improves on the initial model ...
+    assert all(e["auc"] > r["auc_init"] + 0.6 * gain for e in r["engine"]), r      # ... and so does the engine, on both dropout seeds
+    assert r["abs_diff_auc"] < r["tolerance_auc"] <= 3e-2, r
+    assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.1, r
