@@ -70,10 +70,6 @@ kern = {
   'attn_bwd_rowmajor': lambda: ck(lib.nr_attn_bwd_len(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), dctx.data_ptr(), NR_KP, aw.data_ptr(), go.data_ptr(), dqkv.data_ptr(), None, T, 20, p, 1, st())),
   'dX_gemm_hand': lambda: ck(lib.nr_dx_gemm(dqkv_b.data_ptr(), WdX.data_ptr(), dX_hand.data_ptr(), ntok, st())),
   'dX_gemm_hipblaslt': lambda: torch.nn.functional.linear(dqkv_b, WpT),
-  'dWqkv_tn_hand': lambda: ops._wgrad_parts_hand(dqkv_b.view(torch.int16), NR_LDG, xs_b.view(torch.int16), 'x'),
-  'dWqkv_hipblaslt_chunked': lambda: ops._wgrad_parts(dqkv_b, xs_b, 'x'),
-  'dWa_tn_hand': lambda: ops._wgrad_parts_hand(dpre_b.view(torch.int16), NR_QP, xs_b.view(torch.int16), 'x'),
-  'dWa_hipblaslt_chunked': lambda: ops._wgrad_parts(dpre_b, xs_b, 'x'),
   'attn_bwd_hm': lambda: ck(lib.nr_attn_bwd_hm(qkv.data_ptr(), dctx.data_ptr(), NR_KP, aw.data_ptr(), go.data_ptr(), dqkv.data_ptr(), None, T, 20, p, 1, st())),
 }
 only = os.environ.get('KB_ONLY')
@@ -95,10 +91,6 @@ if 'dX_gemm_hand' in res and 'dX_gemm_hipblaslt' in res:
     err = (dX_hand.float() - ref).abs().max().item() / ref.abs().max().item()
     print(f'dX hand vs hipBLASLt: max rel diff {err:.3g}; TFLOP/s (algorithmic 2*900*300 per token): hand {ntok * 2 * 900 * 300 / res["dX_gemm_hand"] / 1e6:.0f}, '
           f'hipBLASLt {ntok * 2 * 900 * 300 / res["dX_gemm_hipblaslt"] / 1e6:.0f}')
-if 'dWqkv_tn_hand' in res:
-    a = ops._wgrad_parts_hand(dqkv_b.view(torch.int16), NR_LDG, xs_b.view(torch.int16), 'x').sum(0)
-    b = ops._wgrad_parts(dqkv_b, xs_b, 'x').sum(0)
-    print(f'dWqkv hand vs hipBLASLt: max rel diff {(a - b).abs().max().item() / b.abs().max().item():.3g}, partitions {ops._wgrad_parts_hand(dqkv_b.view(torch.int16), NR_LDG, xs_b.view(torch.int16), "x").shape[0]}')
 flop_proj = ntok * 2 * 300 * 900
 out = {'B': B, 'us': res, 'env': {k: v for k, v in os.environ.items() if k.startswith('NR_')}}
 for k in res:
