@@ -88,8 +88,8 @@ def test_naml_title_14_abstract_33_history_25_k3():
     lg = m(cl, hl)
     assert lg.shape == (c['B'], c['C'])
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(c['B'], dtype=torch.long, device=DEV)).backward()
-    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 1.5e-2
-    check_grads(m, {k: p.grad.numpy() for k, p in ref.named_parameters()}, 6e-2)
+    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 1e-3          # measured 1.5e-4
+    check_grads(m, {k: p.grad.numpy() for k, p in ref.named_parameters()}, 6e-2)      # measured <= 2.5e-2
 
 
 @pytest.mark.parametrize('attrs', [('title', 'subcategory'), ('abstract',), ('category', 'subcategory', 'title')])
@@ -120,11 +120,11 @@ def test_naml_view_subsets(attrs):
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(c['B'], dtype=torch.long)).backward()
     lg = m(cl, hl)
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(c['B'], dtype=torch.long, device=DEV)).backward()
-    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 2e-2
+    assert rel_err(lg.detach().cpu().numpy(), lr.detach().numpy()) < 1e-3          # measured <= 2.3e-4
     rg = {k: p.grad.numpy() for k, p in ref.named_parameters()}
     fl = grad_floor(rg)
     for k, p in m.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), rg[k], fl) < 6e-2, k
+        assert rel_err(p.grad.cpu().numpy(), rg[k], fl) < 9e-2, k           # measured <= 5.6e-2 (abstract-only model: one view carries every gradient)
 
 
 def _ref_mhsa(x, mod, length):

@@ -64,7 +64,7 @@ def test_golden_base_forward_and_grads(golden_dir):
     logits = m(cl, hl)
     assert logits.shape == (c['B'], c['C']) and logits.is_cuda
     # bf16 operands through two pooling levels: 1.5e-2 of the logit scale
-    assert rel_err(logits.detach().cpu().numpy(), g['f32_logits']) < 1.5e-2
+    assert rel_err(logits.detach().cpu().numpy(), g['f32_logits']) < 1e-3          # measured 1.4e-4 (bounds: ~3x profiles/r05_measured_rel_err.txt, rounded up)
     loss = torch.nn.CrossEntropyLoss()(logits, torch.zeros(c['B'], dtype=torch.long, device=DEV))
     loss.backward()
     # gradients vs the fp32 reference: recompute them with the pinned oracle (the golden file stores norms/slices for big tensors)
@@ -74,14 +74,14 @@ def test_golden_base_forward_and_grads(golden_dir):
     np.testing.assert_allclose(lr.detach().numpy(), g['f32_logits'], rtol=0, atol=1e-2 * np.abs(g['f32_logits']).max())
     rg = {k: p.grad.numpy() for k, p in ref.named_parameters()}
     # the logits here are ~9 in magnitude with near-one-hot softmax: gradients carry the bf16 error of the logits -> 6e-2 bound
-    check_grads(m, rg, 6e-2)
+    check_grads(m, rg, 6e-2)              # measured <= 2.4e-2 (the pooling layers' bias gradients over their floor); 5e-2 below: <= 3.0e-2
     with torch.no_grad():
         flat = {k: torch.from_numpy(v.reshape(-1, *v.shape[2:])) for k, v in cand.items()}
         nv = m.get_news_vector(flat)
-        assert rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 1.5e-2
+        assert rel_err(nv.cpu().numpy(), g['f32_news_vec']) < 7e-3          # measured 2.3e-3
         cv = torch.stack([m.get_news_vector(x) for x in hl], dim=1)
         uv = m.get_user_vector(cv)
-        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 1.5e-2
+        assert rel_err(uv.cpu().numpy(), g['f32_user_vec']) < 3e-3          # measured 8.4e-4
         pr = m.get_prediction(nv[:c['C']], uv[0])
         assert pr.shape == (c['C'],) and np.abs(pr.cpu().numpy() - g['f32_pred0']).max() < 1.5e-2 * np.abs(g['f32_logits']).max()
 
@@ -105,7 +105,7 @@ def test_mind_shape_vs_torch_oracle():
     m = build(c, params).eval()
     lg = m(cl, hl)
     torch.nn.CrossEntropyLoss()(lg, torch.zeros(c['B'], dtype=torch.long, device=DEV)).backward()
-    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 1.5e-2          # vs the un-quantised fp32 reference math
+    assert rel_err(lg.detach().cpu().numpy(), l_plain.numpy()) < 1e-3          # vs the un-quantised fp32 reference math; measured 1.7e-4
     check_grads(m, {k: p.grad.numpy() for k, p in ref.named_parameters()}, 5e-2)
     we = m.news_encoder.text_encoders['title'].word_embedding.weight
     assert torch.all(we.grad[0] == 0)                                           # padding_idx row of the word table
@@ -142,7 +142,7 @@ def test_training_mode_dropout_matches_oracle_with_exported_masks():
                       'abstract1': torch.from_numpy(a1[idx]), 'abstract2': torch.from_numpy(a2[idx])})
     ref = oracle_with_engine_operands(c, params, train=True)
     lr = ref(cl, hl, keeps)
-    assert rel_err(l1.detach().cpu().numpy(), lr.detach().numpy()) < 1.5e-2
+    assert rel_err(l1.detach().cpu().numpy(), lr.detach().numpy()) < 1e-3          # measured 1.2e-4
     torch.nn.CrossEntropyLoss()(lr, torch.zeros(B, dtype=torch.long)).backward()
     m.zero_grad()
     torch.nn.CrossEntropyLoss()(l1, torch.zeros(B, dtype=torch.long, device=DEV)).backward()
@@ -164,9 +164,9 @@ def test_optimizer_step_sees_live_parameters_and_text_encoder_alone():
     ref = OracleNAML(c['V'], c['d'], c['ncat'], c['dcat'], c['F'], c['window'], c['Q'], 0.2)
     ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     ref.eval()
-    assert rel_err(l1.detach().cpu().numpy(), ref(cl, hl).detach().numpy()) < 1.5e-2
+    assert rel_err(l1.detach().cpu().numpy(), ref(cl, hl).detach().numpy()) < 1e-3          # measured 9.0e-5
     # TextEncoder.forward on its own
     te, rte = m.news_encoder.text_encoders['abstract'], ref.news_encoder.text_encoders['abstract']
     ids = torch.from_numpy(cand['abstract'][:, 0])
     with torch.no_grad():
-        assert rel_err(te(ids).cpu().numpy(), rte(ids).numpy()) < 1.5e-2
+        assert rel_err(te(ids).cpu().numpy(), rte(ids).numpy()) < 4e-3          # measured 1.3e-3

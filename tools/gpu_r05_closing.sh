@@ -1,0 +1,7 @@
+#!/bin/bash
+# Round-5 closing pass on ONE box: the profile pass (tools/gpu_r05_profiles.sh), its JSON products copied into profiles/ of the box's checkout so
+# that the bench lines taken right after quote traffic / MFMA-busy figures of THIS library, then the bench lines (tools/gpu_r05_final.sh).
+export TMPDIR=/tmp
+( time bash tools/gpu_r05_profiles.sh r05prof2 ) 2>&1 | tail -40
+for f in traffic.json mfma_busy.json step_traffic.json; do [ -f gpurun_out/r05prof2/$f ] && cp gpurun_out/r05prof2/$f profiles/$f; done
+( time bash tools/gpu_r05_final.sh r05final2 ) 2>&1 | tail -60

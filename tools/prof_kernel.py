@@ -105,7 +105,7 @@ if name.startswith('pool_flat'):     # flat pooling backward (csrc/k_pool3.h): p
     act_ = 'act' in name
     fns[name] = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
                                                     tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
-                                                    0.2 if act_ else 0.0, Tn, S, st()))
+                                                    0.2 if act_ else 0.0, Tn, S, 200, st()))
 fn = fns[name]
 for _ in range(2): fn()
 torch.cuda.synchronize()
