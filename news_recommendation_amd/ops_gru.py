@@ -116,15 +116,11 @@ class _GruFn(torch.autograd.Function):
         nbuf = lib.nr_gru_seq_buffers(B, Hd, N)                      # sized for the longest history, so that the shape does not change with T
         ht = _workspace('gru_h_t', (nbuf, _ceil(B, 16) * Hp), _BF16_AS_I16, dev, zero=True)
         _call('nr_tile_rows_bf16', lib.nr_tile_rows_bf16, _ptr(H_all[0]), B, Hp, _ptr(ht[0]), _stream())
+        # the whole recurrence from one C call (on MI355X: one persistent launch, csrc/k_gru_persist.h; elsewhere T step launches); a profile
+        # records it as ONE entry -- the per-step entry points remain for the kernel tests and tools/prof_gru.py
         ops.seq_launches['nr_gru_fwd_seq'] = T
-        if not ops.profiling('nr_gru_fwd_step'):        # one FFI crossing for the whole recurrence (per-step form: per-kernel profiling)
-            _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq_n, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht), nbuf,
-                  _ptr(H_all) if need_grad else None, _ptr(hf), _ptr(gates) if need_grad else None, B, N, Hd, T, _stream())
-        else:
-            for t in range(T):
-                _call('nr_gru_fwd_step', lib.nr_gru_fwd_step, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht[t % 2]),
-                      _ptr(H_all[t + 1]) if need_grad else None, _ptr(ht[(t + 1) % 2]), _ptr(hf[t % 2]), _ptr(hf[(t + 1) % 2]),
-                      _ptr(gates[t]) if need_grad else None, B, N, Hd, t, _stream())
+        _call('nr_gru_fwd_seq', lib.nr_gru_fwd_seq_n, _ptr(gi), _ptr(Whh_p), _ptr(bi), _ptr(bh), _ptr(lens_dev), _ptr(ht), nbuf,
+              _ptr(H_all) if need_grad else None, _ptr(hf), _ptr(gates) if need_grad else None, B, N, Hd, T, _stream())
         out = hf[T % 2][:, :Hd].contiguous()
         if need_grad:
             ctx.save_for_backward(Xb, H_all, gates, lens_dev, Wih_p, WhhT)
@@ -147,17 +143,9 @@ class _GruFn(torch.autograd.Function):
         carry = torch.empty(2, B, Hp, dtype=torch.float32, device=dev)
         nbuf = lib.nr_gru_seq_buffers(B, Hd, N)
         dght = _workspace('gru_dgh_t', (nbuf, _ceil(B, 16) * Kp), _BF16_AS_I16, dev, zero=True)   # step-to-step operand, tile order (see forward)
-        per_step = ops.profiling('nr_gru_bwd_step')
         ops.seq_launches['nr_gru_bwd_seq'] = T + 1
-        if not per_step:
-            _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq_n, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
-                  _ptr(dght), nbuf, _ptr(carry), B, N, Hd, T, _stream())
-        for i, t in enumerate(range(T - 1, -2, -1) if per_step else ()):
-            first = 1 if i == 0 else 0
-            _call('nr_gru_bwd_step', lib.nr_gru_bwd_step, _ptr(g) if first else None, None if first else _ptr(dght[(i + 1) % 2]),
-                  None if first else _ptr(carry[(i + 1) % 2]), _ptr(WhhT), _ptr(gates[t]) if t >= 0 else None, _ptr(H_all[t]) if t >= 0 else None,
-                  _ptr(lens_dev), _ptr(dgi) if t >= 0 else None, _ptr(dgh[t]) if t >= 0 else None, _ptr(dght[i % 2]) if t >= 0 else None,
-                  _ptr(carry[i % 2]), B, N, Hd, t, first, _stream())
+        _call('nr_gru_bwd_seq', lib.nr_gru_bwd_seq_n, _ptr(g), _ptr(WhhT), _ptr(gates), _ptr(H_all), _ptr(lens_dev), _ptr(dgi), _ptr(dgh),
+              _ptr(dght), nbuf, _ptr(carry), B, N, Hd, T, _stream())
         d_h0 = carry[T % 2][:, :Hd].contiguous() if has_h0 else None
         # the three time-independent products of the backward in the hand-written ring kernels (csrc/k_gemm.h): dX = dGi W_ih as an NT product
         # against W_ih^T (re-packed once per optimiser step, K padding zero), fp32 result in place of a bf16 one + conversion pass; the two

@@ -25,8 +25,10 @@ if "gather_roofline" in d:
 print("   kernels", dict(list(d["kernel_breakdown_us_per_step"].items())[:14]))
 PY
 }
-( time timeout 900 python bench.py > $O/bench_line_NRMS_small.json 2> $O/bench_line_NRMS_small.err ) 2>&1 | grep real; q $O/bench_line_NRMS_small.json
-timeout 900 python bench.py --model NAML --no-train-parity > $O/bench_line_NAML_small.json 2> $O/bench_line_NAML_small.err; q $O/bench_line_NAML_small.json
-timeout 1200 python bench.py --model LSTUR --shape large --no-train-parity > $O/bench_line_LSTUR_large.json 2> $O/bench_line_LSTUR_large.err; q $O/bench_line_LSTUR_large.json
-timeout 900 python bench.py --model LSTUR --no-train-parity --no-parity > $O/bench_line_LSTUR_small.json 2> $O/bench_line_LSTUR_small.err; q $O/bench_line_LSTUR_small.json
-timeout 900 python bench.py --shape large --no-train-parity --no-parity > $O/bench_line_NRMS_large.json 2> $O/bench_line_NRMS_large.err; q $O/bench_line_NRMS_large.json
+( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_NRMS_small.json 2> $O/bench_line_NRMS_small.err ) 2>&1 | grep real; q $O/bench_line_NRMS_small.json
+# the other workloads: timing + roofline legs only (their parity is the test suite's; the CPU baseline and the parity legs are on the default line)
+QUICK="--no-train-parity --no-parity --no-cpu-baseline"
+timeout 900 python bench.py --model NAML $QUICK > $O/bench_line_NAML_small.json 2> $O/bench_line_NAML_small.err; q $O/bench_line_NAML_small.json
+timeout 900 python bench.py --model LSTUR --shape large $QUICK > $O/bench_line_LSTUR_large.json 2> $O/bench_line_LSTUR_large.err; q $O/bench_line_LSTUR_large.json
+timeout 900 python bench.py --model LSTUR $QUICK > $O/bench_line_LSTUR_small.json 2> $O/bench_line_LSTUR_small.err; q $O/bench_line_LSTUR_small.json
+timeout 900 python bench.py --shape large $QUICK > $O/bench_line_NRMS_large.json 2> $O/bench_line_NRMS_large.err; q $O/bench_line_NRMS_large.json
