@@ -14,6 +14,7 @@ import torch
 from oracle import metrics
 from oracle.nrms_torch import OracleNRMS
 from oracle.naml_torch import OracleNAML, random_naml_params
+from oracle.lstur_torch import OracleLSTUR, random_lstur_params
 
 
 def make_task(num_words=6000, n_news=2500, steps=200, B=16, n_eval=1000, seed=0, beta=3.0, neg_k=2, num_clicked=50, title_len=20):
@@ -224,4 +225,114 @@ def oracle_eval_scores_naml(task, state):
     cands, ptr = task["eval_cands"], task["eval_ptr"]
     with torch.no_grad():
         nv, uv = _naml_vectors(m, task["news"], task["eval_hist"])
+        return np.concatenate([(nv[cands[ptr[i]:ptr[i + 1]]] @ uv[i]).numpy() for i in range(len(task["eval_hist"]))])
+
+
+# ---- LSTUR leg (src/model/LSTUR: title CNN + two category views, GRU over the click history initialised from a per-user row) -------------------
+LSTUR_ATTRS = ('title', 'category', 'subcategory')
+
+
+def _lstur(num_words, num_categories, num_users, p_drop, pm):
+    return OracleLSTUR(num_words, 300, num_categories, num_users, 300, 3, 200, p_drop, pm, 'ini')
+
+
+def _lstur_vectors(model, news, hist, users):
+    """news vectors of the whole table and user vectors of the histories (PADDED_NEWS = zero vector; lengths = real history lengths,
+    evaluate.py:203-233)."""
+    n_news = news['title'].shape[0]
+    tn = {k: torch.from_numpy(v) for k, v in news.items()}
+    nv = torch.cat([model.get_news_vector({k: v[i:i + 512] for k, v in tn.items()}) for i in range(0, n_news, 512)])
+    nvp = torch.cat([nv, torch.zeros(1, nv.shape[1])])
+    idx = torch.from_numpy(np.where(hist < 0, n_news, hist))
+    lengths = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))
+    ut = torch.from_numpy(users)
+    uv = torch.cat([model.get_user_vector(ut[i:i + 256], lengths[i:i + 256].clone(), nvp[idx[i:i + 256]]) for i in range(0, len(hist), 256)])
+    return nv, uv
+
+
+def make_task_lstur(num_words=6000, num_categories=40, num_users=300, n_news=2000, steps=100, B=16, n_eval=800, seed=0, beta=3.0, neg_k=2,
+                    num_clicked=50):
+    """The LSTUR counterpart of make_task_naml: a seeded OracleLSTUR teacher labels training impressions (clicked candidate ~ softmax(beta z),
+    put first) and eval impressions (Bernoulli); every impression has a user id (row 0 = the padding user is never drawn) and a history of
+    at least one click.  Batches are news indices; lstur_batch() turns one into attribute arrays + user ids + lengths."""
+    from news_recommendation_amd import synth
+    rng = np.random.default_rng(seed)
+    news = {'title': synth.news_titles(rng, n_news, 20, num_words),
+            'category': rng.integers(1, num_categories, size=n_news).astype(np.int64),
+            'subcategory': rng.integers(1, num_categories, size=n_news).astype(np.int64)}
+    teacher = _lstur(num_words, num_categories, num_users, 0.0, 0.0).eval()
+    teacher.load_state_dict(random_lstur_params(10_000 + seed, num_words, 300, num_categories, num_users, 300, 3, 200, 'ini', emb_std=0.5))
+    n_train = steps * B
+    cand = rng.integers(0, n_news, size=(n_train, 1 + neg_k))
+    hl = np.maximum(synth.history_lengths(rng, n_train, num_clicked), 1)
+    hist = rng.integers(0, n_news, size=(n_train, num_clicked))
+    hist[np.arange(num_clicked)[None, :] < (num_clicked - hl)[:, None]] = -1
+    users = rng.integers(1, num_users, size=n_train).astype(np.int64)
+    e_hist, e_cands, e_ptr = synth.eval_impressions(rng, n_news, n_eval, num_clicked)
+    for i in range(n_eval):                                  # at least one click per eval history too
+        if (e_hist[i] >= 0).sum() == 0:
+            e_hist[i, -1] = rng.integers(0, n_news)
+    e_users = rng.integers(1, num_users, size=n_eval).astype(np.int64)
+    with torch.no_grad():
+        nv, uv = _lstur_vectors(teacher, news, np.concatenate([hist, e_hist]), np.concatenate([users, e_users]))
+        z = torch.einsum('bcd,bd->bc', nv[torch.from_numpy(cand)], uv[:n_train]).numpy().astype(np.float64)
+        e_uv = uv[n_train:]
+        e_sc = np.concatenate([(nv[e_cands[e_ptr[i]:e_ptr[i + 1]]] @ e_uv[i]).numpy() for i in range(n_eval)])
+    z = (z - z.mean(1, keepdims=True)) / (z.std(1, keepdims=True) + 1e-9)
+    pr = np.exp(beta * z)
+    pr /= pr.sum(1, keepdims=True)
+    pick = (rng.random(n_train)[:, None] > np.cumsum(pr, axis=1)).sum(1).clip(max=neg_k)
+    first = cand[np.arange(n_train), pick].copy()
+    cand[np.arange(n_train), pick] = cand[:, 0]
+    cand[:, 0] = first
+    labels = synth.teacher_labels(np.random.default_rng(seed + 77), e_sc.astype(np.float64), e_ptr)
+    return {"news": news, "cand": cand.reshape(steps, B, 1 + neg_k), "hist": hist.reshape(steps, B, num_clicked), "users": users.reshape(steps, B),
+            "eval_hist": e_hist, "eval_cands": e_cands, "eval_ptr": e_ptr, "eval_users": e_users, "eval_labels": labels, "teacher_scores": e_sc,
+            "num_words": num_words, "num_categories": num_categories, "num_users": num_users, "steps": steps, "B": B}
+
+
+def lstur_batch(task, i):
+    """(candidates, history, user ids, history lengths) of training step i."""
+    cand = {k: _take(task["news"], k, task["cand"][i]) for k in LSTUR_ATTRS}
+    click = {k: _take(task["news"], k, task["hist"][i]) for k in LSTUR_ATTRS}
+    return cand, click, task["users"][i], (task["hist"][i] >= 0).sum(1).astype(np.int64)
+
+
+def init_state_lstur(num_words, num_categories, num_users, seed=1):
+    return random_lstur_params(20_000 + seed, num_words, 300, num_categories, num_users, 300, 3, 200, 'ini', emb_std=0.5)
+
+
+def train_oracle_lstur(task, state, lr=1e-3, p_drop=0.2, pm=0.5, torch_seed=0):
+    """The reference's training loop (src/train.py:127-128,183-233) on OracleLSTUR: dropout and whole-row user masking on, torch.optim.Adam."""
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthr))          # (see train_oracle)
+    try:
+        m = _lstur(task["num_words"], task["num_categories"], task["num_users"], p_drop, pm)
+        m.load_state_dict(state)
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=lr)
+        crit = torch.nn.CrossEntropyLoss()
+        torch.manual_seed(torch_seed)
+        target = torch.zeros(task["B"], dtype=torch.long)
+        lists = lambda d: [{k: torch.from_numpy(np.ascontiguousarray(v[:, j])) for k, v in d.items()} for j in range(d['title'].shape[1])]
+        losses = []
+        for i in range(task["steps"]):
+            cand, click, user, length = lstur_batch(task, i)
+            loss = crit(m(torch.from_numpy(user), torch.from_numpy(length), lists(cand), lists(click)), target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}, losses
+    finally:
+        torch.set_num_threads(nthr)
+
+
+def oracle_eval_scores_lstur(task, state):
+    m = _lstur(task["num_words"], task["num_categories"], task["num_users"], 0.0, 0.0)
+    m.load_state_dict(state)
+    m.eval()
+    cands, ptr = task["eval_cands"], task["eval_ptr"]
+    with torch.no_grad():
+        nv, uv = _lstur_vectors(m, task["news"], task["eval_hist"], task["eval_users"])
         return np.concatenate([(nv[cands[ptr[i]:ptr[i + 1]]] @ uv[i]).numpy() for i in range(len(task["eval_hist"]))])

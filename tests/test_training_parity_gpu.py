@@ -52,3 +52,22 @@ def test_naml_engine_and_oracle_train_to_the_same_auc():
     assert all(e["auc"] > r["auc_init"] + 0.6 * gain for e in r["engine"]), r      # ... and so does the engine, on both dropout seeds
     assert r["abs_diff_auc"] < r["tolerance_auc"] <= 3e-2, r
     assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.1, r
+
+
+def test_lstur_engine_and_oracle_train_to_the_same_auc():
+    """The LSTUR leg: 100 steps with dropout and user masking on from the same initial weights (oracle/train_parity.py make_task_lstur /
+    train_oracle_lstur); the engine runs its persistent GRU sweeps and the row-sparse lazy Adam of the user table."""
+    import bench
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    r = bench.train_parity_lstur(dev, steps=100, B=16)
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, 'train_parity_lstur.json'), 'w') as f:
+            json.dump(r, f, indent=1)
+    assert r["auc_init"] < 0.56, r                                      # starts at chance
+    gain = r["oracle"]["auc"] - r["auc_init"]
+    assert gain > 0.08, r                                               # the reference's loop learns the task ...
+    assert all(e["auc"] > r["auc_init"] + 0.6 * gain for e in r["engine"]), r      # ... and so does the engine, on both seeds
+    assert r["abs_diff_auc"] < r["tolerance_auc"] <= 6e-2, r
