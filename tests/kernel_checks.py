@@ -346,12 +346,33 @@ def check_bad_args(be):
 # ---------------------------------------------------------------------------------------------------
 # backward kernels
 # ---------------------------------------------------------------------------------------------------
-def close_bf16(got, ref, what, rel=2.0 ** -6, floor=6e-3):
+def _note_kernel_err(what, rms, worst):
+    """Measured errors of a GPU run go to gpurun_out/measured_kernel_err.jsonl (the source of the rms bounds below; profiles/r05_measured_kernel_err.txt)."""
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir) and os.environ.get('NR_NOTE_KERNEL_ERR', '1') == '1':
+        try:
+            with open(os.path.join(out_dir, 'measured_kernel_err.jsonl'), 'a') as f:
+                f.write(json.dumps({"what": what, "rms_rel": rms, "max_over_scale": worst}) + "\n")
+        except OSError:
+            pass
+
+
+def close_bf16(got, ref, what, rel=2.0 ** -6, floor=6e-3, rms_max=5e-3):
+    """Element by element: |err| <= rel |ref| + floor * max|ref| (a bf16 result of bf16-operand arithmetic); AND in aggregate: the rms error is at
+    most rms_max of the rms of the reference -- the element bound alone would let a kernel drop one k-step of one tile in thirty (every element
+    still inside its floor); the aggregate moves by an order of magnitude when that happens.  Measured on MI355X (profiles/r05_measured_kernel_err.txt):
+    1.65e-3 - 1.71e-3 for single-product kernels (the bf16 rounding of the result), 1.8e-3 - 2.4e-3 for the attention backward (P and dS are bf16
+    operands of its second products: its callers pass 7.5e-3); the defaults are ~3x those."""
     got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
     err = np.abs(got - ref)
     scale = np.abs(ref).max() + 1e-30
     bad = err > rel * np.abs(ref) + floor * scale
     assert not bad.any(), f'{what}: {bad.sum()}/{bad.size} off, max err {err.max():.4g}, scale {scale:.4g}'
+    rms = float(np.sqrt((err ** 2).mean()) / (np.sqrt((ref ** 2).mean()) + 1e-30))
+    _note_kernel_err(what, rms, float(err.max() / scale))
+    assert rms <= rms_max, f'{what}: rms error {rms:.3g} of the reference rms (bound {rms_max:.3g})'
     return err.max() / scale
 
 
@@ -413,7 +434,7 @@ def check_attn_bwd(be, S=20, n_seq=5, p_drop=0.0, seed=77, with_key_len=False, l
     rels = []
     for i, (name, ref) in enumerate((('dQ', dq), ('dK', dkk), ('dV', dv))):
         got = bf16_to_f32(out[:, i * NR_KP:i * NR_KP + NR_D])
-        rels.append(close_bf16(got, mg(ref), f'attn_bwd {name} S={S}'))
+        rels.append(close_bf16(got, mg(ref), f'attn_bwd {name} S={S}', rms_max=7.5e-3))
         assert not out[:, i * NR_KP + NR_D:(i + 1) * NR_KP].any()
     return rels
 

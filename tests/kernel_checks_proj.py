@@ -378,6 +378,6 @@ def check_attn_bwd_hm_oracle(be, n_seq=7, p_drop=0.0, seed=78, with_key_len=Fals
         mg = lambda t: t.transpose(0, 2, 1, 3).reshape(n * S, NR_D)
         for i, (name, ref) in enumerate((('dQ', dq), ('dK', dkk), ('dV', dv))):
             blk = out[lo * S:hi * S, i * NR_KP:(i + 1) * NR_KP]
-            worst[i] = max(worst[i], kc.close_bf16(bf16_to_f32(blk[:, :NR_D]), mg(ref), f'attn_bwd_hm {name} seqs {lo}..{hi}'))
+            worst[i] = max(worst[i], kc.close_bf16(bf16_to_f32(blk[:, :NR_D]), mg(ref), f'attn_bwd_hm {name} seqs {lo}..{hi}', rms_max=7.5e-3))
             assert not blk[:, NR_D:].any()
     return worst
