@@ -306,9 +306,31 @@ int nr_debug_pool3_stamps(uint64_t* buf);
 /* Probe of the XCD-local phase barrier (csrc/k_xcd.h; tools/xcd_probe.py): 256 workgroups, `phases` write / barrier / read-back rounds.
  * sync_words: 32 uint32 (zeroed by the call); rec: 8 * 32 * 512 uint32; out: 768 uint32 (stale words per workgroup, XCC ids, slots). */
 int nr_debug_xcd_probe(uint32_t* sync_words, uint32_t* rec, uint32_t* out, int phases, void* stream);
-/* Error words of the last persistent GRU sweeps (csrc/k_gru_persist.h; nr_gru_fwd_seq / nr_gru_bwd_seq take that form on a 256-CU device for
- * Hd = 900 / 450 and B <= 512 unless NR_GRU_PERSIST=0): 0 clean, 1 a workgroup found its XCD's team full, 2 a bounded wait gave up -- the
- * sweep's outputs are then invalid.  SYNCHRONISES the device (not for use inside a stream capture). */
+/* Fault words of the persistent GRU sweeps (csrc/k_gru_persist.h, csrc/k_xcd.h; nr_gru_fwd_seq / nr_gru_bwd_seq take that form on a 256-CU
+ * device for Hd = 900 / 450 and B <= 512 unless NR_GRU_PERSIST=0).  A sweep whose XCD-local wait gives up (or whose team comes out wrong)
+ * produces garbage; the reference's nn.GRU (src/model/LSTUR/user_encoder.py:30-37) has no such failure mode, so the engine guarantees that
+ * such a sweep is never TRAINED on: four uint32 words in device memory --
+ *   [0] / [1]  STICKY error bits of the forward / backward sweeps since the last clear (bit 0: a workgroup found its XCD's team full, bit 1: a
+ *              bounded wait gave up); no launch clears them (the per-launch error word of round 5 was erased by the next sweep);
+ *   [2]        index of the first optimiser step that was SKIPPED because of them (0: none);
+ *   [3]        spare --
+ * and while [0] | [1] != 0 every optimiser kernel (nr_adam_flat, nr_row_adam_step, nr_row_adam_catchup) applies NO update (nr_adam_flat still
+ * clears the gradient when asked to): parameters and moments stay as of the last good step until the host has looked.  The host then repeats
+ * the steps from [2] on with NR_GRU_PERSIST=0 (news_recommendation_amd/train_fast.py) after nr_fault_clear().
+ *   nr_set_fault_words   attach four caller-owned, zero-initialised device words (NULL: back to the library's own block) -- a data-parallel
+ *                        trainer all-reduces (max) them before the optimiser kernels so that every rank skips the same steps;
+ *   nr_fault_state       copies the four words to out4 (HOST memory); SYNCHRONISES the device (never inside a stream capture);
+ *   nr_fault_clear       zeroes them; SYNCHRONISES;
+ *   nr_gru_persist_status  words [0] and [1] (kept from round 5: now sticky);
+ *   nr_debug_gru_fault   test knob: the nth next persistent sweep of kind `which` (0 forward, 1 backward) is launched with workgroup 0 never
+ *                        arriving at a barrier and a short spin limit, so that the give-up path runs for real (0: off). */
+int nr_set_fault_words(uint32_t* words);
+int nr_fault_state(uint32_t* out4);
+int nr_fault_clear(void);
+int nr_debug_gru_fault(int which, int nth);
+/* Which sweeps of a [B] x T recurrence with hidden size Hd take the persistent form on the current device under the current NR_GRU_PERSIST: bit 0
+ * forward, bit 1 backward; 0 = the step-per-launch kernels (any other device, shape or NR_GRU_PERSIST=0). */
+int nr_gru_persist_enabled(int B, int Hd, int T);
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd);
 /* debug: constant-clock (100 MHz) stamps of the persistent forward sweep, [256 workgroups][T][8 waves][8] int64 (null = off) */
 int nr_debug_gru_stamps(int64_t* buf);

@@ -43,6 +43,11 @@ SIGNATURES = {
     'nr_debug_attnb_stamps': ([_P], c_int),
     'nr_debug_xcd_probe': ([_P, _P, _P, c_int, _P], c_int),
     'nr_gru_persist_status': ([_P, _P], c_int),
+    'nr_set_fault_words': ([_P], c_int),
+    'nr_fault_state': ([_P], c_int),
+    'nr_fault_clear': ([], c_int),
+    'nr_debug_gru_fault': ([c_int, c_int], c_int),
+    'nr_gru_persist_enabled': ([c_int, c_int, c_int], c_int),
     'nr_debug_gru_stamps': ([_P], c_int),
     'nr_debug_gru_stamps_bwd': ([_P], c_int),
     'nr_additive_bwd_flat': ([_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_float, c_int64, c_int, c_int, _P], c_int),

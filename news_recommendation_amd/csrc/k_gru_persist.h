@@ -14,7 +14,9 @@
 //   * per step a workgroup copies its XCD's 64 state rows (4 sample tiles x 29 KB, tile order, contiguous) into LDS, six waves multiply,
 //     accumulators meet in LDS, all eight waves do the gate arithmetic of one (unit tile, sample tile) each and store.
 // Placement is never assumed: workgroups join the team of the XCC they find themselves on (k_xcd.h); teams that do not come out at exactly 32
-// raise the error word, every wait is bounded, and the host falls back to the step kernels.
+// raise the error word, every wait is bounded.  A failed sweep's outputs are garbage; nothing falls back by itself: the failure is recorded in
+// the process's STICKY fault words, the optimiser kernels skip every step from then on (k_optim.h), and the trainer repeats those steps on the
+// step kernels after its next look (news_recommendation_amd/train_fast.py; include/nr_engine.h "Fault words").
 #pragma once
 #include "nr_common.h"
 #include "k_gru.h"

@@ -25,6 +25,11 @@ struct AdamCfg {
   const uint32_t* t_dev; // optional device-resident step counter (nr_set_step_counter): the dense kernel and the row-sparse step / catch-up
                         // kernels then take their step index from it instead of their by-value argument, so that a step captured into a
                         // HIP graph advances at every replay (the flush kernel is never part of a step and keeps its argument)
+  const uint32_t* gate; // optional fault words of the process (nr_set_fault_words / the library's own): while word 0 or 1 is non-zero -- a
+                        // persistent GRU sweep gave up a wait, its outputs and every gradient of that step are garbage -- NO update is
+                        // applied: the dense kernel only clears the gradient, the row-sparse step and catch-up leave.  The first skipped step
+                        // index is recorded in word 2 (the host repeats the steps from there: train_fast.py).  The flush kernel (never part
+                        // of a step) is not gated.
   const float* sched;   // [2 * (max_step + 1)]
   float om_b1;          // 1 - beta1
   float b2, om_b2;      // beta2, 1 - beta2
@@ -52,6 +57,15 @@ __device__ __forceinline__ void adam_elem_idle(float& p, float& m, float& v, flo
   p = p - step_size * (m / denom);
 }
 
+// true = skip this optimiser step (see AdamCfg::gate); one thread of the launch records the step index of the first skipped step
+__device__ __forceinline__ bool adam_gated(const AdamCfg& c, int64_t step) {
+  if (c.gate == nullptr) return false;
+  uint32_t* gw = const_cast<uint32_t*>(c.gate);
+  if ((ld_relaxed_u32(gw) | ld_relaxed_u32(gw + 1)) == 0u) return false;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomic_cas_u32(gw + 2, 0u, (uint32_t)step);
+  return true;
+}
+
 __global__ __launch_bounds__(64) void step_counter_add_kernel(uint32_t* ctr, uint32_t inc) {
   if (threadIdx.x == 0) *ctr += inc;
 }
@@ -60,9 +74,17 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
                                                         float* __restrict__ v, int64_t n, AdamCfg c, int64_t step, float grad_scale,
                                                         int zero_grad) {
   if (c.t_dev != nullptr) step = (int64_t)*c.t_dev;
-  const float step_size = c.sched[2 * step], bc2_sqrt = c.sched[2 * step + 1];
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (adam_gated(c, step)) {               // a failed sweep upstream: the gradients are garbage -- drop them, move nothing
+    if (zero_grad) {
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) *(f32x4*)(g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int64_t tt = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (tt < n) g[tt] = 0.0f;
+    }
+    return;
+  }
+  const float step_size = c.sched[2 * step], bc2_sqrt = c.sched[2 * step + 1];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 pp = *(f32x4*)(p + i * 4), gg = *(const f32x4*)(g + i * 4), mm = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
 #pragma unroll
@@ -125,6 +147,7 @@ __global__ __launch_bounds__(256) void row_adam_catchup_kernel(const int64_t* __
   // with a device step counter attached (HIP-graph replays, graph.py) the counter was bumped at the START of the step this launch belongs
   // to: the steps taken so far are one less
   if (c.t_dev != nullptr) upto = (int64_t)*c.t_dev - 1;
+  if (adam_gated(c, upto + 1)) return;      // (the rows stay as of the last good step: the repeated steps catch them up again)
   const int64_t i = (int64_t)blockIdx.x * 4 + wave_id();
   if (i >= n || upto <= 0) return;
   const int l = lane_id();
@@ -170,6 +193,7 @@ __global__ __launch_bounds__(256) void row_adam_step_kernel(const int64_t* __res
                                                             int64_t num_rows, int d, int64_t step, AdamCfg c, float grad_scale,
                                                             int pad_row) {
   if (c.t_dev != nullptr) step = (int64_t)*c.t_dev;             // as in adam_flat_kernel: the step index of a replayed graph comes from the counter
+  if (adam_gated(c, step)) return;
   const int64_t a = (int64_t)blockIdx.x * 4 + wave_id();
   if (a >= n) return;
   const int l = lane_id();

@@ -8,8 +8,11 @@
 //
 // Nothing here relies on WHICH XCD a workgroup lands on: a workgroup reads its own XCC id from the hardware register and joins that XCD's
 // team (a ticket from that XCD's counter); a team must come out complete (NR_XCD_TEAM workgroups, checked: an incomplete or overfull team
-// raises the error word and every wait gives up) -- the kernel's result is then garbage and the host falls back, it never hangs and never
-// silently mixes data across L2s.  Every spin is bounded.
+// raises the error word and every wait gives up) -- the kernel's result is then garbage; it never hangs and never silently mixes data across
+// L2s.  Every spin is bounded.  What happens to the garbage: besides the per-launch error word (zeroed with the team words before every launch)
+// a failure ORs its code into a STICKY word that no launch clears (XcdSync::sticky; the process's fault words, nr_set_fault_words), and the
+// optimiser kernels are gated on those words (k_optim.h): from the failed sweep on, no Adam update is applied until the host has looked
+// (nr_fault_state), repeated the step on the step-per-launch kernels and cleared the words (train_fast.py).  Nothing falls back by itself.
 #pragma once
 #include "nr_common.h"
 
@@ -18,11 +21,20 @@ namespace nr {
 constexpr int NR_XCDS = 8;
 constexpr int NR_XCD_TEAM = 32;          // CUs (= resident workgroups of a one-per-CU grid) per XCD
 constexpr uint32_t NR_XCD_SPIN_LIMIT = 1u << 22;      // polls (with s_sleep) before a wait gives up: ~1 s
+constexpr uint32_t NR_XCD_SPIN_LIMIT_FAULT = 1u << 12; // ... of a launch with an injected fault (nr_debug_gru_fault): the test need not wait a second per barrier
 
 // state words of one launch (zeroed by the launcher with a memset node before the kernel): [0..7] tickets, [8..15] arrival counters, [16] error
 struct XcdSync {
   unsigned int* w;
+  unsigned int* sticky;    // one word OUTSIDE the per-launch block: every error code is ORed into it as well and stays until the host clears it
+                           // (nr_fault_clear); null in the probe
+  int fault;               // debug (nr_debug_gru_fault): workgroup 0 never arrives at a barrier, its team mates' waits give up after a short spin
 };
+
+__device__ __forceinline__ void xcd_raise(XcdSync s, unsigned code) {
+  __hip_atomic_fetch_or(s.w + 16, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // OR: a later code does not erase an earlier one
+  if (s.sticky != nullptr) __hip_atomic_fetch_or(s.sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ int xcc_id() {
 #ifdef NR_EMU
@@ -37,7 +49,7 @@ __device__ __forceinline__ int xcc_id() {
 __device__ __forceinline__ int xcd_join(XcdSync s, int xcd, int* bcast) {
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(s.w + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t >= (unsigned)NR_XCD_TEAM) __hip_atomic_store(s.w + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t >= (unsigned)NR_XCD_TEAM) xcd_raise(s, 1u);
     *bcast = t < (unsigned)NR_XCD_TEAM ? (int)t : -1;
   }
   __syncthreads();
@@ -51,14 +63,15 @@ __device__ __forceinline__ int xcd_join(XcdSync s, int xcd, int* bcast) {
 __device__ __forceinline__ bool xcd_barrier(XcdSync s, int xcd, unsigned phase) {
   __syncthreads();
   bool ok = true;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !(s.fault != 0 && blockIdx.x == 0)) {
     __hip_atomic_fetch_add(s.w + 8 + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned want = phase * (unsigned)NR_XCD_TEAM;
+    const uint32_t limit = s.fault != 0 ? NR_XCD_SPIN_LIMIT_FAULT : NR_XCD_SPIN_LIMIT;
     uint32_t spins = 0;
     while (__hip_atomic_load(s.w + 8 + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > NR_XCD_SPIN_LIMIT || (spins & 1023u) == 0 && __hip_atomic_load(s.w + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        __hip_atomic_store(s.w + 16, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > limit || (spins & 1023u) == 0 && __hip_atomic_load(s.w + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        xcd_raise(s, 2u);
         ok = false;
         break;
       }

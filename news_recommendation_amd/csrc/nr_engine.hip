@@ -965,19 +965,41 @@ int nr_gru_bwd_step(const float* g_last, const uint16_t* dgh_next, const float* 
 int nr_debug_xcd_probe(uint32_t* sync_words, uint32_t* rec, uint32_t* out, int phases, void* stream) {
   if (!sync_words || !rec || !out || phases < 1 || phases > 1000) return fail(NR_ERR_BADARG, "nr_debug_xcd_probe: bad argument");
   if (hipMemsetAsync(sync_words, 0, 32 * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_debug_xcd_probe: memset");
-  nr::XcdSync s{sync_words};
+  nr::XcdSync s{sync_words, nullptr, 0};
   NR_LAUNCH(nr::xcd_probe_kernel, nr::NR_XCDS * nr::NR_XCD_TEAM, 512, 0, (hipStream_t)stream, s, rec, out, phases);
   return check_launch("nr_debug_xcd_probe");
 }
 
 // ---- persistent sweeps (csrc/k_gru_persist.h): one launch per sweep, state exchanged inside each XCD ---------------------------------------
 // The team words of the two sweeps (forward / backward) live in the module: at most ONE forward and ONE backward sweep of a process may be in
-// flight at a time (they are stream-ordered in every caller of this library).
+// flight at a time (they are stream-ordered in every caller of this library).  Resolved per DEVICE (a module global has one address per device).
 __device__ unsigned int g_xcd_words[2][32];
+// Fault words of the process (include/nr_engine.h, nr_set_fault_words): [0] / [1] sticky error bits of the forward / backward sweeps, [2] the
+// step index of the first optimiser step that was skipped because of them, [3] spare.  The library's own block unless the caller attached one.
+__device__ unsigned int g_fault_default[4];
+static unsigned int* g_fault_user = nullptr;
+static unsigned int* device_symbol(int which) {            // 0: g_xcd_words, 1: g_fault_default -- cached per device
+  static unsigned int* cache[2][64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (cache[which][dev] == nullptr) {
+    unsigned int* base = nullptr;
+    const hipError_t e = which == 0 ? hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_xcd_words)) : hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_fault_default));
+    if (e != hipSuccess) return nullptr;
+    cache[which][dev] = base;
+  }
+  return cache[which][dev];
+}
 static unsigned int* xcd_words(int which) {
-  static unsigned int* base = nullptr;
-  if (base == nullptr && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_xcd_words)) != hipSuccess) base = nullptr;
+  unsigned int* base = device_symbol(0);
   return base ? base + which * 32 : nullptr;
+}
+static unsigned int* fault_words() { return g_fault_user != nullptr ? g_fault_user : device_symbol(1); }
+// debug (nr_debug_gru_fault): countdown of persistent sweeps of each kind until one is launched with an injected fault (0 = off)
+static int g_gru_fault_countdown[2] = {0, 0};
+static int take_fault(int which) {
+  if (g_gru_fault_countdown[which] <= 0) return 0;
+  return --g_gru_fault_countdown[which] == 0 ? 1 : 0;
 }
 static long long* g_gru_stamps = nullptr;
 static long long* g_gru_stamps_bwd = nullptr;
@@ -997,10 +1019,11 @@ static int gru_fwd_persist_launch(const float* gi, const uint16_t* Whh, const fl
                                   uint16_t* H_all, float* h_f2, uint16_t* gates, int B, int N, int Hd, int T, void* stream) {
   if (!gi || !Whh || !b_ih || !b_hh || !len) return fail(NR_ERR_BADARG, "nr_gru_fwd_seq: bad argument");
   unsigned int* words = xcd_words(0);
-  if (words == nullptr) return NR_ERR_UNSUPPORTED;
+  unsigned int* fw = fault_words();
+  if (words == nullptr || fw == nullptr) return NR_ERR_UNSUPPORTED;
   nr::GruSeqFwdParams p;
   p.gi = gi; p.Whh = Whh; p.b_ih = b_ih; p.b_hh = b_hh; p.len = len; p.h_t2 = h_t2; p.H_all = H_all; p.h_f2 = h_f2; p.gates = gates;
-  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.T = T; p.sync = nr::XcdSync{words}; p.stamps = g_gru_stamps;
+  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.T = T; p.sync = nr::XcdSync{words, fw, take_fault(0)}; p.stamps = g_gru_stamps;
   if (hipMemsetAsync(words, 0, 32 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_fwd_seq: memset");
   const int grid = nr::NR_XCDS * nr::NR_XCD_TEAM;
   if (p.Hp == 29 * 32) {
@@ -1019,10 +1042,11 @@ static int gru_bwd_persist_launch(const float* g_last, const uint16_t* WhhT, con
                                   uint16_t* dgh, uint16_t* dgh_t2, float* carry2, int B, int N, int Hd, int T, void* stream) {
   if (!WhhT || !len) return fail(NR_ERR_BADARG, "nr_gru_bwd_seq: bad argument");
   unsigned int* words = xcd_words(1);
-  if (words == nullptr) return NR_ERR_UNSUPPORTED;
+  unsigned int* fw = fault_words();
+  if (words == nullptr || fw == nullptr) return NR_ERR_UNSUPPORTED;
   nr::GruSeqBwdParams p;
   p.g_last = g_last; p.WhhT = WhhT; p.gates = gates; p.H_all = H_all; p.len = len; p.dgi = dgi; p.dgh = dgh; p.dgh_t2 = dgh_t2; p.carry2 = carry2;
-  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.Kp = ceil_to(3 * p.Hg, 32); p.T = T; p.sync = nr::XcdSync{words}; p.stamps = g_gru_stamps_bwd;
+  p.B = B; p.N = N; p.Hd = Hd; p.Hg = ceil_to(Hd, 16); p.Hp = ceil_to(Hd + 1, 32); p.Kp = ceil_to(3 * p.Hg, 32); p.T = T; p.sync = nr::XcdSync{words, fw ? fw + 1 : nullptr, take_fault(1)}; p.stamps = g_gru_stamps_bwd;
   if (hipMemsetAsync(words, 0, 32 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_bwd_seq: memset");
   const int grid = nr::NR_XCDS * nr::NR_XCD_TEAM;
   if (p.Kp == 86 * 32) {
@@ -1039,18 +1063,39 @@ static int gru_bwd_persist_launch(const float* g_last, const uint16_t* WhhT, con
   return check_launch("nr_gru_bwd_seq");
 }
 
-// error word of the last persistent sweeps (0 = clean; 1 = a workgroup found its XCD's team full; 2 = a wait gave up): SYNCHRONISES the device.
-// A non-zero word means the sweep's outputs are garbage: callers re-run with NR_GRU_PERSIST=0 (bench.py and the tests check it after every run).
+// STICKY error bits of the persistent sweeps since the last nr_fault_clear (0 = clean; bit 0 = a workgroup found its XCD's team full; bit 1 = a
+// wait gave up): SYNCHRONISES the device.  Non-zero means: the outputs of that sweep were garbage, and every optimiser step from that one on
+// was skipped (k_optim.h) -- the caller repeats them with NR_GRU_PERSIST=0 after nr_fault_clear (train_fast.py does).
+int nr_fault_state(uint32_t* out4) {
+  if (!out4) return fail(NR_ERR_BADARG, "nr_fault_state: null pointer");
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  unsigned int* fw = fault_words();
+  if (fw == nullptr) return NR_OK;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_fault_state: device error");
+  if (hipMemcpy(out4, fw, 16, hipMemcpyDeviceToHost) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_fault_state: copy");
+  return NR_OK;
+}
+int nr_fault_clear(void) {
+  unsigned int* fw = fault_words();
+  if (fw == nullptr) return NR_OK;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemset(fw, 0, 16) != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_fault_clear: device error");
+  return NR_OK;
+}
+int nr_set_fault_words(uint32_t* words) {
+  g_fault_user = (unsigned int*)words;
+  return NR_OK;
+}
+int nr_debug_gru_fault(int which, int nth) {
+  if (which < 0 || which > 1 || nth < 0) return fail(NR_ERR_BADARG, "nr_debug_gru_fault: bad argument");
+  g_gru_fault_countdown[which] = nth;
+  return NR_OK;
+}
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
-  unsigned int* w0 = xcd_words(0);
-  unsigned int h[2] = {0, 0};
-  if (w0 != nullptr) {
-    if (hipDeviceSynchronize() != hipSuccess) return fail(NR_ERR_LAUNCH, "nr_gru_persist_status: device error");
-    if (hipMemcpy(&h[0], w0 + 16, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&h[1], w0 + 32 + 16, 4, hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(NR_ERR_LAUNCH, "nr_gru_persist_status: copy");
-  }
-  if (fwd) *fwd = (int32_t)h[0];
-  if (bwd) *bwd = (int32_t)h[1];
+  uint32_t w[4];
+  const int rc = nr_fault_state(w);
+  if (rc != NR_OK) return rc;
+  if (fwd) *fwd = (int32_t)w[0];
+  if (bwd) *bwd = (int32_t)w[1];
   return NR_OK;
 }
 #else       // emulator build: the step-per-launch form only
@@ -1063,12 +1108,29 @@ static int gru_fwd_persist_launch(const float*, const uint16_t*, const float*, c
                                   int, void*) { return NR_ERR_UNSUPPORTED; }
 static int gru_bwd_persist_launch(const float*, const uint16_t*, const uint16_t*, const uint16_t*, const int32_t*, uint16_t*, uint16_t*, uint16_t*, float*, int,
                                   int, int, int, void*) { return NR_ERR_UNSUPPORTED; }
+// fault words in the emulator build: host memory (the optimiser gate of k_optim.h is exercised by the CPU tests through nr_set_fault_words)
+static unsigned int g_fault_default[4];
+static unsigned int* g_fault_user = nullptr;
+static unsigned int* fault_words() { return g_fault_user != nullptr ? g_fault_user : g_fault_default; }
+int nr_fault_state(uint32_t* out4) {
+  if (!out4) return fail(NR_ERR_BADARG, "nr_fault_state: null pointer");
+  for (int i = 0; i < 4; ++i) out4[i] = fault_words()[i];
+  return NR_OK;
+}
+int nr_fault_clear(void) {
+  for (int i = 0; i < 4; ++i) fault_words()[i] = 0;
+  return NR_OK;
+}
+int nr_set_fault_words(uint32_t* words) { g_fault_user = (unsigned int*)words; return NR_OK; }
+int nr_debug_gru_fault(int, int) { return fail(NR_ERR_UNSUPPORTED, "nr_debug_gru_fault: not in the emulator build"); }
 int nr_gru_persist_status(int32_t* fwd, int32_t* bwd) {
-  if (fwd) *fwd = 0;
-  if (bwd) *bwd = 0;
+  if (fwd) *fwd = (int32_t)fault_words()[0];
+  if (bwd) *bwd = (int32_t)fault_words()[1];
   return NR_OK;
 }
 #endif
+
+int nr_gru_persist_enabled(int B, int Hd, int T) { return gru_persist_ok(B, Hd, T) ? gru_persist_knob() : 0; }
 
 int nr_gru_seq_buffers(int B, int Hd, int T) { (void)B; (void)Hd; (void)T; return 2; }      // a ping-pong pair (the per-step buffers of the removed persistent form are gone)
 
@@ -1170,6 +1232,7 @@ int nr_impression_metrics(const float* scores, const int32_t* labels, const int6
 static nr::AdamCfg make_adam(const float* sched, double beta1, double beta2, double eps) {
   nr::AdamCfg c;
   c.t_dev = nullptr;
+  c.gate = fault_words();                 // the optimiser never applies a step computed from a failed persistent sweep (k_optim.h)
   c.sched = sched; c.om_b1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.om_b2 = (float)(1.0 - beta2); c.eps = (float)eps;
   return c;
 }

@@ -169,6 +169,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ int atomic_exch(int* p, int v) { return atomicExch(p, v); }
 __device__ __forceinline__ int atomic_add_i32(int* p, int v) { return atomicAdd(p, v); }
+// a word other kernels / the host change behind this kernel's back (fault words): read from the L2, compare-and-swap there
+__device__ __forceinline__ uint32_t ld_relaxed_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void atomic_cas_u32(uint32_t* p, uint32_t expect, uint32_t v) { atomicCAS(p, expect, v); }
 // a value the program knows to be identical in all lanes, as a scalar (see wave_id())
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // 64-bit mask of the lanes whose predicate is true

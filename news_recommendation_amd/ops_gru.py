@@ -161,20 +161,34 @@ class _GruFn(torch.autograd.Function):
 
 
 def persist_status():
-    """(forward, backward) error words of the last persistent GRU sweeps (csrc/k_gru_persist.h; nr_gru_persist_status): 0 = clean.  SYNCHRONISES
-    the device -- call it where the host waits anyway (end of a timed region, an epoch, a test), never inside a stream capture."""
+    """(forward, backward) STICKY error bits of the persistent GRU sweeps since the last fault_clear() (csrc/k_gru_persist.h; nr_gru_persist_status):
+    0 = clean.  SYNCHRONISES the device -- call it where the host waits anyway (end of a timed region, a logging step, a test), never inside a
+    stream capture."""
     f, b = ctypes.c_int32(0), ctypes.c_int32(0)
     _call('nr_gru_persist_status', _lib().nr_gru_persist_status, ctypes.byref(f), ctypes.byref(b))
     return f.value, b.value
 
 
+def fault_state():
+    """The four fault words of the process (include/nr_engine.h): (forward bits, backward bits, first skipped optimiser step, spare).  While the
+    first two are non-zero the optimiser kernels apply no update.  SYNCHRONISES."""
+    w = (ctypes.c_uint32 * 4)()
+    _call('nr_fault_state', _lib().nr_fault_state, w)
+    return tuple(int(x) for x in w)
+
+
+def fault_clear():
+    _call('nr_fault_clear', _lib().nr_fault_clear)
+
+
 def persist_check():
-    """Raises when a persistent sweep since the last check gave up a wait or found its XCD team wrong: its outputs (and everything computed
-    from them) are invalid.  The step-per-launch form (NR_GRU_PERSIST=0) has no such failure mode."""
-    st = persist_status()
-    if st != (0, 0):
-        raise RuntimeError(f'persistent GRU sweep failed (error words forward / backward = {st}): results since the last check are invalid; '
-                           'run with NR_GRU_PERSIST=0')
+    """Raises when a persistent sweep since the last fault_clear() gave up a wait or found its XCD team wrong: its outputs were garbage, and
+    every optimiser step from that one on has been skipped (the parameters are those of the last good step).  Callers that can repeat steps
+    (train_fast.py) handle the words themselves; everybody else stops here.  The step-per-launch form (NR_GRU_PERSIST=0) has no such failure mode."""
+    st = fault_state()
+    if st[0] or st[1]:
+        raise RuntimeError(f'persistent GRU sweep failed (sticky error bits forward / backward = {st[:2]}, optimiser steps skipped from step {st[2]}): '
+                           'results since then are invalid; run with NR_GRU_PERSIST=0')
 
 
 def gru_last_state(x, h0, clicked_news_length, gru):

@@ -241,6 +241,53 @@ class EngineAdam:
     def _ck(self, rc):
         _capi.check(self.lib, rc)
 
+    # ---- fault words (include/nr_engine.h: nr_set_fault_words; csrc/k_xcd.h, k_optim.h) ------------------------------------------------------
+    fault_words = None
+
+    def attach_fault_words(self):
+        """Own the process's fault words (int32 [4] on the device): a persistent GRU sweep that gives up a wait sets sticky bits there and the
+        optimiser kernels skip every step from then on.  Under a process group the words are max-reduced before the update kernels of every
+        step, so that all ranks skip the SAME steps (a rank whose sweep failed has already poured garbage into the gradient exchange)."""
+        if self.fault_words is None:
+            self.fault_words = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self._ck(self.lib.nr_set_fault_words(self.fault_words.data_ptr()))
+        return self.fault_words
+
+    def detach_fault_words(self):
+        """The library goes back to its own block (call before the optimiser is dropped: the words are this object's memory)."""
+        if self.fault_words is not None:
+            self._ck(self.lib.nr_set_fault_words(None))
+            self.fault_words = None
+
+    def __del__(self):
+        try:
+            if self.fault_words is not None:
+                self.lib.nr_set_fault_words(None)
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _fault_exchange(self):
+        if self.fault_words is not None and self._dist_on() and not self.skip_comm:
+            return dist.all_reduce(self.fault_words, op=dist.ReduceOp.MAX, async_op=True)
+        return None
+
+    def rewind_after_fault(self):
+        """SYNCHRONISES.  None when no sweep failed since the last call.  Otherwise: the index s of the first optimiser step that was skipped
+        (parameters, moments and row stamps are those after step s - 1: the kernels applied nothing since); the optimiser's step count is set
+        back to s - 1, pending gradients are dropped and the words cleared -- the caller repeats its steps from s on (with NR_GRU_PERSIST=0).
+        Every rank of a process group gets the same answer."""
+        if self.fault_words is None:
+            return None
+        w = self.fault_words.tolist()
+        if not (w[0] or w[1]):
+            return None
+        s = int(w[2]) if w[2] else self.t + 1              # (no optimiser step has run since the failure: nothing to take back)
+        self.discard_grads()
+        self.t = s - 1
+        self.fault_words.zero_()
+        ops.invalidate_packed()
+        return s
+
     # ---- the optimiser interface -------------------------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
         """No-op in the steady state: ``step()`` clears the gradient buffer in the same pass that consumes it.  (Gradients of a backward
@@ -284,6 +331,9 @@ class EngineAdam:
                 if r.name != 'small' and r.work is None:
                     r.work = self._start_table_exchange(r)
             gathered = [self._exchange_rows(st) for st in self.sparse]
+            fw = self._fault_exchange()
+            if fw is not None:
+                fw.wait()
             for r in self.regions:
                 if r.name == 'small':
                     self.comm_bytes['small'] = (r.hi - r.lo) * 4
@@ -378,6 +428,9 @@ class EngineAdam:
             if r.name == 'small':
                 self.comm_bytes['small'] = (r.hi - r.lo) * 4
                 works.append(dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True))
+        fw = self._fault_exchange()
+        if fw is not None:
+            works.append(fw)
         for w in works:
             w.wait()
 

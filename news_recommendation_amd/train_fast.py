@@ -129,6 +129,20 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
     recent = torch.zeros(256, dtype=torch.float32, device=device)
     t0, seen = time.time(), 0
     val_plan = None
+    # LSTUR's persistent GRU sweeps can fail (a bounded XCD-local wait gives up: csrc/k_xcd.h).  The device never trains on such a sweep -- sticky
+    # fault words gate every optimiser kernel from the failed step on (csrc/k_optim.h) -- and the host, at its next look (the steps that print or
+    # validate synchronise anyway), repeats the skipped steps on the step-per-launch kernels: `window` keeps their batches until then.
+    guard = model_name == 'LSTUR'
+    if guard:
+        optimizer.attach_fault_words()
+    window = []                           # (iteration, optimiser step index, batch) since the last look
+
+    def train_step(b):
+        loss = criterion(forward_batch(model, b), target)
+        loss.backward()                   # table all-reduce starts inside; gradients accumulate into the optimiser's flat buffer
+        optimizer.step()                  # remaining exchange + fused Adam (clears the gradients: no zero_grad pass)
+        return loss.detach()
+
     for i in range(1, n_iter + 1):
         try:
             b = next(it)
@@ -136,17 +150,30 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
             it = data.batches(per_rank_batch)
             b = next(it)
         step += 1
-        loss = criterion(forward_batch(model, b), target)
-        loss.backward()                   # table all-reduce starts inside; gradients accumulate into the optimiser's flat buffer
-        optimizer.step()                  # remaining exchange + fused Adam (clears the gradients: no zero_grad pass)
-        ld = loss.detach()
-        loss_sum += ld
+        t_step = optimizer.t + 1
+        ld = train_step(b)
         recent[(i - 1) % 256] = ld
+        if guard:
+            window.append([i, t_step, b, ld])
+        else:
+            loss_sum += ld
         seen += per_rank_batch * world
+        look = i % config.num_batches_show_loss == 0 or i == n_iter or i % config.num_batches_validate == 0
+        if guard and look:
+            first = optimizer.rewind_after_fault()          # synchronises; every rank gets the same answer
+            if first is not None:
+                os.environ['NR_GRU_PERSIST'] = '0'          # read per call by the library: from here on one launch per GRU step
+                redo = [e for e in window if e[1] >= first]
+                if rank == 0:
+                    log(f"persistent GRU sweep failed at optimiser step {first}: that update and the {max(len(redo) - 1, 0)} after it were skipped "
+                        f"on the device; repeating {len(redo)} step(s) with NR_GRU_PERSIST=0")
+                for e in redo:
+                    e[3] = ld = train_step(e[2])
+                    recent[(e[0] - 1) % 256] = ld
+            if window:
+                loss_sum += torch.stack([e[3] for e in window]).double().sum()
+            window.clear()
         if i % config.num_batches_show_loss == 0 or i == n_iter:
-            if model_name == 'LSTUR':             # (the loss read below synchronises anyway) the persistent GRU sweeps since the last check were clean
-                from . import ops_gru
-                ops_gru.persist_check()
             if rank == 0:        # same three numbers as train.py:241-244: current, mean over all steps, mean over the latest 256
                 log(f"Time {time.strftime('%H:%M:%S', time.gmtime(time.time() - t0))}, batches {i}, current loss {float(ld):.4f}, "
                     f"average loss: {float(loss_sum) / i:.4f}, latest average loss: {float(recent[:min(i, 256)].mean()):.4f}, "
@@ -180,7 +207,9 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
             if flags[0] > 0:
                 break
     torch.cuda.synchronize()
-    return {'steps': i, 'impressions_per_s': seen / max(time.time() - t0, 1e-9), 'last_loss': float(loss.item()), 'model': model}
+    if guard:
+        optimizer.detach_fault_words()
+    return {'steps': i, 'impressions_per_s': seen / max(time.time() - t0, 1e-9), 'last_loss': float(ld.item()), 'model': model, 'optimizer_steps': optimizer.t}
 
 
 def main(argv=None):

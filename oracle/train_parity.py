@@ -54,6 +54,7 @@ def make_task(num_words=6000, n_news=2500, steps=200, B=16, n_eval=1000, seed=0,
     labels = synth.teacher_labels(np.random.default_rng(seed + 77), e_sc.astype(np.float64), e_ptr)
     cand_ids, click_ids = synth.batch_token_ids(titles, cand, hist)
     return {"titles": titles, "cand_ids": cand_ids.reshape(steps, B, 1 + neg_k, title_len), "click_ids": click_ids.reshape(steps, B, num_clicked, title_len),
+            "cand": cand.reshape(steps, B, 1 + neg_k), "hist": hist.reshape(steps, B, num_clicked),
             "eval_hist": e_hist, "eval_cands": e_cands, "eval_ptr": e_ptr, "eval_labels": labels, "teacher_scores": e_sc,
             "num_words": num_words, "steps": steps, "B": B}
 
@@ -336,3 +337,60 @@ def oracle_eval_scores_lstur(task, state):
     with torch.no_grad():
         nv, uv = _lstur_vectors(m, task["news"], task["eval_hist"], task["eval_users"])
         return np.concatenate([(nv[cands[ptr[i]:ptr[i + 1]]] @ uv[i]).numpy() for i in range(len(task["eval_hist"]))])
+
+
+# ---- committed fixtures of the statistical legs (tests/golden/train_parity/*.npz, written by oracle/make_golden_train_parity.py) ------------------
+# The task arrays (teacher-labelled batches as NEWS INDICES, the held-out eval set) + the results of the REAL reference trained on them.  The
+# teacher and the reference runs only exist in the build container; the GPU test rebuilds the task from these arrays, never from the teacher.
+_SCALARS = ("num_words", "num_categories", "num_users", "steps", "B")
+
+
+def task_to_arrays(task):
+    """Compact arrays of a make_task* result (ids as int32 / int16)."""
+    out = {}
+    news = task["news"] if "news" in task else {"title": task["titles"]}
+    for k, v in news.items():
+        out[f"news_{k}"] = v.astype(np.int16 if v.max() < 32000 else np.int32)
+    for k in ("cand", "hist", "eval_hist"):
+        out[k] = task[k].astype(np.int16 if task[k].max() < 32000 else np.int32)
+    out["eval_cands"] = task["eval_cands"].astype(np.int32)
+    out["eval_ptr"] = task["eval_ptr"].astype(np.int64)
+    out["eval_labels"] = task["eval_labels"].astype(np.int8)
+    out["teacher_scores"] = task["teacher_scores"].astype(np.float32)
+    for k in ("users", "eval_users"):
+        if k in task:
+            out[k] = task[k].astype(np.int32)
+    for k in _SCALARS:
+        if k in task:
+            out[f"scalar_{k}"] = np.array(task[k], dtype=np.int64)
+    return out
+
+
+def task_from_arrays(z):
+    """Inverse of task_to_arrays (z: a loaded npz or a dict)."""
+    from news_recommendation_amd import synth
+    news = {k[5:]: z[k].astype(np.int64) for k in z.keys() if k.startswith("news_")}
+    task = {k: z[k].astype(np.int64) for k in ("cand", "hist", "eval_hist", "eval_ptr", "eval_labels")}
+    task["eval_cands"] = z["eval_cands"].astype(np.int32)
+    task["teacher_scores"] = z["teacher_scores"].astype(np.float64)
+    for k in ("users", "eval_users"):
+        if k in z.keys():
+            task[k] = z[k].astype(np.int64)
+    for k in _SCALARS:
+        if f"scalar_{k}" in z.keys():
+            task[k] = int(z[f"scalar_{k}"])
+    if set(news) == {"title"}:                     # the NRMS task carries token ids per step
+        task["titles"] = news["title"]
+        steps, B = task["steps"], task["B"]
+        c, h = synth.batch_token_ids(news["title"], task["cand"].reshape(steps * B, -1), task["hist"].reshape(steps * B, -1))
+        task["cand_ids"] = c.reshape(steps, B, -1, c.shape[-1])
+        task["click_ids"] = h.reshape(steps, B, -1, h.shape[-1])
+    else:
+        task["news"] = news
+    return task
+
+
+def state_checksum(state):
+    """A few float64 numbers that pin an initial state_dict across machines (sum, sum of squares, first element of every tensor)."""
+    ks = sorted(state)
+    return np.array([[float(state[k].double().sum()), float((state[k].double() ** 2).sum()), float(state[k].reshape(-1)[0])] for k in ks])

@@ -295,6 +295,8 @@ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __forceinline__ void atomic_add(float* p, float v) { *p += v; }
 __forceinline__ int atomic_exch(int* p, int v) { int o = *p; *p = v; return o; }
 __forceinline__ int atomic_add_i32(int* p, int v) { int o = *p; *p += v; return o; }
+__forceinline__ uint32_t ld_relaxed_u32(const uint32_t* p) { return *p; }
+__forceinline__ void atomic_cas_u32(uint32_t* p, uint32_t expect, uint32_t v) { if (*p == expect) *p = v; }
 __forceinline__ int uniform(int v) { return v; }
 __forceinline__ uint64_t ballot(bool pred) {
   nr_emu::BlockState* blk = nr_emu::g_blk;

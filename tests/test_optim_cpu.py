@@ -251,3 +251,63 @@ def test_engine_adam_matches_torch_adam_and_state_dict_format(emu):
         opt_c.step()
     np.testing.assert_allclose(c.state_dict()['user_embedding.weight'].numpy(), a.user_embedding.weight.detach().numpy(), rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(c.lin.bias.detach().numpy(), a.lin.bias.detach().numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_fault_words_gate_every_optimiser_kernel_and_the_steps_are_repeated(emu):
+    """A persistent GRU sweep that gives up a wait sets STICKY bits in the process's fault words (csrc/k_xcd.h); from then on no optimiser kernel
+    applies an update (csrc/k_optim.h) until the host has looked.  Here the bits are set by hand in the middle of a run: the gated steps change
+    nothing but the (cleared) gradient buffer, the first skipped step index is recorded, a clean sweep afterwards does NOT erase the evidence
+    (the per-launch error word was zeroed by the next launch), and after rewind_after_fault() the repeated steps reproduce the
+    undisturbed run bit for bit."""
+    from news_recommendation_amd.optim import EngineAdam
+    torch.manual_seed(0)
+    a, b = _Toy(), _Toy()
+    b.load_state_dict(a.state_dict())
+    mk = lambda m: EngineAdam(m, lr=1e-2, row_sparse=('user_embedding.weight',), lib=emu.lib, stream_fn=lambda: None)
+    ref_opt, opt = mk(a), mk(b)
+    words = opt.attach_fault_words()
+    try:
+        g = torch.Generator().manual_seed(3)
+        batches = [(torch.randint(0, 40, (6,), generator=g), torch.randint(0, 3, (6,), generator=g)) for _ in range(9)]
+        for ids, y in batches:                                       # the undisturbed run (its kernels see the attached words too: all zero)
+            _toy_loss(a, ids, y).backward()
+            ref_opt.step()
+        assert words.tolist() == [0, 0, 0, 0]
+        snap = None
+        for k, (ids, y) in enumerate(batches):
+            if k == 4:                                               # the sweep of step 5 fails (backward sweep, "a wait gave up")
+                words[1] = 2
+                snap = ({n: p.detach().clone() for n, p in b.named_parameters()}, opt.flat_m.clone(), opt.flat_v.clone(),
+                        opt.sparse[0].m.clone(), opt.sparse[0].last.clone())
+            _toy_loss(b, ids, y).backward()
+            opt.step()
+            if k >= 4:
+                assert not opt.flat_g.any()                          # the garbage gradient is dropped, not kept for the next step
+        assert words.tolist() == [0, 2, 5, 0]                        # sticky bits + the first skipped step; later (clean) steps erase nothing
+        for n, p in b.named_parameters():
+            assert torch.equal(p.detach(), snap[0][n]), n            # nothing moved since step 4: dense ...
+        assert torch.equal(opt.flat_m, snap[1]) and torch.equal(opt.flat_v, snap[2])
+        assert torch.equal(opt.sparse[0].m, snap[3]) and torch.equal(opt.sparse[0].last, snap[4])       # ... and row-sparse (catch-up included)
+        fw, bw = ctypes_words(emu)
+        assert (fw, bw) == (0, 2)
+        first = opt.rewind_after_fault()
+        assert first == 5 and opt.t == 4 and words.tolist() == [0, 0, 0, 0] and opt.rewind_after_fault() is None
+        for ids, y in batches[first - 1:]:
+            _toy_loss(b, ids, y).backward()
+            opt.step()
+        assert opt.t == ref_opt.t == 9
+        sa, sb = a.state_dict(), b.state_dict()
+        for n in sa:
+            assert torch.equal(sa[n], sb[n]), n
+        assert torch.equal(opt.flat_m, ref_opt.flat_m) and torch.equal(opt.sparse[0].v, ref_opt.sparse[0].v)
+    finally:
+        opt.detach_fault_words()
+    w4 = (__import__('ctypes').c_uint32 * 4)()
+    assert emu.lib.nr_fault_state(w4) == 0 and list(w4) == [0, 0, 0, 0]        # back on the library's own block
+
+
+def ctypes_words(emu):
+    import ctypes
+    f, b = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    assert emu.lib.nr_gru_persist_status(ctypes.byref(f), ctypes.byref(b)) == 0
+    return f.value, b.value

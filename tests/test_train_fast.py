@@ -108,3 +108,82 @@ def test_load_checkpoint_accepts_reference_format_with_weights_only(tmp_path):
     torch.save({'x': Evil()}, path)
     with pytest.raises(Exception):
         train_fast.load_checkpoint(path, 'cpu')
+
+
+@pytest.mark.gpu
+def test_failed_persistent_sweep_stays_on_record_and_gates_the_optimiser():
+    """the error word of a persistent GRU sweep was erased by the next launch's memset.  A forced give-up (nr_debug_gru_fault:
+    workgroup 0 never arrives, its team mates' bounded waits run out) must stay visible through a CLEAN sweep that follows, and while it does no
+    optimiser kernel applies an update."""
+    from news_recommendation_amd import _capi, ops_gru
+    lib = _capi.load()
+    dev = torch.device('cuda', 0)
+    B, N, Hd = 64, 6, 900
+    if not (lib.nr_gru_persist_enabled(B, Hd, N) & 1):
+        pytest.skip("the persistent GRU sweeps are not enabled on this device / under this NR_GRU_PERSIST")
+    ops_gru.fault_clear()
+    gru = torch.nn.GRU(Hd, Hd, batch_first=True).to(dev)
+    x = torch.randn(B, N, Hd, device=dev) * 0.3
+    length = torch.full((B,), N, dtype=torch.int64)
+    with torch.no_grad():
+        good = ops_gru.gru_last_state(x, None, length, gru).clone()
+        assert ops_gru.fault_state()[:2] == (0, 0)
+        assert lib.nr_debug_gru_fault(0, 1) == 0                     # the NEXT forward sweep fails
+        ops_gru.gru_last_state(x, None, length, gru)
+        st = ops_gru.fault_state()
+        assert st[0] & 2 and st[1] == 0, st                          # "a wait gave up" on the forward sweep
+        again = ops_gru.gru_last_state(x, None, length, gru).clone() # a clean sweep: correct output ...
+        assert torch.equal(again, good)
+        assert ops_gru.fault_state()[:2] == st[:2]                   # ... and the evidence is still there
+        with pytest.raises(RuntimeError, match='persistent GRU sweep failed'):
+            ops_gru.persist_check()
+        # the optimiser is gated: nr_adam_flat drops the gradient and moves nothing; the skipped step index is recorded
+        p, g = torch.randn(1024, device=dev), torch.randn(1024, device=dev)
+        m, v = torch.zeros(1024, device=dev), torch.zeros(1024, device=dev)
+        from news_recommendation_amd.optim import AdamSchedule
+        sched = AdamSchedule(1e-3, (0.9, 0.999), dev)
+        p0 = p.clone()
+        args = lambda step: (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1024, sched.table.data_ptr(), step, 0.9, 0.999, 1e-8, 1.0, 1,
+                             torch.cuda.current_stream().cuda_stream)
+        assert lib.nr_adam_flat(*args(7)) == 0
+        assert torch.equal(p, p0) and not g.any() and not m.any() and ops_gru.fault_state()[2] == 7
+        ops_gru.fault_clear()
+        g.normal_()
+        assert lib.nr_adam_flat(*args(7)) == 0
+        assert not torch.equal(p, p0) and ops_gru.fault_state() == (0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+def test_fast_trainer_repeats_the_steps_of_a_failed_persistent_sweep(tmp_path, monkeypatch):
+    """a sweep that gives up must never be trained on, and the step is repeated.  The 6th training forward sweep of an LSTUR
+    run is made to fail; the trainer looks every 4 steps: at step 8 it finds optimiser steps 6-8 skipped, switches to the step-per-launch
+    kernels and repeats them; the run ends with all 12 optimiser steps taken and a falling loss."""
+    from news_recommendation_amd import _capi, ops_gru, synth, train_fast
+    lib = _capi.load()
+    if not (lib.nr_gru_persist_enabled(64, 900, 50) & 1):
+        pytest.skip("the persistent GRU sweeps are not enabled on this device / under this NR_GRU_PERSIST")
+    monkeypatch.setenv('NR_GRU_PERSIST', '3')
+    synth.write_reference_dataset(str(tmp_path), n_news=300, n_train=512, n_val_impr=40, num_words=500)
+    over = ['batch_size=64', 'num_words=500', 'num_users=41', 'num_categories=30', 'learning_rate=0.002', 'num_epochs=2',
+            'num_batches_show_loss=4', 'num_batches_validate=1000']
+    cfg = train_fast.load_config('LSTUR', None, over)
+    lines = []
+    cwd = os.getcwd()
+    ops_gru.fault_clear()
+    try:
+        torch.manual_seed(0)
+        assert lib.nr_debug_gru_fault(0, 6) == 0
+        r = train_fast.train('LSTUR', cfg, str(tmp_path), max_steps=12, log=lines.append)
+    finally:
+        os.chdir(cwd)
+        lib.nr_debug_gru_fault(0, 0)
+    msg = [l for l in lines if 'persistent GRU sweep failed' in l]
+    assert len(msg) == 1 and 'optimiser step 6' in msg[0] and 'repeating 3 step(s)' in msg[0], lines
+    assert r['steps'] == 12 and r['optimizer_steps'] == 12
+    assert os.environ['NR_GRU_PERSIST'] == '0'
+    assert ops_gru.fault_state() == (0, 0, 0, 0)
+    losses = [float(l.split('current loss ')[1].split(',')[0]) for l in lines if 'current loss' in l]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    avg = [float(l.split('average loss: ')[1].split(',')[0]) for l in lines if 'current loss' in l]
+    assert all(np.isfinite(avg)), avg                                   # the failed steps' losses are not in the running mean
+    assert all(torch.isfinite(p).all() for p in r['model'].parameters())
