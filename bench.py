@@ -157,7 +157,21 @@ class Workload:
         """Algorithmic HBM bytes per launch of the kernels that are bandwidth / instruction bound, not dense contractions (the
         attention core is reported against HBM, never against the MFMA peak): bf16 saves read + bf16 results written."""
         tok = B * 53 * 20
+        tok_a = B * 53 * 50
         return {
+            'nr_qkv_proj_fwd[S=20]': tok * (1200 + 8 + 3 * 300 * 2 + 300 * 2),       # table row + id in; Q, K, V and the masked token row (dW operand) out
+            'nr_dx_gemm[S=20]': tok * (3 * 300 * 2 + 300 * 2),                       # dQ | dK | dV in, dX out
+            'nr_gemm_tn_dWqkv[S=20]': tok * (3 * 300 * 2 + 300 * 2),                 # dqkv and the token rows in (the 1.2 MB result is noise)
+            'nr_gemm_tn_dWa[S=20]': tok * (200 * 2 + 300 * 2),
+            'nr_additive_bwd[S=20]': tok * (300 * 2 + 200 * 2 + 300 * 2),            # ctx in; dpre, dctx out (DESIGN 5.4c: 1,696 B with padding, 1,600 without)
+            'nr_additive_bwd[title]': tok * (300 * 2 + 200 * 2 + 300 * 2),
+            'nr_additive_bwd[abstract]': tok_a * (300 * 2 + 200 * 2 + 300 * 2),
+            'nr_additive_fwd[title]': tok * 300 * 2 + B * 53 * (300 * 2 + 20 * 4),    # act rows in; pooled vector + weights out
+            'nr_additive_fwd[abstract]': tok_a * 300 * 2 + B * 53 * (300 * 2 + 50 * 4),
+            'nr_conv3_fwd[title]': tok * (1200 + 8 + 300 * 2 + 300 * 2),             # table row + id in; activation + masked token row out
+            'nr_conv3_fwd[abstract]': tok_a * (1200 + 8 + 300 * 2 + 300 * 2),
+            'nr_conv3_dgrad[title]': tok * (300 * 2 + 300 * 2), 'nr_conv3_dgrad[abstract]': tok_a * (300 * 2 + 300 * 2),
+            'nr_gemm_tn_dWconv[title]': tok * (300 * 2 + 300 * 2), 'nr_gemm_tn_dWconv[abstract]': tok_a * (300 * 2 + 300 * 2),
             'nr_attn_fwd[S=20]': tok * (3 * 300 * 2 + 300 * 2),                      # Q, K, V in; ctx out
             'nr_attn_pool_fwd[S=20]': tok * (3 * 300 * 2 + 300 * 2) + B * 53 * (300 + 20) * 4,   # + pooled vectors and attention weights out
             'nr_attn_bwd[S=20]': tok * (3 * 300 * 2 + 300 * 2 + 3 * 300 * 2),        # Q, K, V, dctx in; dQ, dK, dV out
@@ -176,7 +190,10 @@ class Workload:
             'nr_mhsa_fwd[S=50]': B * (2 * 50 * 300 * 900 + 2 * 2 * 15 * 50 * 50 * 20),
             'nr_attn_bwd[S=20]': T * 15 * 6 * 2 * 20 * 20 * 20,
             'nr_attn_bwd[S=50]': B * 15 * 6 * 2 * 50 * 50 * 20,
-            'nr_additive_fwd[S=20]': pool20, 'nr_additive_bwd[S=20]': pool20,
+            'nr_additive_fwd[S=20]': pool20, 'nr_additive_bwd[S=20]': 3 * pool20 // 2 + pool20,      # projection recomputed, dctx = dpre Wa, (dWa is its own GEMM)
+            'nr_attn_pool_fwd[S=20]': T * 2 * 2 * 15 * 20 * 20 * 20 + pool20,
+            'nr_dx_gemm[S=20]': T * 2 * 20 * 900 * 300, 'nr_gemm_tn_dWqkv[S=20]': T * 2 * 20 * 900 * 300, 'nr_gemm_tn_dWa[S=20]': pool20,
+            'nr_gemm_tn_dWconv[title]': conv(20), 'nr_gemm_tn_dWconv[abstract]': conv(50),
             'nr_additive_fwd[title]': pool20, 'nr_additive_bwd[title]': pool20,
             'nr_additive_fwd[abstract]': T * 2 * 50 * 300 * 200, 'nr_additive_bwd[abstract]': T * 2 * 50 * 300 * 200,
             'nr_conv3_fwd[title]': conv(20), 'nr_conv3_dgrad[title]': conv(20),
@@ -185,6 +202,49 @@ class Workload:
             'nr_gru_fwd_seq': self.cfg.num_clicked_news_a_user * 2 * B * 900 * 2700,
             'nr_gru_bwd_seq': (self.cfg.num_clicked_news_a_user + 1) * 2 * B * 2700 * 900,
         }
+
+
+def price_kernel(name, rec, flops, hbm, traffic=None, busy=None):
+    """One kernel against BOTH roofs (the record must be comparable from round to round whichever kernel happens to be the
+    arg-max): rec = (launches, average us, total us) from HIP events on the launch stream; algorithmic flops / bytes per launch from
+    Workload.flops / hbm_bytes (None where no figure is tabulated); PMC traffic / MFMA-busy from the committed rocprofv3 passes when they were
+    taken on these kernel sources."""
+    n, avg, tot = rec
+    o = {"kernel": name, "avg_us": avg, "launches": n}
+    if name in flops:
+        o["flop_per_launch"] = flops[name]
+        o["frac_mfma"] = flops[name] / (avg * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF
+    if name in hbm:
+        o["bytes_per_launch"] = hbm[name]
+        o["frac_hbm"] = hbm[name] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS
+    o["traffic"] = (traffic or {}).get(name)
+    if o["traffic"] is not None and avg > 0:
+        o["frac_hbm_traffic"] = o["traffic"] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS
+    if busy and name in busy:
+        o["mfma_busy_frac"] = busy[name]
+    return o
+
+
+def committed_counters(model, shape, B):
+    """(per-kernel PMC HBM traffic, per-kernel MFMA-busy fraction) from profiles/traffic.json / profiles/mfma_busy.json -- only entries measured
+    on the kernel sources this library was built from (source hash) and, for traffic, on this workload."""
+    traffic, busy = {}, {}
+    h = kernel_source_hash()
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            for k, v in json.load(f).items():
+                if isinstance(v, dict) and v.get("source_hash") == h and v.get("workload") == f"{model}/{shape}/B{B}":
+                    traffic[k] = v["bytes"]
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'mfma_busy.json')) as f:
+            for k, v in json.load(f).items():
+                if isinstance(v, dict) and v.get("source_hash") == h:
+                    busy[k] = v["mfma_busy_frac"]
+    except (OSError, ValueError):
+        pass
+    return traffic, busy
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -511,6 +571,98 @@ def train_parity_lstur(device, steps=100, B=16, lr=1e-3, engine_seeds=(0, 1), or
     return out
 
 
+def train_parity_fixture(device, model_name, engine_seeds=8, fixture_dir=None):
+    """Statistical training parity against the REAL reference.  tests/golden/train_parity/<model>.npz (written in the build
+    container by oracle/make_golden_train_parity.py) holds the teacher-labelled task and the held-out metrics of the reference's OWN model class
+    trained on it with torch's dropout and torch.optim.Adam, one run per torch seed (8).  Here the ENGINE (bf16 operands, counter-based dropout,
+    EngineAdam) trains on the same batches from the same initial weights, `engine_seeds` dropout streams, and the two samples are compared:
+    |mean_e - mean_r| against 3 standard errors of the difference, sqrt(s_e^2 / n_e + s_r^2 / n_r), from the MEASURED spreads -- no floor.  The
+    sign of the difference is in the record (r05 saw the engine below the oracle in 4 of 4 pairings with two seeds a side)."""
+    from news_recommendation_amd import ops, ops_gru
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle import train_parity as tp
+    t0 = time.perf_counter()
+    fixture_dir = fixture_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'train_parity')
+    z = np.load(os.path.join(fixture_dir, f'{model_name.lower()}.npz'))
+    meta = json.loads(str(z['meta']))
+    task = tp.task_from_arrays(z)
+    steps, B, lr = task["steps"], task["B"], meta["lr"]
+    if model_name == 'NRMS':
+        st0 = tp.init_state(task["num_words"])
+    elif model_name == 'NAML':
+        st0 = tp.init_state_naml(task["num_words"], task["num_categories"])
+    else:
+        st0 = tp.init_state_lstur(task["num_words"], task["num_categories"], task["num_users"])
+    if not np.allclose(tp.state_checksum(st0), z['init_checksum'], rtol=1e-9, atol=1e-12):
+        raise RuntimeError(f"train_parity_fixture[{model_name}]: the seeded initial state differs from the one the reference was trained from")
+    cfg = make_cfg(model_name, 'small', vocab=task["num_words"])
+    for k in ("num_categories", "num_users"):
+        if k in task:
+            setattr(cfg, k, task[k])
+    wl = Workload(model_name, cfg)
+    crit = torch.nn.CrossEntropyLoss()
+    target = torch.zeros(B, dtype=torch.long, device=device)
+    to_dev = lambda d: {k: torch.from_numpy(v).to(device) for k, v in d.items()}
+    if model_name == 'NRMS':
+        cand_d, click_d = torch.from_numpy(task["cand_ids"]).to(device), torch.from_numpy(task["click_ids"]).to(device)
+        fwd = [lambda m, i=i: m.forward_ids(cand_d[i], click_d[i]) for i in range(steps)]
+        es = ({'title': task["titles"]}, task["eval_hist"], task["eval_cands"], task["eval_ptr"], None)
+    elif model_name == 'NAML':
+        bs = [tuple(to_dev(x) for x in tp.naml_batch(task, i)) for i in range(steps)]
+        fwd = [lambda m, b=b: m.forward_ids(b[0], b[1]) for b in bs]
+        es = (task["news"], task["eval_hist"], task["eval_cands"], task["eval_ptr"], None)
+    else:
+        bs = []
+        for i in range(steps):
+            cand, click, user, length = tp.lstur_batch(task, i)
+            bs.append((to_dev(cand), to_dev(click), torch.from_numpy(user).to(device), torch.from_numpy(length)))
+        fwd = [lambda m, b=b: m.forward_ids(b[2], b[3].clone(), b[0], b[1]) for b in bs]
+        es = (task["news"], task["eval_hist"], task["eval_cands"], task["eval_ptr"], task["eval_users"])
+
+    def engine_run(seed):
+        m = wl.make_model().to(device)
+        m.load_state_dict(st0)
+        m.train()
+        opt = EngineAdam(m, lr=lr, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else ())
+        torch.manual_seed(1000 + seed)                   # ops.new_seed() draws the kernels' dropout seeds from torch's CPU generator
+        losses = []
+        for f in fwd:
+            loss = crit(f(m), target)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        if model_name == 'LSTUR':
+            opt.flush()
+        sc = engine_scores(wl, m, device, es)
+        if model_name == 'LSTUR':
+            ops_gru.persist_check()
+        return [float(x) for x in tp.eval_metrics(task, sc)], float(torch.stack(losses[-10:]).mean())
+    seeds = list(range(engine_seeds)) if isinstance(engine_seeds, int) else list(engine_seeds)
+    runs = [engine_run(s_) for s_ in seeds]
+    ops.invalidate_packed()
+    em = np.array([r[0] for r in runs])
+    rm = z['ref_metrics']
+    out = {"model": model_name, "steps": steps, "batch": B, "lr": lr, "dropout": meta["dropout"], "vocab": task["num_words"],
+           "eval_impressions": len(task["eval_ptr"]) - 1, "reference": meta["reference"], "fixture": f"tests/golden/train_parity/{model_name.lower()}.npz",
+           "auc_init": float(z['init_metrics'][0]), "auc_teacher": float(tp.eval_metrics(task, task["teacher_scores"])[0]),
+           "engine_auc": [float(x) for x in em[:, 0]], "reference_auc": [float(x) for x in rm[:, 0]],
+           "engine_ndcg10": [float(x) for x in em[:, 3]], "reference_ndcg10": [float(x) for x in rm[:, 3]],
+           "engine_last10_loss": [r[1] for r in runs], "reference_last10_loss": [float(x) for x in z['ref_last10_loss']]}
+    for tag, col in (("auc", 0), ("ndcg10", 3)):
+        e, r = em[:, col], rm[:, col]
+        se = float(np.sqrt(e.var(ddof=1) / len(e) + r.var(ddof=1) / len(r)))
+        out[f"mean_engine_{tag}"], out[f"mean_reference_{tag}"] = float(e.mean()), float(r.mean())
+        out[f"sd_engine_{tag}"], out[f"sd_reference_{tag}"] = float(e.std(ddof=1)), float(r.std(ddof=1))
+        out[f"diff_{tag}"] = float(e.mean() - r.mean())                     # signed: negative = the engine's trained models rank worse
+        out[f"stderr_diff_{tag}"] = se
+        out[f"z_{tag}"] = float((e.mean() - r.mean()) / max(se, 1e-12))
+    out["engine_below_reference_pairs"] = int((em[:, 0][:, None] < rm[:, 0][None, :]).sum())
+    out["pairs"] = int(em.shape[0] * rm.shape[0])
+    out["within_3_stderr"] = bool(abs(out["z_auc"]) < 3.0 and abs(out["z_ndcg10"]) < 3.0)
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def score_eval(wl, model, device, n_impr_cap=100000):
     """Eval-shaped scoring throughput: phases A (encode every news once), B (one user vector per impression history), C
     (ragged candidate scoring + per-impression AUC / MRR / nDCG on the device) of src/evaluate.py:185-272 via evaluate_fast.run_plan,
@@ -541,9 +693,42 @@ def score_eval(wl, model, device, n_impr_cap=100000):
         m = torch.nanmean(out.double(), dim=0).cpu()
         dts.append(time.perf_counter() - t0)
     dt = min(dts)
+    # phase C's two kernels against the HBM roof (K7 is bandwidth-bound; per impression C x d x 4 + d x 4 + C x (4 B index + 4 B out)
+    # = 46.5 KB at C = 37.5), HIP events on the launch stream, 5 launches each on the plan's own arrays
+    from news_recommendation_amd import ops
+    out, scores = evaluate_fast.run_plan(model, plan, 2048, wl.name)
+    nnz = int(len(cands))
+    with ops.profile(only={'nr_score_csr', 'nr_impression_metrics'}) as rec:
+        for _ in range(5):
+            evaluate_fast.phase_c(model, plan, wl.name)
+    rs = rec.summary()
+    D = evaluate_fast.phase_c.last_dim
+    bytes_csr = nnz * (D * 4 + 4 + 4) + n_impr * (D * 4 + 8 + 4)
+    bytes_met = nnz * (4 + 4) + n_impr * (8 + 16)
+    roof = {}
+    if 'nr_score_csr' in rs:
+        a = bytes_csr / (rs['nr_score_csr'][1] * 1e-6) / 1e9
+        roof["nr_score_csr"] = {"bound": "hbm", "avg_us": rs['nr_score_csr'][1], "bytes_per_launch": bytes_csr, "bytes_per_impression": bytes_csr / n_impr,
+                                "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                                "note": "the news matrix (%.0f MB) is Infinity-Cache resident: candidate rows are re-read from MALL, not HBM" % (n_news * D * 4 / 1e6)}
+    if 'nr_impression_metrics' in rs:
+        a = bytes_met / (rs['nr_impression_metrics'][1] * 1e-6) / 1e9
+        roof["nr_impression_metrics"] = {"bound": "hbm (latency: one wave per impression, rank by comparison)", "avg_us": rs['nr_impression_metrics'][1],
+                                         "bytes_per_launch": bytes_met, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
+    # fp32 device metrics vs the float64 numpy metrics of the reference's formulas (oracle/metrics.py) on the same device scores
+    from oracle import metrics as om
+    sc = scores.cpu().numpy().astype(np.float64)
+    k = min(n_impr, 5000)
+    ref = np.array([om.single_impression_metrics(plan.labels[ptr[i]:ptr[i + 1]], sc[ptr[i]:ptr[i + 1]]) for i in range(k)], dtype=np.float64)
+    dev_m = out[:k].double().cpu().numpy()
+    both = ~np.isnan(ref) & ~np.isnan(dev_m)
+    dev_dev = {"impressions": k, "max_abs_per_impression": float(np.abs(np.where(both, dev_m - ref, 0.0)).max()),
+               "abs_diff_of_means": [float(abs(np.nanmean(dev_m[:, j]) - np.nanmean(ref[:, j]))) for j in range(4)],
+               "nan_pattern_equal": bool((np.isnan(ref) == np.isnan(dev_m)).all()),
+               "what": "device metrics (fp32: log2f, 1.0f / rank) vs float64 numpy of src/evaluate.py:24-42,160-168 on the same scores: AUC, MRR, nDCG@5, nDCG@10"}
     model.train(was_training)
     return {"value": n_impr / dt, "unit": "impressions/s", "impressions": n_impr, "news": n_news, "candidates": int(len(cands)),
-            "seconds": dt, "seconds_all_runs": dts,
+            "seconds": dt, "seconds_all_runs": dts, "roofline": roof, "metrics_fp32_vs_f64": dev_dev,
             "what": "phases A+B+C of src/evaluate.py:185-272 (batched driver), host index arrays -> four metric means; best of 3 runs"}
 
 
@@ -734,6 +919,8 @@ def other_workload(name, shape, vocab, B, device, steps=10):
         # operand traffic out of each XCD's L2 and the inter-workgroup wait: the MFMA fraction is reported, not claimed as the bound
         roof["note"] = "sweep kernel: bound by L2 -> CU operand traffic and the XCD-local wait, not by the matrix pipe (DESIGN.md 5.3b)"
     roof["launches_per_step"] = dom[0] // 2
+    traffic_k, busy_k = committed_counters(name, shape, B)
+    roof["top3"] = [price_kernel(k, hand[k], flops, hbm, traffic_k, busy_k) for k in sorted(hand, key=lambda k: -hand[k][2])[:3]]
     tag = {('NAML', 'small'): "BASELINE.json configs[2]", ('LSTUR', 'large'): "single-GPU shard of BASELINE.json configs[4]",
            ('NRMS', 'large'): "single-GPU shard of BASELINE.json configs[3]"}.get((name, shape), "")
     out = {"workload": f"{name} bf16, MIND-{shape}-shaped synthetic, batch {B} ({tag})", "value": B * steps / dt, "unit": "impressions/s",
@@ -756,7 +943,7 @@ def main():
     ap.add_argument('--vocab', type=int, default=0, help='override the vocabulary size of the shape (rows of the word-embedding table)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
-    ap.add_argument('--no-train-parity', action='store_true', help='skip the 200-step engine-vs-oracle training leg (~1 min of host time)')
+    ap.add_argument('--no-train-parity', action='store_true', help='skip the training-parity leg (8 engine trainings vs the committed runs of the reference, ~30 s)')
     ap.add_argument('--parity-seeds', type=int, default=8, help='independent n = 1000 evaluation sets per weight state of the parity leg')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the NAML / LSTUR graph-replay legs of the default line (~30 s)')
     ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
@@ -806,6 +993,7 @@ def main():
     assert opt.check_views(), "parameter / gradient views detached from the optimiser's flat buffers"
     hand = {k: v for k, v in prof.items() if k.startswith('nr_') and not k.startswith(('nr_pack', 'nr_sort', 'nr_adam', 'nr_row_adam'))}
     dominant = max(hand, key=lambda k: hand[k][2]) if hand else 'nr_mhsa_fwd[S=20]'
+    top3 = sorted(hand, key=lambda k: -hand[k][2])[:3] or [dominant]        # all three are timed over the K steps and priced on both roofs
 
     # ---- single GPU: the step as ONE HIP graph (news_recommendation_amd/graph.py); the per-kernel HIP-event pass that the
     # roofline needs then runs as an eager pass of the same K steps AFTER the timed region (events cannot bracket nodes of a replayed graph)
@@ -862,7 +1050,7 @@ def main():
             loss = run_(*flat(batches[i % len(batches)]))
         rec2 = None
     else:
-        with ops.profile(only={timed_name}) as rec2:
+        with ops.profile(only=set(top3)) as rec2:
             for i in range(args.steps):
                 loss = step(i)
     t_enq = time.perf_counter() - t0       # host time to ENQUEUE the timed steps (launch-bound if it approaches dt)
@@ -874,7 +1062,7 @@ def main():
         loss_graph = float(loss.item())
         barrier()
         t1 = time.perf_counter()
-        with ops.profile(only={timed_name}) as rec2:
+        with ops.profile(only=set(top3)) as rec2:
             for i in range(args.steps):
                 loss = sg.eager_step(*flat(batches[i % len(batches)]))
         barrier()
@@ -890,11 +1078,12 @@ def main():
     if seg is not None:
         # per-kernel HIP events cannot bracket graph nodes: the dominant kernel's duration comes from a short eager pass on the same counter
         # protocol (collective steps: every rank takes part)
-        with ops.profile(only={timed_name}) as rec2:
+        with ops.profile(only=set(top3)) as rec2:
             for i in range(min(args.steps, 5)):
                 seg.eager_step(*flat(batches[i % len(batches)]))
         barrier()
-    dom = rec2.summary().get(timed_name, (0, float('nan'), 0.0))
+    timed = rec2.summary()
+    dom = timed.get(timed_name, (0, float('nan'), 0.0))
 
     comm = None
     if world > 1:
@@ -964,6 +1153,12 @@ def main():
         roofline["mfma_busy_frac_by_kernel"] = {k: round(v["mfma_busy_frac"], 4) for k, v in cur.items()} or None
     except (OSError, ValueError):
         pass
+    # the three largest kernels of the step, each against BOTH roofs with its PMC traffic: the same record whichever of them is the arg-max
+    traffic_k, busy_k = committed_counters(args.model, shape, B)
+    roofline["top3"] = [price_kernel(k, timed[k], flops, hbm, traffic_k, busy_k) for k in top3 if k in timed]
+    roofline["top3_note"] = ("avg_us: HIP events on the launch stream over the timed eager pass; frac_mfma = algorithmic flops / avg / 2.5 PFLOP/s, "
+                             "frac_hbm = algorithmic bytes / avg / 8 TB/s (SURVEY d6 figures, padding not counted), traffic = PMC HBM bytes per launch "
+                             "(profiles/traffic.json, only when measured on these kernel sources)")
     # the dense contraction of the forward on its own (the dominant kernel above may be a bandwidth-bound one)
     pj = prof.get('nr_qkv_proj_fwd[S=20]')
     if pj is not None:
@@ -1105,7 +1300,11 @@ def main():
             del mo, wo
         out["parity_models"] = others
         if not args.no_train_parity:
-            out["train_parity"] = train_parity(device)
+            # the engine, eight dropout streams, against the REAL reference's eight runs on the same task (committed fixture; no oracle training here)
+            try:
+                out["train_parity"] = train_parity_fixture(device, args.model, engine_seeds=8)
+            except FileNotFoundError as e:
+                out["train_parity"] = {"error": f"fixture missing: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, shape, args.vocab)
     else:

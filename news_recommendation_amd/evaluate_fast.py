@@ -123,12 +123,28 @@ def run_plan(model, plan, batch, model_name):
     uv = torch.cat(uv) if uv else torch.zeros(0, D, device=dev)
     # phase C
     n_impr = len(plan.imp_user_row)
-    ptr = torch.from_numpy(plan.cand_ptr).to(dev)
-    scores = ops.score_csr(nv, uv, torch.from_numpy(plan.cand_idx).to(dev), ptr, torch.from_numpy(plan.imp_user_row).to(dev))
-    out = torch.empty(n_impr, 4, dtype=torch.float32, device=dev)
-    labels = torch.from_numpy(plan.labels).to(dev)
-    _call('nr_impression_metrics', _lib().nr_impression_metrics, _ptr(scores), _ptr(labels), _ptr(ptr), _ptr(out), n_impr, _stream())
+    c = {'nv': nv, 'uv': uv, 'ptr': torch.from_numpy(plan.cand_ptr).to(dev), 'cand': torch.from_numpy(plan.cand_idx).to(dev),
+         'urow': torch.from_numpy(plan.imp_user_row).to(dev), 'labels': torch.from_numpy(plan.labels).to(dev), 'n_impr': n_impr}
+    phase_c.operands = c
+    return phase_c(model, plan, model_name)
+
+
+@torch.no_grad()
+def phase_c(model, plan, model_name):
+    """Phase C alone on the device-resident operands of the last run_plan (bench.py times its two kernels against the HBM roof): one nr_score_csr
+    launch over all impressions (evaluate.py:245-260) + one nr_impression_metrics launch (evaluate.py:24-42,160-168)."""
+    from . import ops
+    from .ops import _lib, _call, _ptr, _stream
+    c = phase_c.operands
+    phase_c.last_dim = int(c['nv'].shape[1])
+    scores = ops.score_csr(c['nv'], c['uv'], c['cand'], c['ptr'], c['urow'])
+    out = torch.empty(c['n_impr'], 4, dtype=torch.float32, device=scores.device)
+    _call('nr_impression_metrics', _lib().nr_impression_metrics, _ptr(scores), _ptr(c['labels']), _ptr(c['ptr']), _ptr(out), c['n_impr'], _stream())
     return out, scores
+
+
+phase_c.operands = None
+phase_c.last_dim = 0
 
 
 @torch.no_grad()

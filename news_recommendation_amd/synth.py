@@ -102,18 +102,31 @@ def teacher_labels(rng, scores, ptr):
 
 
 def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_impr=60, num_words=500, seed=0,
-                            title_len=20, num_clicked=50, neg_k=2):
+                            title_len=20, num_clicked=50, neg_k=2, learnable=False):
     """Write a tiny synthetic data tree in the reference's on-disk formats so that its UNCHANGED train.py /
     evaluate.py can run from ``root`` as cwd (file schemas: src/dataset.py:27-37, src/evaluate.py:57-65,87-93,
-    135-143; writers: src/data_preprocess.py:45-49,77-81,205).  Returns the directory."""
+    135-143; writers: src/data_preprocess.py:45-49,77-81,205).  Returns the directory.
+    learnable: clicks follow a rule a model can learn (default: uniformly random clicks, AUC 0.5 whatever is trained) -- every news has a
+    topic (= its category; 70 % of its real tokens come from the topic's slice of the vocabulary), every user a preferred topic; 80 % of a
+    history and the clicked training candidate are of that topic, and an evaluation candidate is labelled 1 with probability 0.85 / 0.08
+    when its topic is / is not the user's."""
     import os
     import pandas as pd
     rng = np.random.default_rng(seed)
     titles = news_titles(rng, n_news, title_len, num_words)
     abstracts = news_titles(rng, n_news, 50, num_words)
     nid = [f'N{i + 1}' for i in range(n_news)]
+    n_topics = 9
+    if learnable:
+        topic = rng.integers(0, n_topics, n_news)
+        width = max((num_words - 1) // n_topics, 1)
+        for arr in (titles, abstracts):
+            own = 1 + topic[:, None] * width + rng.integers(0, width, size=arr.shape)
+            arr[...] = np.where((arr != 0) & (rng.random(arr.shape) < 0.7), own, arr)
+        by_topic = [np.flatnonzero(topic == t) for t in range(n_topics)]
+        user_topic = rng.integers(0, n_topics, n_users + 1)
     news = pd.DataFrame({
-        'id': nid, 'category': rng.integers(1, 10, n_news), 'subcategory': rng.integers(1, 30, n_news),
+        'id': nid, 'category': (topic + 1) if learnable else rng.integers(1, 10, n_news), 'subcategory': rng.integers(1, 30, n_news),
         'title': [str(list(map(int, t))) for t in titles],
         'abstract': [str(list(map(int, t))) for t in abstracts],
         'title_entities': [str([0] * title_len)] * n_news, 'abstract_entities': [str([0] * 50)] * n_news})
@@ -124,23 +137,48 @@ def write_reference_dataset(root, n_news=300, n_users=40, n_train=256, n_val_imp
     pd.DataFrame({'user': users, 'int': np.arange(1, n_users + 1)}).to_csv(
         os.path.join(root, 'data', 'train', 'user2int.tsv'), sep='\t', index=False)
 
-    def hist_str(k):
-        return ' '.join(rng.choice(nid, size=k)) if k > 0 else ' '
+    def of_topic(t, k):
+        pool = by_topic[t]
+        return pool[rng.integers(0, len(pool), size=k)] if len(pool) else rng.integers(0, n_news, size=k)
+
+    def hist_str(k, u=None):
+        if k <= 0:
+            return ' '
+        if not learnable:
+            return ' '.join(rng.choice(nid, size=k))
+        idx = np.where(rng.random(k) < 0.8, of_topic(user_topic[u], k), rng.integers(0, n_news, size=k))
+        return ' '.join(nid[j] for j in idx)
     rows = []
     for _ in range(n_train):
         k = int(history_lengths(rng, 1, num_clicked)[0])
-        rows.append({'user': int(rng.integers(1, n_users + 1)), 'clicked_news': hist_str(k),
-                     'candidate_news': ' '.join(rng.choice(nid, size=1 + neg_k)), 'clicked': '1 ' + ' '.join(['0'] * neg_k)})
+        u = int(rng.integers(1, n_users + 1))
+        h = hist_str(k, u)
+        if learnable:
+            cand = [nid[int(of_topic(user_topic[u], 1)[0])]] + [nid[j] for j in rng.integers(0, n_news, size=neg_k)]
+        else:
+            cand = list(rng.choice(nid, size=1 + neg_k))
+        rows.append({'user': u, 'clicked_news': h, 'candidate_news': ' '.join(cand), 'clicked': '1 ' + ' '.join(['0'] * neg_k)})
     pd.DataFrame(rows).to_csv(os.path.join(root, 'data', 'train', 'behaviors_parsed.tsv'), sep='\t', index=False)
     for split in ('val', 'test'):
         with open(os.path.join(root, 'data', split, 'behaviors.tsv'), 'w') as f:
             for i in range(n_val_impr):
                 k = int(history_lengths(rng, 1, num_clicked)[0])
                 c = int(rng.integers(2, 12))
-                lab = rng.integers(0, 2, c)
-                lab[0], lab[1] = 1, 0
-                imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c, replace=False), lab))     # an impression lists a news once
-                f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist_str(k)}\t{imp}\n")
+                if not learnable:
+                    lab = rng.integers(0, 2, c)
+                    lab[0], lab[1] = 1, 0
+                    imp = ' '.join(f'{n}-{l}' for n, l in zip(rng.choice(nid, size=c, replace=False), lab))     # an impression lists a news once
+                    f.write(f"{i + 1}\t{users[int(rng.integers(0, n_users))]}\t11/11/2019 9:00:00 AM\t{hist_str(k)}\t{imp}\n")
+                    continue
+                u = int(rng.integers(0, n_users))
+                picks = rng.choice(n_news, size=c, replace=False)
+                lab = (rng.random(c) < np.where(topic[picks] == user_topic[u + 1], 0.85, 0.08)).astype(np.int64)
+                if lab.sum() == 0:
+                    lab[0] = 1
+                if lab.sum() == c:
+                    lab[1] = 0
+                imp = ' '.join(f'{nid[n]}-{l}' for n, l in zip(picks, lab))
+                f.write(f"{i + 1}\t{users[u]}\t11/11/2019 9:00:00 AM\t{hist_str(k, u + 1)}\t{imp}\n")
     return root
 
 

@@ -52,6 +52,12 @@ class OracleAdditive(nn.Module):
         return torch.bmm(w.unsqueeze(1), x).squeeze(1)
 
 
+def _dropout(x, p, training, keep):
+    if keep is not None:
+        return x * keep.to(x.dtype) / (1.0 - p)
+    return F.dropout(x, p=p, training=training)
+
+
 class OracleNewsEncoder(nn.Module):
     """src/model/NRMS/news_encoder.py:10-48."""
 
@@ -62,9 +68,11 @@ class OracleNewsEncoder(nn.Module):
         self.additive_attention = OracleAdditive(qdim, d)
         self.p = p_drop
 
-    def forward(self, title):
-        x = F.dropout(self.word_embedding(title), p=self.p, training=self.training)
-        y = F.dropout(self.multihead_self_attention(x), p=self.p, training=self.training)
+    def forward(self, title, keep1=None, keep2=None):
+        """keep1 / keep2: optional explicit keep-masks (1.0 = keep) of the two dropout sites (news_encoder.py:38-40, :43-45) -- for parity
+        with the engine the same masks must be used on both sides (tests/test_trajectory_gpu.py); None: F.dropout like the reference."""
+        x = _dropout(self.word_embedding(title), self.p, self.training, keep1)
+        y = _dropout(self.multihead_self_attention(x), self.p, self.training, keep2)
         return self.additive_attention(y)
 
 
@@ -88,10 +96,13 @@ class OracleNRMS(nn.Module):
         self.news_encoder = OracleNewsEncoder(num_words, d, heads, qdim, p_drop)
         self.user_encoder = OracleUserEncoder(d, heads, qdim)
 
-    def forward(self, candidate_news, clicked_news):
+    def forward(self, candidate_news, clicked_news, keeps=None):
+        """keeps: optional list (one per position, candidates first) of {'title1': mask, 'title2': mask} keep-masks for the two dropout sites."""
         # the per-position loop of the reference (:38-42) is kept on purpose
-        cand = torch.stack([self.news_encoder(x['title']) for x in candidate_news], dim=1)
-        clicked = torch.stack([self.news_encoder(x['title']) for x in clicked_news], dim=1)
+        k = keeps or [{}] * (len(candidate_news) + len(clicked_news))
+        C = len(candidate_news)
+        cand = torch.stack([self.news_encoder(x['title'], k[j].get('title1'), k[j].get('title2')) for j, x in enumerate(candidate_news)], dim=1)
+        clicked = torch.stack([self.news_encoder(x['title'], k[C + j].get('title1'), k[C + j].get('title2')) for j, x in enumerate(clicked_news)], dim=1)
         user = self.user_encoder(clicked)
         return torch.bmm(cand, user.unsqueeze(-1)).squeeze(-1)          # dot_product.py:17-18
 

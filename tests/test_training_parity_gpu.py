@@ -1,8 +1,17 @@
-"""Statistical training parity: 200 training steps with dropout ON, engine (bf16 operands, counter-based dropout,
-EngineAdam) vs the CPU oracle (the reference's fp32 loop: torch dropout, torch.optim.Adam; oracle/train_parity.py), same initial weights, same
-teacher-labelled batches -- the two TRAINED models must rank a held-out impression set equally well.  The comparison is statistical: the two
-runs draw different dropout masks, so their AUCs differ like two seeds of one trainer do (measured on the build host, oracle vs oracle,
-100 steps: 3e-3).  Both sides run TWO dropout seeds; the bound on the difference of the means is 1.5 x the larger recorded spread."""
+"""Statistical training parity against the REAL reference.
+
+tests/golden/train_parity/{nrms,naml,lstur}.npz were written in the build container by oracle/make_golden_train_parity.py: a teacher-labelled
+task and the held-out AUC / nDCG@10 of the reference's OWN model classes (imported from its checkout) trained on it with torch's dropout and
+torch.optim.Adam -- the loop body of src/train.py:202-233 -- from a seeded initial state, EIGHT torch seeds each.  Here the engine (bf16
+operands, its counter-based dropout, EngineAdam; LSTUR: persistent GRU sweeps, row-sparse lazy Adam, user masking 0.5) trains on the same
+batches from the same initial state with eight dropout streams of its own, and the two samples of eight are compared:
+
+    |mean_engine - mean_reference|  <  3 * sqrt(s_e^2 / 8 + s_r^2 / 8)        for AUC and for nDCG@10,
+
+a bound DERIVED from the measured spreads (r05's legs used floors of 5e-3 .. 1.5e-2 that could not see a 1e-2 deficit).  The signed difference
+and the number of (engine, reference) pairs with the engine below are in the record (gpurun_out/train_parity_fixture_<model>.json, copied to
+profiles/r06_train_parity_*.json)."""
+import json
 import os
 import sys
 
@@ -15,59 +24,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def test_engine_and_oracle_train_to_the_same_auc():
+@pytest.mark.parametrize('model_name', ['NRMS', 'NAML', 'LSTUR'])
+def test_engine_and_reference_train_to_the_same_auc(model_name):
     import bench
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
-    r = bench.train_parity(dev, steps=200, B=16)
+    r = bench.train_parity_fixture(dev, model_name, engine_seeds=8)
     out_dir = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(out_dir):
-        import json
-        with open(os.path.join(out_dir, 'train_parity.json'), 'w') as f:
+        with open(os.path.join(out_dir, f'train_parity_fixture_{model_name}.json'), 'w') as f:
             json.dump(r, f, indent=1)
-    assert r["auc_init"] < 0.56, r                                  # the task starts at chance ...
-    assert r["oracle"]["auc"] > r["auc_init"] + 0.15, r             # ... the reference's loop learns it ...
-    assert all(e["auc"] > r["auc_init"] + 0.15 for e in r["engine"]), r      # ... and so does the engine, on both dropout seeds
-    # the means of two engine seeds and two oracle seeds: within 1.5 x the larger of the two RECORDED seed-to-seed spreads (floor 5e-3); r04 measured
-    # |diff| 1.8e-3 with an engine spread of 3.6e-3
-    assert len(r["oracle_runs"]) == 2 and r["abs_diff_auc"] < r["tolerance_auc"] <= 1.5e-2, r
-    assert r["abs_diff_ndcg10"] < max(6e-3, 2.0 * max(r["oracle_seed_spread_ndcg10"], 3e-3)), r
-    assert r["engine_seed_spread_auc"] < 1.5e-2 and r["oracle_seed_spread_auc"] < 1.5e-2, r
-    assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.08, r
-
-
-def test_naml_engine_and_oracle_train_to_the_same_auc():
-    """The NAML leg: 100 steps with dropout on from the same initial weights (oracle/train_parity.py make_task_naml / train_oracle_naml)."""
-    import bench
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(0)
-    r = bench.train_parity_naml(dev, steps=100, B=16)
-    out_dir = os.path.join(ROOT, 'gpurun_out')
-    if os.path.isdir(out_dir):
-        import json
-        with open(os.path.join(out_dir, 'train_parity_naml.json'), 'w') as f:
-            json.dump(r, f, indent=1)
-    gain = r["oracle"]["auc"] - r["auc_init"]
-    assert gain > 0.03, r                                               # the reference's loop improves on the initial model ...
-    assert all(e["auc"] > r["auc_init"] + 0.6 * gain for e in r["engine"]), r      # ... and so does the engine, on both dropout seeds
-    assert r["abs_diff_auc"] < r["tolerance_auc"] <= 3e-2, r
-    assert abs(r["oracle"]["last10_loss"] - r["engine"][0]["last10_loss"]) < 0.1, r
-
-
-def test_lstur_engine_and_oracle_train_to_the_same_auc():
-    """The LSTUR leg: 100 steps with dropout and user masking on from the same initial weights (oracle/train_parity.py make_task_lstur /
-    train_oracle_lstur); the engine runs its persistent GRU sweeps and the row-sparse lazy Adam of the user table."""
-    import bench
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(0)
-    r = bench.train_parity_lstur(dev, steps=100, B=16)
-    out_dir = os.path.join(ROOT, 'gpurun_out')
-    if os.path.isdir(out_dir):
-        import json
-        with open(os.path.join(out_dir, 'train_parity_lstur.json'), 'w') as f:
-            json.dump(r, f, indent=1)
-    assert r["auc_init"] < 0.56, r                                      # starts at chance
-    gain = r["oracle"]["auc"] - r["auc_init"]
-    assert gain > 0.08, r                                               # the reference's loop learns the task ...
-    assert all(e["auc"] > r["auc_init"] + 0.6 * gain for e in r["engine"]), r      # ... and so does the engine, on both seeds
-    assert r["abs_diff_auc"] < r["tolerance_auc"] <= 6e-2, r
+    assert len(r["reference_auc"]) >= 8 and len(r["engine_auc"]) >= 8, r
+    gain = r["mean_reference_auc"] - r["auc_init"]
+    assert gain > 0.03, r                                                # the reference's loop learns the task ...
+    assert min(r["engine_auc"]) > r["auc_init"] + 0.6 * gain, r          # ... and so does the engine, on every dropout stream
+    assert abs(r["z_auc"]) < 3.0, (r["diff_auc"], r["stderr_diff_auc"], r)
+    assert abs(r["z_ndcg10"]) < 3.0, (r["diff_ndcg10"], r["stderr_diff_ndcg10"], r)
+    # the two trainers also end at the same training loss (mean of the last ten steps, averaged over the seeds)
+    le = sum(r["engine_last10_loss"]) / len(r["engine_last10_loss"])
+    lr_ = sum(r["reference_last10_loss"]) / len(r["reference_last10_loss"])
+    assert abs(le - lr_) < 0.05, (le, lr_)

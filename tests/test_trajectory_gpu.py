@@ -1,0 +1,218 @@
+"""DETERMINISTIC multi-step training parity ("make training parity able to fail"): K = 20 consecutive training steps of the
+engine against the reference's training math restated on the CPU -- the fp32 torch oracle (pinned to the imported reference by
+tests/golden/*), torch.optim.Adam (src/train.py:127-128) and, at every step, the SAME dropout masks: the engine's own, exported per step
+with nr_dropout_mask from the seed the step drew (LSTUR: plus the whole-row user mask the forward drew).  Nothing is statistical here: both
+sides see identical batches, identical masks and start from identical weights; what differs is bf16 operand rounding in the engine, and how
+that compounds through Adam over 20 steps is what the bounds state.
+
+Compared after steps 1, 5 and 20: the step's logits (computed from the parameters of the previous step), and for every parameter tensor the
+UPDATE it has accumulated, delta = p_k - p_0: rel = |delta_engine - delta_oracle|_F / |delta_oracle|_F.  Rows of the embedding tables that
+no batch touched must be bit-identical to their initial values on both sides (dense Adam never moves a row without a gradient).
+Adam normalises every element's step to ~lr whatever the size of its gradient, so an element whose gradient is rounding noise moves by +-lr
+in an arbitrary direction on BOTH sides: tensors whose reference gradient is analytically zero (W_K.bias: a per-query shift of the scores
+cancels in exp / (sum + 1e-8)) are excluded from the delta comparison and only held to |delta| <= k lr.
+Bounds: ~3x the values measured on MI355X (profiles/r06_trajectory_*.json holds the measurements)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K, B, LR, P = 20, 4, 1e-3, 0.2
+CHECK = (1, 5, 20)
+
+
+def _record(name, rec):
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, f'trajectory_{name}.json'), 'w') as f:
+            json.dump(rec, f, indent=1)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _masks(seed, n_elem, site):
+    from tests.backends import GpuBackend
+    from tests.kernel_checks import export_mask
+    return export_mask(GpuBackend(), n_elem, P, seed, site)
+
+
+def _compare(name, m, ref, p0, logits, k, rec, zero_grad_keys, table_keys, touched, bounds):
+    """One checkpoint of the trajectory (after step k)."""
+    le, lo = logits
+    r = {"step": k, "logits_rel": _rel(le, lo), "delta_rel": {}}
+    sd_e = {n: v.detach().cpu().numpy() for n, v in m.state_dict().items()}
+    sd_o = {n: v.detach().numpy() for n, v in ref.state_dict().items()}
+    for n in sd_o:
+        de, do = sd_e[n] - p0[n], sd_o[n] - p0[n]
+        if n in table_keys:
+            rows = touched[table_keys[n]]
+            idle = np.ones(p0[n].shape[0], dtype=bool)
+            idle[rows] = False
+            assert not de[idle].any() and not do[idle].any(), f'{n}: a row no batch touched has moved'
+            de, do = de[rows], do[rows]
+        if any(n.endswith(z) for z in zero_grad_keys):
+            assert np.abs(de).max() <= k * LR * 1.01 and np.abs(do).max() <= k * LR * 1.01, n
+            continue
+        r["delta_rel"][n] = _rel(de, do)
+    worst = max(r["delta_rel"].items(), key=lambda kv: kv[1])
+    r["delta_rel_worst"] = list(worst)
+    r["bounds"] = {"logits": bounds['logits'][k], "delta": bounds['delta'][k]}
+    rec.append(r)
+
+
+def _run(name, m, ref, opt_e, opt_o, step_fn, p0, zero_grad_keys, table_keys, touched, bounds, flush=None):
+    rec = []
+    crit = torch.nn.CrossEntropyLoss()
+    for k in range(1, K + 1):
+        le, lo = step_fn(k)
+        y = torch.zeros(B, dtype=torch.long)
+        loss_o = crit(lo, y)
+        opt_o.zero_grad()
+        loss_o.backward()
+        opt_o.step()
+        loss_e = crit(le, y.to(DEV))
+        loss_e.backward()
+        opt_e.step()
+        if k in CHECK:
+            if flush is not None:
+                flush()
+            _compare(name, m, ref, p0, (le.detach().cpu().numpy(), lo.detach().numpy()), k, rec, zero_grad_keys, table_keys, touched, bounds)
+    _record(name, {"model": name, "steps": K, "batch": B, "lr": LR, "dropout": P, "checkpoints": rec,
+                   "last_step_loss_engine_oracle": [float(loss_e), float(loss_o)]})
+    for r in rec:                                   # (asserted after the record is written: a failing run leaves its measurements behind)
+        assert r["logits_rel"] < r["bounds"]["logits"], (name, r["step"], r["logits_rel"])
+        assert r["delta_rel_worst"][1] < r["bounds"]["delta"], (name, r["step"], r["delta_rel_worst"])
+    return rec
+
+
+def test_nrms_20_step_trajectory_with_exported_masks():
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle import nrms_numpy as onp
+    from oracle.nrms_torch import OracleNRMS
+    from tests.test_model_gpu import build, as_lists, mind_batch
+    rng = np.random.default_rng(70)
+    V, C, N, L = 3000, 3, 50, 20
+    params = onp.random_nrms_params(rng, V, 300, 200, np.float32, emb_std=0.4)
+    params['news_encoder.word_embedding.weight'][0] = 0
+    batches = [mind_batch(rng, B, V=V) for _ in range(K)]
+    m = build(V, 300, 15, 200, N, L, params, p=P).train()
+    ref = OracleNRMS(V, 300, 15, 200, P)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    ref.train()
+    opt_e, opt_o = EngineAdam(m, lr=LR), torch.optim.Adam(ref.parameters(), lr=LR)
+    T = B * (C + N)
+    touched = {'words': np.unique(np.concatenate([np.concatenate([c.reshape(-1), h.reshape(-1)]) for c, h in batches]))}
+    touched['words'] = touched['words'][touched['words'] != 0]
+
+    def step_fn(k):
+        cand, click = batches[k - 1]
+        torch.manual_seed(5000 + k)
+        le = m(as_lists(cand), as_lists(click))
+        torch.manual_seed(5000 + k)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())           # what ops.new_seed() drew for this step
+        m1 = _masks(seed, T * L * 300, 1).reshape(T, L, 300)
+        m2 = _masks(seed, T * L * 300, 2).reshape(T, L, 300)
+        keeps = []
+        for j in range(C + N):                                        # engine title order: candidates b*C+c, then clicked B*C + b*N + n
+            idx = np.arange(B) * C + j if j < C else B * C + np.arange(B) * N + (j - C)
+            keeps.append({'title1': torch.from_numpy(m1[idx]), 'title2': torch.from_numpy(m2[idx])})
+        return le, ref(as_lists(cand), as_lists(click), keeps)
+    bounds = {'logits': {1: 8e-3, 5: 4e-2, 20: 1.2e-1}, 'delta': {1: 0.5, 5: 0.5, 20: 0.5}}
+    _run('NRMS', m, ref, opt_e, opt_o, step_fn, {k: v.copy() for k, v in params.items()}, ('W_K.bias',),
+         {'news_encoder.word_embedding.weight': 'words'}, touched, bounds)
+
+
+def test_naml_20_step_trajectory_with_exported_masks():
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle.naml_torch import random_naml_params
+    from tests.test_naml_gpu import build, oracle_with_engine_operands, as_lists, synth_batch
+    c = dict(V=3000, d=300, ncat=275, dcat=100, F=300, window=3, Q=200, C=3, N=50, L=20, La=50, B=B, seed=71)
+    C, N, L, La = c['C'], c['N'], c['L'], c['La']
+    params = random_naml_params(71, c['V'], c['d'], c['ncat'], c['dcat'], c['F'], c['window'], c['Q'], emb_std=0.3)
+    rng = np.random.default_rng(71)
+    batches = [synth_batch(rng, c, True)[:2] for _ in range(K)]
+    m = build(c, params, p=P).train()
+    ref = oracle_with_engine_operands(c, params, train=True)
+    opt_e, opt_o = EngineAdam(m, lr=LR), torch.optim.Adam(ref.parameters(), lr=LR)
+    T = B * (C + N)
+    tw = np.unique(np.concatenate([np.concatenate([x[k_].reshape(-1) for x in b for k_ in ('title', 'abstract')]) for b in batches]))
+    tc = np.unique(np.concatenate([np.concatenate([x[k_].reshape(-1) for x in b for k_ in ('category', 'subcategory')]) for b in batches]))
+    touched = {'words': tw[tw != 0], 'cats': tc[tc != 0]}
+
+    def step_fn(k):
+        cand, click = batches[k - 1]
+        cl, hl = as_lists(cand, click)
+        torch.manual_seed(6000 + k)
+        le = m(cl, hl)
+        torch.manual_seed(6000 + k)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ntok = T * L + T * La
+        m1, m2 = _masks(seed, ntok * 300, 1), _masks(seed, ntok * 300, 2)
+        t1, t2 = m1[:T * L * 300].reshape(T, L, 300), m2[:T * L * 300].reshape(T, L, 300)
+        a1, a2 = m1[T * L * 300:].reshape(T, La, 300), m2[T * L * 300:].reshape(T, La, 300)
+        keeps = []
+        for j in range(C + N):
+            idx = np.arange(B) * C + j if j < C else B * C + np.arange(B) * N + (j - C)
+            keeps.append({'title1': torch.from_numpy(t1[idx]), 'title2': torch.from_numpy(t2[idx]),
+                          'abstract1': torch.from_numpy(a1[idx]), 'abstract2': torch.from_numpy(a2[idx])})
+        return le, ref(cl, hl, keeps)
+    p0 = {k: v.numpy().copy() for k, v in params.items()}
+    tables = {k: 'words' for k in p0 if k.endswith('word_embedding.weight')}
+    tables.update({k: 'cats' for k in p0 if k.endswith('element_encoders.category.embedding.weight') or k.endswith('element_encoders.subcategory.embedding.weight')})
+    bounds = {'logits': {1: 3e-3, 5: 2e-2, 20: 8e-2}, 'delta': {1: 0.5, 5: 0.5, 20: 0.5}}
+    _run('NAML', m, ref, opt_e, opt_o, step_fn, p0, (), tables, touched, bounds)
+
+
+def test_lstur_20_step_trajectory_with_exported_masks():
+    from news_recommendation_amd import ops_gru
+    from news_recommendation_amd.optim import EngineAdam
+    from oracle.lstur_torch import random_lstur_params
+    from tests.test_lstur_gpu import build, oracle, as_lists, synth_batch, MIND
+    c = dict(MIND, V=3000, nusers=101, B=B, seed=72)
+    C, N, L = c['C'], c['N'], c['L']
+    params = random_lstur_params(72, c['V'], c['d'], c['ncat'], c['nusers'], c['F'], c['window'], c['Q'], 'ini', emb_std=0.3)
+    rng = np.random.default_rng(72)
+    batches = []
+    for _ in range(K):
+        cand, click, hist = synth_batch(rng, c, False)
+        batches.append((cand, click, torch.from_numpy(rng.integers(1, c['nusers'], size=B).astype(np.int64)), torch.from_numpy(hist)))
+    m = build(c, params, p=P).train()
+    ref = oracle(c, params, train=True)
+    opt_e = EngineAdam(m, lr=LR, row_sparse=('user_embedding.weight',))
+    opt_o = torch.optim.Adam(ref.parameters(), lr=LR)
+    T = B * (C + N)
+    tw = np.unique(np.concatenate([np.concatenate([x['title'].reshape(-1) for x in b[:2]]) for b in batches]))
+    tc = np.unique(np.concatenate([np.concatenate([x[k_].reshape(-1) for x in b[:2] for k_ in ('category', 'subcategory')]) for b in batches]))
+    tu = np.unique(np.concatenate([b[2].numpy() for b in batches]))
+    touched = {'words': tw[tw != 0], 'cats': tc[tc != 0], 'users': tu[tu != 0]}
+
+    def step_fn(k):
+        cand, click, user, length = batches[k - 1]
+        cl, hl = as_lists(cand, click)
+        torch.manual_seed(7000 + k)
+        le = m(user, length.clone(), cl, hl)
+        keep_u = m.last_user_keep.clone().cpu()
+        torch.manual_seed(7000 + k)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # ops.new_seed() is the first draw of the forward
+        t1 = _masks(seed, T * L * 300, 1).reshape(T, L, 300)
+        t2 = _masks(seed, T * L * 300, 2).reshape(T, L, 300)
+        keeps = []
+        for j in range(C + N):
+            idx = np.arange(B) * C + j if j < C else B * C + np.arange(B) * N + (j - C)
+            keeps.append({'title1': torch.from_numpy(t1[idx]), 'title2': torch.from_numpy(t2[idx])})
+        return le, ref(user, length.clone(), cl, hl, keeps, keep_u)
+    p0 = {k: v.numpy().copy() for k, v in params.items()}
+    tables = {k: 'words' for k in p0 if k.endswith('word_embedding.weight')}
+    tables.update({k: 'cats' for k in p0 if k.endswith('category_embedding.weight')})
+    tables['user_embedding.weight'] = 'users'
+    bounds = {'logits': {1: 1e-2, 5: 5e-2, 20: 1.5e-1}, 'delta': {1: 0.5, 5: 0.5, 20: 0.5}}
+    _run('LSTUR', m, ref, opt_e, opt_o, step_fn, p0, (), tables, touched, bounds, flush=opt_e.flush)
+    ops_gru.persist_check()

@@ -32,6 +32,17 @@ import torch         # noqa: E402
 ATTRS = {'NRMS': ('title',), 'NAML': ('title', 'abstract', 'category', 'subcategory'), 'LSTUR': ('title', 'category', 'subcategory')}
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def timed(fn, budget, max_iter=64):
     fn()                                     # warm-up
     t0, n = time.perf_counter(), 0
@@ -56,7 +67,8 @@ def main():
     shape = dict(synth.SHAPES[a.shape])
     if a.vocab:
         shape['num_words'] = a.vocab
-    threads = min(32, os.cpu_count() or 1)   # more threads on the reference's tiny per-title ops is slower
+    nproc = os.cpu_count() or 1
+    threads = min(32, nproc)                 # more threads on the reference's tiny per-title ops is slower
     torch.set_num_threads(threads)
     use_ref = bool(a.reference) and os.path.isdir(a.reference)
     name = a.model
@@ -111,7 +123,8 @@ def main():
             return model(users, lengths.clone(), cl, hl)
         return model(cl, hl)
 
-    out = {'kind': 'reference' if use_ref else 'port', 'cores': threads, 'unit': 'impressions/s', 'model': name, 'shape': a.shape, 'batch': B}
+    out = {'kind': 'reference' if use_ref else 'port', 'cores': threads, 'threads': threads, 'nproc': nproc, 'cpu_model': cpu_model(),
+           'unit': 'impressions/s', 'model': name, 'shape': a.shape, 'batch': B}
     leg = a.budget / 3.0
     # (i) eval forward
     model.eval()
@@ -149,35 +162,62 @@ def main():
             dt = time.perf_counter() - t0
         finally:
             os.chdir(cwd)
-    out['evaluate'] = {'value': n_val / dt, 'impressions': n_val, 'news': 1500, 'seconds': dt, 'auc': float(metrics[0]), 'ndcg10': float(metrics[3])}
+    out['evaluate'] = {'value': n_val / dt, 'impressions': n_val, 'news': 1500, 'seconds': dt, 'auc': float(metrics[0]), 'ndcg10': float(metrics[3]),
+                       'what': ("the reference's own evaluate() (src/evaluate.py:171-272): DataLoaders, batch-size-1 impression loop, metric Pool" if use_ref else
+                                "oracle model in the reference's loop shape (evaluate.py:185-272): per-news / per-history dicts, one impression at a time with "
+                                ".tolist(), metric Pool of num_workers; without its DataLoader workers")}
     out['sample'] = (f"{out['train_step']['iterations']} train steps (fwd+bwd+Adam) of B={B} train-shaped impressions; also "
                      f"{out['eval_forward']['iterations']} eval-mode forwards and evaluate() on {n_val} impressions / 1500 news; "
-                     f"{'reference model imported from ' + a.reference if use_ref else 'oracle torch port of the reference'}, CPU fp32, {threads} threads")
+                     f"{'reference model imported from ' + a.reference if use_ref else 'oracle torch port of the reference'}, CPU fp32, "
+                     f"{threads} torch threads on a host with {nproc} logical CPUs ({out['cpu_model']})")
     print(json.dumps(out))
 
 
-def port_evaluate(model, directory, config, name):
-    """The reference's evaluate() loop (src/evaluate.py:185-272) on the oracle model: per-news vectors in a dict, per-history user
-    vectors, one get_prediction per impression, metrics by oracle/metrics.py."""
-    from news_recommendation_amd import evaluate_fast
+def _single_metric(pair):
     from oracle import metrics
+    return metrics.single_impression_metrics(np.asarray(pair[0]), np.asarray(pair[1]))
+
+
+def port_evaluate(model, directory, config, name):
+    """The reference's evaluate() in ITS loop shape (src/evaluate.py:185-272) on the oracle model: news vectors in chunks of batch_size * 16 into a
+    dict keyed by news id (:185-203), user vectors per chunk of histories from per-news dict look-ups + torch.stack into a dict keyed by the
+    history (:218-233), then ONE impression at a time (:235-260: the batch-size-1 loader): stack the candidates' vectors from the dict,
+    get_prediction, .tolist(); the per-impression metrics in a multiprocessing Pool (:267-268).  What is not restated: the DataLoader worker
+    processes and pandas row parsing (the files are parsed once by evaluate_fast.build_plan)."""
+    from multiprocessing import Pool
+    from news_recommendation_amd import evaluate_fast
     plan = evaluate_fast.build_plan(directory, config.dataset_attributes['news'], config.num_clicked_news_a_user)
+    chunk = config.batch_size * 16
     with torch.no_grad():
         n = len(plan.news_ids)
-        nv = torch.cat([model.get_news_vector({k: torch.from_numpy(v[i:i + 2048]) for k, v in plan.news.items()}) for i in range(0, n, 2048)])
-        nvp = torch.cat([nv, torch.zeros(1, nv.shape[1])])
-        hidx = torch.from_numpy(plan.hist_idx)
-        if name == 'LSTUR':
-            uv = torch.cat([model.get_user_vector(torch.from_numpy(plan.hist_user[i:i + 256]), torch.from_numpy(plan.hist_len[i:i + 256].copy()),
-                                                  nvp[hidx[i:i + 256]]) for i in range(0, hidx.shape[0], 256)])
-        else:
-            uv = torch.cat([model.get_user_vector(nvp[hidx[i:i + 256]]) for i in range(0, hidx.shape[0], 256)])
-        labels, scores = [], []
+        news2vector = {}
+        for i in range(0, n, chunk):
+            vec = model.get_news_vector({k: torch.from_numpy(v[i:i + chunk]) for k, v in plan.news.items()})
+            for nid, v in zip(plan.news_ids[i:i + chunk], vec):
+                if nid not in news2vector:
+                    news2vector[nid] = v
+        pad = torch.zeros(next(iter(news2vector.values())).size())
+        ids = list(plan.news_ids)
+        user2vector = {}
+        nh = plan.hist_idx.shape[0]
+        for i in range(0, nh, chunk):
+            rows = plan.hist_idx[i:i + chunk]
+            cv = torch.stack([torch.stack([news2vector[ids[j]] if 0 <= j < n else pad for j in row], dim=0) for row in rows], dim=0)
+            if name == 'LSTUR':
+                uv = model.get_user_vector(torch.from_numpy(plan.hist_user[i:i + chunk]), torch.from_numpy(plan.hist_len[i:i + chunk].copy()), cv)
+            else:
+                uv = model.get_user_vector(cv)
+            for r, v in enumerate(uv):
+                user2vector[i + r] = v
+        tasks = []
         for i in range(len(plan.imp_user_row)):
             lo, hi = plan.cand_ptr[i], plan.cand_ptr[i + 1]
-            scores.append(model.get_prediction(nv[torch.from_numpy(plan.cand_idx[lo:hi].astype(np.int64))], uv[plan.imp_user_row[i]]).numpy())
-            labels.append(plan.labels[lo:hi])
-    return metrics.evaluate_impressions(labels, scores)
+            cand = torch.stack([news2vector[ids[j]] if j >= 0 else pad for j in plan.cand_idx[lo:hi]], dim=0)
+            y_pred = model.get_prediction(cand, user2vector[int(plan.imp_user_row[i])]).tolist()
+            tasks.append((plan.labels[lo:hi].tolist(), y_pred))
+    with Pool(processes=config.num_workers) as pool:
+        res = np.array(pool.map(_single_metric, tasks), dtype=np.float64)
+    return np.nanmean(res, axis=0)
 
 
 if __name__ == '__main__':
