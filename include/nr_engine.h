@@ -169,7 +169,7 @@ int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint1
  *                gradients with split K (sum over p = the gradient; nr_sum_parts reduces in a fixed order).  taps = 1: X bf16[n_tok][ldx],
  *                N = tapw <= ldx columns (dW_ih = dGi^T X, dW_hh = dGh^T H of nn.GRU; the nn.Linear weights of multihead_self.py:53-55 /
  *                additive.py:35).  taps = 3: X is a seqpad buffer (nr_conv3_fwd's x_save) with n_tok + 2 readable rows, and the N = 3 tapw
- *                result columns are the three tap gradients of Conv2d(1, F, (3, D)) side by side (src/model/NAML/news_encoder.py:27-28,
+ *                (taps <= 9: any odd window_size on the general-geometry path; the tuned path uses 3) result columns are the three tap gradients of Conv2d(1, F, (3, D)) side by side (src/model/NAML/news_encoder.py:27-28,
  *                src/model/LSTUR/news_encoder.py:26-30): one pass over G for all taps.  P: multiple of 8 (nr_gemm_tn_parts = one workgroup
  *                per CU); zeros: 16 zero bytes in device memory.
  *   nr_transpose_bf16  dst[c][r] = src[r][c] (weight re-packing, once per optimiser step); nr_sum_parts  out[i] (+)= sum_p parts[p][i]. */
@@ -441,6 +441,49 @@ int nr_gru_gate_rows(const float* gi, const int32_t* gi_row, const float* gh, co
                      uint16_t* h_b, int B, int N, int Hd, int t, void* stream);
 int nr_gru_bwd_seq_n(const float* g_last, const uint16_t* WhhT, const uint16_t* gates, const uint16_t* H_all, const int32_t* len, uint16_t* dgi,
                      uint16_t* dgh, uint16_t* dgh_t2, int n_buf, float* carry2, int B, int N, int Hd, int T, void* stream);
+
+/* ---- GENERAL GEOMETRY (csrc/k_generic.h): src/config.py's model-geometry knobs away from the tuned instantiation ------------------------------
+ * word_embedding_dim (config.py:34), num_attention_heads (:45, any divisor with d_k <= 32), num_filters (:54), window_size (:55, odd),
+ * query_vector_dim (:39): the reference builds any of them (multihead_self.py:27-38, NAML/news_encoder.py:10-19, LSTUR/news_encoder.py:23).
+ * On this path every dense contraction runs in nr_gemm_nt / nr_gemm_tn on bf16 operands (rows padded to a multiple of 32 columns, one
+ * column of 1.0 that carries the bias -- nr_rows_to_bf16 / nr_g_rows_to_seqpad); these entry points are everything else, on f32 rows.
+ * Limits: sequence length <= 64, d_k <= 32; counts of elements multiples of 4 where stated.  Not tuned (the tuned kernels keep 300 / 15 /
+ * 300 / 3).
+ *   nr_g_dropout         y = F.dropout(x) (news_encoder.py:38-40,43-45): element i uses counter elem0 + i of dropout `site` -- nr_dropout_mask's
+ *                        numbering; the same call on a gradient is the backward.  n_elem, elem0 multiples of 4; y may alias x.
+ *   nr_g_attn_fwd        ScaledDotProductAttention (multihead_self.py:15-23: exp / (sum + 1e-8), optional key lengths :60-70) per (sequence,
+ *                        head) from qkv f32 [n_seq * S][ld] (Q at column 0, K at H * dk, V at 2 H * dk) -> ctx f32 [n_seq * S][H * dk].
+ *   nr_g_attn_bwd        its backward: dctx f32 [n_seq * S][H * dk] -> dqkv f32 [n_seq * S][ld] (columns 0 .. 3 H dk - 1 written).
+ *   nr_g_additive_fwd    AdditiveAttention (additive.py:27-53) given proj = x Wa^T + ba (f32 [n_seq * S][ldp], from the GEMM): softmax over
+ *                        the first `valid` tokens of q . tanh(proj), out f32 [n_seq][ldo], attn_w f32 [n_seq][S] (may be NULL).
+ *   nr_g_additive_bwd    g_out f32 [n_seq][ldg] -> dpre f32 [n_seq * S][ldq] (gradient of proj) and dq_part f32 [n_seq][Q] (sum over rows =
+ *                        gradient of attention_query_vector); the input gradient is dpre @ Wa (a GEMM) + the direct term:
+ *   nr_g_rows_axpy       y[r][0:d] (+)= a[r] * g[r / S][0:d]  (a = the attention weights, g = g_out).
+ *   nr_g_rows_to_seqpad  f32 token rows -> bf16 rows of dp columns in the seqpad layout of a window-w convolution (pad = (w - 1) / 2: token s
+ *                        of sequence q at row pad + q (S + pad) + s; the other rows must be zero: zero-fill once), column d = 1.0 when `one`.
+ *                        Conv2d(1, F, (w, D), padding = (pad, 0)) (NAML/news_encoder.py:15-17, LSTUR/news_encoder.py:24-28) is then ONE
+ *                        nr_gemm_nt with A = that buffer, lda = dp, K = w * dp (the w rows of a window are contiguous), M = n_seq (S + pad)
+ *                        virtual rows; its weight gradient ONE nr_gemm_tn with taps = w.
+ *   nr_g_relu_drop       act f32 [n_tok][F] = dropout(relu(y[virtual row])) (news_encoder.py: F.dropout(F.relu(conv))), site 2 counters from elem0.
+ *   nr_g_relu_drop_bwd   dy bf16 seqpad rows (fp columns) = dact * [act != 0] / (1 - p).
+ *   nr_g_unpad_rows      virtual GEMM rows -> token rows;  nr_g_relu  y = scale * x where gate > 0 (gate = x when NULL), else 0: relu forward, and the
+ *                        backward of dropout(relu(.)) read off the output's zeros (ElementEncoder, NAML news_encoder.py:40-47; TextEncoder :29-32). */
+int nr_g_dropout(const float* x, float* y, int64_t n_elem, int64_t elem0, float p, uint64_t seed, int site, void* stream);
+int nr_g_attn_fwd(const float* qkv, int64_t ld, float* ctx, const int32_t* key_len, int64_t n_seq, int S, int H, int dk, void* stream);
+int nr_g_attn_bwd(const float* qkv, int64_t ld, const float* dctx, float* dqkv, const int32_t* key_len, int64_t n_seq, int S, int H, int dk, void* stream);
+int nr_g_additive_fwd(const float* x, int64_t ldx, int D, const float* proj, int64_t ldp, int Q, const float* qv, float* out, int64_t ldo, float* attn_w,
+                      int64_t n_seq, int S, int valid, void* stream);
+int nr_g_additive_bwd(const float* x, int64_t ldx, int D, const float* proj, int64_t ldp, int Q, const float* qv, const float* attn_w, const float* g_out,
+                      int64_t ldg, float* dpre, int64_t ldq, float* dq_part, int64_t n_seq, int S, void* stream);
+int nr_g_rows_axpy(float* y, int64_t ldy, const float* a, const float* g, int64_t ldg, int S, int d, int64_t n_rows, int accumulate, void* stream);
+int nr_g_rows_to_seqpad(const float* src, int64_t lds, int d, uint16_t* dst, int dp, int S, int pad, int64_t n_tok, int one, void* stream);
+int nr_g_relu_drop(const float* y, int64_t ldy, float* act, int F, int S, int pad, int64_t n_tok, float p, uint64_t seed, int64_t elem0, void* stream);
+int nr_g_relu_drop_bwd(const float* dact, const float* act, uint16_t* dy, int F, int fp, int S, int pad, int64_t n_tok, float p, void* stream);
+int nr_g_unpad_rows(const float* src, int64_t lds, float* dst, int d, int S, int pad, int64_t n_tok, void* stream);
+int nr_g_relu(const float* x, const float* gate, float* y, int64_t n, float scale, void* stream);
+/* nr_gemm_nt with OVERLAPPING A rows (lda < K allowed): row m of the product reads the K contiguous elements from A + m * lda -- the w rows of a
+ * convolution window in a seqpad buffer (nr_g_rows_to_seqpad).  The caller guarantees (M - 1) * lda + K readable elements. */
+int nr_gemm_nt_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* stream);
 
 /* Per-impression ranking metrics of src/evaluate.py:24-42,160-168 for a CSR batch of impressions: scores f32[nnz], labels
  * int32[nnz] (0/1), ptr int64[n_impr+1]; out f32[n_impr][4] = AUC, MRR, nDCG@5, nDCG@10 (four NaNs when an impression has a

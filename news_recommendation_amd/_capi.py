@@ -106,6 +106,18 @@ SIGNATURES = {
     'nr_dropout_mask': ([_P, c_int64, c_float, c_uint64, c_int, _P], c_int),
     'nr_set_step_counter': ([_P], c_int),
     'nr_step_counter_add': ([_P, ctypes.c_uint32, _P], c_int),
+    'nr_g_dropout': ([_P, _P, c_int64, c_int64, c_float, c_uint64, c_int, _P], c_int),
+    'nr_g_attn_fwd': ([_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
+    'nr_g_attn_bwd': ([_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
+    'nr_g_additive_fwd': ([_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, c_int64, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_g_additive_bwd': ([_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P], c_int),
+    'nr_g_rows_axpy': ([_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int64, c_int, _P], c_int),
+    'nr_g_rows_to_seqpad': ([_P, c_int64, c_int, _P, c_int, c_int, c_int, c_int64, c_int, _P], c_int),
+    'nr_g_relu_drop': ([_P, c_int64, _P, c_int, c_int, c_int, c_int64, c_float, c_uint64, c_int64, _P], c_int),
+    'nr_g_relu_drop_bwd': ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_float, _P], c_int),
+    'nr_g_unpad_rows': ([_P, c_int64, _P, c_int, c_int, c_int, c_int64, _P], c_int),
+    'nr_g_relu': ([_P, _P, _P, c_int64, c_float, _P], c_int),
+    'nr_gemm_nt_rows': ([_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
     'nr_probe_tr16': ([_P, _P, _P], c_int),
 }

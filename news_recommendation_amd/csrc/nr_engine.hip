@@ -18,6 +18,7 @@
 #include "k_eval.h"
 #include "k_optim.h"
 #include "k_sort.h"
+#include "k_generic.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -426,6 +427,21 @@ int nr_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, f
   return launch_gemm<0, 4, 2, 4>(p, grid, stream, "nr_gemm_nt");
 }
 
+// nr_gemm_nt whose A rows OVERLAP: row m reads the K contiguous elements from A + m * lda with lda < K allowed (a convolution window = w contiguous
+// rows of a seqpad buffer: csrc/k_generic.h).  The caller guarantees (M - 1) * lda + K readable elements.
+int nr_gemm_nt_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* stream) {
+  if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || (K & 31) || lda < 8 || ldb < K || ldc < N || (lda & 7) || (ldb & 7))
+    return fail(NR_ERR_BADARG, "nr_gemm_nt_rows: bad argument (K must be a multiple of 32, row strides multiples of 8 elements)");
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return fail(NR_ERR_BADARG, "nr_gemm_nt_rows: operands must be 16-byte aligned");
+  if (M == 0) return NR_OK;
+  nr::GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.tapw = 1 << 30;
+  using G = nr::GemmGeom<0, 4, 2, 4>;
+  p.tiles_m = (int)((M + G::BM - 1) / G::BM); p.tiles_n = (N + G::BN - 1) / G::BN;
+  const int64_t grid = (int64_t)((p.tiles_m + 7) / 8) * 8 * p.tiles_n;
+  return launch_gemm<0, 4, 2, 4>(p, grid, stream, "nr_gemm_nt_rows");
+}
+
 // output tile of the TN kernel: 256 x 320 (4 x 2 waves of 2 x 5 tiles) when the output has at most 320 columns (projection gradients 960 x 320,
 // pooling gradients 208 x 320), 320 x 256 (2 x 4 waves of 5 x 2 tiles) for 257 .. 320 rows (conv tap gradients: 320 filters x 3 x 320), else 256 x 256
 static void gemm_tn_tile(int M, int N, int* bm, int* bn) {
@@ -448,7 +464,7 @@ int nr_gemm_tn_parts(int M, int N, int64_t n_tok) {
 
 int nr_gemm_tn(const uint16_t* G, int64_t ldg, int M, const uint16_t* X, int64_t ldx, int tapw, int taps, const uint16_t* zeros, float* out,
                int64_t ldo, int64_t n_tok, int P, void* stream) {
-  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || (ldx & 7) || tapw <= 0 || tapw > ldx || (tapw & 7) || taps < 1 || taps > 3 ||
+  if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || (ldx & 7) || tapw <= 0 || tapw > ldx || (tapw & 7) || taps < 1 || taps > 9 ||
       n_tok < 0 || P <= 0 || (P & 7) || ldo < (int64_t)taps * tapw)
     return fail(NR_ERR_BADARG, "nr_gemm_tn: bad argument");
   if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)zeros) & 15) != 0) return fail(NR_ERR_BADARG, "nr_gemm_tn: operands must be 16-byte aligned");
@@ -469,6 +485,91 @@ int nr_tn_gemm_parts(int M, int64_t n_tok) { return nr_gemm_tn_parts(M, NR_KP, n
 int nr_tn_gemm(const uint16_t* G, int ldg, int M, const uint16_t* X, const uint16_t* zeros, float* out, int64_t n_tok, int P, void* stream) {
   if (!G || !X || !zeros || !out || M <= 0 || M > ldg || (ldg & 7) || n_tok < 0 || P <= 0 || (P & 7)) return fail(NR_ERR_BADARG, "nr_tn_gemm: bad argument");
   return nr_gemm_tn(G, ldg, M, X, NR_KP, NR_KP, 1, zeros, out, NR_KP, n_tok, P, stream);
+}
+
+// ---- general-geometry kernels (csrc/k_generic.h): what is not a GEMM on the path for config knobs away from 300 / 15 / 300 / 3 -------------------
+int nr_g_dropout(const float* x, float* y, int64_t n_elem, int64_t elem0, float p, uint64_t seed, int site, void* stream) {
+  if (!x || !y || n_elem < 0 || (n_elem & 3) || elem0 < 0 || (elem0 & 3) || p < 0.0f || p >= 1.0f || site < 1) return fail(NR_ERR_BADARG, "nr_g_dropout: bad argument");
+  if (n_elem == 0) return NR_OK;
+  NR_LAUNCH(nr::g_dropout_kernel, grid_for(n_elem / 4, 256, 4096), 256, 0, (hipStream_t)stream, x, y, n_elem / 4, elem0 / 4, make_drop(p, seed), site);
+  return check_launch("nr_g_dropout");
+}
+static bool g_attn_ok(int64_t n_seq, int S, int H, int dk, int64_t ld) {
+  return n_seq >= 0 && S >= 1 && S <= nr::G_SMAX && H >= 1 && dk >= 1 && dk <= nr::G_DKMAX && ld >= 3LL * H * dk && n_seq * H < (1LL << 31);
+}
+int nr_g_attn_fwd(const float* qkv, int64_t ld, float* ctx, const int32_t* key_len, int64_t n_seq, int S, int H, int dk, void* stream) {
+  if (!qkv || !ctx || !g_attn_ok(n_seq, S, H, dk, ld)) return fail(NR_ERR_BADARG, "nr_g_attn_fwd: bad argument (S <= 64, d_k <= 32)");
+  if (n_seq == 0) return NR_OK;
+  nr::GAttnParams p{qkv, ld, nullptr, ctx, key_len, n_seq, S, H, dk, H * dk};
+  NR_LAUNCH(nr::g_attn_fwd_kernel, n_seq * H, 64, 2 * S * dk * 4, (hipStream_t)stream, p);
+  return check_launch("nr_g_attn_fwd");
+}
+int nr_g_attn_bwd(const float* qkv, int64_t ld, const float* dctx, float* dqkv, const int32_t* key_len, int64_t n_seq, int S, int H, int dk, void* stream) {
+  if (!qkv || !dctx || !dqkv || !g_attn_ok(n_seq, S, H, dk, ld)) return fail(NR_ERR_BADARG, "nr_g_attn_bwd: bad argument (S <= 64, d_k <= 32)");
+  if (n_seq == 0) return NR_OK;
+  nr::GAttnParams p{qkv, ld, dctx, dqkv, key_len, n_seq, S, H, dk, H * dk};
+  NR_LAUNCH(nr::g_attn_bwd_kernel, n_seq * H, 64, (4 * S * dk + 2 * nr::G_SMAX) * 4, (hipStream_t)stream, p);
+  return check_launch("nr_g_attn_bwd");
+}
+int nr_g_additive_fwd(const float* x, int64_t ldx, int D, const float* proj, int64_t ldp, int Q, const float* qv, float* out, int64_t ldo, float* attn_w,
+                      int64_t n_seq, int S, int valid, void* stream) {
+  if (!x || !proj || !qv || !out || D < 1 || Q < 1 || ldx < D || ldp < Q || ldo < D || n_seq < 0 || S < 1 || S > nr::G_SMAX || valid < 1 || valid > S)
+    return fail(NR_ERR_BADARG, "nr_g_additive_fwd: bad argument (S <= 64)");
+  if (n_seq == 0) return NR_OK;
+  nr::GPoolParams p{};
+  p.x = x; p.ldx = ldx; p.D = D; p.proj = proj; p.ldp = ldp; p.Q = Q; p.qv = qv; p.out = out; p.ldo = ldo; p.attn_w = attn_w; p.n_seq = n_seq; p.S = S; p.valid = valid;
+  NR_LAUNCH(nr::g_additive_fwd_kernel, n_seq, 256, nr::G_SMAX * 4, (hipStream_t)stream, p);
+  return check_launch("nr_g_additive_fwd");
+}
+int nr_g_additive_bwd(const float* x, int64_t ldx, int D, const float* proj, int64_t ldp, int Q, const float* qv, const float* attn_w, const float* g_out,
+                      int64_t ldg, float* dpre, int64_t ldq, float* dq_part, int64_t n_seq, int S, void* stream) {
+  if (!x || !proj || !qv || !attn_w || !g_out || !dpre || !dq_part || D < 1 || Q < 1 || ldx < D || ldp < Q || ldg < D || ldq < Q || n_seq < 0 || S < 1 ||
+      S > nr::G_SMAX)
+    return fail(NR_ERR_BADARG, "nr_g_additive_bwd: bad argument (S <= 64)");
+  if (n_seq == 0) return NR_OK;
+  nr::GPoolParams p{};
+  p.x = x; p.ldx = ldx; p.D = D; p.proj = proj; p.ldp = ldp; p.Q = Q; p.qv = qv; p.g_out = g_out; p.ldg = ldg; p.attn_w = const_cast<float*>(attn_w);
+  p.dpre = dpre; p.ldq = ldq; p.dq_part = dq_part; p.n_seq = n_seq; p.S = S; p.valid = S;
+  NR_LAUNCH(nr::g_additive_bwd_kernel, n_seq, 256, nr::G_SMAX * 4, (hipStream_t)stream, p);
+  return check_launch("nr_g_additive_bwd");
+}
+int nr_g_rows_axpy(float* y, int64_t ldy, const float* a, const float* g, int64_t ldg, int S, int d, int64_t n_rows, int accumulate, void* stream) {
+  if (!y || !a || !g || S < 1 || d < 1 || ldy < d || ldg < d || n_rows < 0) return fail(NR_ERR_BADARG, "nr_g_rows_axpy: bad argument");
+  if (n_rows == 0) return NR_OK;
+  NR_LAUNCH(nr::g_rows_axpy_kernel, grid_for(n_rows * d, 256, 4096), 256, 0, (hipStream_t)stream, y, ldy, a, g, ldg, S, d, n_rows, accumulate);
+  return check_launch("nr_g_rows_axpy");
+}
+int nr_g_rows_to_seqpad(const float* src, int64_t lds, int d, uint16_t* dst, int dp, int S, int pad, int64_t n_tok, int one, void* stream) {
+  if (!src || !dst || d < 1 || dp < d || lds < d || S < 1 || pad < 0 || n_tok < 0 || n_tok % S) return fail(NR_ERR_BADARG, "nr_g_rows_to_seqpad: bad argument");
+  if (n_tok == 0) return NR_OK;
+  NR_LAUNCH(nr::g_rows_to_seqpad_kernel, grid_for(n_tok * dp, 256, 4096), 256, 0, (hipStream_t)stream, src, lds, d, dst, dp, S, pad, n_tok,
+            (uint16_t)(one ? 0x3F80 : 0));
+  return check_launch("nr_g_rows_to_seqpad");
+}
+int nr_g_relu_drop(const float* y, int64_t ldy, float* act, int F, int S, int pad, int64_t n_tok, float p, uint64_t seed, int64_t elem0, void* stream) {
+  if (!y || !act || F < 4 || (F & 3) || ldy < F || (ldy & 3) || S < 1 || pad < 0 || n_tok < 0 || n_tok % S || p < 0.0f || p >= 1.0f || elem0 < 0 || (elem0 & 3))
+    return fail(NR_ERR_BADARG, "nr_g_relu_drop: bad argument (F and ldy multiples of 4)");
+  if (n_tok == 0) return NR_OK;
+  NR_LAUNCH(nr::g_relu_drop_kernel, grid_for(n_tok * (F / 4), 256, 4096), 256, 0, (hipStream_t)stream, y, ldy, act, F, S, pad, n_tok, make_drop(p, seed), elem0 / 4);
+  return check_launch("nr_g_relu_drop");
+}
+int nr_g_relu_drop_bwd(const float* dact, const float* act, uint16_t* dy, int F, int fp, int S, int pad, int64_t n_tok, float p, void* stream) {
+  if (!dact || !act || !dy || F < 1 || fp < F || S < 1 || pad < 0 || n_tok < 0 || n_tok % S || p < 0.0f || p >= 1.0f) return fail(NR_ERR_BADARG, "nr_g_relu_drop_bwd: bad argument");
+  if (n_tok == 0) return NR_OK;
+  NR_LAUNCH(nr::g_relu_drop_bwd_kernel, grid_for(n_tok * F, 256, 4096), 256, 0, (hipStream_t)stream, dact, act, dy, F, fp, S, pad, n_tok, 1.0f / (1.0f - p));
+  return check_launch("nr_g_relu_drop_bwd");
+}
+int nr_g_unpad_rows(const float* src, int64_t lds, float* dst, int d, int S, int pad, int64_t n_tok, void* stream) {
+  if (!src || !dst || d < 1 || lds < d || S < 1 || pad < 0 || n_tok < 0 || n_tok % S) return fail(NR_ERR_BADARG, "nr_g_unpad_rows: bad argument");
+  if (n_tok == 0) return NR_OK;
+  NR_LAUNCH(nr::g_unpad_rows_kernel, grid_for(n_tok * d, 256, 4096), 256, 0, (hipStream_t)stream, src, lds, dst, d, S, pad, n_tok);
+  return check_launch("nr_g_unpad_rows");
+}
+int nr_g_relu(const float* x, const float* gate, float* y, int64_t n, float scale, void* stream) {
+  if (!x || !y || n < 0) return fail(NR_ERR_BADARG, "nr_g_relu: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::g_relu_kernel, grid_for(n, 256, 4096), 256, 0, (hipStream_t)stream, x, gate, y, n, scale);
+  return check_launch("nr_g_relu");
 }
 
 int nr_pack_conv_dgrad(const float* W, int F, int D, uint16_t* Wd2, void* stream) {

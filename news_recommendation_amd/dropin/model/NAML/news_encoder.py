@@ -57,7 +57,10 @@ class NewsEncoder(torch.nn.Module):
         if unknown:
             raise NotImplementedError(f"NAML news attributes {sorted(unknown)} are not views of the reference's NAML encoder")
         self.attrs = tuple(a for a in ALL_ATTRS if a in attrs)               # fixed order (the reference iterates a set: SURVEY 5.9 #12)
-        self.fused = self.attrs == ALL_ATTRS
+        # the fused kernel chain is the tuned geometry's; any other word_embedding_dim / num_filters / window_size / query_vector_dim composes the
+        # views one by one on the general-geometry kernels, exactly as the reference's forward does (:100-114)
+        self.fused = self.attrs == ALL_ATTRS and ops_conv.conv_tuned(config.word_embedding_dim, config.num_filters, config.window_size,
+                                                                     config.query_vector_dim)
         if pretrained_word_embedding is None:
             word_embedding = nn.Embedding(config.num_words, config.word_embedding_dim, padding_idx=0)
         else:

@@ -13,6 +13,8 @@ class UserEncoder(torch.nn.Module):
     def forward(self, clicked_news_vector, ctx_rows=None):
         """clicked_news_vector: [batch, num_clicked_news_a_user, num_filters] -> [batch, num_filters].
         ctx_rows: optional bf16 ctx-layout copy of the same vectors (NAML.forward passes the one the news encoder made)."""
+        if clicked_news_vector.shape[2] != ops_conv.NR_D or self.additive_attention.linear.weight.shape[0] > ops_conv.NR_QP:
+            return self.additive_attention(clicked_news_vector)          # any other num_filters / query_vector_dim: the general-geometry path
         if ctx_rows is None:
             ctx_rows = ops_conv.to_ctx_rows(clicked_news_vector)
         return ops_conv.pool_rows(clicked_news_vector, ctx_rows, self.additive_attention)

@@ -193,13 +193,11 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def check_dims(d_model, heads, qdim=None):
-    if d_model != NR_D or heads != NR_HEADS:
-        raise NotImplementedError(
-            f"the HIP kernels are instantiated for word_embedding_dim={NR_D}, num_attention_heads={NR_HEADS} "
-            f"(got {d_model}, {heads})")
-    if qdim is not None and not (0 < qdim <= NR_QP):
-        raise NotImplementedError(f"query_vector_dim must be in [1, {NR_QP}] (got {qdim})")
+def tuned_dims(d_model, heads, qdim=None, length=None):
+    """Whether the TUNED kernels take this geometry: word_embedding_dim (or the pooled width) 300, num_attention_heads 15, query_vector_dim
+    <= 208, sequence length <= 50 (src/config.py:21-22,34,39,45).  Everything else runs on the general-geometry path (ops_generic.py,
+    csrc/k_generic.h): same results, not tuned."""
+    return (d_model == NR_D and heads == NR_HEADS and (qdim is None or 0 < qdim <= NR_QP) and (length is None or 1 <= length <= 50))
 
 
 _CHECK_DEVICE_IDS = os.environ.get('NR_CHECK_IDS', '0') == '1'
@@ -764,7 +762,9 @@ class _EncoderFn(torch.autograd.Function):
 def encode_titles(ids, table, mhsa, additive, p_drop, training):
     """NRMS news encoder on a [n_titles, L] int64 id tensor (already on the GPU)."""
     _require_cuda(table, "word_embedding.weight")
-    check_dims(table.shape[1], mhsa.num_attention_heads, additive.linear.weight.shape[0])
+    if not tuned_dims(table.shape[1], mhsa.num_attention_heads, additive.linear.weight.shape[0], ids.shape[1]):
+        from . import ops_generic
+        return ops_generic.encode_titles(ids, table, mhsa, additive, p_drop, training)
     p = float(p_drop) if training else 0.0
     seed = new_seed() if p > 0 else 0
     L = ids.shape[1]
@@ -779,7 +779,9 @@ def encode_titles(ids, table, mhsa, additive, p_drop, training):
 def encode_dense(x, mhsa, additive):
     """NRMS user encoder on a dense [n_seq, S, D] float tensor."""
     _require_cuda(x, "clicked_news_vector")
-    check_dims(x.shape[2], mhsa.num_attention_heads, additive.linear.weight.shape[0])
+    if not tuned_dims(x.shape[2], mhsa.num_attention_heads, additive.linear.weight.shape[0], x.shape[1]):
+        from . import ops_generic
+        return ops_generic.encode_dense(x, mhsa, additive)
     N = x.shape[1]
     S = padded_len(N, "num_clicked_news_a_user")
     if S != N:
@@ -912,7 +914,10 @@ def mhsa_dense(x, mhsa, length=None):
     instantiated length and the padding is masked as keys; `length` (int tensor [batch], multihead_self.py:60-70) masks keys per
     sequence on top of that.  Rows of padded query positions are sliced off the result."""
     _require_cuda(x, "MultiHeadSelfAttention input")
-    check_dims(x.shape[2], mhsa.num_attention_heads)
+    if not tuned_dims(x.shape[2], mhsa.num_attention_heads, None, x.shape[1]):
+        from . import ops_generic
+        x = x.to(torch.float32)
+        return ops_generic.mhsa(x, x, x, mhsa, length)
     n_seq, L, _ = x.shape
     S = padded_len(L, "sequence length")
     key_len = None
@@ -980,10 +985,14 @@ class _AdditiveFn(torch.autograd.Function):
         return dx, dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], dq_part.sum(dim=0)[:qdim], None
 
 
-def additive_dense(x, additive):
-    """AdditiveAttention.forward on [batch, L, D], L in [1, 50]: zero-padded to an instantiated length and pooled over the first L."""
+def additive_dense(x, additive, return_weights=False):
+    """AdditiveAttention.forward on [batch, L, D], L in [1, 50]: zero-padded to an instantiated length and pooled over the first L.
+    return_weights: also the attention weights [batch, L] (the tensorboard hook of additive.py:40-49 logs their batch mean) -- through the
+    general-geometry kernels, which hand them out."""
     _require_cuda(x, "AdditiveAttention input")
-    check_dims(x.shape[2], NR_HEADS, additive.linear.weight.shape[0])
+    if return_weights or not tuned_dims(x.shape[2], NR_HEADS, additive.linear.weight.shape[0], x.shape[1]):
+        from . import ops_generic
+        return ops_generic.additive(x.to(torch.float32), additive, return_weights)
     L = x.shape[1]
     S = padded_len(L, "sequence length")
     if S != L:

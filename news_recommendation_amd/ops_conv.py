@@ -13,14 +13,28 @@ from .ops import (_lib, _stream, _call, _ptr, _f32c, _bf16, _workspace, _require
 WGRAD_CHUNKS = 64     # batched-GEMM chunks of the conv weight gradient ([320 x rows]^T x [rows x 320] per tap: ~4 output tiles each)
 
 
-def check_conv_dims(config_like_d, num_filters, window, qdim):
-    if config_like_d != NR_D or num_filters != NR_D:
-        raise NotImplementedError(f"the HIP conv kernels are instantiated for word_embedding_dim = num_filters = {NR_D} "
-                                  f"(got {config_like_d}, {num_filters})")
-    if window != 3:
-        raise NotImplementedError(f"window_size must be 3 (got {window})")
-    if not (0 < qdim <= NR_QP):
-        raise NotImplementedError(f"query_vector_dim must be in [1, {NR_QP}] (got {qdim})")
+def conv_tuned(word_embedding_dim, num_filters, window, qdim):
+    """Whether the TUNED conv / pooling kernels take this geometry (word_embedding_dim = num_filters = 300, window_size 3, query_vector_dim <=
+    208: src/config.py:34,39,54,55); anything else -- any dims that are multiples of 4, any odd window <= 9 -- runs the general-geometry path
+    (ops_generic.py)."""
+    return word_embedding_dim == NR_D and num_filters == NR_D and window == 3 and 0 < qdim <= NR_QP
+
+
+def check_conv_dims(word_embedding_dim, num_filters, window, qdim):
+    """Constructor-time check of a conv text encoder's geometry: what NEITHER path can run raises here (the reference asserts an odd window,
+    LSTUR/news_encoder.py:23)."""
+    if conv_tuned(word_embedding_dim, num_filters, window, qdim):
+        return
+    from . import ops_generic
+    if window < 1 or window % 2 == 0 or window > ops_generic.WINDOW_MAX:
+        raise NotImplementedError(f"window_size must be odd and in [1, {ops_generic.WINDOW_MAX}] (got {window})")
+    if word_embedding_dim % 4 or num_filters % 4 or qdim < 1:
+        raise NotImplementedError(f"word_embedding_dim and num_filters must be multiples of 4 (got {word_embedding_dim}, {num_filters})")
+
+
+def _module_tuned(conv, additive, L):
+    F, _, w, D = conv.weight.shape
+    return conv_tuned(D, F, w, additive.linear.weight.shape[0]) and 1 <= L <= 50
 
 
 def pack_conv(W, b):
@@ -329,6 +343,8 @@ def pool_rows(x, x_b, additive):
     pooling excludes (ops.padded_len)."""
     _require_cuda(x, "clicked_news_vector")
     n, N, d = x.shape
+    if not ops.tuned_dims(d, ops.NR_HEADS, additive.linear.weight.shape[0], N):
+        return ops.additive_dense(x, additive)
     S = ops.padded_len(N, "num_clicked_news_a_user")
     if S != N:
         x = torch.nn.functional.pad(x, (0, 0, 0, S - N))
@@ -393,6 +409,11 @@ class _LsturNewsFn(torch.autograd.Function):
 
 def lstur_news(title, cat, sub, table, cat_table, conv, additive, p_drop, training):
     _require_cuda(table, "word_embedding.weight")
+    if not _module_tuned(conv, additive, title.shape[1]):
+        # any other geometry (LSTUR/news_encoder.py:52-76): the two category rows and the title vector side by side, from the general kernels
+        from . import ops_generic
+        return torch.cat([ops_generic._GatherFn.apply(cat, cat_table), ops_generic._GatherFn.apply(sub, cat_table),
+                          ops_generic.text_encode(title, table, conv, additive, p_drop, training)], dim=1)
     p = float(p_drop) if training else 0.0
     seed = ops.new_seed() if p > 0 else 0
     title, valid = pad_text(title, "num_words_title")
@@ -431,6 +452,9 @@ class _TextFn(torch.autograd.Function):
 
 def text_only(ids, table, conv, additive, p_drop, training):
     _require_cuda(table, "word_embedding.weight")
+    if not _module_tuned(conv, additive, ids.shape[1]):
+        from . import ops_generic
+        return ops_generic.text_encode(ids, table, conv, additive, p_drop, training)
     p = float(p_drop) if training else 0.0
     seed = ops.new_seed() if p > 0 else 0
     ids, valid = pad_text(ids, "text length")
@@ -481,4 +505,7 @@ class _ElementFn(torch.autograd.Function):
 def element_only(ids, embedding, linear):
     _require_cuda(embedding.weight, "category embedding")
     ops.check_ids(ids, embedding.weight.shape[0], "category / subcategory id")
+    if linear.weight.shape[0] != NR_D:
+        from . import ops_generic
+        return ops_generic.element_encode(ids, embedding, linear)
     return _ElementFn.apply(ids, embedding.weight, linear.weight, linear.bias)

@@ -72,9 +72,13 @@ def test_naml_lstur_dropin_state_dicts_match_reference_keys():
         want = random_lstur_params(0, 321, 300, 275, 77, 300, 3, 200, method)
         assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
         assert tuple(m.user_embedding.weight.shape) == (77, width)
+    # geometry knobs away from the tuned instantiation construct (general-geometry path, tests/test_generic_gpu.py); what neither path runs raises
+    class Other(NamlCfg):
+        num_filters, window_size, word_embedding_dim, query_vector_dim = 128, 5, 100, 256
+    assert tuple(NAML(Other).news_encoder.text_encoders['title'].CNN.weight.shape) == (128, 1, 5, 100)
     with pytest.raises(NotImplementedError):
         class Bad(NamlCfg):
-            num_filters = 128
+            window_size = 4                  # the reference asserts an odd window (LSTUR/news_encoder.py:23)
         NAML(Bad)
 
 

@@ -44,7 +44,7 @@ model_mod = importlib.import_module(f'model.{a.model}')
 origin = os.path.relpath(model_mod.__file__, repo) if model_mod.__file__.startswith(repo) else model_mod.__file__
 model = ref_eval.Model(ref_eval.config).to(ref_eval.device)
 path = latest_checkpoint(os.path.join('./checkpoint', a.model))
-model.load_state_dict(torch.load(path)['model_state_dict'])
+model.load_state_dict(torch.load(path, map_location=ref_eval.device)['model_state_dict'])      # (the checkpoint was written from cuda:0; evaluate.py's own bare torch.load needs a GPU)
 model.eval()
 t0 = time.perf_counter()
 auc, mrr, n5, n10 = ref_eval.evaluate(model, f'./data/{a.split}', ref_eval.config.num_workers)
