@@ -571,7 +571,7 @@ def train_parity_lstur(device, steps=100, B=16, lr=1e-3, engine_seeds=(0, 1), or
     return out
 
 
-def train_parity_fixture(device, model_name, engine_seeds=8, fixture_dir=None):
+def train_parity_fixture(device, model_name, engine_seeds=8, fixture_dir=None, optimizer='engine', p_drop=None, oracle_scored=False):
     """Statistical training parity against the REAL reference.  tests/golden/train_parity/<model>.npz (written in the build
     container by oracle/make_golden_train_parity.py) holds the teacher-labelled task and the held-out metrics of the reference's OWN model class
     trained on it with torch's dropout and torch.optim.Adam, one run per torch seed (8).  Here the ENGINE (bf16 operands, counter-based dropout,
@@ -619,23 +619,36 @@ def train_parity_fixture(device, model_name, engine_seeds=8, fixture_dir=None):
         fwd = [lambda m, b=b: m.forward_ids(b[2], b[3].clone(), b[0], b[1]) for b in bs]
         es = (task["news"], task["eval_hist"], task["eval_cands"], task["eval_ptr"], task["eval_users"])
 
+    if p_drop is not None:                               # diagnostic variants (tools/train_parity_diag.py): another dropout probability
+        cfg.dropout_probability = p_drop
+        wl = Workload(model_name, cfg)
+    extra = []
+
     def engine_run(seed):
         m = wl.make_model().to(device)
         m.load_state_dict(st0)
         m.train()
-        opt = EngineAdam(m, lr=lr, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else ())
+        if optimizer == 'torch':                         # diagnostic: the reference's own optimiser on the engine's gradients
+            opt = torch.optim.Adam(m.parameters(), lr=lr)
+        else:
+            opt = EngineAdam(m, lr=lr, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else ())
         torch.manual_seed(1000 + seed)                   # ops.new_seed() draws the kernels' dropout seeds from torch's CPU generator
         losses = []
         for f in fwd:
             loss = crit(f(m), target)
+            if optimizer == 'torch':
+                opt.zero_grad()
             loss.backward()
             opt.step()
             losses.append(loss.detach())
-        if model_name == 'LSTUR':
+        if model_name == 'LSTUR' and optimizer != 'torch':
             opt.flush()
         sc = engine_scores(wl, m, device, es)
         if model_name == 'LSTUR':
             ops_gru.persist_check()
+        if oracle_scored and model_name == 'NRMS':       # the SAME trained weights ranked by the CPU oracle: separates training from scoring
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            extra.append([float(x) for x in tp.eval_metrics(task, tp.oracle_eval_scores(task, sd))])
         return [float(x) for x in tp.eval_metrics(task, sc)], float(torch.stack(losses[-10:]).mean())
     seeds = list(range(engine_seeds)) if isinstance(engine_seeds, int) else list(engine_seeds)
     runs = [engine_run(s_) for s_ in seeds]
@@ -656,6 +669,9 @@ def train_parity_fixture(device, model_name, engine_seeds=8, fixture_dir=None):
         out[f"diff_{tag}"] = float(e.mean() - r.mean())                     # signed: negative = the engine's trained models rank worse
         out[f"stderr_diff_{tag}"] = se
         out[f"z_{tag}"] = float((e.mean() - r.mean()) / max(se, 1e-12))
+    if extra:
+        out["engine_weights_scored_by_oracle_auc"] = [x[0] for x in extra]
+    out["optimizer"], out["dropout"] = optimizer, cfg.dropout_probability
     out["engine_below_reference_pairs"] = int((em[:, 0][:, None] < rm[:, 0][None, :]).sum())
     out["pairs"] = int(em.shape[0] * rm.shape[0])
     out["within_3_stderr"] = bool(abs(out["z_auc"]) < 3.0 and abs(out["z_ndcg10"]) < 3.0)
@@ -947,6 +963,8 @@ def main():
     ap.add_argument('--parity-seeds', type=int, default=8, help='independent n = 1000 evaluation sets per weight state of the parity leg')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the NAML / LSTUR graph-replay legs of the default line (~30 s)')
     ap.add_argument('--no-extras', action='store_true', help='skip value_dropin / score_eval / gather points (quick A/B timing runs)')
+    ap.add_argument('--seg-overlap', type=int, default=1, choices=[0, 1],
+                    help='N > 1: 1 = three graph segments, the table exchange in flight under the weight-gradient segment (default); 0 = round 4 two segments (A/B)')
     ap.add_argument('--no-graph', action='store_true',
                     help='issue the step kernel by kernel (default on 1 GPU: one HIP graph of forward + backward + Adam, replayed)')
     args = ap.parse_args()
@@ -1025,7 +1043,7 @@ def main():
                 l_ = crit(lg_, target)
                 l_.backward()
                 return l_
-            seg = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=1)
+            seg = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=1, overlap=bool(args.seg_overlap))
         except Exception as e:               # noqa: BLE001 -- the measured line matters more than the issue mode
             seg, seg_note = None, f"segmented graphs unavailable ({e!r}): kernel-by-kernel step"
         # the ranks must agree on the issue mode (two graphs + exchange_all vs step() with overlap are DIFFERENT collective sequences): one
@@ -1257,7 +1275,9 @@ def main():
         "roofline": roofline,
         "step_issue": ("one HIP graph per step (forward + backward + Adam), replayed; roofline durations from an eager pass of the same "
                        f"{args.steps} steps after the timed region" if sg is not None else
-                       ("two HIP graphs per step ([forward + backward] | RCCL collectives | [Adam]), replayed" if seg is not None else
+                       (("three HIP graphs per step ([forward + backward to the embedding scatter] | table exchange started | [weight-gradient GEMMs + row "
+                         "staging] | rows + small bucket | [Adam]), replayed" if args.seg_overlap else
+                         "two HIP graphs per step ([forward + backward] | RCCL collectives | [Adam]), replayed (--seg-overlap 0)") if seg is not None else
                         (seg_note or "kernel by kernel"))),
         "ms_per_step_eager": eager_ms,
         "loss": float(loss.item()),

@@ -481,6 +481,10 @@ int nr_g_relu_drop(const float* y, int64_t ldy, float* act, int F, int S, int pa
 int nr_g_relu_drop_bwd(const float* dact, const float* act, uint16_t* dy, int F, int fp, int S, int pad, int64_t n_tok, float p, void* stream);
 int nr_g_unpad_rows(const float* src, int64_t lds, float* dst, int d, int S, int pad, int64_t n_tok, void* stream);
 int nr_g_relu(const float* x, const float* gate, float* y, int64_t n, float scale, void* stream);
+/* f32 rows -> bf16 rows [hi | hi | lo] of 3 dp columns (hi = bf16(x), lo = bf16(x - hi), column d of both hi blocks = 1.0): with weights packed
+ * [Wh | Wl | Wh] ONE nr_gemm_nt (K = 3 dp) gives x W^T + b to ~2^-16 relative -- the ElementEncoder's linear layer (NAML news_encoder.py:46),
+ * whose relu must not flip against the fp32 reference. */
+int nr_g_rows_split_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream);
 /* nr_gemm_nt with OVERLAPPING A rows (lda < K allowed): row m of the product reads the K contiguous elements from A + m * lda -- the w rows of a
  * convolution window in a seqpad buffer (nr_g_rows_to_seqpad).  The caller guarantees (M - 1) * lda + K readable elements. */
 int nr_gemm_nt_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* stream);

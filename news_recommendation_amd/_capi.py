@@ -117,6 +117,7 @@ SIGNATURES = {
     'nr_g_relu_drop_bwd': ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_float, _P], c_int),
     'nr_g_unpad_rows': ([_P, c_int64, _P, c_int, c_int, c_int, c_int64, _P], c_int),
     'nr_g_relu': ([_P, _P, _P, c_int64, c_float, _P], c_int),
+    'nr_g_rows_split_bf16': ([_P, c_int64, c_int, _P, c_int, c_int64, _P], c_int),
     'nr_gemm_nt_rows': ([_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P], c_int),
     'nr_probe_mfma': ([_P, _P, _P, _P], c_int),
     'nr_probe_tr16': ([_P, _P, _P], c_int),

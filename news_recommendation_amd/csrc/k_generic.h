@@ -307,6 +307,27 @@ __global__ __launch_bounds__(256) void g_unpad_rows_kernel(const float* __restri
   }
 }
 
+// f32 rows -> bf16 rows [hi | hi | lo] of 3 dp columns (hi = bf16(x), lo = bf16(x - hi); column d of the two hi blocks = 1.0): against packed
+// weights [Wh | Wl | Wh] one bf16 GEMM with K = 3 dp evaluates x W^T + b to ~2^-16 relative (xh Wh + xh Wl + xl Wh) -- for the few products
+// whose SIGN decides a relu (the ElementEncoder's linear layer over the category table: a flipped unit changes a whole row of its weight gradient)
+__global__ __launch_bounds__(256) void g_rows_split_kernel(const float* __restrict__ src, int64_t lds_, int d, u16* __restrict__ dst, int dp, int64_t n) {
+  const int64_t total = n * dp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dp;
+    const int c = (int)(i - r * dp);
+    u16 hi = 0, lo = 0;
+    if (c < d) {
+      const float x = src[r * lds_ + c];
+      hi = f2bf(x);
+      lo = f2bf(x - bf2f(hi));
+    } else if (c == d) {
+      hi = 0x3F80;
+    }
+    u16* o = dst + r * 3 * dp + c;
+    o[0] = hi; o[dp] = hi; o[2 * dp] = lo;
+  }
+}
+
 // y = scale * x where gate > 0 (gate = x when null), else 0: relu forward (scale 1), and the backward of dropout(relu(.)) read off the OUTPUT's
 // zeros (gate = the activation, scale = 1 / (1 - p))
 __global__ __launch_bounds__(256) void g_relu_kernel(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y, int64_t n,

@@ -565,6 +565,12 @@ int nr_g_unpad_rows(const float* src, int64_t lds, float* dst, int d, int S, int
   NR_LAUNCH(nr::g_unpad_rows_kernel, grid_for(n_tok * d, 256, 4096), 256, 0, (hipStream_t)stream, src, lds, dst, d, S, pad, n_tok);
   return check_launch("nr_g_unpad_rows");
 }
+int nr_g_rows_split_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream) {
+  if (!src || !dst || d <= 0 || dp <= d || ld < d || n < 0) return fail(NR_ERR_BADARG, "nr_g_rows_split_bf16: bad argument");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::g_rows_split_kernel, grid_for(n * dp, 256, 4096), 256, 0, (hipStream_t)stream, src, ld, d, dst, dp, n);
+  return check_launch("nr_g_rows_split_bf16");
+}
 int nr_g_relu(const float* x, const float* gate, float* y, int64_t n, float scale, void* stream) {
   if (!x || !y || n < 0) return fail(NR_ERR_BADARG, "nr_g_relu: bad argument");
   if (n == 0) return NR_OK;

@@ -131,19 +131,24 @@ class StepGraph:
 
 
 class SegmentedStep:
-    """A DATA-PARALLEL training step as two HIP graphs with the RCCL collectives between them:
+    """A DATA-PARALLEL training step as HIP graphs with the RCCL collectives between them.  Two issue modes:
 
-        graph A   counter bump, forward, backward (gradients land in the optimiser's flat buffer), touched rows staged for the exchange
-        eager     all-reduce of the table bucket(s), all-gather of the touched rows, all-reduce of the small bucket   (RCCL, its own stream)
-        graph B   fused Adam over the dense buckets, row-sparse Adam over the gathered rows
+    overlap=True (default)  THREE segments, the table exchange in flight under the second one:
+        graph A   counter bump, forward, backward up to and including the embedding scatter (the backward passes postpone their weight-gradient
+                  GEMMs: ops.defer_wgrad)
+        eager     table bucket(s): all-reduce -- or reduce-scatter onto this rank's shard (table_rs) -- started on RCCL's stream
+        graph B   the postponed weight-gradient GEMMs (ops.run_deferred), touched rows staged for the exchange       <- runs while the tables fly
+        eager     all-gather of the touched rows, all-reduce of the small bucket (+ the fault words), wait for everything
+        graph C   fused Adam over the dense buckets (table_rs: this rank's shard), row-sparse Adam over the gathered rows
+        eager     table_rs only: all-gather of the updated table
+    overlap=False           round 4's TWO segments: [forward + whole backward + staging] | every collective | [Adam]: the table all-reduce
+                  (85 - 156 MB) is then fully exposed (kept for A/B: bench.py --gpus N reports exposed_comm_ms for both).
 
-    Issued kernel by kernel, the step costs 2.2 ms (NRMS) of host time -- under a 3.6 ms step at B = 512 today, but the first thing an 8-GPU
-    run would be bound by once the kernels get faster; in this form the host issues two graph launches and three to five collectives.  What
-    it gives up: the table all-reduce no longer starts from INSIDE the backward (it starts when graph A has finished, i.e. after the
-    weight-gradient GEMMs that used to cover it: ~0.5 ms of overlap), which `bench.py --gpus N` reports as `exposed_comm_ms`.
-    Same arithmetic as ``EngineAdam.step()``; ``eager_step`` is that path on the same counter protocol (the tests hold the two together)."""
+    Issued kernel by kernel, the step costs ~2 ms of host time; in either form the host issues two or three graph launches and three to six
+    collectives.  Same arithmetic as ``EngineAdam.step()``; ``eager_step`` is that path on the same counter protocol (the tests hold the two
+    together: tests/test_rccl_gpu.py over RCCL, tests/test_dist_cpu.py for the exchange protocol over gloo)."""
 
-    def __init__(self, fwd_bwd_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20):
+    def __init__(self, fwd_bwd_fn, example_inputs, optimizer, warmup=2, max_steps=1 << 20, overlap=True):
         if not optimizer._dist_on():
             raise RuntimeError("SegmentedStep: no process group (single process: use StepGraph)")
         if _attached:
@@ -151,8 +156,10 @@ class SegmentedStep:
         self.lib = _capi.load()
         self.opt = optimizer
         self.fn = fwd_bwd_fn
+        self.overlap = bool(overlap)
         dev = optimizer.device
-        optimizer.overlap = False            # the table collective is issued between the segments, not from inside the backward
+        optimizer.overlap = False            # no collective is issued from INSIDE the backward: they sit between the segments
+        optimizer.enable_deferred_wgrad(self.overlap)
         self.static = [torch.empty_like(x) for x in example_inputs]
         for s, x in zip(self.static, example_inputs):
             s.copy_(x)
@@ -171,15 +178,24 @@ class SegmentedStep:
         torch.cuda.synchronize(dev)
         optimizer.prepare_segments()
         ops.invalidate_packed()
+        ops.drop_deferred()
         # thread_local: RCCL's watchdog thread polls events of its own while this thread captures
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
             with _CounterStep(optimizer):
                 self.loss = fwd_bwd_fn(*self.static)
-            optimizer.stage_rows()
+            if not self.overlap:
+                optimizer.stage_rows()
+        self.graph_w = None
+        if self.overlap:
+            # the weight-gradient phases the backward queued (closures over tensors of graph A's pool, which the two graphs share)
+            self.graph_w = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_w, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+                ops.run_deferred()
+                optimizer.stage_rows()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
             optimizer.apply_all()
         # the capture RECORDED the packing launches without running them: the operands it left in the cache hold no data yet (a replay fills
         # them; an eager step taken now must not find them)
@@ -189,7 +205,7 @@ class SegmentedStep:
         _capi.check(self.lib, self.lib.nr_step_counter_add(self.ctr.data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
         with _CounterStep(self.opt):
             loss = self.fn(*inputs)
-        self.opt.step()
+        self.opt.step()                      # (runs the postponed weight-gradient phases first)
         return loss
 
     def __call__(self, *inputs):
@@ -200,12 +216,26 @@ class SegmentedStep:
                 s.copy_(x, non_blocking=True)
         self.graph_a.replay()
         self.opt.begin_step()
-        self.opt.exchange_all()
+        if self.overlap:
+            works = self.opt.start_tables()  # on RCCL's stream, behind graph A
+            self.graph_w.replay()            # weight-gradient GEMMs + row staging under the table exchange
+            self.opt.exchange_all(works)
+        else:
+            self.opt.exchange_all()
         self.graph_b.replay()
+        self.opt.gather_tables()
         ops.invalidate_packed()
         return self.loss
 
-    close = StepGraph.close
+    def close(self):
+        StepGraph.close(self)
+        self.opt.enable_deferred_wgrad(False)
+
     __enter__ = StepGraph.__enter__
     __exit__ = StepGraph.__exit__
-    __del__ = StepGraph.__del__
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -461,7 +461,7 @@ def pool_flat_ok(S, act, n_seq=None, *, qdim):
             and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK))
 
 
-def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0):
+def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag=''):
     """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
     y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused
     activation gradient goes there instead of dgemm."""
@@ -469,8 +469,8 @@ def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, 
     dev = ctx_b.device
     ntok = n_seq * S
     nwg = lib.nr_additive_bwd_flat_grid(ntok)
-    dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-    dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+    dpre = _workspace(f'dpre[{ws_tag}]' if ws_tag else 'dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+    dq_part = _workspace(f'dqp[{ws_tag}]' if ws_tag else 'dqp', (nwg, NR_QP), torch.float32, dev)
     tot = _workspace('pool_tot', (n_seq,), torch.float32, dev)
     dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev) if (want_dctx and dy is None) else None
     _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), y_ptr, y_stride,
@@ -479,6 +479,21 @@ def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, 
 
 
 _WGRAD_UNPACK = os.environ.get('NR_WGRAD_UNPACK', '1') == '1'       # A/B knob: 0 = hand the nine weight gradients to autograd
+
+# Weight-gradient phases postponed past the end of loss.backward() (see _EncoderFn.backward): set by a trainer whose gradient buffers are
+# persistent (optim.EngineAdam under a process group); the trainer calls run_deferred() before it reads any weight gradient.
+defer_wgrad = False
+_deferred = []
+
+
+def run_deferred():
+    """Run (and forget) the postponed weight-gradient phases of the backward passes since the last call, in their backward order."""
+    while _deferred:
+        _deferred.pop(0)()
+
+
+def drop_deferred():
+    _deferred.clear()
 
 
 def inplace_grads(params):
@@ -703,30 +718,33 @@ class _EncoderFn(torch.autograd.Function):
         dev = cbuf.device
         ntok = n_seq * S
         g_out = g_out.to(torch.float32).contiguous()
-        # ---- additive attention backward: dpre (kernel), then two plain GEMMs ---------------------------------
+        # Two phases.  Phase 1 is everything the INPUT gradient needs -- pooling backward, attention backward, dX, the embedding scatter -- and ends
+        # with table_grad_ready: under data parallelism the table bucket's all-reduce starts there.  Phase 2, the weight-gradient GEMMs (dWa, dWqkv)
+        # and their hand-off, needs nothing from the exchange and is what runs WHILE the table is on the wire: immediately after phase 1, or --
+        # when a trainer with persistent gradient buffers asks for it (ops.defer_wgrad: EngineAdam under a process group, graph.SegmentedStep)
+        # -- postponed to ops.run_deferred(), which the trainer calls after loss.backward() has returned (a HIP-graph boundary can then sit
+        # between the two phases).  Scratch that phase 2 reads (dpre, dqkv) is keyed per encoder shape so that a later encoder's phase 1 cannot
+        # overwrite it.
+        # ---- phase 1: additive attention backward -> dpre (kernel) --------------------------------------------------------------------------
         if pool_flat_ok(S, False, n_seq, qdim=qdim):
-            dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, f'S={S}')
+            dpre, dq_part, dctx_gemm = pool_bwd_flat(cbuf, Wap, bap, qvp, aw, g_out, _ptr(y), y.stride(0), n_seq, S, qdim, f'S={S}',
+                                                     ws_tag=f'{S},{int(gather)}')
             nwg = dq_part.shape[0]
         else:
             nwg = lib.nr_additive_bwd_grid(n_seq, S)
-            dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-            dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+            dpre = _workspace(f'dpre[{S},{int(gather)}]', (ntok, NR_QP), _BF16_AS_I16, dev)
+            dq_part = _workspace(f'dqp[{S},{int(gather)}]', (nwg, NR_QP), torch.float32, dev)
             dctx_gemm = _workspace('dctx', (ntok, NR_KP), _BF16_AS_I16, dev)       # = dpre @ Wa, produced inside the kernel
             _call(f'nr_additive_bwd[S={S}]', lib.nr_additive_bwd_ex, _ptr(cbuf), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g_out), _ptr(dpre),
                   _ptr(dq_part), _ptr(WaT), _ptr(dctx_gemm), n_seq, S, _stream())
-        # weight gradient of the pooling layer, dWa_ext = dpre^T @ [ctx | 1]: split-K ring kernel (csrc/k_gemm.h), partials [P, QP, KP]; column D =
-        # bias gradient (ctx[:, D] == 1)
-        dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')
         # ---- attention backward (kernel) -> dqkv ------------------------------------------------------------------
-        dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero
+        dqkv = _workspace('dqkv', (ntok, NR_LDG), _BF16_AS_I16, dev, zero=True)   # padding columns stay zero; one buffer per shape (news / user encoder)
         if split:
             _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_hm, _ptr(qs), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv), _ptr(key_len),
                   n_seq, S, p_drop, seed, _stream())
         else:
             _call(f'nr_attn_bwd[S={S}]', lib.nr_attn_bwd_len, _ptr(qs), _ptr(ks), _ptr(vts), _ptr(dctx_gemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(dqkv),
                   _ptr(key_len), n_seq, S, p_drop, seed, _stream())
-        # weight gradients of the projections, dW_ext = dqkv^T @ [X | 1]: 256 x 320 tiles of the ring kernel, partials [P, 960, KP]
-        dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')
         # ---- input gradient: dX = dqkv @ [Wq; Wk; Wv] (nr_dx_gemm), then the embedding scatter.  The table gradient is the large message of the
         # data-parallel exchange: its all-reduce is started by table_grad_ready on RCCL's stream as soon as the scatter is enqueued -----
         dX = torch.empty(ntok, NR_KP, dtype=torch.bfloat16, device=dev)
@@ -734,22 +752,35 @@ class _EncoderFn(torch.autograd.Function):
         d_table = d_x = None
         if gather:
             if ctx.needs_input_grad[1]:
-                dst, d_table = grad_target(ctx.table_param)
+                tdst, d_table = grad_target(ctx.table_param)
                 dXi = dX.view(_BF16_AS_I16)
                 # sort token ids so that every table row is reduced by adjacent lanes instead of contended atomics
                 ids_sorted, perm = sorted_ids_ready(ctx.sorted)
                 _call(f'nr_embed_scatter_sorted[S={S}]', lib.nr_embed_scatter_sorted, _ptr(ids_sorted), _ptr(perm), _ptr(dXi), NR_KP,
-                      _ptr(dst), table.shape[0], ntok, p_drop, seed, _stream())
+                      _ptr(tdst), table.shape[0], ntok, p_drop, seed, _stream())
                 table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
             d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
-        # ---- the nine weight gradients.  A trainer with persistent gradient buffers: summed over the chunks and accumulated there in one
-        # launch; plain autograd: chunk sums, then slices of the packed geometry that AccumulateGrad adds into .grad one by one ----------
+        # ---- phase 2: the nine weight gradients.  dWa_ext = dpre^T @ [ctx | 1] and dW_ext = dqkv^T @ [X | 1]: split-K ring kernel (csrc/k_gemm.h),
+        # partials [P, rows, KP]; column D = bias gradient (ctx[:, D] == X[:, D] == 1).  A trainer with persistent gradient buffers: summed over the
+        # partitions and accumulated there in one launch; plain autograd: sums, then slices of the packed geometry that AccumulateGrad adds ------
         dst = inplace_grads(ctx.wparams) if all(ctx.needs_input_grad[3:12]) else None
+
+        def weight_grads():
+            dWa_parts = gemm_tn_parts(dpre, NR_QP, cbuf, NR_KP, f'nr_gemm_tn_dWa[S={S}]')
+            dW_parts = gemm_tn_parts(dqkv, NR_LDG, Xb, NR_KP, f'nr_gemm_tn_dWqkv[S={S}]')
+            return dWa_parts, dW_parts
         if dst is not None:
-            _call('nr_wgrad_unpack', lib.nr_wgrad_unpack, _ptr(dW_parts), dW_parts.shape[0], _ptr(dWa_parts), dWa_parts.shape[0],
-                  _ptr(dq_part), nwg, qdim, *[_ptr(g) for g in dst], _stream())
+            def phase2():
+                dWa_parts, dW_parts = weight_grads()
+                _call('nr_wgrad_unpack', lib.nr_wgrad_unpack, _ptr(dW_parts), dW_parts.shape[0], _ptr(dWa_parts), dWa_parts.shape[0],
+                      _ptr(dq_part), nwg, qdim, *[_ptr(g) for g in dst], _stream())
+            if defer_wgrad:
+                _deferred.append(phase2)
+            else:
+                phase2()
             return (None, d_table, d_x) + (None,) * 13
+        dWa_parts, dW_parts = weight_grads()
         d_qv = dq_part.sum(dim=0)[:qdim]
         dWa_ext = dWa_parts[0] if dWa_parts.shape[0] == 1 else dWa_parts.sum(dim=0)
         dW_ext = dW_parts[0] if dW_parts.shape[0] == 1 else dW_parts.sum(dim=0)

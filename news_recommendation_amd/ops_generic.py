@@ -55,6 +55,22 @@ def _pack_cols(W):
     return ops._packed('g_cols', (W,), build)[0]
 
 
+def _pack_rows_split(W, b):
+    """[Wh | Wl | Wh] with W = Wh + Wl split into two bf16 numbers (bias likewise, in the 1.0 columns of the first two blocks): the B operand of
+    the 3-term product that evaluates a linear layer to ~2^-16 relative on the bf16 GEMM (nr_g_rows_split_bf16 makes the matching rows)."""
+    def build():
+        N, D = W.shape
+        Dp = pad32(D)
+        full = torch.zeros(N, Dp, dtype=torch.float32, device=W.device)
+        full[:, :D] = W.detach()
+        if b is not None:
+            full[:, D] = b.detach()
+        hi = full.to(torch.bfloat16)
+        lo = (full - hi.float()).to(torch.bfloat16)
+        return (torch.cat([hi, lo, hi], dim=1).contiguous().view(_BF16_AS_I16),)
+    return ops._packed('g_rows_split', (W,) if b is None else (W, b), build)[0]
+
+
 def _sum0(parts):
     return ops.sum_parts(parts) if parts[0].numel() % 4 == 0 else parts.sum(dim=0)
 
@@ -64,11 +80,20 @@ class _LinearFn(torch.autograd.Function):
     nr_gemm_nt on bf16 operands; backward: dW | db = dy^T [x | 1] (nr_gemm_tn, split K), dx = dy W (nr_gemm_nt against W^T)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, precise=False):
+        """precise: the forward product from split operands (x = xh + xl, W = Wh + Wl: three bf16 products in one GEMM, ~2^-16 relative) -- for
+        a layer whose output feeds a relu that must not flip against the fp32 reference; the backward products stay plain bf16."""
         n, D = x.shape
         N = W.shape[0]
-        xb = _rows_bf16(_f32c(x), D)
-        y = ops.gemm_nt(xb, _pack_rows(W, b), n, N, pad32(D), 'nr_gemm_nt[g_linear]')
+        x = _f32c(x)
+        xb = _rows_bf16(x, D)
+        if precise:
+            Dp = pad32(D)
+            x3 = torch.empty(n, 3 * Dp, dtype=_BF16_AS_I16, device=x.device)
+            _call('nr_g_rows_split_bf16', _lib().nr_g_rows_split_bf16, _ptr(x), x.stride(0), D, _ptr(x3), Dp, n, _stream())
+            y = ops.gemm_nt(x3, _pack_rows_split(W, b), n, N, 3 * Dp, 'nr_gemm_nt[g_linear3]')
+        else:
+            y = ops.gemm_nt(xb, _pack_rows(W, b), n, N, pad32(D), 'nr_gemm_nt[g_linear]')
         ctx.save_for_backward(xb, W)
         ctx.has_bias = b is not None
         return y
@@ -85,7 +110,7 @@ class _LinearFn(torch.autograd.Function):
             dW, db = ext[:, :D], (ext[:, D] if ctx.has_bias else None)
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dyb, _pack_cols(W), n, D, pad32(N), 'nr_gemm_nt[g_linear_dx]')
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -381,5 +406,5 @@ def element_encode(ids, embedding, linear):
     """ElementEncoder.forward (NAML news_encoder.py:40-47): relu(linear(embedding(ids)))."""
     flat = ids.reshape(-1)
     e = _GatherFn.apply(flat, embedding.weight)
-    y = _LinearFn.apply(e, linear.weight, linear.bias)
+    y = _LinearFn.apply(e, linear.weight, linear.bias, True)          # split operands: the relu must not flip against the fp32 reference
     return _ReluDropFn.apply(y, 0.0, 0, 0).view(*ids.shape, linear.weight.shape[0])

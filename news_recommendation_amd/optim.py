@@ -185,6 +185,8 @@ class EngineAdam:
                               'params': list(range(len(self.params)))}]
         if self._module is not None and self.sparse:
             self._module.register_state_dict_pre_hook(lambda *_a, **_k: self.flush())
+        if self._dist_on() and self.overlap and lib is None:
+            self.enable_deferred_wgrad(True)
 
     # ---- hooks the engine's backward calls ------------------------------------------------------------------------------------------------
     def _make_ready(self, region):
@@ -294,6 +296,7 @@ class EngineAdam:
         that is NOT followed by step() are dropped by ``discard_grads()``.)"""
 
     def discard_grads(self):
+        ops.drop_deferred()
         self.flat_g.zero_()
         for r in self.regions:
             r.work = None
@@ -317,7 +320,16 @@ class EngineAdam:
                                        self.flat_v.data_ptr() + lo * 4, hi - lo, self.sched.table.data_ptr(), self.t, self.betas[0],
                                        self.betas[1], self.eps, scale, 1, self._stream_fn()))
 
+    def enable_deferred_wgrad(self, on=True):
+        """Ask the engine's backward passes to postpone their weight-gradient GEMMs past the end of loss.backward() (ops.defer_wgrad): they then
+        run -- from step() / run_deferred() -- WHILE the table bucket, whose all-reduce the embedding scatter has just started, is on the wire.
+        On by default under a process group with overlap; a process-wide switch (one trainer per process)."""
+        ops.defer_wgrad = bool(on)
+        if not on:
+            ops.run_deferred()
+
     def step(self):
+        ops.run_deferred()                       # weight-gradient phases the backward postponed (the table exchange is already in flight)
         self.t += 1
         self.sched.ensure(self.t)
         ops.invalidate_packed()                  # the kernels below rewrite parameter memory behind torch's version counters
@@ -373,8 +385,6 @@ class EngineAdam:
     def prepare_segments(self):
         """Static send / receive buffers of the touched-row exchange (their addresses are frozen into the graphs).  Needs the per-rank row
         capacity: agreed by the first eager exchange, or set_row_capacity()."""
-        if self.table_rs:
-            raise NotImplementedError("EngineAdam: the segmented step supports the all-reduce form of the table bucket (table_rs=False)")
         world = _world()
         for st in self.sparse:
             cap = self._row_cap.get(st.name)
@@ -408,16 +418,24 @@ class EngineAdam:
         self.sched.ensure(self.t)
         ops.invalidate_packed()
 
-    def exchange_all(self):
-        """Every collective of the step, issued between the two graph segments; returns once the current stream waits for all of them."""
+    def start_tables(self):
+        """First half of the exchange: the table bucket(s) -- all-reduce, or reduce-scatter onto this rank's shard (table_rs) -- asynchronous on
+        the process group's stream.  graph.SegmentedStep(overlap=True) issues it right after the segment that ends with the embedding scatter,
+        so that the weight-gradient segment runs while the tables are on the wire.  Returns the work handles for exchange_all(works=...)."""
+        if self.skip_comm:
+            return []
+        return [self._start_table_exchange(r) for r in self.regions if r.name != 'small']
+
+    def exchange_all(self, works=None):
+        """Every collective of the step (those not yet started by start_tables), issued between graph segments; returns once the current stream
+        waits for all of them."""
         if self.skip_comm:
             return
-        works = []
         world = _world()
-        for r in self.regions:
-            if r.name != 'small':
-                self.comm_bytes[r.name] = (r.hi - r.lo) * 4
-                works.append(dist.all_reduce(self.flat_g[r.lo:r.hi], op=dist.ReduceOp.SUM, async_op=True))
+        if works is None:
+            works = self.start_tables()
+        else:
+            works = list(works)
         for st in self.sparse:
             cap, d = st.send_ids.shape[0], st.param.shape[1]
             if cap:
@@ -435,14 +453,36 @@ class EngineAdam:
             w.wait()
 
     def apply_all(self):
-        """The update launches of the step (second graph segment): fused Adam over every dense bucket with the 1 / world scale, the
-        row-sparse step over the gathered rows."""
+        """The update launches of the step (last graph segment): fused Adam over every dense bucket with the 1 / world scale -- a table bucket
+        exchanged by reduce-scatter (table_rs) on this rank's shard only, the other shards' (local) gradients cleared --, the row-sparse step
+        over the gathered rows.  With table_rs the caller then collects the updated table: gather_tables() (a collective, outside the graph)."""
         scale = 1.0 / _world()
         for r in self.regions:
-            self._adam(r.lo, r.end, scale)
+            if self.table_rs and r.name != 'small':
+                lo, hi = self._shard(r)
+                self._adam(lo, hi, scale)
+                if lo > r.lo:
+                    self.flat_g[r.lo:lo].zero_()
+                if hi < r.end:
+                    self.flat_g[hi:r.end].zero_()
+            else:
+                self._adam(r.lo, r.end, scale)
         for st in self.sparse:
             if st.recv_ids.numel():
                 self._row_step(st, st.recv_ids, st.recv_rows, scale)
+
+    def gather_tables(self):
+        """table_rs: every rank collects the table parameters the other ranks' shards of the Adam pass updated (all-gather; the same bytes as the
+        second half of an all-reduce).  A no-op for the all-reduce form."""
+        if not self.table_rs or self.skip_comm:
+            return
+        works = []
+        for r in self.regions:
+            if r.name != 'small':
+                lo, hi = self._shard(r)
+                works.append(dist.all_gather_into_tensor(self.flat_p[r.lo:r.end], self.flat_p[lo:hi], async_op=True))
+        for w in works:
+            w.wait()
 
     def _exchange_rows(self, st):
         """All ranks' (row id, gradient row) pairs, in rank order: B x (8 + 4 d) bytes per rank instead of a table-sized all-reduce."""

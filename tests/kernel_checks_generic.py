@@ -137,7 +137,7 @@ def check_conv(be, n_seq=5, S=9, D=20, F=24, w=3, p=0.25, seed=4):
     dypad = be.empty((M + 2 * pad + 1, Fp), np.uint16)
     kc.ck(be, be.lib.nr_g_relu_drop_bwd(be.ptr(be.dev(dact)), be.ptr(act), be.ptr(dypad), F, Fp, S, pad, n_seq * S, p, be.stream))
     be.sync()
-    dy_tok = np.where(be.np(act) != 0, dact / F32(1.0 - p), 0).astype(F32)
+    dy_tok = np.where(be.np(act) != 0, dact * (F32(1.0) / (F32(1.0) - F32(p))), 0).astype(F32)        # (the kernel multiplies by the reciprocal)
     dyp = bf16_to_f32(be.np(dypad))
     for q in range(n_seq):
         assert np.array_equal(dyp[pad + q * (S + pad):pad + q * (S + pad) + S, :F], bf16_round(dy_tok[q * S:(q + 1) * S]))
@@ -171,3 +171,24 @@ def check_relu(be, n=1000):
     kc.ck(be, be.lib.nr_g_relu(be.ptr(be.dev(x)), be.ptr(be.dev(gate)), be.ptr(y), n, 1.25, be.stream))
     be.sync()
     assert np.array_equal(be.np(y), np.where(gate > 0, x * F32(1.25), 0).astype(F32))
+
+
+def check_split_linear(be, n=37, D=100, N=24, seed=6):
+    """[hi | hi | lo] rows x [Wh | Wl | Wh] weights through ONE bf16 GEMM = x W^T + b to ~2^-16 relative."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 0.7, size=(n, D)).astype(F32)
+    W = rng.normal(0, 0.3, size=(N, D)).astype(F32)
+    b = rng.normal(0, 0.2, size=N).astype(F32)
+    Dp = pad32(D)
+    x3 = be.poison((n, 3 * Dp), np.uint16)
+    kc.ck(be, be.lib.nr_g_rows_split_bf16(be.ptr(be.dev(x)), D, D, be.ptr(x3), Dp, n, be.stream))
+    full = np.zeros((N, Dp), dtype=F32); full[:, :D] = W; full[:, D] = b
+    hi = bf16_round(full); lo = bf16_round(full - hi)
+    W3 = f32_to_bf16(np.concatenate([hi, lo, hi], axis=1))
+    y = be.poison((n, N), F32)
+    kc.ck(be, be.lib.nr_gemm_nt(be.ptr(x3), 3 * Dp, be.ptr(be.dev(W3)), 3 * Dp, be.ptr(y), N, n, N, 3 * Dp, be.stream))
+    be.sync()
+    ref = x.astype(np.float64) @ W.astype(np.float64).T + b
+    np.testing.assert_allclose(be.np(y), ref, rtol=0, atol=6e-5 * np.abs(ref).max())
+    plain = bf16_round(x).astype(np.float64) @ bf16_round(W).astype(np.float64).T + bf16_round(b)
+    assert np.abs(be.np(y) - ref).max() < 0.05 * np.abs(plain - ref).max()          # ... i.e. far below the plain bf16 product's error

@@ -167,7 +167,14 @@ def _engine_worker(rank, world, port, overlap, q, table_rs=False, ragged=False, 
         opt.prepare_segments()
     for words, users, y in _toy_batches(rank, 4, ragged):
         torch.nn.functional.cross_entropy(model(words, users), y).backward()
-        if segmented:
+        if segmented == 'overlap':              # the three-segment form: the table exchange in flight under the weight-gradient segment
+            opt.begin_step()
+            works = opt.start_tables()          # (behind graph A, which ends with the embedding scatter)
+            opt.stage_rows()                    # (graph W: postponed weight-gradient GEMMs + row staging)
+            opt.exchange_all(works)             # rows, small bucket, then wait for everything
+            opt.apply_all()                     # (graph B: Adam -- under table_rs on this rank's shard)
+            opt.gather_tables()                 # table_rs: collect the updated table
+        elif segmented:
             opt.stage_rows()                    # (tail of graph A)
             opt.begin_step()
             opt.exchange_all()                  # the collectives between the segments
@@ -293,3 +300,17 @@ def test_engine_adam_segmented_step_equals_step(ragged):
     for k in ref[0]:
         assert np.array_equal(seg[0][k], seg[1][k]), f"replicas diverged in {k}"
         assert np.array_equal(seg[0][k], ref[0][k]), f"segmented step differs from step() in {k}"
+
+
+@pytest.mark.parametrize('table_rs', [False, True])
+def test_engine_adam_overlapped_segments_equal_step(table_rs):
+    """the three-segment issue mode of graph.SegmentedStep (table exchange started behind the scatter segment, weight
+    gradients + row staging under it, then rows / small bucket, Adam, and -- reduce-scatter form -- the gather of the updated table) leaves the
+    replicas bit-identical to each other AND to EngineAdam.step(), parameters and Adam moments, in the all-reduce and the reduce-scatter form
+    of the table bucket (which the two-segment mode of round 4 refused)."""
+    import numpy as np
+    seg, ref = _run_world2(False, table_rs=table_rs, segmented='overlap'), _run_world2(True, table_rs=table_rs)
+    assert any(k.startswith('opt/') for k in seg[0])
+    for k in ref[0]:
+        assert np.array_equal(seg[0][k], seg[1][k]), f"replicas diverged in {k}"
+        assert np.array_equal(seg[0][k], ref[0][k]), f"overlapped segments differ from step() in {k}"

@@ -18,3 +18,4 @@ def test_dropout_uses_the_exported_masks(be): kg.check_dropout(be)
 @pytest.mark.parametrize('w', [1, 3, 5])
 def test_convolution_any_window(be, w): kg.check_conv(be, n_seq=4, S=9, D=20, F=24, w=w)
 def test_relu(be): kg.check_relu(be)
+def test_split_operand_linear(be): kg.check_split_linear(be)

@@ -23,6 +23,7 @@ import os, sys, numpy as np, torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 mode, model_name, out = sys.argv[2], sys.argv[3], sys.argv[4]
+overlap, table_rs = sys.argv[6] == '1', sys.argv[7] == '1'
 from bench import Workload, make_cfg
 from news_recommendation_amd import optim
 optim.TABLE_MIN_NUMEL = 1 << 18                   # the reduced word table below is still "the table bucket"
@@ -102,6 +103,7 @@ import os, sys, numpy as np, torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 mode, model_name, out = sys.argv[2], sys.argv[3], sys.argv[4]
+overlap, table_rs = sys.argv[6] == '1', sys.argv[7] == '1'
 from bench import Workload, make_cfg
 from news_recommendation_amd import ops, optim
 from news_recommendation_amd.graph import SegmentedStep
@@ -114,7 +116,7 @@ cfg = make_cfg(model_name, 'small', vocab=5000)
 cfg.num_news, cfg.num_users = 3000, 700
 wl = Workload(model_name, cfg)
 model = wl.make_model(seed=11).to(dev).train()
-opt = optim.EngineAdam(model, lr=1e-3, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else (), force_dist=True)
+opt = optim.EngineAdam(model, lr=1e-3, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else (), force_dist=True, table_rs=table_rs)
 B = 64
 batches = wl.batches(0, 3, B, dev)
 target = torch.zeros(B, dtype=torch.long, device=dev)
@@ -130,8 +132,8 @@ def fwd_bwd(*xs):
     loss = crit(logits, target)
     loss.backward()
     return loss
-g = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=2)
-assert opt.t == 2 and not opt.overlap
+g = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=2, overlap=overlap)
+assert opt.t == 2 and not opt.overlap and ops.defer_wgrad == overlap and (g.graph_w is not None) == overlap
 losses = []
 for i in range(5):
     xs = flat(batches[i % 3])
@@ -141,11 +143,13 @@ for i in range(5):
 assert opt.t == 7 and int(g.ctr.item()) == 7, (opt.t, int(g.ctr.item()))
 assert opt.comm_bytes and all(v > 0 for v in opt.comm_bytes.values()), opt.comm_bytes
 g.close()
+opt.gather_state()
 sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 osd = opt.state_dict()
 for i, st in osd['state'].items():
     sd[f'opt/{i}/exp_avg_sq'] = st['exp_avg_sq'].cpu().numpy()
     assert float(st['step']) == 7.0
+assert not ops._deferred
 sd['losses'] = np.array(losses)
 np.savez(out, **sd)
 dist.destroy_process_group()
@@ -153,23 +157,25 @@ print('ok', mode, model_name, losses)
 '''
 
 
-def _run_seg(mode, model_name, tmp_path):
-    out = str(tmp_path / f'seg_{mode}_{model_name}.npz')
+def _run_seg(mode, model_name, tmp_path, overlap=True, table_rs=False):
+    out = str(tmp_path / f'seg_{mode}_{model_name}_{int(overlap)}{int(table_rs)}.npz')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
-    r = subprocess.run([sys.executable, '-c', CHILD_SEG, ROOT, mode, model_name, out, str(_free_port())], env=env, cwd=ROOT, capture_output=True,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, '-c', CHILD_SEG, ROOT, mode, model_name, out, str(_free_port()), str(int(overlap)), str(int(table_rs))], env=env,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     return dict(np.load(out))
 
 
-@pytest.mark.parametrize('model_name', ['NRMS', 'LSTUR'])
-def test_segmented_step_graphs_over_rccl_equal_eager_steps(tmp_path, model_name):
+@pytest.mark.parametrize('model_name,overlap,table_rs', [('NRMS', True, False), ('NRMS', True, True), ('NRMS', False, False), ('LSTUR', True, False)])
+def test_segmented_step_graphs_over_rccl_equal_eager_steps(tmp_path, model_name, overlap, table_rs):
     """graph.SegmentedStep on a process group over RCCL (world 1, multi-rank branch forced): [forward + backward + row staging] and [Adam]
     replayed as two HIP graphs with the collectives issued between them == the eager data-parallel step on the same device step counter,
     up to the run-to-run noise of the embedding scatter's fp32 atomics.  What it exercises: capture next to RCCL's watchdog thread, the
     stream ordering graph A -> collectives on RCCL's stream -> graph B, static row-exchange buffers, the row-sparse Adam under the counter."""
-    eager, graph = _run_seg('eager', model_name, tmp_path), _run_seg('graph', model_name, tmp_path)
-    again = _run_seg('eager', model_name, tmp_path)
+    # overlap: the THREE-segment mode (r06): graph A ends with the embedding scatter, the table exchange (all-reduce, or reduce-scatter with
+    # table_rs) is started behind it, graph W replays the postponed weight-gradient GEMMs under it, graph B is Adam (+ the gather of the table)
+    eager, graph = _run_seg('eager', model_name, tmp_path, overlap, table_rs), _run_seg('graph', model_name, tmp_path, overlap, table_rs)
+    again = _run_seg('eager', model_name, tmp_path, overlap, table_rs)
     assert np.isfinite(eager['losses']).all() and len(set(np.round(eager['losses'], 6))) > 1
     assert set(eager) == set(graph)
     noise = max(float(np.abs(again[k].astype(np.float64) - eager[k]).max()) for k in eager)

@@ -17,7 +17,7 @@ for M in ${MODELS:-NRMS NAML LSTUR}; do
 import sys
 sys.path.insert(0, "$PWD")
 from news_recommendation_amd import synth
-synth.write_reference_dataset("$RUN", n_news=4000, n_users=3000, n_train=25600, n_val_impr=1500, num_words=20000, seed=1, learnable=True)
+synth.write_reference_dataset("$RUN", n_news=4000, n_users=3000, n_train=25600, n_val_impr=10000, num_words=20000, seed=1, learnable=True)
 PY
   L=$O/launcher_unchanged_train_evaluate_$M.log
   SET="num_words=20000 num_users=3001 learning_rate=0.0005 num_batches_validate=200 num_batches_show_loss=100"
