@@ -731,9 +731,19 @@ int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, cons
     return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: dropout probability out of range");
   if (n_tokens == 0) return NR_OK;
-  const int64_t waves = (n_tokens + nr::SC_CH - 1) / nr::SC_CH;
-  NR_LAUNCH(nr::embed_scatter_sorted_kernel<nr::u16>, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, (int64_t)ldx,
-            grad_table, num_rows, n_tokens, make_drop(p_drop, seed), 0);
+  // positions per wave: NR_SCATTER_SPAN (A/B; 64 / 128 / 256 / 512), default 256 -- see the kernel's comment on atomic contention under Zipf ids
+  static int span = -1;
+  if (span < 0) { const char* e = std::getenv("NR_SCATTER_SPAN"); span = e ? std::atoi(e) : nr::SC_SPAN; }
+  auto go = [&](auto tag) {
+    constexpr int SPAN = decltype(tag)::value;
+    const int64_t waves = (n_tokens + SPAN - 1) / SPAN;
+    NR_LAUNCH((nr::embed_scatter_sorted_kernel<nr::u16, SPAN>), (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, (int64_t)ldx,
+              grad_table, num_rows, n_tokens, make_drop(p_drop, seed), 0);
+  };
+  if (span == 64) go(nr::IntTag<64>{});
+  else if (span == 128) go(nr::IntTag<128>{});
+  else if (span == 512) go(nr::IntTag<512>{});
+  else go(nr::IntTag<256>{});
   return check_launch("nr_embed_scatter_sorted");
 }
 
@@ -743,8 +753,8 @@ int nr_scatter_sorted_f32(const int64_t* ids_sorted, const int64_t* perm, const 
       num_rows >= (1LL << 31) || pad_row < -1)
     return fail(NR_ERR_BADARG, "nr_scatter_sorted_f32: bad argument");
   if (n == 0) return NR_OK;
-  const int64_t waves = (n + nr::SC_CH - 1) / nr::SC_CH;
-  NR_LAUNCH(nr::embed_scatter_sorted_kernel<float>, (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, src, ld, dst, num_rows, n,
+  const int64_t waves = (n + nr::SC_SPAN - 1) / nr::SC_SPAN;
+  NR_LAUNCH((nr::embed_scatter_sorted_kernel<float, nr::SC_SPAN>), (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, src, ld, dst, num_rows, n,
             make_drop(0.0f, 0), pad_row);
   return check_launch("nr_scatter_sorted_f32");
 }

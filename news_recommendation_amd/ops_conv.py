@@ -70,7 +70,8 @@ def _seqpad_alloc(n_seq, S):
 
 class _TextState:
     """What one text encoder keeps between forward and backward."""
-    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset', 'y', 'y_ptr', 'y_stride', 'y_version')
+    __slots__ = ('S', 'n_seq', 'act', 'xstore', 'aw', 'Wd', 'Wd2', 'Wap', 'bap', 'qvp', 'WaT', 'qdim', 'tok_offset', 'y', 'y_ptr', 'y_stride', 'y_version',
+                 'params')
 
 
 def pad_text(ids, what):
@@ -92,6 +93,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     dev = table.device
     st = _TextState()
     st.S, st.n_seq, st.tok_offset, st.qdim = S, n_seq, tok_offset, Wa.shape[0]
+    st.params = (conv_w, conv_b, Wa, ba, qv)              # the caller's tensor objects (nn.Parameters): ops.inplace_grads()
     Wc, st.Wd, bc = pack_conv(conv_w, conv_b)
     st.Wd2 = pack_conv_dgrad(conv_w) if need_grad else None       # operand of the data gradient as ONE GEMM over virtual 3-tap rows (csrc/k_gemm.h, NT3 form)
     st.Wap, st.bap, st.qvp = pack_additive(Wa, ba, qv)
@@ -129,22 +131,25 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0, y_ptr=None, y_stride=NR_D):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0, y_ptr=None, y_stride=NR_D, later=False):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
     Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.
     With ``dy`` (seqpad buffer of a conv text encoder whose activations ctx_b are) the gradient goes on through the relu / dropout stage
     into dy in the same call (nr_additive_bwd_act: fused into the pooling kernel's epilogue where the register-resident kernels run);
-    dgemm is then only scratch."""
+    dgemm is then only scratch.
+    later: the weight-gradient part (dWa = dpre^T [ctx | 1], the sum of the dq partials) is NOT computed here: returns (fn, dgemm) with fn() ->
+    (d_Wa, d_ba, d_qv); dpre / dq live in scratch keyed by `tag` until then (two-phase backward: ops.defer_wgrad)."""
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
     flat = ops.pool_flat_ok(S, dy is not None, n_seq, qdim=qdim) and y_ptr is not None
+    wt = tag if later else ''
     if flat:
-        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop)
+        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop, ws_tag=wt)
     else:
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
-        dpre = _workspace('dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-        dq_part = _workspace('dqp', (nwg, NR_QP), torch.float32, dev)
+        dpre = _workspace(f'dpre[{wt}]' if wt else 'dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
+        dq_part = _workspace(f'dqp[{wt}]' if wt else 'dqp', (nwg, NR_QP), torch.float32, dev)
         dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
     if flat:
         pass
@@ -154,15 +159,23 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     else:
         _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_act, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
-    d_qv = dq_part.sum(dim=0)[:qdim]
-    # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
-    dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
-    return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv, dgemm
+
+    def weight_part():
+        d_qv = dq_part.sum(dim=0)[:qdim]
+        # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
+        dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
+        return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv
+    if later:
+        return weight_part, dgemm
+    return (*weight_part(), dgemm)
 
 
-def text_bwd(st, g, g_stride, p, dx_out, tag):
+def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
     """Backward of text_fwd for pooled-vector gradients g (f32 device pointer/tensor rows of stride g_stride).
-    Writes the token gradient (bf16 [n_seq*S][KP]) into dx_out and returns (d_conv_w, d_conv_b, d_Wa, d_ba, d_qv)."""
+    Writes the token gradient (bf16 [n_seq*S][KP]) into dx_out and returns (d_conv_w, d_conv_b, d_Wa, d_ba, d_qv) -- or, with later=True,
+    a function that computes them: phase 1 (here) is what the INPUT gradient needs (pooling backward with the fused activation gradient, the
+    data-gradient GEMM), phase 2 (the function) the weight gradients (pooling dWa, the three conv tap gradients): under data parallelism phase
+    2 runs while the table bucket, complete once every text's phase 1 and the embedding scatter are done, is on the wire."""
     lib = _lib()
     n_seq, S = st.n_seq, st.S
     dev = st.act.device
@@ -173,18 +186,40 @@ def text_bwd(st, g, g_stride, p, dx_out, tag):
     # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
     if getattr(st, 'y_version', None) is not None and st.y._version != st.y_version:
         raise RuntimeError("text_bwd: the pooled vectors were modified in place after the forward; the pooling backward needs them unchanged")
-    d_Wa, d_ba, d_qv, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
-                                    y_ptr=st.y_ptr, y_stride=st.y_stride)
-
-    # the three tap gradients as ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap shift
-    # is a row offset of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three taps
-    both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, st.xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
-    taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
+    pool_w, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
+                          y_ptr=st.y_ptr, y_stride=st.y_stride, later=True)
     # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
     _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
-    d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
-    d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
-    return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
+    xstore = st.xstore
+
+    def weight_part():
+        d_Wa, d_ba, d_qv = pool_w()
+        # the three tap gradients as ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap
+        # shift is a row offset of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three
+        both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
+        taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
+        d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
+        d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
+        return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
+    return weight_part if later else weight_part()
+
+
+def finish_weight_grads(parts):
+    """parts: [(function -> gradients, the parameter objects they belong to), ...] of one backward call, in its order.  Plain autograd, or no
+    postponement asked for: evaluate now, return the gradients (flat tuple).  A trainer with persistent gradient buffers that asked for the
+    two-phase backward (ops.defer_wgrad): queue ONE postponed phase that evaluates them and accumulates into the parameters' .grad buffers
+    (what AccumulateGrad would do), and hand autograd None for each."""
+    params = [q for _, ps in parts for q in ps]
+    dst = ops.inplace_grads(params) if ops.defer_wgrad else None
+    if dst is None:
+        return tuple(v for fn, _ in parts for v in fn())
+
+    def phase2():
+        vals = [v for fn, _ in parts for v in fn()]
+        for gbuf, v in zip(dst, vals):
+            gbuf.add_(v.reshape(gbuf.shape))
+    ops._deferred.append(phase2)
+    return (None,) * len(params)
 
 
 def sort_tokens_async(ids_list, num_rows):
@@ -281,11 +316,13 @@ class _NamlNewsFn(torch.autograd.Function):
         # text encoders; token gradients of both texts land in one buffer -> one embedding scatter
         nt, na = title.numel(), abstract.numel()
         dx = _workspace('dx_tok', (nt + na, NR_KP), _BF16_AS_I16, dev)
-        gt = text_bwd(st_t, gv[0], NR_D, p, dx.data_ptr(), 'title')
-        ga = text_bwd(st_a, gv[1], NR_D, p, dx.data_ptr() + nt * NR_KP * 2, 'abstract')
+        gt = text_bwd(st_t, gv[0], NR_D, p, dx.data_ptr(), 'title', later=True)
+        ga = text_bwd(st_a, gv[1], NR_D, p, dx.data_ptr() + nt * NR_KP * 2, 'abstract', later=True)
         d_table = embed_scatter(ctx.sorted, nt + na, dx, ctx.table_param, p, seed) if ctx.needs_input_grad[4] else None
+        # the weight gradients of the two text encoders (pooling dWa, conv taps): after the scatter -- under data parallelism while the table flies
+        wg = finish_weight_grads([(gt, st_t.params), (ga, st_a.params)])
         ctx.st = None
-        return (None, None, None, None, d_table, demb, *gt, *ga, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None, None, None)
+        return (None, None, None, None, d_table, demb, *wg, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None, None, None)
 
 
 def naml_news(title, abstract, cat, sub, table, cat_table, text_t, text_a, elem_c, elem_s, final_att, p_drop, training):
@@ -401,10 +438,11 @@ class _LsturNewsFn(torch.autograd.Function):
         d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0) + _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0)
         g_title = g[:, 2 * NR_D:].contiguous()
         dx = _workspace('dx_tok', (title.numel(), NR_KP), _BF16_AS_I16, dev)
-        gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title')
+        gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title', later=True)
         d_table = embed_scatter(ctx.sorted, title.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[3] else None
+        wg = finish_weight_grads([(gt, st.params)])
         ctx.st = None
-        return (None, None, None, d_table, d_cat, *gt, None, None, None)
+        return (None, None, None, d_table, d_cat, *wg, None, None, None)
 
 
 def lstur_news(title, cat, sub, table, cat_table, conv, additive, p_drop, training):

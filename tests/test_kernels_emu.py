@@ -159,3 +159,10 @@ def test_pool_flat_group_boundaries(be):
     k3.check_flat(be, S=48, n_seq=1, seed=1); k3.check_flat(be, S=49, n_seq=1, seed=2); k3.check_flat(be, S=7, n_seq=1, seed=3)
     k3.check_flat(be, S=200, n_seq=2, seed=4)
 def test_pool_flat_act_lengths(be): k3.check_flat_act(be, S=16, n_seq=3, seed=5); k3.check_flat_act(be, S=17, n_seq=20, seed=6); k3.check_flat_act(be, S=128, n_seq=2, seed=7)
+
+
+def test_scatter_sorted_long_runs_across_spans(be):
+    """Zipf-like ids: runs far longer than a wave's span (256 positions) and than a sub-chunk (64), a span that starts inside the padding ids,
+    spans shared by three runs -- the seams where a run continues in the neighbouring wave take the atomic path, everything else the direct one."""
+    kc.check_scatter_sorted(be, n_tokens=1500, V=7, p_drop=0.2, seed=11)
+    kc.check_scatter_sorted(be, n_tokens=700, V=3, p_drop=0.0, seed=12)
