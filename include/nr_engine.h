@@ -350,6 +350,12 @@ int nr_additive_fwd_ex(const uint16_t* ctx, const uint16_t* Wap, const float* ba
  * every gradient of nr_additive_bwd_ex.  Sequences shorter than an instantiated S are zero-padded by the host. */
 int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride,
                       uint16_t* out_b, int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, void* stream);
+/* nr_additive_fwd_v over WHOLE SEQUENCES PER WAVE, persistent (csrc/k_pool4.h; additive.py:27-53): the projection matrix stays in LDS for the
+ * kernel's life, a wave pools floor(64 / S) sequences at a time with no workgroup barrier, the weighted sum runs on the matrix core.  Any S in
+ * [16, 64]; qdim = query_vector_dim of the packed operands must be <= 200 (else NR_ERR_UNSUPPORTED: the LDS-tile entries handle all NR_QP rows).
+ * Same outputs as nr_additive_fwd_v up to the order of fp32 additions; the forward of every large pooling level of the conv text encoders. */
+int nr_additive_fwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride, uint16_t* out_b,
+                         int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, int qdim, void* stream);
 /* Input gradient of a pooling level: dx[t][:] = dgemm[t][:] + attn_w[t] * g_out[seq(t)][:], f32 [n_seq*S][D]; view_major != 0
  * stores row t at (t % S) * n_seq + t / S (S contiguous [n_seq][D] blocks, one per view). */
 int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const float* g_out, float* dx, int64_t n_seq, int S,

@@ -32,6 +32,7 @@ SIGNATURES = {
     'nr_attn_pool_fwd': ([_P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_float, c_uint64, _P], c_int),
     'nr_attn_bwd_hm': ([_P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_fwd_v': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_additive_fwd_flat': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P], c_int),
     'nr_attn_bwd': ([_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, c_int, c_float, c_uint64, _P], c_int),
     'nr_additive_bwd_grid': ([c_int64, c_int], c_int64),
     'nr_additive_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),

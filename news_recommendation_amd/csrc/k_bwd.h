@@ -709,122 +709,163 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* _
 // Sorted variant: positions are sorted by id (ids_sorted ascending, perm = original token index), so all
 // contributions to one table row are adjacent.  One wave reduces SPAN consecutive positions in registers (lane =
 // one 4-column quad, lanes 0..10 a second quad) and writes each finished row once; only rows whose run touches
-// the span boundary (and may continue in a neighbour wave) use atomics.  The result is ADDED to grad_table (a row that only this
+// the span boundary (and may continue in a neighbour wave) are combined per workgroup and flushed with atomics.  The result is ADDED to grad_table (a row that only this
 // wave touches is read, added and written back), so the destination may be the live .grad buffer of the parameter.
 //
-// SPAN (round 6): token ids are Zipf-distributed -- in a NAML batch (1.9 M tokens) the most frequent word occurs 98,831 times, the top ten
-// hold 26 % of the positions and 77 % of the positions sit in runs longer than 32.  With the 32-position spans of rounds 1-5 such a run was
-// reduced by thousands of waves that each ended with 300 ATOMIC adds into the same table row (3,088 waves on the top row): the kernel ran
-// at ~1.1 TB/s of row reads (608 us per NAML step, 164 us per NRMS step), serialised in the L2's atomic units, not bound by the gather.
-// A wave now walks SPAN = 256 positions in sub-chunks of 64 (the lanes hold the sub-chunk's (id, token) pairs), carrying the run in
-// progress across sub-chunks: 8x fewer seams, i.e. 8x fewer atomic flushes per hot row, and a long run costs ONE flush per 256 positions.
+// Round 6: token ids are Zipf-distributed -- in a NAML batch (1.9 M tokens) the most frequent word occurs 98,831 times, the top ten hold 26 % of
+// the positions and 77 % of the positions sit in runs longer than 32.  A run that continues in the neighbouring wave must be flushed with
+// ATOMIC adds (300 per flush), and with one flush per wave the hot rows took thousands of them (3,088 waves on the top row).  A measured
+// dead end (profiles/r06_scatter_ab.txt): longer spans per wave cut the flushes but also the number of waves -- each walks its rows with four
+// loads in flight, so the gather starves (span 256: NRMS 164 -> 266 us).  What is kept: spans of 64 positions (all waves resident at once) and
+// the flushes of a WORKGROUP's eight waves combined -- a wave deposits the partial sums of its first / last run in LDS when the run is shared
+// with a neighbour, and wave 0 adds up the consecutive deposits of equal id and flushes each merged run once: an eighth of the atomic traffic
+// on the hot rows at unchanged parallelism.
 constexpr int SC_SUB = 64;       // positions whose (id, token) pairs the lanes hold at a time
-constexpr int SC_SPAN = 256;     // positions per wave
+constexpr int SC_SPAN = 64;      // positions per wave (default instantiation)
+constexpr int SC_WAVES = 8;      // waves per workgroup
+constexpr int SC_EROW = 304;     // floats per deposited partial: 64 quads + 11 quads (+ padding)
+constexpr int SC_SMEM = SC_WAVES * 2 * SC_EROW * 4 + SC_WAVES * 2 * 4;
 __device__ __forceinline__ f32x4 ld_row4(const u16* p) { u16x4 v = *(const u16x4*)p; return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
 __device__ __forceinline__ f32x4 ld_row4(const float* p) { return *(const f32x4*)p; }
 
 // SRC = u16 (bf16 rows) or float.  Rows with id <= pad_row are skipped (pad_row = 0: nn.Embedding(padding_idx=0); -1: none).
 template <typename SRC, int SPAN>
-__global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const int64_t* __restrict__ ids_sorted,
-                                                                   const int64_t* __restrict__ perm, const SRC* __restrict__ dx,
-                                                                   int64_t ldx, float* __restrict__ grad_table, int64_t num_rows,
-                                                                   int64_t n_tokens, DropCfg dc, int pad_row) {
+__global__ __launch_bounds__(SC_WAVES * 64) void embed_scatter_sorted_kernel(const int64_t* __restrict__ ids_sorted,
+                                                                             const int64_t* __restrict__ perm, const SRC* __restrict__ dx,
+                                                                             int64_t ldx, float* __restrict__ grad_table, int64_t num_rows,
+                                                                             int64_t n_tokens, DropCfg dc, int pad_row) {
   static_assert(SPAN % SC_SUB == 0, "whole sub-chunks");
+  NR_SMEM_DECL(smem);
+  float* edge = (float*)smem;                                // [SC_WAVES][2][SC_EROW]
+  int* edge_id = (int*)(smem + SC_WAVES * 2 * SC_EROW * 4);  // [SC_WAVES][2]: id of the deposit, -1 = none
   dc = drop_resolve(dc);
-  const int l = lane_id();
-  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave_id()) * SPAN;
-  if (s0 >= n_tokens) return;
-  const int span = (int)((n_tokens - s0) < SPAN ? (n_tokens - s0) : SPAN);
-  if ((int)ids_sorted[s0 + span - 1] <= pad_row) return;   // the span is all padding (sorted: ids <= pad_row come first)
-  const int id_before = s0 > 0 ? (int)ids_sorted[s0 - 1] : -2;
-  const int id_after = s0 + span < n_tokens ? (int)ids_sorted[s0 + span] : -2;
+  const int l = lane_id(), w = wave_id();
   const bool two = l < (D4 - 64);
-  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  int cur = (int)ids_sorted[s0];
-  // current contents of the destination row of the run in progress, requested when the run starts so that the read-add-write of
-  // flush() does not wait on a round trip per finished row
-  f32x4 pd0 = f32x4{0.f, 0.f, 0.f, 0.f}, pd1 = pd0;
-  auto peek = [&](int id) {
-    if (id <= pad_row || id >= num_rows) return;
-    const float* src = grad_table + ((int64_t)id * D4 + l) * 4;
-    pd0 = *(const f32x4*)src;
-    if (two) pd1 = *(const f32x4*)(src + 256);
-  };
-  peek(cur);
-  auto flush = [&](int id, bool shared) {
-    if (id <= pad_row || id >= num_rows) return;
-    float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
-    if (shared) {
+  if (l < 2) edge_id[w * 2 + l] = -1;
+  const int64_t s0 = ((int64_t)blockIdx.x * SC_WAVES + w) * SPAN;
+  const int span = s0 >= n_tokens ? 0 : (int)((n_tokens - s0) < SPAN ? (n_tokens - s0) : SPAN);
+  const bool active = span > 0 && (int)ids_sorted[s0 + (span > 0 ? span - 1 : 0)] > pad_row;      // (sorted: ids <= pad_row come first -- an all-padding span has nothing to do)
+  if (active) {
+    const int id_before = s0 > 0 ? (int)ids_sorted[s0 - 1] : -2;
+    const int id_after = s0 + span < n_tokens ? (int)ids_sorted[s0 + span] : -2;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur = (int)ids_sorted[s0];
+    // current contents of the destination row of the run in progress, requested when the run starts so that the read-add-write of
+    // flush() does not wait on a round trip per finished row
+    f32x4 pd0 = f32x4{0.f, 0.f, 0.f, 0.f}, pd1 = pd0;
+    auto peek = [&](int id) {
+      if (id <= pad_row || id >= num_rows) return;
+      const float* src = grad_table + ((int64_t)id * D4 + l) * 4;
+      pd0 = *(const f32x4*)src;
+      if (two) pd1 = *(const f32x4*)(src + 256);
+    };
+    peek(cur);
+    // a finished run: not shared with a neighbouring wave -> the row is this wave's alone: read (peeked) + add + write; shared -> deposit the partial
+    // in LDS slot `which` (0: the span's first run, 1: its last) for the workgroup's merge below
+    auto flush = [&](int id, bool shared, int which) {
+      if (id <= pad_row || id >= num_rows) return;
+      if (shared) {
+        float* e = edge + (w * 2 + which) * SC_EROW;
+        *(f32x4*)(e + l * 4) = a0;
+        if (two) *(f32x4*)(e + 256 + l * 4) = a1;
+        if (l == 0) edge_id[w * 2 + which] = id;
+      } else {
+        float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
+        *(f32x4*)dst = pd0 + a0;              // the value peeked at run start is current: no other wave touches this row
+        if (two) *(f32x4*)(dst + 256) = pd1 + a1;
+      }
+    };
+    bool first = true;
+    for (int sub = 0; sub < span; sub += SC_SUB) {
+      const int cnt = span - sub < SC_SUB ? span - sub : SC_SUB;
+      // each lane keeps one (id, token) pair of the sub-chunk; broadcast by shuffle while walking it
+      int id_lo = -1, tok_lo = 0;                              // ids and token indices fit in 31 bits
+      if (l < cnt) { id_lo = (int)ids_sorted[s0 + sub + l]; tok_lo = (int)perm[s0 + sub + l]; }
+      if (__builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), cnt - 1)) <= pad_row) continue;      // (leading padding of the span)
+      // The rows are fetched in groups of four, one group ahead of the accumulation (two register sets): a plain loop walks dependent
+      // load -> add round trips.  Same additions in the same order as the position-by-position walk.
+      constexpr int GR = 4;
+      f32x4 c0[GR], c1[GR], n0[GR], n1[GR];
+      auto fetch_group = [&](int base, f32x4 (&r0)[GR], f32x4 (&r1)[GR]) {
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          const int i = base + u < cnt ? base + u : cnt - 1;
+          const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
+          const SRC* row = dx + (int64_t)tok * ldx;
+          r0[u] = ld_row4(row + l * 4);
+          r1[u] = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      };
+      fetch_group(0, c0, c1);
+      for (int base = 0; base < cnt; base += GR) {
+        if (base + GR < cnt) fetch_group(base + GR, n0, n1);
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          const int i = base + u;
+          if (i < cnt) {
+            const int id = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), i));
+            const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
+            if (id != cur) {
+              flush(cur, first && cur == id_before, 0);
+              first = false;
+              cur = id;
+              peek(cur);
+              a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
+            }
+            if (id > pad_row) {
+              const f32x4 v0 = c0[u], v1 = c1[u];
+              uint32_t k0 = 0xF, k1 = 0xF;
+              float sc = 1.0f;
+              if (dc.enabled) {
+                k0 = drop_keep4(dc, 1u, (uint64_t)tok * D4 + l);
+                k1 = two ? drop_keep4(dc, 1u, (uint64_t)tok * D4 + 64 + l) : 0u;
+                sc = dc.scale;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if ((k0 >> j) & 1u) a0[j] += v0[j] * sc;
+                if ((k1 >> j) & 1u) a1[j] += v1[j] * sc;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GR; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+      }
+    }
+    const bool sh_prev = first && cur == id_before;           // the last run is also the span's first run and began in the previous wave
+    flush(cur, sh_prev || cur == id_after, sh_prev ? 0 : 1);
+  }
+  __syncthreads();
+  // ---- the workgroup's deposits in position order (wave 0 slot 0, slot 1, wave 1 slot 0, ...): consecutive deposits of one id are one run -- summed
+  // and flushed ONCE, atomically (the run may go on in the neighbouring workgroups, and nobody peeked at its row) ------------------------------------
+  if (w == 0) {
+    int cur = -1;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    auto flush_atomic = [&](int id) {
+      if (id < 0) return;
+      float* dst = grad_table + ((int64_t)id * D4 + l) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) atomic_add(dst + j, a0[j]);
       if (two) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomic_add(dst + 256 + j, a1[j]);
       }
-    } else {
-      *(f32x4*)dst = pd0 + a0;              // not shared: no other wave touches this row, the value peeked at run start is current
-      if (two) *(f32x4*)(dst + 256) = pd1 + a1;
-    }
-  };
-  bool first = true;
-  for (int sub = 0; sub < span; sub += SC_SUB) {
-    const int cnt = span - sub < SC_SUB ? span - sub : SC_SUB;
-    // each lane keeps one (id, token) pair of the sub-chunk; broadcast by shuffle while walking it
-    int id_lo = -1, tok_lo = 0;                              // ids and token indices fit in 31 bits
-    if (l < cnt) { id_lo = (int)ids_sorted[s0 + sub + l]; tok_lo = (int)perm[s0 + sub + l]; }
-    if (__builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), cnt - 1)) <= pad_row) continue;      // (leading padding of the span)
-    // The rows are fetched in groups of four, one group ahead of the accumulation (two register sets): a plain loop walks dependent
-    // load -> add round trips.  Same additions in the same order as the position-by-position walk.
-    constexpr int GR = 4;
-    f32x4 c0[GR], c1[GR], n0[GR], n1[GR];
-    auto fetch_group = [&](int base, f32x4 (&r0)[GR], f32x4 (&r1)[GR]) {
-#pragma unroll
-      for (int u = 0; u < GR; ++u) {
-        const int i = base + u < cnt ? base + u : cnt - 1;
-        const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
-        const SRC* row = dx + (int64_t)tok * ldx;
-        r0[u] = ld_row4(row + l * 4);
-        r1[u] = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
     };
-    fetch_group(0, c0, c1);
-    for (int base = 0; base < cnt; base += GR) {
-      if (base + GR < cnt) fetch_group(base + GR, n0, n1);
-#pragma unroll
-      for (int u = 0; u < GR; ++u) {
-        const int i = base + u;
-        if (i < cnt) {
-          const int id = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), i));
-          const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
-          if (id != cur) {
-            flush(cur, first && cur == id_before);
-            first = false;
-            cur = id;
-            peek(cur);
-            a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
-          }
-          if (id > pad_row) {
-            const f32x4 v0 = c0[u], v1 = c1[u];
-            uint32_t k0 = 0xF, k1 = 0xF;
-            float sc = 1.0f;
-            if (dc.enabled) {
-              k0 = drop_keep4(dc, 1u, (uint64_t)tok * D4 + l);
-              k1 = two ? drop_keep4(dc, 1u, (uint64_t)tok * D4 + 64 + l) : 0u;
-              sc = dc.scale;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if ((k0 >> j) & 1u) a0[j] += v0[j] * sc;
-              if ((k1 >> j) & 1u) a1[j] += v1[j] * sc;
-            }
-          }
-        }
+    for (int e = 0; e < SC_WAVES * 2; ++e) {
+      const int id = edge_id[e];
+      if (id < 0) continue;
+      if (id != cur) {
+        flush_atomic(cur);
+        cur = id;
+        a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
       }
-#pragma unroll
-      for (int u = 0; u < GR; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+      const float* er = edge + e * SC_EROW;
+      a0 += *(const f32x4*)(er + l * 4);
+      if (two) a1 += *(const f32x4*)(er + 256 + l * 4);
     }
+    flush_atomic(cur);
   }
-  flush(cur, (first && cur == id_before) || cur == id_after);
 }
 
 // d_cand[b,c,:] = dl[b,c] * user[b,:];  d_user[b,:] = sum_c dl[b,c] * cand[b,c,:]

@@ -9,6 +9,7 @@
 #include "k_gemm.h"
 #include "k_conv.h"
 #include "k_pool3.h"
+#include "k_pool4.h"
 #include "k_naml.h"
 #include "k_gru.h"
 #ifndef NR_EMU      // inter-workgroup waits: nothing the emulator (one workgroup after the other) can run
@@ -245,6 +246,27 @@ int nr_additive_fwd_v(const uint16_t* ctx, const uint16_t* Wap, const float* bap
     return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd: sequence length not instantiated (4, 20, 50)");
   }
   return check_launch("nr_additive_fwd");
+}
+
+// The same forward over whole sequences per wave, persistent (csrc/k_pool4.h): any S in [16, 64], query_vector_dim <= 200 (the rows of Wa the kernel
+// keeps in LDS).  Same outputs as nr_additive_fwd_v up to the order of fp32 additions.
+int nr_additive_fwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out, int64_t out_stride, uint16_t* out_b,
+                         int64_t out_b_stride, float* attn_w, int64_t n_seq, int S, int valid, int qdim, void* stream) {
+  if (!ctx || !Wap || !bap || !qvp || (!out && !out_b) || n_seq < 0 || valid < 1 || valid > S) return fail(NR_ERR_BADARG, "nr_additive_fwd_flat: bad argument");
+  if ((out && (out_stride < NR_D || (out_stride & 3))) || (out_b && (out_b_stride < NR_KP || (out_b_stride & 7))))
+    return fail(NR_ERR_BADARG, "nr_additive_fwd_flat: bad output stride");
+  if (S < 16 || S > nr::Pool4Geom::ROWS || qdim < 1 || qdim > nr::Pool4Geom::WROWS || n_seq * S >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_fwd_flat: needs 16 <= S <= 64 and query_vector_dim <= 200");
+  if (n_seq == 0) return NR_OK;
+  nr::Pool4Params p;
+  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.out = out; p.out_stride = out_stride; p.out_b = out_b; p.out_b_stride = out_b_stride;
+  p.attn_w = attn_w; p.n_seq = n_seq; p.S = S; p.valid = valid;
+  const int nslot = nr::Pool4Geom::ROWS / S;
+  const int64_t groups = (n_seq + nslot - 1) / nslot, wgs = (groups + nr::Pool4Geom::NWAVE - 1) / nr::Pool4Geom::NWAVE;
+  const int cus = nr::device_cus();
+  if (allow_smem(nr::pool4_fwd_kernel, nr::Pool4Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd_flat: cannot reserve LDS");
+  NR_LAUNCH(nr::pool4_fwd_kernel, wgs < cus ? wgs : cus, nr::Pool4Geom::THREADS, nr::Pool4Geom::SMEM, (hipStream_t)stream, p);
+  return check_launch("nr_additive_fwd_flat");
 }
 
 int nr_additive_fwd(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, float* out,
@@ -731,19 +753,20 @@ int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, cons
     return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_embed_scatter_sorted: dropout probability out of range");
   if (n_tokens == 0) return NR_OK;
-  // positions per wave: NR_SCATTER_SPAN (A/B; 64 / 128 / 256 / 512), default 256 -- see the kernel's comment on atomic contention under Zipf ids
+  // positions per wave: NR_SCATTER_SPAN (A/B; 64 / 128 / 256 / 512), default 64 -- see the kernel's comment on atomic contention under Zipf ids
   static int span = -1;
-  if (span < 0) { const char* e = std::getenv("NR_SCATTER_SPAN"); span = e ? std::atoi(e) : nr::SC_SPAN; }
+  if (span < 0) { const char* e = std::getenv("NR_SCATTER_SPAN"); span = e ? std::atoi(e) : 64; }
   auto go = [&](auto tag) {
     constexpr int SPAN = decltype(tag)::value;
     const int64_t waves = (n_tokens + SPAN - 1) / SPAN;
-    NR_LAUNCH((nr::embed_scatter_sorted_kernel<nr::u16, SPAN>), (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, dx, (int64_t)ldx,
-              grad_table, num_rows, n_tokens, make_drop(p_drop, seed), 0);
+    NR_LAUNCH((nr::embed_scatter_sorted_kernel<nr::u16, SPAN>), (waves + nr::SC_WAVES - 1) / nr::SC_WAVES, nr::SC_WAVES * 64, nr::SC_SMEM, (hipStream_t)stream,
+              ids_sorted, perm, dx, (int64_t)ldx, grad_table, num_rows, n_tokens, make_drop(p_drop, seed), 0);
   };
   if (span == 64) go(nr::IntTag<64>{});
   else if (span == 128) go(nr::IntTag<128>{});
   else if (span == 512) go(nr::IntTag<512>{});
-  else go(nr::IntTag<256>{});
+  else if (span == 256) go(nr::IntTag<256>{});
+  else go(nr::IntTag<64>{});
   return check_launch("nr_embed_scatter_sorted");
 }
 
@@ -754,8 +777,8 @@ int nr_scatter_sorted_f32(const int64_t* ids_sorted, const int64_t* perm, const 
     return fail(NR_ERR_BADARG, "nr_scatter_sorted_f32: bad argument");
   if (n == 0) return NR_OK;
   const int64_t waves = (n + nr::SC_SPAN - 1) / nr::SC_SPAN;
-  NR_LAUNCH((nr::embed_scatter_sorted_kernel<float, nr::SC_SPAN>), (waves + 3) / 4, 256, 0, (hipStream_t)stream, ids_sorted, perm, src, ld, dst, num_rows, n,
-            make_drop(0.0f, 0), pad_row);
+  NR_LAUNCH((nr::embed_scatter_sorted_kernel<float, nr::SC_SPAN>), (waves + nr::SC_WAVES - 1) / nr::SC_WAVES, nr::SC_WAVES * 64, nr::SC_SMEM,
+            (hipStream_t)stream, ids_sorted, perm, src, ld, dst, num_rows, n, make_drop(0.0f, 0), pad_row);
   return check_launch("nr_scatter_sorted_f32");
 }
 

@@ -461,6 +461,16 @@ def pool_flat_ok(S, act, n_seq=None, *, qdim):
             and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK))
 
 
+# NR_POOL_FWD_FLAT: 1 (default) = the pooling FORWARD of large launches over whole sequences per wave (csrc/k_pool4.h); 0 = the LDS-tile kernel (A/B)
+_POOL_FWD_FLAT = os.environ.get('NR_POOL_FWD_FLAT', '1') == '1'
+
+
+def pool_fwd_flat_ok(S, n_seq, *, qdim):
+    """Whether the persistent whole-sequence forward takes a pooling level: 16 <= S <= 64, query_vector_dim <= 200 (the rows it keeps in LDS), and
+    enough tokens to be worth one workgroup per CU loading the projection matrix (the same threshold as the flat backward)."""
+    return _POOL_FWD_FLAT and 16 <= S <= 64 and qdim <= NR_POOL_FLAT_QMAX and n_seq * S >= _POOL_FLAT_MIN_TOK
+
+
 def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag=''):
     """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
     y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused

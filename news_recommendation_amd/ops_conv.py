@@ -126,8 +126,13 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
             st.y = y_keep.detach()
             st.y_version = y_keep._version          # (the buffer is the autograd function's own output: an in-place edit before the backward would go unnoticed)
     st.y_ptr, st.y_stride = out, out_stride
-    _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_v, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
-          out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, _stream())
+    if ops.pool_fwd_flat_ok(S, n_seq, qdim=st.qdim):
+        # whole sequences per wave, persistent, the projection matrix resident in LDS (csrc/k_pool4.h)
+        _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_flat, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
+              out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, st.qdim, _stream())
+    else:
+        _call(f'nr_additive_fwd[{tag}]', lib.nr_additive_fwd_v, _ptr(st.act), _ptr(st.Wap), _ptr(st.bap), _ptr(st.qvp), out, out_stride,
+              out_b, out_b_stride, _ptr(st.aw), n_seq, S, valid, _stream())
     return st
 
 

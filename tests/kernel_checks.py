@@ -779,3 +779,42 @@ def check_additive_bwd_scale(be, S=20, n_seq=27136, chunk=2048):
         close_bf16(bf16_to_f32(dctx_n[lo * S:hi * S, :NR_D]), dref, f'pooling bwd fused dctx, seqs {lo}..{hi}', rel=2.0 ** -7, floor=1e-3)
     dq = be.np(dqp).astype(np.float64).sum(0)
     np.testing.assert_allclose(dq[:200], dq_ref, rtol=2e-3, atol=2e-4 * np.abs(dq_ref).max())
+
+
+def check_additive_flat(be, S=20, n_seq=11, valid=None, seed=29):
+    """nr_additive_fwd_flat (csrc/k_pool4.h: whole sequences per wave, persistent, weighted sum on the matrix core) vs the numpy restatement of
+    additive.py:27-53: pooled vectors (f32 rows and the bf16 ctx-layout copy) and attention weights; groups of floor(64 / S) sequences incl. a
+    ragged last group; optional valid prefix."""
+    params = make_params(8)
+    rng = np.random.default_rng(seed)
+    V_ = S if valid is None else valid
+    ctx = np.zeros((n_seq * S, NR_KP), dtype=np.float32)
+    ctx[:, :NR_D] = rng.normal(0, 0.6, size=(n_seq * S, NR_D))
+    ctx[:, NR_D] = 1.0
+    ctx_u = f32_to_bf16(ctx)
+    Wap, bap, qvp = pack_additive(be, params, 'news_encoder.')
+    stride, bstride = NR_D + 4, NR_KP + 8
+    out = be.poison((n_seq, stride), np.float32)
+    out_b = be.poison((n_seq, bstride), np.uint16)
+    aw = be.poison((n_seq, S), np.float32)
+    ck(be, be.lib.nr_additive_fwd_flat(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), stride, be.ptr(out_b), bstride,
+                                       be.ptr(aw), n_seq, S, V_, 200, be.stream))
+    be.sync()
+    a = 'news_encoder.additive_attention.'
+    x = bf16_to_f32(ctx_u)[:, :NR_D].reshape(n_seq, S, NR_D).astype(np.float64)[:, :V_]
+    ref, w, _ = onp.additive(x, bf16_round(params[a + 'linear.weight']).astype(np.float64), params[a + 'linear.bias'].astype(np.float64),
+                             params[a + 'attention_query_vector'].astype(np.float64))
+    got_w = be.np(aw)
+    np.testing.assert_allclose(got_w[:, :V_], w, rtol=2e-4, atol=2e-6)
+    assert not got_w[:, V_:].any()
+    go = be.np(out)
+    np.testing.assert_allclose(go[:, :NR_D], ref, rtol=2e-4, atol=2e-5)
+    assert np.isnan(go[:, NR_D:]).all(), 'columns >= D of the f32 rows must not be written'
+    gb = be.np(out_b)
+    assert np.array_equal(gb[:, :NR_D], f32_to_bf16(go[:, :NR_D])), 'bf16 copy = the f32 result rounded'
+    assert (gb[:, NR_D] == 0x3F80).all() and not gb[:, NR_D + 1:NR_KP].any(), 'ctx layout: col D = 1.0, rest 0'
+    assert (gb[:, NR_KP:] == 0xFFFF).all()
+    assert be.lib.nr_additive_fwd_flat(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), stride, None, 0, be.ptr(aw), n_seq, 15,
+                                       15, 200, be.stream) != 0            # S < 16
+    assert be.lib.nr_additive_fwd_flat(be.ptr(be.dev(ctx_u)), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(out), stride, None, 0, be.ptr(aw), n_seq, S,
+                                       V_, 208, be.stream) != 0            # query_vector_dim > 200

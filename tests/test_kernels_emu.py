@@ -166,3 +166,7 @@ def test_scatter_sorted_long_runs_across_spans(be):
     spans shared by three runs -- the seams where a run continues in the neighbouring wave take the atomic path, everything else the direct one."""
     kc.check_scatter_sorted(be, n_tokens=1500, V=7, p_drop=0.2, seed=11)
     kc.check_scatter_sorted(be, n_tokens=700, V=3, p_drop=0.0, seed=12)
+
+
+@pytest.mark.parametrize('S,n_seq,valid', [(20, 11, None), (50, 5, None), (20, 4, 13), (33, 3, None), (64, 2, 40)])
+def test_additive_forward_whole_sequences_per_wave(be, S, n_seq, valid): kc.check_additive_flat(be, S=S, n_seq=n_seq, valid=valid)

@@ -186,3 +186,9 @@ def test_pool_flat_valid_strided_any_length(be):
 def test_pool_flat_act(be): k3.check_flat_act(be, S=20, n_seq=1027); k3.check_flat_act(be, S=50, n_seq=2051); k3.check_flat_act(be, S=16, n_seq=333, seed=8)
 def test_pool_flat_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3)
 def test_pool_flat_act_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136, act=True); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3, act=True)
+
+
+@pytest.mark.parametrize('S,n_seq,valid', [(20, 5000, None), (50, 2100, None), (20, 999, 13), (50, 513, 37), (33, 700, None)])
+def test_additive_forward_whole_sequences_per_wave(be, S, n_seq, valid):
+    """csrc/k_pool4.h at launch sizes that give every workgroup several groups per wave and a ragged last group."""
+    kc.check_additive_flat(be, S=S, n_seq=n_seq, valid=valid)

@@ -257,3 +257,28 @@ def test_user_vector_rows_equals_user_vector(method):
         ops_gru._GEMM_STEP_MIN_B = keep
     err2 = (got2 - ref).abs().max().item()
     assert err2 <= 1e-3 * max(1.0, ref.abs().max().item()), f'{method}: GEMM-step user vectors differ by {err2}'
+
+
+def test_xcd_barrier_probe_is_a_gate():
+    """the XCD-local phase barrier of the persistent GRU sweeps (csrc/k_xcd.h) relies on relaxed agent-scope atomics + a vmcnt
+    drain for visibility inside one XCD's L2 -- validated empirically, so the probe is part of the suite: 256 workgroups, 200 write / barrier /
+    read-back phases, every workgroup reading its 31 team mates' records with L1-bypassing loads: no stale word, complete teams of 32, no
+    error word."""
+    from news_recommendation_amd import _capi
+    lib = _capi.load()
+    if not (lib.nr_gru_persist_enabled(64, 900, 50) & 1):
+        pytest.skip("not a 256-CU device: the persistent sweeps (and their barrier) are not used here")
+    sync = torch.zeros(32, dtype=torch.int32, device=DEV)
+    rec = torch.zeros(8 * 32 * 512, dtype=torch.int32, device=DEV)
+    out = torch.zeros(768, dtype=torch.int32, device=DEV)
+    for phases in (1, 200):
+        out.zero_()
+        _capi.check(lib, lib.nr_debug_xcd_probe(sync.data_ptr(), rec.data_ptr(), out.data_ptr(), phases, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        o, s = out.cpu().numpy(), sync.cpu().numpy()
+        assert int(o[:256].sum()) == 0, f'{int(o[:256].sum())} stale words after {phases} phases'
+        assert int(s[16]) == 0
+        xcc, slot = o[256:512], o[512:768]
+        assert np.bincount(xcc, minlength=8).tolist() == [32] * 8
+        for x in range(8):
+            assert sorted(slot[xcc == x].tolist()) == list(range(32))

@@ -23,7 +23,6 @@ import os, sys, numpy as np, torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 mode, model_name, out = sys.argv[2], sys.argv[3], sys.argv[4]
-overlap, table_rs = sys.argv[6] == '1', sys.argv[7] == '1'
 from bench import Workload, make_cfg
 from news_recommendation_amd import optim
 optim.TABLE_MIN_NUMEL = 1 << 18                   # the reduced word table below is still "the table bucket"
