@@ -725,8 +725,23 @@ constexpr int SC_SPAN = 64;      // positions per wave (default instantiation)
 constexpr int SC_WAVES = 8;      // waves per workgroup
 constexpr int SC_EROW = 304;     // floats per deposited partial: 64 quads + 11 quads (+ padding)
 constexpr int SC_SMEM = SC_WAVES * 2 * SC_EROW * 4 + SC_WAVES * 2 * 4;
-__device__ __forceinline__ f32x4 ld_row4(const u16* p) { u16x4 v = *(const u16x4*)p; return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
-__device__ __forceinline__ f32x4 ld_row4(const float* p) { return *(const f32x4*)p; }
+// a row quad as it sits in memory (bf16: 8 bytes, two registers; f32: 16 bytes) and its f32 value: the prefetched rows are HELD in the memory
+// format -- twice as many bf16 rows in flight per register as converted ones (the walk is bound by the depth of its row prefetch)
+template <typename SRC> struct RowQuad;
+template <> struct RowQuad<u16> {
+  typedef u16x4 raw;
+  static constexpr int GR = 8;
+  static __device__ __forceinline__ raw ld(const u16* p) { return *(const u16x4*)p; }
+  static __device__ __forceinline__ raw zero() { return u16x4{0, 0, 0, 0}; }
+  static __device__ __forceinline__ f32x4 val(raw v) { return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
+};
+template <> struct RowQuad<float> {
+  typedef f32x4 raw;
+  static constexpr int GR = 4;
+  static __device__ __forceinline__ raw ld(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ raw zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4 val(raw v) { return v; }
+};
 
 // SRC = u16 (bf16 rows) or float.  Rows with id <= pad_row are skipped (pad_row = 0: nn.Embedding(padding_idx=0); -1: none).
 template <typename SRC, int SPAN>
@@ -782,18 +797,19 @@ __global__ __launch_bounds__(SC_WAVES * 64) void embed_scatter_sorted_kernel(con
       int id_lo = -1, tok_lo = 0;                              // ids and token indices fit in 31 bits
       if (l < cnt) { id_lo = (int)ids_sorted[s0 + sub + l]; tok_lo = (int)perm[s0 + sub + l]; }
       if (__builtin_bit_cast(int, shfl(__builtin_bit_cast(float, id_lo), cnt - 1)) <= pad_row) continue;      // (leading padding of the span)
-      // The rows are fetched in groups of four, one group ahead of the accumulation (two register sets): a plain loop walks dependent
-      // load -> add round trips.  Same additions in the same order as the position-by-position walk.
-      constexpr int GR = 4;
-      f32x4 c0[GR], c1[GR], n0[GR], n1[GR];
-      auto fetch_group = [&](int base, f32x4 (&r0)[GR], f32x4 (&r1)[GR]) {
+      // The rows are fetched in groups of GR (bf16 rows: eight, held as loaded), one group ahead of the accumulation (two register sets): a plain
+      // loop walks dependent load -> add round trips.  Same additions in the same order as the position-by-position walk.
+      using RQ = RowQuad<SRC>;
+      constexpr int GR = RQ::GR;
+      typename RQ::raw c0[GR], c1[GR], n0[GR], n1[GR];
+      auto fetch_group = [&](int base, typename RQ::raw (&r0)[GR], typename RQ::raw (&r1)[GR]) {
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
           const int i = base + u < cnt ? base + u : cnt - 1;
           const int tok = __builtin_bit_cast(int, shfl(__builtin_bit_cast(float, tok_lo), i));
           const SRC* row = dx + (int64_t)tok * ldx;
-          r0[u] = ld_row4(row + l * 4);
-          r1[u] = two ? ld_row4(row + 256 + l * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          r0[u] = RQ::ld(row + l * 4);
+          r1[u] = two ? RQ::ld(row + 256 + l * 4) : RQ::zero();
         }
       };
       fetch_group(0, c0, c1);
@@ -813,7 +829,7 @@ __global__ __launch_bounds__(SC_WAVES * 64) void embed_scatter_sorted_kernel(con
               a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
             }
             if (id > pad_row) {
-              const f32x4 v0 = c0[u], v1 = c1[u];
+              const f32x4 v0 = RQ::val(c0[u]), v1 = RQ::val(c1[u]);
               uint32_t k0 = 0xF, k1 = 0xF;
               float sc = 1.0f;
               if (dc.enabled) {

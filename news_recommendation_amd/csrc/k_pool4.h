@@ -93,18 +93,22 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
 
   // row pieces: xr[ks][t] = columns 32 ks + 8 (l & 3) .. + 7 of row 16 t + (l >> 2) (16 runs of 64 contiguous bytes per instruction)
   u16x8 xr[KSTEPS][MT];
-  auto load_group = [&](int64_t gi) {
-    const int64_t seq0 = gi * nslot, tok0 = seq0 * S;
-    const int64_t left = (p.n_seq - seq0 < nslot ? p.n_seq - seq0 : nslot) * S;       // live rows of this group (the last one may hold fewer sequences)
-    const BufRsrc rx = make_buf(p.ctx + tok0 * KP, (uint32_t)((left > 0 ? left : 0) * KP * 2));   // rows past the end read as zeros
+  auto group_rsrc = [&](int64_t gi) -> BufRsrc {
+    const int64_t seq0 = gi < n_groups ? gi * nslot : 0, tok0 = seq0 * S;
+    const int64_t left = gi < n_groups ? (p.n_seq - seq0 < nslot ? p.n_seq - seq0 : nslot) * S : 0;       // live rows (the last group may hold fewer sequences; past the last group: none)
+    return make_buf(p.ctx + tok0 * KP, (uint32_t)((left > 0 ? left : 0) * KP * 2));                       // rows past the end read as zeros
+  };
+  auto load_ks = [&](BufRsrc rx, int ks) {
     int lq = l;
     NR_OPAQUE(lq);
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) xr[ks][t] = buf_load16<0>(rx, (uint32_t)((t * 16 + (lq >> 2)) * (KP * 2) + (lq & 3) * 16), (uint32_t)(ks * 64));
+    for (int t = 0; t < MT; ++t) xr[ks][t] = buf_load16<0>(rx, (uint32_t)((t * 16 + (lq >> 2)) * (KP * 2) + (lq & 3) * 16), (uint32_t)(ks * 64));
   };
-  if (grp < n_groups) load_group(grp);
+  if (grp < n_groups) {
+    const BufRsrc rx = group_rsrc(grp);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) load_ks(rx, ks);
+  }
 
   // scratch addresses: row-piece writes (row 16 t + (l >> 2), slot l & 3) and fragment-shaped accesses (row 16 m + li, slot g)
   unsigned char* const pw = sc + (l >> 2) * 64 + (((l & 3) ^ sc_swz(l >> 2)) * 16);      // + t * 1024
@@ -222,12 +226,16 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
       }
     }
     wave_barrier();                           // the weights have been read: the scratch becomes a row buffer again
-    // ---- y[slot][d] = sum_tok w[tok] x[tok][d]: per k-step the fragments return to the scratch as rows and come back transposed (k = token) ----------
+    // ---- y[slot][d] = sum_tok w[tok] x[tok][d]: per k-step the fragments return to the scratch as rows and come back transposed (k = token).  A
+    // k-step's registers are free once its rows are in the scratch: the NEXT group's rows of that k-step are requested right there, so their
+    // latency hides behind the rest of this phase ---------------------------------------------------------------------------------------------------
+    const BufRsrc rx_next = group_rsrc(grp + gstride);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) *(u16x8*)(fr + m * 1024) = xr[ks][m];
       wave_barrier();
+      load_ks(rx_next, ks);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -258,9 +266,7 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
       }
       wave_barrier();
     }
-    // ---- the next group's rows: every fragment has served --------------------------------------------------------------------------------------------
     grp += gstride;
-    if (grp < n_groups) load_group(grp);
   }
 }
 
