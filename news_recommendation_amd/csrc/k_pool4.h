@@ -45,6 +45,8 @@ struct Pool4Params {
   float* attn_w;         // [n_seq][S] or null
   int64_t n_seq;
   int S, valid;          // tokens s >= valid of every sequence get weight exactly 0
+  int dbg;               // DBG instantiation only (NR_POOL_DEBUG, tools/prof_kernel.py pool_fwd_flat*): 1 no row loads, 2 no rows -> fragments pass,
+                         // 4 no projection MFMAs, 8 no tanh, 16 no weighted sum, 32 no global stores
 };
 
 __device__ __forceinline__ float row16_max(float v) {
@@ -56,8 +58,10 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+template <bool DBG = false>
 __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Params p) {
   using Gm = Pool4Geom;
+  const int dbg = DBG ? p.dbg : 0;        // the production instantiation folds every switch away
   constexpr int MT = Gm::MT;
   NR_SMEM_DECL(smem);
   const int tid = threadIdx.x, l = lane_id(), w = wave_id(), g = l >> 4, li = l & 15;
@@ -72,7 +76,10 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
     if (row < Gm::WROWS) *(u16x8*)(smem + row * Gm::WROW + ((s ^ w_swz(row)) * 16)) = *(const u16x8*)(p.Wap + (size_t)e * 8);
   }
   for (int i = tid; i < KP / 8; i += Gm::THREADS) *(u16x8*)(smem + Gm::WROWS * Gm::WROW + i * 16) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = tid; i < QP; i += Gm::THREADS) { bq[i] = p.bap[i]; bq[QP + i] = p.qvp[i]; }
+  // tanh(a) = 1 - 2 / (exp(2 a) + 1): sum_n qv[n] tanh(a_n) = sum_n qv[n] - 2 sum_n qv[n] / (exp2(C2 a_n) + 1), and the softmax over the tokens of a
+  // sequence does not see the first (token-independent) term.  LDS keeps C2 ba and -2 qv: per element one multiply-add, exp2, add, rcp, multiply-add.
+  constexpr float C2 = 2.0f * 1.4426950408889634f;
+  for (int i = tid; i < QP; i += Gm::THREADS) { bq[i] = p.bap[i] * C2; bq[QP + i] = -2.0f * p.qvp[i]; }
   __syncthreads();
 
   const int S = p.S;
@@ -90,13 +97,21 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
     pos_m[m] = r - s * S;
   }
   const int valid = (p.valid > 0 && p.valid < S) ? p.valid : S;
+  // output addressing: lane groups 0 / 1 hold the sequences (slots) 2 g, 2 g + 1 of the group; the other lanes' stores fall outside every resource
+  constexpr uint32_t OOR = 0x80000000u;
+  uint32_t oo[2], ob[2];
+#pragma unroll
+  for (int e2 = 0; e2 < 2; ++e2) {
+    oo[e2] = g < 2 ? (uint32_t)(((2 * g + e2) * p.out_stride + li) * 4) : OOR;
+    ob[e2] = g < 2 ? (uint32_t)(((2 * g + e2) * p.out_b_stride + li) * 2) : OOR;
+  }
 
   // row pieces: xr[ks][t] = columns 32 ks + 8 (l & 3) .. + 7 of row 16 t + (l >> 2) (16 runs of 64 contiguous bytes per instruction)
   u16x8 xr[KSTEPS][MT];
   auto group_rsrc = [&](int64_t gi) -> BufRsrc {
     const int64_t seq0 = gi < n_groups ? gi * nslot : 0, tok0 = seq0 * S;
     const int64_t left = gi < n_groups ? (p.n_seq - seq0 < nslot ? p.n_seq - seq0 : nslot) * S : 0;       // live rows (the last group may hold fewer sequences; past the last group: none)
-    return make_buf(p.ctx + tok0 * KP, (uint32_t)((left > 0 ? left : 0) * KP * 2));                       // rows past the end read as zeros
+    return make_buf(p.ctx + tok0 * KP, (uint32_t)((left > 0 && !(dbg & 1) ? left : 0) * KP * 2));         // rows past the end read as zeros
   };
   auto load_ks = [&](BufRsrc rx, int ks) {
     int lq = l;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
     const int live_seq = p.n_seq - seq0 < nslot ? (int)(p.n_seq - seq0) : nslot;
     // ---- row pieces -> B fragments (features 32 ks + 8 g .. + 7 of token 16 m + li), one k-step at a time through the scratch ----------------------
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+    for (int ks = (dbg & 2) ? KSTEPS : 0; ks < KSTEPS; ++ks) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) *(u16x8*)(pw + t * 1024) = xr[ks][t];
       wave_barrier();
@@ -128,36 +143,67 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
       wave_barrier();
     }
     // ---- scores: s[tok] = sum_n qv[n] tanh(x[tok] . Wa[n] + ba[n]): transposed product, the lane holds query rows 16 nt + 4 g .. + 3 of token li ----
-    float sp[MT];
+    f32x2 sp2[MT];                            // two partial sums per token (packed fp32 arithmetic: even / odd query rows of the lane's four)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) sp[m] = 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < Gm::NTQ; ++nt) {
+    for (int m = 0; m < MT; ++m) sp2[m] = f32x2{0.0f, 0.0f};
+    // Wa fragment (nt, ks): row 16 nt + li (rows >= 200: the zero row), slot (4 ks + g) ^ w_swz(row) = 4 (ks ^ b) + c with b, c lane constants.  The reads
+    // run as ONE pipeline over all 130 (nt, ks) steps, two steps ahead of the MFMAs that consume them (three fragment registers; asynchronous reads
+    // with counted waits: see lds_read16_async), across the tanh phases too.  Instruction offsets are 16 bits: one base per 6 n-tiles and k-step parity.
+    {
       int lq = l;
       NR_OPAQUE(lq);
       const int lg = lq >> 4, lr = lq & 15;
-      const int bo = Gm::W_BYTES + 16 * lg;
-      const f32x4 b4 = *(const f32x4*)(smem + bo + nt * 64), q4 = *(const f32x4*)(smem + bo + QP * 4 + nt * 64);
-      f32x4 acc[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = b4;
-      const int wr_ = nt * 16 + lr < Gm::WROWS ? nt * 16 + lr : Gm::WROWS;          // rows >= 200: the zero row (their qv entries are zero too)
       const int wb = w_swz(lr) >> 2, wc = (lg ^ w_swz(lr)) & 3;
-      const unsigned char* wp = smem + wr_ * Gm::WROW + wc * 16;
-      auto frag = [&](int ks) -> u16x8 { return *(const u16x8*)(wp + ((ks ^ wb) * 64)); };
-      u16x8 a = frag(0);
+      const unsigned char* w0 = smem + lr * Gm::WROW + wc * 16;
+      const unsigned char* w12 = smem + (12 * 16 + lr < Gm::WROWS ? 12 * 16 + lr : Gm::WROWS) * Gm::WROW + wc * 16;
+      // (ks ^ wb) * 64 = ks * 64 + 64 wb for even ks, ks * 64 - 64 wb for odd ks
+      const unsigned char* we[3] = {w0 + 64 * wb, w0 + 6 * 16 * Gm::WROW + 64 * wb, w12 + 64 * wb};
+      const unsigned char* wo[3] = {w0 - 64 * wb, w0 + 6 * 16 * Gm::WROW - 64 * wb, w12 - 64 * wb};
+      constexpr int NSTEP = Gm::NTQ * KSTEPS;
+      u16x8 af[3];
+      auto issue = [&](auto tag) {
+        constexpr int e = decltype(tag)::value, nt = e / KSTEPS, ks = e % KSTEPS;
+        constexpr int off = (nt % 6) * 16 * Gm::WROW + ks * 64;
+        af[e % 3] = lds_read16_async<off>((ks & 1) ? wo[nt / 6] : we[nt / 6]);
+      };
+      issue(StaticIdx<0>{});
+      issue(StaticIdx<1>{});
+      f32x4 acc[MT];
+      u16x8 bqr[2];                            // the n-tile's four (scaled) bias and query-vector entries: requested three k-steps before the tanh phase
+      const unsigned char* bqp = smem + Gm::W_BYTES + 16 * lg;
+      constexpr int KBQ = KSTEPS - 3;
+      static_for<NSTEP>([&](auto tag) {
+        constexpr int e = decltype(tag)::value, nt = e / KSTEPS, ks = e % KSTEPS;
+        if (e + 2 < NSTEP) issue(StaticIdx<(e + 2 < NSTEP ? e + 2 : 0)>{});
+        if (ks == KBQ) { bqr[0] = lds_read16_async<nt * 64>(bqp); bqr[1] = lds_read16_async<QP * 4 + nt * 64>(bqp); }
+        constexpr int ahead = e + 2 < NSTEP ? 2 : NSTEP - 1 - e;        // fragment reads issued after the one of (nt, ks)
+        NR_SCHED_BARRIER();
+        NR_WAIT_LGKMCNT(ahead + (ks >= KBQ ? 2 : 0));                   // this wave's LDS operations return in order: at most the reads after (nt, ks) are outstanding
+        NR_SCHED_BARRIER();
+        if (!(dbg & 4)) {
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const u16x8 an = ks + 1 < KSTEPS ? frag(ks + 1) : a;
+          for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(af[e % 3], xr[ks][m], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m]);
+        } else if (ks == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(a, xr[ks][m], acc[m]);
-        a = an;
-      }
+          for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ks == KSTEPS - 1) {
+          NR_SCHED_BARRIER();
+          NR_WAIT_LGKMCNT(ahead);
+          NR_SCHED_BARRIER();
+          const f32x4 b4 = __builtin_bit_cast(f32x4, bqr[0]), q4 = __builtin_bit_cast(f32x4, bqr[1]);
+          const f32x2 c2 = f32x2{C2, C2}, one2 = f32x2{1.0f, 1.0f};
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sp[m] += fast_tanh(acc[m][r]) * q4[r];
-      NR_SCHED_BARRIER();                     // keep the n-tiles apart (register pressure: see k_pool3.h)
+            for (int h = 0; h < 2; ++h) {
+              const f32x2 a2 = f32x2{acc[m][2 * h], acc[m][2 * h + 1]} * c2 + f32x2{b4[2 * h], b4[2 * h + 1]};
+              const f32x2 d2 = ((dbg & 8) ? a2 : f32x2{fast_exp2(a2[0]), fast_exp2(a2[1])}) + one2;
+              const f32x2 r2 = (dbg & 8) ? d2 : f32x2{fast_rcp(d2[0]), fast_rcp(d2[1])};
+              sp2[m] = r2 * f32x2{q4[2 * h], q4[2 * h + 1]} + sp2[m];
+            }
+        }
+      });
     }
     // ---- softmax over the tokens of each sequence of the group (every lane group g ends up with the same numbers) ---------------------------------
     float wt[MT];
@@ -166,7 +212,7 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const bool on = slot_m[m] >= 0 && slot_m[m] < live_seq && pos_m[m] < valid;
-        const float tot = sum_rows4(sp[m]);              // (every lane takes part in the lane swaps)
+        const float tot = sum_rows4(sp2[m][0] + sp2[m][1]);       // (every lane takes part in the lane swaps)
         sv[m] = on ? tot : -3.0e38f;
       }
       float mx[Gm::MAXSLOT], sm[Gm::MAXSLOT];
@@ -203,10 +249,10 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
 #pragma unroll
       for (int m = 0; m < MT; ++m) wl[m * 16 + li] = wt[m];
     }
-    if (p.attn_w != nullptr && g == 1) {
+    {                                         // (rows of sequences past the last one and the rows above `grows`: outside the resource, the store vanishes)
+      const BufRsrc r_aw = make_buf(p.attn_w != nullptr ? p.attn_w + tok0 : nullptr, (uint32_t)(p.attn_w != nullptr && !(dbg & 32) ? live_seq * S * 4 : 0));
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if (slot_m[m] >= 0 && slot_m[m] < live_seq) p.attn_w[tok0 + m * 16 + li] = wt[m];
+      for (int m = 0; m < MT; ++m) buf_store4f(r_aw, g == 1 ? (uint32_t)((m * 16 + li) * 4) : OOR, wt[m]);
     }
     wave_barrier();
     // ---- A fragments of the weighted sum, one per pair of token tiles tp (rows 32 tp .. + 31): row li = (slot li >> 1, part li & 1), k-slot (g, j) =
@@ -230,8 +276,15 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
     // k-step's registers are free once its rows are in the scratch: the NEXT group's rows of that k-step are requested right there, so their
     // latency hides behind the rest of this phase ---------------------------------------------------------------------------------------------------
     const BufRsrc rx_next = group_rsrc(grp + gstride);
+    // outputs: rows seq0 .. seq0 + live_seq - 1 through buffer resources (a null output: an empty resource), no branch around any store
+    const bool st_on = !(dbg & 32);
+    const BufRsrc r_out = make_buf(p.out != nullptr ? p.out + seq0 * p.out_stride : nullptr,
+                                   (uint32_t)(p.out != nullptr && st_on ? ((int64_t)(live_seq - 1) * p.out_stride + D) * 4 : 0));
+    const BufRsrc r_outb = make_buf(p.out_b != nullptr ? p.out_b + seq0 * p.out_b_stride : nullptr,
+                                    (uint32_t)(p.out_b != nullptr && st_on ? ((int64_t)(live_seq - 1) * p.out_b_stride + KP) * 2 : 0));
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (dbg & 16) { load_ks(rx_next, ks); continue; }
 #pragma unroll
       for (int m = 0; m < MT; ++m) *(u16x8*)(fr + m * 1024) = xr[ks][m];
       wave_barrier();
@@ -251,17 +304,12 @@ __global__ __launch_bounds__(Pool4Geom::THREADS) void pool4_fwd_kernel(Pool4Para
           acc = mfma_16x16x32_bf16(aw[tp], cat8(lo, hi), acc);
         }
         // accumulator rows 4 g + r = (slot 2 g + (r >> 1), part r & 1): lane groups 0 and 1 hold slots 0 - 1 and 2 - 3 for feature 32 ks + 16 h + li
-        const int col = ks * 32 + h * 16 + li;
-        if (g < 2) {
+        const int col0 = ks * 32 + h * 16;
 #pragma unroll
-          for (int e2 = 0; e2 < 2; ++e2) {
-            const int s = 2 * g + e2;
-            if (s < live_seq) {
-              const float y = acc[2 * e2] + acc[2 * e2 + 1];
-              if (p.out != nullptr && col < D) p.out[(seq0 + s) * p.out_stride + col] = y;
-              if (p.out_b != nullptr) p.out_b[(seq0 + s) * p.out_b_stride + col] = f2bf(y);       // (col D: sum of the weights = 1.0; cols > D: 0)
-            }
-          }
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const float y = acc[2 * e2] + acc[2 * e2 + 1];
+          if (col0 < D) buf_store4f(r_out, (col0 + 16 <= D || col0 + li < D) ? oo[e2] : OOR, y, (uint32_t)(col0 * 4));
+          buf_store2(r_outb, ob[e2], f2bf(y), (uint32_t)(col0 * 2));        // (col D: sum of the weights = 1.0; cols > D: 0)
         }
       }
       wave_barrier();

@@ -264,8 +264,15 @@ int nr_additive_fwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
   const int nslot = nr::Pool4Geom::ROWS / S;
   const int64_t groups = (n_seq + nslot - 1) / nslot, wgs = (groups + nr::Pool4Geom::NWAVE - 1) / nr::Pool4Geom::NWAVE;
   const int cus = nr::device_cus();
-  if (allow_smem(nr::pool4_fwd_kernel, nr::Pool4Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd_flat: cannot reserve LDS");
-  NR_LAUNCH(nr::pool4_fwd_kernel, wgs < cus ? wgs : cus, nr::Pool4Geom::THREADS, nr::Pool4Geom::SMEM, (hipStream_t)stream, p);
+  const char* d = getenv("NR_POOL_DEBUG");        // profiling: phase switches of the DBG instantiation (re-read per call; tools/prof_kernel.py)
+  p.dbg = d ? atoi(d) : 0;
+  if (p.dbg) {
+    if (allow_smem(nr::pool4_fwd_kernel<true>, nr::Pool4Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd_flat: cannot reserve LDS");
+    NR_LAUNCH(nr::pool4_fwd_kernel<true>, wgs < cus ? wgs : cus, nr::Pool4Geom::THREADS, nr::Pool4Geom::SMEM, (hipStream_t)stream, p);
+    return check_launch("nr_additive_fwd_flat");
+  }
+  if (allow_smem(nr::pool4_fwd_kernel<false>, nr::Pool4Geom::SMEM)) return fail(NR_ERR_LAUNCH, "nr_additive_fwd_flat: cannot reserve LDS");
+  NR_LAUNCH(nr::pool4_fwd_kernel<false>, wgs < cus ? wgs : cus, nr::Pool4Geom::THREADS, nr::Pool4Geom::SMEM, (hipStream_t)stream, p);
   return check_launch("nr_additive_fwd_flat");
 }
 

@@ -4,6 +4,7 @@
 //   B: lane l holds B[k = (l>>4)*8 + j][n = l&15]
 //   C/D: lane l, reg r  ->  row = (l>>4)*4 + r, col = l&15      (4 fp32)
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
@@ -114,6 +115,21 @@ __device__ __forceinline__ u16x4 lds_tr16_b64_async(const u16* piece) {
   return v;
 }
 
+// A plain 16-byte LDS read under the same contract (result awaited by the caller with NR_WAIT_LGKMCNT): lets a kernel keep fragment reads of LATER
+// k-steps in flight across its MFMAs.  (Given `a = frag(k); an = frag(k + 1); mfma(a ..); a = an`, the compiler under register pressure merges the two
+// registers and waits lgkmcnt(0) right after each read: one LDS latency per k-step, k_pool4.h round 6.)
+template <int OFF>
+__device__ __forceinline__ u16x8 lds_read16_async(const void* p) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read offset field");
+  u16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p), "n"(OFF) : "memory");
+  return v;
+}
+// f(IntTag<0>{}), f(IntTag<1>{}), ... f(IntTag<N - 1>{}): a loop whose index is a compile-time constant in the body (instruction offset fields)
+template <int V> struct StaticIdx { static constexpr int value = V; };
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(StaticIdx<Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 // sum over the four 16-lane rows of the wave (= over lane ^ 16 and lane ^ 32), result in every lane: two VALU lane swaps
 // (v_permlane32_swap / v_permlane16_swap, gfx950) instead of two ds_bpermute round trips through the LDS crossbar
@@ -202,6 +218,13 @@ template <int IMM = 0> __device__ __forceinline__ void buf_store16(BufRsrc r, ui
 }
 template <int IMM = 0> __device__ __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, off + IMM, soff, 0);
+}
+
+__device__ __forceinline__ void buf_store4f(BufRsrc r, uint32_t off, float v, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, off, soff, 0);
+}
+__device__ __forceinline__ void buf_store2(BufRsrc r, uint32_t off, u16 v, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b16((short)v, r, off, soff, 0);
 }
 
 template <typename T> __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }

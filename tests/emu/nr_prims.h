@@ -15,6 +15,7 @@
 //   v_mfma_f32_16x16x32_bf16: lane l holds A[i=l&15][k=(l>>4)*8+j], B[k=(l>>4)*8+j][n=l&15],
 //   C/D: col = l&15, row = (l>>4)*4 + reg.
 #pragma once
+#include <utility>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -239,6 +240,12 @@ __forceinline__ u16x4 lds_tr16_b64(const u16* piece) {
 template <int OFF>
 __forceinline__ u16x4 lds_tr16_b64_async(const u16* piece) { return lds_tr16_b64((const u16*)((const unsigned char*)piece + OFF)); }     // (the emulator's LDS reads complete at once)
 
+template <int OFF>
+__forceinline__ u16x8 lds_read16_async(const void* p) { u16x8 v; memcpy(&v, (const unsigned char*)p + OFF, 16); return v; }
+template <int V> struct StaticIdx { static constexpr int value = V; };
+template <class F, int... Is> __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(StaticIdx<Is>{}), ...); }
+template <int N, class F> __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 __forceinline__ float shfl_xor(float v, int mask) {
   nr_emu::BlockState* blk = nr_emu::g_blk;
   int l = lane_id();
@@ -337,6 +344,15 @@ template <int IMM = 0> __forceinline__ void buf_store16(BufRsrc r, uint32_t off,
 }
 template <int IMM = 0> __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
   if ((uint64_t)off + IMM + soff + 8 <= r.nbytes) memcpy(r.base + off + IMM + soff, &v, 8);
+  nr_emu::dma_issue(nullptr, nullptr);
+}
+
+__forceinline__ void buf_store4f(BufRsrc r, uint32_t off, float v, uint32_t soff = 0) {
+  if ((uint64_t)off + soff + 4 <= r.nbytes) memcpy(r.base + off + soff, &v, 4);
+  nr_emu::dma_issue(nullptr, nullptr);
+}
+__forceinline__ void buf_store2(BufRsrc r, uint32_t off, u16 v, uint32_t soff = 0) {
+  if ((uint64_t)off + soff + 2 <= r.nbytes) memcpy(r.base + off + soff, &v, 2);
   nr_emu::dma_issue(nullptr, nullptr);
 }
 

@@ -106,6 +106,12 @@ if name.startswith('pool_flat'):     # flat pooling backward (csrc/k_pool3.h): p
     fns[name] = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
                                                     tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
                                                     0.2 if act_ else 0.0, Tn, S, 200, st()))
+if name.startswith('pool_fwd_flat'):     # whole-sequence pooling forward (csrc/k_pool4.h): pool_fwd_flat (titles) / pool_fwd_flat50 (abstracts); NR_POOL_DEBUG switches phases off
+    S = 50 if '50' in name else 20
+    Tn = B * (55 if S == 50 else 55)
+    cx = torch.relu(torch.randn(Tn * S, NR_KP, generator=g).mul_(0.3)).to(torch.bfloat16).view(torch.int16).to(dev)
+    y_ = torch.empty(Tn, NR_D, device=dev); aw_ = torch.empty(Tn, S, device=dev)
+    fns[name] = lambda: ck(lib.nr_additive_fwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), y_.data_ptr(), NR_D, None, 0, aw_.data_ptr(), Tn, S, S, 200, st()))
 fn = fns[name]
 for _ in range(2): fn()
 torch.cuda.synchronize()
