@@ -8,6 +8,7 @@
 #include "k_attn_bwd2.h"
 #include "k_gemm.h"
 #include "k_conv.h"
+#include "k_convgemm.h"
 #include "k_pool3.h"
 #include "k_pool4.h"
 #include "k_naml.h"
@@ -105,6 +106,29 @@ int launch_conv_t(nr::ConvParams& p, void* stream) {
   if (allow_smem(nr::conv3_kernel<S, NSEQ, NW>, G::SMEM)) return fail(NR_ERR_LAUNCH, "conv3: cannot reserve LDS");
   NR_LAUNCH((nr::conv3_kernel<S, NSEQ, NW>), (p.n_seq + NSEQ - 1) / NSEQ, NW * 64, G::SMEM, (hipStream_t)stream, p);
   return NR_OK;
+}
+
+// The persistent form of the convolution GEMM (csrc/k_convgemm.h): usable while the token rows fit a 2 GiB buffer resource.  NR_CONV_GEMM_PERSIST=0
+// (A/B switch, read once) keeps the one-tile-per-workgroup kernels.
+static bool conv_gemm_persist_ok(int64_t n_seq, int S) {
+  static const int on = [] { const char* e = getenv("NR_CONV_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+  return on != 0 && n_seq * S * (int64_t)(NR_KP * 2) < (1LL << 31) && n_seq * (S + 1) < (1LL << 31);
+}
+static int launch_conv_gemm(nr::ConvGemmParams& p, int64_t n_seq, int S, void* stream, const char* who) {
+  using G = nr::ConvGemmGeom;
+  p.n_rows = n_seq * (S + 1) - 1; p.n_tok = n_seq * S;
+  p.n_tiles = (int)((p.n_rows + G::BN - 1) / G::BN);
+  p.S1 = (uint32_t)(S + 1); p.s1_magic = (uint32_t)((1ULL << 32) / (uint32_t)(S + 1)) + 1u;
+  { const char* d = getenv("NR_CONVGEMM_DEBUG"); p.debug = d ? atoi(d) : 0; }      // profiling: phase switches (re-read per call)
+  const int cus = nr::device_cus();
+  if (p.debug) {
+    if (allow_smem(nr::conv_gemm_kernel<true>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
+    NR_LAUNCH((nr::conv_gemm_kernel<true>), p.n_tiles < cus ? p.n_tiles : cus, 512, G::SMEM, (hipStream_t)stream, p);
+    return check_launch(who);
+  }
+  if (allow_smem(nr::conv_gemm_kernel<false>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
+  NR_LAUNCH((nr::conv_gemm_kernel<false>), p.n_tiles < cus ? p.n_tiles : cus, 512, G::SMEM, (hipStream_t)stream, p);
+  return check_launch(who);
 }
 
 }  // namespace
@@ -617,6 +641,11 @@ int nr_conv3_dgrad_gemm(const uint16_t* dy_pad, const uint16_t* Wd2, uint16_t* d
   if (!dy_pad || !Wd2 || !dx || n_seq < 0 || S < 1) return fail(NR_ERR_BADARG, "nr_conv3_dgrad_gemm: bad argument");
   if ((((uintptr_t)dy_pad | (uintptr_t)Wd2 | (uintptr_t)dx) & 15) != 0) return fail(NR_ERR_BADARG, "nr_conv3_dgrad_gemm: buffers must be 16-byte aligned");
   if (n_seq == 0) return NR_OK;
+  if (conv_gemm_persist_ok(n_seq, S)) {
+    nr::ConvGemmParams q{};
+    q.A = Wd2; q.R = dy_pad; q.C = dx;
+    return launch_conv_gemm(q, n_seq, S, stream, "nr_conv3_dgrad_gemm");
+  }
   nr::GemmParams p{};
   p.A = Wd2; p.lda = 3 * NR_KP; p.B = dy_pad; p.ldb = NR_KP; p.M = NR_KP; p.K = 3 * NR_KP; p.tapw = 1 << 30;
   const int64_t rows = n_seq * (S + 1) + 1 - 2;                  // virtual rows i = seqpad rows 1 .. rp - 2 (the last seqpad row is a separator)

@@ -46,6 +46,14 @@ __device__ __forceinline__ void glds4_sbase(const void* base, uint32_t voff, voi
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_dst)) : "memory");      // (low 32 bits of a generic LDS pointer = the LDS byte address)
 }
 
+// The lean form for loops that issue a copy per MFMA: M0 is declared clobbered instead of saved / restored and the 5-slot nop in front is gone --
+// the caller's base and destination must come from SCALAR arithmetic (a base freshly written by v_readfirstlane needs the form above).
+__device__ __forceinline__ void glds16_lean(const void* base, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+// (destination = LDS byte address of `lds_base`, read once by the caller with lds_addr32(), + a scalar byte offset)
+__device__ __forceinline__ uint32_t lds_addr32(const void* lds_ptr) { return (uint32_t)(uintptr_t)lds_ptr; }
+#define NR_GLDS16_L(base, voff, lds_base, lds_base32, off) glds16_lean((base), (voff), (lds_base32) + (uint32_t)(off))
 #define NR_GLDS16_S(base, voff, lds_dst) glds16_sbase((base), (voff), (lds_dst))
 #define NR_GLDS4_S(base, voff, lds_dst) glds4_sbase((base), (voff), (lds_dst))
 
@@ -213,8 +221,15 @@ __device__ __forceinline__ float buf_load4f(BufRsrc r, uint32_t off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 // soff: a wave-uniform byte offset (scalar operand of the instruction)
+// A store of more than 8 bytes reads its data registers AFTER it has issued: a VALU instruction that overwrites them needs wait states in between.
+// LLVM inserts them -- except when the scalar-offset field holds a REGISTER (GCNHazardRecognizer::createsVALUHazard: "this hazard only exists if the
+// instruction is not using a register in the soffset field"), which is every soff that is not an inline constant.  On MI355X the hazard exists there
+// too: round 6, k_convgemm.h -- `buffer_store_dwordx4 v[82:85], v91, s[8:11], s51 offen` followed by `v_or_b32 v84, ..` stored the NEW v84 in the last
+// lanes of each 16 (4 wrong rows per wave and tile; tools/isa_store_hazard_audit.py finds such pairs in the device assembly).  Guard: an empty-bodied
+// two-wait-state asm that READS the data, so that no write to those registers can be scheduled in front of it.
 template <int IMM = 0> __device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t off, u16x8 v, uint32_t soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, off + IMM, soff, 0);
+  if (!(__builtin_constant_p(soff) && soff <= 64u)) asm volatile("s_nop 1" : : "v"(v));
 }
 template <int IMM = 0> __device__ __forceinline__ void buf_store8(BufRsrc r, uint32_t off, u16x4 v, uint32_t soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, off + IMM, soff, 0);

@@ -4,6 +4,8 @@ title text encoder).  Same rules as ops.py: all encoder math runs in the HIP ker
 memory, streams and autograd bookkeeping, and the only library calls are plain bf16 GEMMs of the backward pass.
 No CPU path.
 """
+import os
+
 import torch
 
 from . import ops

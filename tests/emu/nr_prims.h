@@ -138,6 +138,8 @@ void launch(Dim3 grid, Dim3 block, size_t smem_bytes, std::function<void()> body
 // emulation of global_load_lds_dwordx4: every lane copies its 16 B to lds_base + 16 * lane
 #define NR_GLDS16(gptr, lds_base) nr_emu::dma_issue((const void*)(gptr), (unsigned char*)(lds_base) + 16 * (threadIdx.x & 63))
 #define NR_GLDS16_S(base, voff, lds_dst) nr_emu::dma_issue((const unsigned char*)(base) + (voff), (unsigned char*)(lds_dst) + 16 * (threadIdx.x & 63))
+__forceinline__ uint32_t lds_addr32(const void*) { return 0; }
+#define NR_GLDS16_L(base, voff, lds_base, lds_base32, off) NR_GLDS16_S(base, voff, (unsigned char*)(lds_base) + (off))
 #define NR_GLDS4_S(base, voff, lds_dst) nr_emu::dma_issue(nullptr, nullptr)
 #define NR_GLDS4(gptr, lds_base) nr_emu::dma_issue(nullptr, nullptr)      // a cache-line touch: one slot of the in-order counter, no data anybody reads
 #define NR_WAIT_VMCNT(n) nr_emu::dma_land(n)

@@ -96,6 +96,7 @@ def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=3, val
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
 def test_conv_dgrad_gemm_form(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=14); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=3)       # 293 / 152 virtual rows: two tiles, the second partial
+def test_conv_dgrad_gemm_persistent_stream(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=50)       # 1,049 virtual rows = 5 tiles over the emulator's 3 "CUs": two tiles per workgroup, the ring runs across the tile boundary
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be)
 def test_additive_bwd_act_fused_s20(be): kcc.check_additive_bwd_act(be, S=20, n_seq=7); kcc.check_additive_bwd_act(be, S=20, n_seq=17)
 def test_additive_bwd_act_two_kernels_s50(be): kcc.check_additive_bwd_act(be, S=50, n_seq=3)       # below 2048 sequences: LDS-tile kernel + conv_act_bwd

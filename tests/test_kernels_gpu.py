@@ -88,6 +88,7 @@ def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=131, v
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=515)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=131)
 def test_conv_dgrad_gemm_form(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=2051); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=1031)
+def test_conv_dgrad_gemm_many_tiles_per_cu(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=7013)       # 575 tiles: 2-3 per CU, the ring runs across tile boundaries
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be, S=20, n_seq=1027)
 def test_additive_bwd_act_fused_s20(be): kcc.check_additive_bwd_act(be, S=20, n_seq=1027)
 def test_additive_bwd_act_fused_s50(be): kcc.check_additive_bwd_act(be, S=50, n_seq=2051)

@@ -106,6 +106,17 @@ if name.startswith('pool_flat'):     # flat pooling backward (csrc/k_pool3.h): p
     fns[name] = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
                                                     tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
                                                     0.2 if act_ else 0.0, Tn, S, 200, st()))
+if name.startswith('cgemm'):          # the convolution as a persistent ring GEMM (csrc/k_convgemm.h): cgemm_dgrad50 / cgemm_dgrad20; NR_CONVGEMM_DEBUG switches phases off, NR_CONV_GEMM_PERSIST=0: the one-tile-per-workgroup kernel
+    S = 50 if '50' in name else 20
+    Tn = B * 55
+    Wcv = torch.randn(300, 1, 3, 300, generator=g).mul_(0.03).to(dev)
+    Wd2 = torch.empty(NR_KP, 3 * NR_KP, dtype=torch.int16, device=dev)
+    ck(lib.nr_pack_conv_dgrad(Wcv.data_ptr(), 300, 300, Wd2.data_ptr(), st()))
+    if int(os.environ.get('NR_CONVGEMM_DEBUG', '0')) & 16:      # experiment: the filter bank chunk-major [30 chunks = (column block, tap)][KP rows][32]
+        Wd2 = Wd2.view(NR_KP, 3, 10, 32).permute(2, 1, 0, 3).contiguous()
+    dyp = torch.randn(Tn * (S + 1) + 1, NR_KP, generator=g).mul_(0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    dxo = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
+    fns[name] = lambda: ck(lib.nr_conv3_dgrad_gemm(dyp.data_ptr(), Wd2.data_ptr(), dxo.data_ptr(), Tn, S, st()))
 if name.startswith('pool_fwd_flat'):     # whole-sequence pooling forward (csrc/k_pool4.h): pool_fwd_flat (titles) / pool_fwd_flat50 (abstracts); NR_POOL_DEBUG switches phases off
     S = 50 if '50' in name else 20
     Tn = B * (55 if S == 50 else 55)
