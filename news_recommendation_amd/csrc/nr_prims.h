@@ -133,6 +133,10 @@ __device__ __forceinline__ u16x8 lds_read16_async(const void* p) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p), "n"(OFF) : "memory");
   return v;
 }
+// *p += v on an LDS float, no return value, nothing to wait for (ds_add_f32; the location belongs to this wave or the addition order does not matter)
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+  asm volatile("ds_add_f32 %0, %1" : : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p), "v"(v) : "memory");
+}
 // f(IntTag<0>{}), f(IntTag<1>{}), ... f(IntTag<N - 1>{}): a loop whose index is a compile-time constant in the body (instruction offset fields)
 template <int V> struct StaticIdx { static constexpr int value = V; };
 template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(StaticIdx<Is>{}), ...); }

@@ -244,6 +244,7 @@ __forceinline__ u16x4 lds_tr16_b64_async(const u16* piece) { return lds_tr16_b64
 
 template <int OFF>
 __forceinline__ u16x8 lds_read16_async(const void* p) { u16x8 v; memcpy(&v, (const unsigned char*)p + OFF, 16); return v; }
+__forceinline__ void lds_add_f32(float* p, float v) { *p += v; }
 template <int V> struct StaticIdx { static constexpr int value = V; };
 template <class F, int... Is> __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(StaticIdx<Is>{}), ...); }
 template <int N, class F> __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
