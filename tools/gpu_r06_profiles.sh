@@ -5,13 +5,13 @@ export TMPDIR=/tmp
 TAG=${1:-r06prof}
 O=gpurun_out/$TAG
 mkdir -p $O
-for K in proj_train attn_pool_fwd attn_bwd_hm pool_flat; do
+for K in proj_train attn_pool_fwd attn_bwd_hm pool_flat pool_fwd_flat50 pool_flat50_act cgemm_dgrad50 conv_abs; do
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${K}_fetch -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_fetch.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${K}_write -o pmc -- python tools/prof_kernel.py $K > $O/pmc_${K}_write.log 2>&1
 done
 python tools/pmc_traffic.py $O profiles/r06_pmc_traffic.txt | tee $O/pmc_traffic.txt
 rm -rf $O/pmc_*_fetch $O/pmc_*_write
-for K in "attn_bwd_hm attn_bwd" "proj_train qkv_proj" "attn_pool_fwd attn_fwd_kernel" "pool_flat pool3_bwd" "pool_flat50_act pool3_bwd" "dx_gemm dx_gemm" "tn_gemm gemm_ring"; do
+for K in "attn_bwd_hm attn_bwd" "proj_train qkv_proj" "attn_pool_fwd attn_fwd_kernel" "pool_flat pool3_bwd" "pool_flat50_act pool3_bwd" "dx_gemm dx_gemm" "tn_gemm gemm_ring" "pool_fwd_flat50 pool4_fwd" "cgemm_dgrad50 conv_gemm" "conv_abs conv3_kernel"; do
   set -- $K
   bash tools/pmc_kernel.sh $1 $2 $O/pmc_sq_$1 > /dev/null 2>&1
 done

@@ -11,7 +11,7 @@ import bench
 out, tag = sys.argv[1], sys.argv[2]
 names = {'proj_train': 'nr_qkv_proj_fwd[S=20]', 'attn_fwd': 'nr_attn_fwd[S=20]', 'attn_pool_fwd': 'nr_attn_pool_fwd[S=20]', 'attn_bwd_hm': 'nr_attn_bwd[S=20]', 'additive_bwd': 'nr_additive_bwd[S=20] (sequence-shaped)', 'pool_flat': 'nr_additive_bwd[S=20]', 'pool_flat50_act': 'nr_additive_bwd[abstract]',
          'additive_fwd': 'nr_additive_fwd[S=20]', 'additive_bwd50': 'nr_additive_bwd[abstract] (sequence-shaped)', 'conv_abs': 'nr_conv3_fwd[abstract]',
-         'dx_gemm': 'nr_dx_gemm[S=20]', 'tn_gemm': 'nr_gemm_tn_dWqkv[S=20]'}
+         'dx_gemm': 'nr_dx_gemm[S=20]', 'tn_gemm': 'nr_gemm_tn_dWqkv[S=20]', 'pool_fwd_flat50': 'nr_additive_fwd[abstract]', 'cgemm_dgrad50': 'nr_conv3_dgrad[abstract]'}
 res = {"_note": __doc__.split('\n', 2)[2].strip()}
 for k, name in names.items():
     f = os.path.join(out, f'pmc_sq_{k}', 'summary.txt')

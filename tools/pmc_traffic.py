@@ -9,7 +9,11 @@ sys.path.insert(0, ROOT)
 import bench
 out = sys.argv[1]
 tags = {'proj_train': ('nr_qkv_proj_fwd[S=20]', 'qkv_proj'), 'attn_fwd': ('nr_attn_fwd[S=20]', 'attn_fwd_kernel'), 'attn_pool_fwd': ('nr_attn_pool_fwd[S=20]', 'attn_fwd_kernel'), 'attn_bwd_hm': ('nr_attn_bwd[S=20]', 'attn_bwd'),
-        'additive_bwd': ('nr_additive_bwd[S=20] (sequence-shaped)', 'pool2_bwd'), 'pool_flat': ('nr_additive_bwd[S=20]', 'pool3_bwd'), 'mhsa_infer': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2')}
+        'additive_bwd': ('nr_additive_bwd[S=20] (sequence-shaped)', 'pool2_bwd'), 'pool_flat': ('nr_additive_bwd[S=20]', 'pool3_bwd'), 'mhsa_infer': ('nr_mhsa_fwd[S=20]', 'mhsa_fwd2'),
+        # NAML-shaped stand-alone launches (tools/prof_kernel.py: 28,160 sequences of 50 rows)
+        'pool_fwd_flat50': ('nr_additive_fwd[abstract]', 'pool4_fwd'), 'pool_flat50_act': ('nr_additive_bwd[abstract]', 'pool3_bwd'), 'cgemm_dgrad50': ('nr_conv3_dgrad[abstract]', 'conv_gemm'),
+        'conv_abs': ('nr_conv3_fwd[abstract]', 'conv3_kernel')}
+NAML_TAGS = ('pool_fwd_flat50', 'pool_flat50_act', 'cgemm_dgrad50', 'conv_abs')
 SRC = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r03_pmc_traffic.txt'
 
 
@@ -29,6 +33,6 @@ for tag, (name, sub) in tags.items():
         print('missing', tag, f, w)
         continue
     res[name] = {"fetch_kib_raw": f, "write_kib_raw": w, "bytes": int((2 * f + w) * 1024), "source": SRC,
-                 "source_hash": bench.kernel_source_hash(), "workload": "NRMS/small/B512"}
+                 "source_hash": bench.kernel_source_hash(), "workload": "NAML/small/B512" if tag in NAML_TAGS else "NRMS/small/B512"}
     print(f"{name}: FETCH_SIZE {f:.0f} KiB (x2 = {2 * f / 1e6:.3f} GB), WRITE_SIZE {w:.0f} KiB ({w * 1024 / 1e9:.3f} GB), total {(2 * f + w) * 1024 / 1e9:.3f} GB per launch")
 json.dump(res, open(os.path.join(ROOT, 'gpurun_out', os.path.basename(out.rstrip('/')), 'traffic.json'), 'w'), indent=1)
