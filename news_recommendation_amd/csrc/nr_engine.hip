@@ -858,12 +858,17 @@ static int launch_conv(nr::ConvParams& p, int S, void* stream, const char* what)
   { static int dbg = -1; if (dbg < 0) { const char* d = getenv("NR_CONV_DEBUG"); dbg = d ? atoi(d) : 0; } p.debug = dbg; }
   // 8 waves on 8 titles / 4 abstracts: one workgroup per CU, the filter bank is re-read from L2 half as often as with 4 waves on 4 / 2
   // (~10 % at B = 512, profiles/r02_ab_switches.txt; the 4-wave instantiations are gone)
+  // NR_CONV_HALF_TILE=1 (A/B, read once): half the sequences per workgroup -> two workgroups of 8 waves per CU (70 / 57 KB of LDS each), one's gather
+  // phase beside the other's GEMM phase.  Measured in round 6 (profiles/r06_ab_conv_half_tile.txt): 1,483 -> 1,800 us stand-alone for the abstracts,
+  // 670 -> 818 us for the titles -- every workgroup streams the 614 KB filter bank from L2, and twice as many workgroups stream it twice as often
+  // (~0.3 ms of the kernel is that stream).  Not the default.
+  static const int half = [] { const char* e = getenv("NR_CONV_HALF_TILE"); return e ? atoi(e) : 0; }();
   int rc;
   if (S == 20) {
-    rc = launch_conv_t<20, 8, 8>(p, stream);
+    rc = half ? launch_conv_t<20, 4, 8>(p, stream) : launch_conv_t<20, 8, 8>(p, stream);
     if (rc) return rc;
   } else if (S == 50) {
-    rc = launch_conv_t<50, 4, 8>(p, stream);
+    rc = half ? launch_conv_t<50, 2, 8>(p, stream) : launch_conv_t<50, 4, 8>(p, stream);
     if (rc) return rc;
   } else {
     return fail(NR_ERR_UNSUPPORTED, "conv3: sequence length not instantiated (20, 50)");
