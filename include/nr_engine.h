@@ -286,7 +286,7 @@ int nr_additive_bwd_act(const uint16_t* act, const uint16_t* Wap, const float* b
                         int64_t n_seq, int S, void* stream);
 
 /* The pooling backward over a FLAT token stream (csrc/k_pool3.h; autograd of additive.py:27-53): every output of nr_additive_bwd_ex /
- * nr_additive_bwd_act for any sequence length S >= 7 (S >= 16 with dy_pad: 48 consecutive tokens must belong to at most 8 / 4 sequences;
+ * nr_additive_bwd_act for any sequence length S >= 4 (S >= 16 with dy_pad: 48 consecutive tokens must belong to at most 16 / 4 sequences;
  * shorter ones return NR_ERR_UNSUPPORTED and stay with the sequence-shaped entries) from one persistent kernel.  The sum inside the softmax backward,
  * sum_s w[s] (g_out . x[s]), equals g_out[seq] . y[seq] with y the pooled vector of the FORWARD (nr_additive_fwd*'s `out`: f32 rows of stride
  * y_stride), so token rows are independent and are dealt to waves 48 at a time regardless of sequence boundaries.  tot: f32 [n_seq]

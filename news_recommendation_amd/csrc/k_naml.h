@@ -9,20 +9,38 @@
 
 namespace nr {
 
+// The element tables are tiny (2 x 275 x 300 outputs of a 100-term dot product; gradients: 88 K outputs of 275- / 600-term sums), and a thread per
+// output made their launches chains of dependent load -> FMA round trips: 68 + 139 us of the NAML step for 0.2 GFLOP (round 5).  Round 6: EIGHT lanes
+// per output, each walking every eighth term, combined with three lane exchanges in a fixed order (deterministic).
+constexpr int ET_LANES = 8;
+__device__ __forceinline__ float et_reduce8(float a) {           // sum over the 8 consecutive lanes of an output
+  a += shfl_xor(a, 1);
+  a += shfl_xor(a, 2);
+  a += shfl_xor(a, 4);
+  return a;
+}
+
 // E[which][c][f] = relu(b_which[f] + sum_k emb[c][k] * W_which[f][k]);  which = 0 (category), 1 (subcategory)
 __global__ __launch_bounds__(256) void element_table_fwd_kernel(const float* __restrict__ emb, int ncat, int dcat,
                                                                 const float* __restrict__ W0, const float* __restrict__ b0,
                                                                 const float* __restrict__ W1, const float* __restrict__ b1,
                                                                 float* __restrict__ E, int F_) {
   const int total = 2 * ncat * F_;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int which = i / (ncat * F_), rem = i - which * ncat * F_;
+  const int sub = threadIdx.x & (ET_LANES - 1);
+  const int per = blockDim.x / ET_LANES;
+  const int rounds = (total + gridDim.x * per - 1) / (gridDim.x * per);      // every lane of a wave runs the same number of rounds (lane exchanges)
+  for (int r = 0; r < rounds; ++r) {
+    const int i = (r * gridDim.x + blockIdx.x) * per + (threadIdx.x / ET_LANES);
+    const bool live = i < total;
+    const int ii = live ? i : 0;
+    const int which = ii / (ncat * F_), rem = ii - which * ncat * F_;
     const int c = rem / F_, f = rem - c * F_;
     const float* W = (which ? W1 : W0) + (size_t)f * dcat;
     const float* e = emb + (size_t)c * dcat;
-    float a = (which ? b1 : b0)[f];
-    for (int k = 0; k < dcat; ++k) a += e[k] * W[k];
-    E[i] = fmaxf(a, 0.0f);
+    float a = 0.0f;
+    for (int k = sub; k < dcat; k += ET_LANES) a += e[k] * W[k];
+    a = et_reduce8(a) + (which ? b1 : b0)[f];
+    if (live && sub == 0) E[i] = fmaxf(a, 0.0f);
   }
 }
 
@@ -34,49 +52,39 @@ __global__ __launch_bounds__(256) void element_table_bwd_kernel(const float* __r
                                                                 const float* __restrict__ E, const float* __restrict__ dE, int F_,
                                                                 float* __restrict__ dW /*[2][F][dcat]*/, float* __restrict__ db /*[2][F]*/,
                                                                 float* __restrict__ demb /*[ncat][dcat]*/) {
-  const int nW = 2 * F_ * dcat, nb = 2 * F_, ne = ncat * dcat;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nW + nb + ne; i += gridDim.x * blockDim.x) {
+  const int nW = 2 * F_ * dcat, nb = 2 * F_, ne = ncat * dcat, total = nW + nb + ne;
+  const int sub = threadIdx.x & (ET_LANES - 1);
+  const int per = blockDim.x / ET_LANES;
+  const int rounds = (total + gridDim.x * per - 1) / (gridDim.x * per);
+  for (int r = 0; r < rounds; ++r) {
+    const int i0 = (r * gridDim.x + blockIdx.x) * per + (threadIdx.x / ET_LANES);
+    const bool live = i0 < total;
+    const int i = live ? i0 : 0;
+    float a = 0.0f;
     if (i < nW) {
       const int which = i / (F_ * dcat), rem = i - which * F_ * dcat;
       const int f = rem / dcat, k = rem - f * dcat;
       const float* Ew = E + (size_t)which * ncat * F_;
       const float* dEw = dE + (size_t)which * ncat * F_;
-      // four independent partial sums: a single accumulator made this a chain of ncat (275) dependent load -> FMA round trips per thread
-      // (236 us per NAML step for 0.1 GFLOP); fixed combination order -> deterministic
-      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-      auto term = [&](int c) { return (Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f) * emb[(size_t)c * dcat + k]; };
-      int c = 0;
-      for (; c + 4 <= ncat; c += 4) { a0 += term(c); a1 += term(c + 1); a2 += term(c + 2); a3 += term(c + 3); }
-      for (; c < ncat; ++c) a0 += term(c);
-      dW[i] = (a0 + a1) + (a2 + a3);
+      for (int c = sub; c < ncat; c += ET_LANES) a += (Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f) * emb[(size_t)c * dcat + k];
     } else if (i < nW + nb) {
       const int j = i - nW, which = j / F_, f = j - which * F_;
       const float* Ew = E + (size_t)which * ncat * F_;
       const float* dEw = dE + (size_t)which * ncat * F_;
-      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-      auto term = [&](int c) { return Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f; };
-      int c = 0;
-      for (; c + 4 <= ncat; c += 4) { a0 += term(c); a1 += term(c + 1); a2 += term(c + 2); a3 += term(c + 3); }
-      for (; c < ncat; ++c) a0 += term(c);
-      db[j] = (a0 + a1) + (a2 + a3);
+      for (int c = sub; c < ncat; c += ET_LANES) a += Ew[c * F_ + f] > 0.0f ? dEw[c * F_ + f] : 0.0f;
     } else {
       const int j = i - nW - nb, c = j / dcat, k = j - c * dcat;
-      float a = 0.0f;
       if (c != 0) {
         for (int which = 0; which < 2; ++which) {
           const float* Ew = E + ((size_t)which * ncat + c) * F_;
           const float* dEw = dE + ((size_t)which * ncat + c) * F_;
           const float* W = which ? W1 : W0;
-          float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
-          auto term = [&](int f) { return (Ew[f] > 0.0f ? dEw[f] : 0.0f) * W[(size_t)f * dcat + k]; };
-          int f = 0;
-          for (; f + 4 <= F_; f += 4) { b0 += term(f); b1 += term(f + 1); b2 += term(f + 2); b3 += term(f + 3); }
-          for (; f < F_; ++f) b0 += term(f);
-          a += (b0 + b1) + (b2 + b3);
+          for (int f = sub; f < F_; f += ET_LANES) a += (Ew[f] > 0.0f ? dEw[f] : 0.0f) * W[(size_t)f * dcat + k];
         }
       }
-      demb[j] = a;
     }
+    a = et_reduce8(a);
+    if (live && sub == 0) (i < nW ? dW + i : i < nW + nb ? db + (i - nW) : demb + (i - nW - nb))[0] = a;
   }
 }
 

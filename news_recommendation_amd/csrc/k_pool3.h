@@ -203,32 +203,37 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
     const BufRsrc r_aw = make_buf(p.attn_w + tok0, (uint32_t)(nrows * 4));
     const BufRsrc r_g = make_buf(p.g_out, (uint32_t)(p.n_seq * (D * 4))), r_tot = make_buf(p.tot, (uint32_t)(p.n_seq * 4));
     const BufRsrc r_dpre = make_buf(p.dpre + tok0 * QP, (uint32_t)(nrows * QP * 2));
-    // dw[tok] = g_out[seq(tok)] . x[tok] on the matrix core: the group's rows belong to at most 8 sequences (S >= 7), "slots" sq0 .. sq0 + 7.  A tile:
+    // dw[tok] = g_out[seq(tok)] . x[tok] on the matrix core: the group's rows belong to at most 8 sequences (S >= 7; 16 for S >= 3: a second tile), "slots" sq0 .. sq0 + 7.  A tile:
     // row li = (slot li >> 1, part li & 1) of g_out split into two bf16 numbers (g = hi + lo to 2^-17: the products with the bf16 rows are exact,
     // the accumulation fp32); B = the rows' own fragments.  A token then picks the two accumulator rows of ITS slot.  [As 3 x 80 multiply-adds per
     // lane with 60 sixteen-byte loads of g_out in front of them this phase took a fifth of the kernel -- latency of six load batches per group.]
     const uint32_t sq0 = (uint32_t)uniform((int)seq_of(0));
+    const bool two = p.S < 7;                 // sequences shorter than 7 tokens (NAML's 4 views): up to 16 per group -> a second tile of slots 8 .. 15 (round 6)
     float ds[MT];
     {
-      f32x4 accg[MT];
+      f32x4 accg[MT], accg2[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) accg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MT; ++m) { accg[m] = f32x4{0.f, 0.f, 0.f, 0.f}; accg2[m] = accg[m]; }
       uint32_t go = (sq0 + (uint32_t)(li >> 1)) * (uint32_t)(D * 4) + (uint32_t)(g * 32);      // (slots past the last sequence: outside the buffer, zeros)
       NR_OPAQUE(go);
       auto gstep = [&](auto ks_tag) {
         constexpr int ks = decltype(ks_tag)::value;
-        f32x4 g0 = f32x4{0.f, 0.f, 0.f, 0.f}, g1 = g0;
-        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 4 <= D) g0 = buf_load16f<ks * 128>(r_g, go);            // (columns >= D: the bias column of ctx, zeros)
-        if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 8 <= D) g1 = buf_load16f<ks * 128 + 16>(r_g, go);
-        u16x8 fr;
+        auto slots = [&](uint32_t off, f32x4 (&acc)[MT]) {
+          f32x4 g0 = f32x4{0.f, 0.f, 0.f, 0.f}, g1 = g0;
+          if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 4 <= D) g0 = buf_load16f<ks * 128>(r_g, off);          // (columns >= D: the bias column of ctx, zeros)
+          if (ks * 32 + 32 <= D || ks * 32 + g * 8 + 8 <= D) g1 = buf_load16f<ks * 128 + 16>(r_g, off);
+          u16x8 fr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u16 h0 = f2bf(g0[j]), h1 = f2bf(g1[j]);
-          fr[j] = (li & 1) ? f2bf(g0[j] - bf2f(h0)) : h0;
-          fr[4 + j] = (li & 1) ? f2bf(g1[j] - bf2f(h1)) : h1;
-        }
+          for (int j = 0; j < 4; ++j) {
+            const u16 h0 = f2bf(g0[j]), h1 = f2bf(g1[j]);
+            fr[j] = (li & 1) ? f2bf(g0[j] - bf2f(h0)) : h0;
+            fr[4 + j] = (li & 1) ? f2bf(g1[j] - bf2f(h1)) : h1;
+          }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) accg[m] = mfma_16x16x32_bf16(fr, xr[ks][m], accg[m]);
+          for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(fr, xr[ks][m], acc[m]);
+        };
+        slots(go, accg);
+        if (two) slots(go + 8u * (uint32_t)(D * 4), accg2);
       };
       if (!(dbg & 2)) {
         gstep(IntTag<0>{}); gstep(IntTag<1>{}); gstep(IntTag<2>{}); gstep(IntTag<3>{}); gstep(IntTag<4>{});
@@ -237,8 +242,9 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const uint32_t sq = seq_of(m * 16 + li), slot = sq - sq0;                 // accumulator rows 4 g + r = (slot 2 g + (r >> 1), part r & 1)
-        const float pair = (slot & 1) ? accg[m][2] + accg[m][3] : accg[m][0] + accg[m][1];
-        const float dw = sum_rows4((int)(slot >> 1) == g ? pair : 0.0f);
+        const f32x4 ag = slot < 8u ? accg[m] : accg2[m];
+        const float pair = (slot & 1) ? ag[2] + ag[3] : ag[0] + ag[1];
+        const float dw = sum_rows4((int)((slot & 7u) >> 1) == g ? pair : 0.0f);
         ds[m] = buf_load4f(r_aw, (uint32_t)((m * 16 + li) * 4)) * (dw - buf_load4f(r_tot, sq * 4u));      // (rows past the end: weight 0)
       }
     }

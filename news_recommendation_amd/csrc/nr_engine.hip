@@ -957,9 +957,9 @@ int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* 
   if (qdim < 1 || qdim > NR_QP) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: query_vector_dim out of range");
   if (qdim > nr::Pool3Geom::WROWS)
     return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: the flat kernel keeps 200 rows of Wa in LDS (query_vector_dim <= 200); use nr_additive_bwd_ex / _act");
-  // 48 consecutive tokens belong to 1 + ceil(47 / S) sequences: the kernel has 8 slots for them, 4 in the activation-gradient form
-  if (S < 7 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
-    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 7 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq < 2^31 / 1200");
+  // 48 consecutive tokens belong to 1 + ceil(47 / S) sequences: the kernel has 8 slots for them (16 below S = 7), 4 in the activation-gradient form
+  if (S < 4 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 4 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq < 2^31 / 1200");
   if (n_seq == 0) return NR_OK;
   NR_LAUNCH(nr::rowdot_kernel, grid_for(n_seq, 4, 4096), 256, 0, (hipStream_t)stream, g_out, (int64_t)NR_D, y, y_stride, n_seq, NR_D, tot);
   nr::Pool3Params p;
@@ -993,14 +993,14 @@ int nr_additive_dx(const uint16_t* dgemm, int ldc, const float* attn_w, const fl
 int nr_element_table_fwd(const float* emb, int ncat, int dcat, const float* W0, const float* b0, const float* W1, const float* b1, float* E,
                          void* stream) {
   if (!emb || !W0 || !b0 || !W1 || !b1 || !E || ncat <= 0 || dcat <= 0) return fail(NR_ERR_BADARG, "nr_element_table_fwd: bad argument");
-  NR_LAUNCH(nr::element_table_fwd_kernel, grid_for(2LL * ncat * NR_D, 256, 2048), 256, 0, (hipStream_t)stream, emb, ncat, dcat, W0, b0, W1, b1, E, NR_D);
+  NR_LAUNCH(nr::element_table_fwd_kernel, grid_for(2LL * ncat * NR_D * nr::ET_LANES, 256, 8192), 256, 0, (hipStream_t)stream, emb, ncat, dcat, W0, b0, W1, b1, E, NR_D);
   return check_launch("nr_element_table_fwd");
 }
 
 int nr_element_table_bwd(const float* emb, int ncat, int dcat, const float* W0, const float* W1, const float* E, const float* dE, float* dW,
                          float* db, float* demb, void* stream) {
   if (!emb || !W0 || !W1 || !E || !dE || !dW || !db || !demb || ncat <= 0 || dcat <= 0) return fail(NR_ERR_BADARG, "nr_element_table_bwd: bad argument");
-  NR_LAUNCH(nr::element_table_bwd_kernel, grid_for(2LL * NR_D * dcat + 2 * NR_D + (int64_t)ncat * dcat, 256, 2048), 256, 0, (hipStream_t)stream,
+  NR_LAUNCH(nr::element_table_bwd_kernel, grid_for((2LL * NR_D * dcat + 2 * NR_D + (int64_t)ncat * dcat) * nr::ET_LANES, 256, 8192), 256, 0, (hipStream_t)stream,
             emb, ncat, dcat, W0, W1, E, dE, NR_D, dW, db, demb);
   return check_launch("nr_element_table_bwd");
 }

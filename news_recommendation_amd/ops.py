@@ -451,13 +451,18 @@ _POOL_FLAT_MIN_TOK = int(os.environ.get('NR_POOL_FLAT_MIN_TOK', '98304'))
 NR_POOL_FLAT_QMAX = 200      # rows of Wa the flat kernel keeps in LDS (Pool3Geom::WROWS, csrc/k_pool3.h)
 
 
+# NR_POOL_FLAT_VIEWS: 1 (default) = sequences of 4 .. 6 positions (NAML's view level) take the flat pooling backward too (round 6); 0 = the
+# sequence-shaped kernel (A/B)
+_POOL_FLAT_SHORT = os.environ.get('NR_POOL_FLAT_VIEWS', '1') == '1'
+
+
 def pool_flat_ok(S, act, n_seq=None, *, qdim):
     """Whether the flat kernel takes a pooling level of S-token sequences (act: with the fused activation gradient): 48 consecutive tokens must
-    belong to at most 8 sequences (4 with act) -- the final attention over NAML's 4 views stays on the sequence-shaped kernel -- and the
+    belong to at most 16 sequences (4 with act) -- since round 6 that includes the final attention over NAML's 4 views -- and the
     batch must be worth a persistent launch (one workgroup per CU loads the projection matrix once: 512 click histories are faster on the
     sequence-shaped kernel, 36 vs 47 us).  qdim (query_vector_dim, keyword-only so that no call site can forget it): the flat kernel holds
     200 rows of the projection matrix in LDS; 201 .. 208 stay on the sequence-shaped kernels, which keep all 208 packed rows."""
-    return (_POOL_FLAT and qdim <= NR_POOL_FLAT_QMAX and S >= (16 if act else 7)
+    return (_POOL_FLAT and qdim <= NR_POOL_FLAT_QMAX and S >= (16 if act else (4 if _POOL_FLAT_SHORT else 7))
             and (n_seq is None or n_seq * S >= _POOL_FLAT_MIN_TOK))
 
 

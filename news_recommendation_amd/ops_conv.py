@@ -284,7 +284,7 @@ class _NamlNewsFn(torch.autograd.Function):
         _call('nr_element_table_fwd', lib.nr_element_table_fwd, _ptr(embf), ncat, dcat, _ptr(Wc_), _ptr(bc_), _ptr(Ws_), _ptr(bs_), _ptr(E), _stream())
         _call('nr_views_fill', lib.nr_views_fill, _ptr(cat), _ptr(sub), _ptr(E), ncat, _ptr(views), T, _stream())
         Wap, bap, qvp = pack_additive(Wa_f, ba_f, qv_f)
-        WaT = ops.pack_additive_t(Wa_f) if (need_grad and not ops.pool_flat_ok(4, False, qdim=Wa_f.shape[0])) else None
+        WaT = ops.pack_additive_t(Wa_f) if (need_grad and not ops.pool_flat_ok(4, False, title.shape[0], qdim=Wa_f.shape[0])) else None
         out = torch.empty(T, NR_D, dtype=torch.float32, device=dev)
         out_b = torch.empty(T, NR_KP, dtype=_BF16_AS_I16, device=dev)
         aw = torch.empty(T, 4, dtype=torch.float32, device=dev)

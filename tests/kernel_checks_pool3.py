@@ -126,7 +126,7 @@ def check_flat_bad_args(be):
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, pa, pa, 0.0, 4, 20, 200, be.stream) != 0          # dctx AND dy_pad
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D - 4, pa, pa, pa, None, None, 0.0, 4, 20, 200, be.stream) != 0   # y stride
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 1.0, 4, 20, 200, be.stream) != 0       # p_drop
-    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 6, 200, be.stream) != 0         # S < 7: more than 8 sequences in 48 tokens
+    assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 3, 200, be.stream) != 0         # S < 4: more than 16 sequences in 48 tokens
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, pa, 0.0, 4, 15, 200, be.stream) != 0       # S < 16 with dy_pad: more than 4
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 0, 20, 200, be.stream) == 0        # nothing to do
     assert lib.nr_additive_bwd_flat(pa, pa, pa, pa, pa, pa, pa, NR_D, pa, pa, pa, None, None, 0.0, 4, 20, 201, be.stream) != 0 and b'200 rows' in lib.nr_last_error()      # query_vector_dim 201 .. 208: the sequence-shaped kernels

@@ -149,7 +149,8 @@ from tests import kernel_checks_pool3 as k3  # noqa: E402
 def test_pool_flat_bad_args(be): k3.check_flat_bad_args(be)
 def test_pool_flat_s20(be): k3.check_flat(be, S=20, n_seq=6)                      # 120 tokens: sequences straddle the 48-row groups
 def test_pool_flat_s50(be): k3.check_flat(be, S=50, n_seq=5)
-def test_pool_flat_s7(be): k3.check_flat(be, S=7, n_seq=30, seed=3)                  # the shortest sequences the kernel takes: 8 of them in 48 tokens
+def test_pool_flat_s7(be): k3.check_flat(be, S=7, n_seq=30, seed=3)                  # 8 sequences in 48 tokens: the most one slot tile holds
+def test_pool_flat_s4_views(be): k3.check_flat(be, S=4, n_seq=83, seed=6); k3.check_flat(be, S=5, n_seq=40, seed=7); k3.check_flat(be, S=6, n_seq=31, seed=8)     # 13 sequences per group (NAML's 4 views): the second slot tile
 def test_pool_flat_valid_and_strided_y(be): k3.check_flat(be, S=20, n_seq=7, valid=13, y_stride=3 * 300)
 def test_pool_flat_any_length_dpre_only(be): k3.check_flat(be, S=33, n_seq=4, with_dctx=False, seed=5)     # a length no forward kernel is instantiated for
 def test_pool_flat_act_s20(be): k3.check_flat_act(be, S=20, n_seq=7)

@@ -181,6 +181,7 @@ from tests import kernel_checks_pool3 as k3  # noqa: E402
 
 def test_pool_flat_bad_args(be): k3.check_flat_bad_args(be)
 def test_pool_flat_small(be): k3.check_flat(be, S=20, n_seq=6); k3.check_flat(be, S=50, n_seq=5); k3.check_flat(be, S=7, n_seq=30, seed=3)
+def test_pool_flat_s4_views(be): k3.check_flat(be, S=4, n_seq=28160, seed=6); k3.check_flat(be, S=5, n_seq=4001, seed=7); k3.check_flat(be, S=6, n_seq=3001, seed=8)     # NAML's view level at the bench's launch size; the second slot tile
 def test_pool_flat_valid_strided_any_length(be):
     k3.check_flat(be, S=20, n_seq=1027, valid=13, y_stride=3 * 300); k3.check_flat(be, S=50, n_seq=131, valid=37)
     k3.check_flat(be, S=33, n_seq=517, with_dctx=False, seed=5)
