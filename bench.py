@@ -44,6 +44,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
+CRITERION_STEP = os.environ.get('NR_BENCH_CRITERION', '0') == '1'      # A/B: the round-5 step (forward_ids + torch CrossEntropyLoss) instead of train_fast's
 BYTES_PER_TOKEN_F32 = 1200   # one fp32 embedding row
 REFERENCE_SRC = '/root/reference/src'
 
@@ -127,8 +128,25 @@ class Workload:
             if self.name == 'LSTUR':
                 b['user'] = torch.from_numpy(rng.integers(1, c.num_users, size=B).astype(np.int64)).to(device)
                 b['length'] = torch.from_numpy((hist >= 0).sum(1).astype(np.int64))          # CPU, as the reference requires
+            # the engine's own batch layout (data_fast.TrainData.batch, model.forward_stacked): candidates' rows, then the history rows
+            C, N = cand.shape[1], hist.shape[1]
+            b['ids'] = {k: torch.cat([b['cand'][k].reshape(B * C, *b['cand'][k].shape[2:]), b['click'][k].reshape(B * N, *b['click'][k].shape[2:])])
+                        for k in self.attrs}
+            b['B'], b['C'] = B, C
             out.append(b)
         return out
+
+    def loss(self, model, b, crit=None, target=None):
+        """The training loop's `criterion(y_pred, y)` (train.py:205-206) for one batch.  Default: what news_recommendation_amd.train_fast runs -- the
+        stacked-id entry point with the fused scorer + cross-entropy kernels (y = class 0); NR_BENCH_CRITERION=1 (A/B): forward_ids + a
+        torch.nn.CrossEntropyLoss on the logits, the round-5 form of this step."""
+        if CRITERION_STEP:
+            return crit(self.forward(model, b), target)
+        if self.name == 'NRMS':
+            return model.forward_stacked(b['ids']['title'], b['B'], b['C'], loss=True)
+        if self.name == 'NAML':
+            return model.forward_stacked(b['ids'], b['B'], b['C'], loss=True)
+        return model.forward_stacked(b['user'], b['length'].clone(), b['ids'], b['B'], b['C'], loss=True)
 
     def forward(self, model, b):
         if self.name == 'NRMS':
@@ -853,6 +871,32 @@ def gather_source_hash():
     return hashlib.sha256(src[a:src.index('\n}\n', a)].encode()).hexdigest()[:16]
 
 
+def graph_args(wl, model, crit, target):
+    """(flat, loss_of): flat(batch) = the device tensors a captured step takes as arguments, loss_of(*those) = the step's scalar loss."""
+    name, n = wl.name, len(wl.attrs)
+    tail = (lambda b: [b['user'], b['length_dev']]) if name == 'LSTUR' else (lambda b: [])
+    if CRITERION_STEP:
+        flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + tail(b)
+
+        def loss_of(*xs):
+            cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
+            if name == 'LSTUR':
+                lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
+            else:
+                lg_ = model.forward_ids(cand['title'], click['title']) if name == 'NRMS' else model.forward_ids(cand, click)
+            return crit(lg_, target)
+        return flat, loss_of
+    B, C = target.shape[0], 1 + wl.cfg.negative_sampling_ratio
+    flat = lambda b: [b['ids'][a] for a in wl.attrs] + tail(b)
+
+    def loss_of(*xs):
+        ids = dict(zip(wl.attrs, xs[:n]))
+        if name == 'LSTUR':
+            return model.forward_stacked(xs[n], xs[n + 1].clone(), ids, B, C, loss=True)
+        return model.forward_stacked(ids['title'] if name == 'NRMS' else ids, B, C, loss=True)
+    return flat, loss_of
+
+
 def build_step_graph(wl, model, opt, crit, target, batches, device):
     """The training step of workload wl as ONE HIP graph (forward + backward + Adam; news_recommendation_amd/graph.py).  Returns (graph, flat):
     flat(batch) is the graph's argument list for a batch."""
@@ -861,16 +905,10 @@ def build_step_graph(wl, model, opt, crit, target, batches, device):
     if name == 'LSTUR':          # the captured step keeps user ids and history lengths on the device (graph.py)
         for b in batches:
             b['length_dev'] = b['length'].to(device)
-    flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if name == 'LSTUR' else [])
+    flat, loss_of = graph_args(wl, model, crit, target)
 
     def step_fn(*xs):
-        n = len(wl.attrs)
-        cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
-        if name == 'LSTUR':
-            lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
-        else:
-            lg_ = model.forward_ids(cand['title'], click['title']) if name == 'NRMS' else model.forward_ids(cand, click)
-        l_ = crit(lg_, target)
+        l_ = loss_of(*xs)
         l_.backward()
         opt.step()
         return l_
@@ -891,7 +929,7 @@ def other_workload(name, shape, vocab, B, device, steps=10):
     target = torch.zeros(B, dtype=torch.long, device=device)
 
     def step(i):
-        loss = crit(wl.forward(model, batches[i % len(batches)]), target)
+        loss = wl.loss(model, batches[i % len(batches)], crit, target)
         loss.backward()
         opt.step()
         return loss
@@ -990,7 +1028,7 @@ def main():
     target = torch.zeros(B, dtype=torch.long, device=device)
 
     def step(i):
-        loss = crit(wl.forward(model, batches[i % len(batches)]), target)
+        loss = wl.loss(model, batches[i % len(batches)], crit, target)
         loss.backward()                       # gradients land in the optimiser's flat buffer; the table bucket's all-reduce starts inside
         opt.step()                            # small-bucket all-reduce, fused Adam (also clears the gradients: no zero_grad pass)
         return loss
@@ -1031,16 +1069,10 @@ def main():
             if args.model == 'LSTUR':
                 for b in batches:
                     b['length_dev'] = b['length'].to(device)
-            flat = lambda b: [b[s_][a] for s_ in ('cand', 'click') for a in wl.attrs] + ([b['user'], b['length_dev']] if args.model == 'LSTUR' else [])
+            flat, loss_of = graph_args(wl, model, crit, target)
 
             def fwd_bwd(*xs):
-                n = len(wl.attrs)
-                cand, click = dict(zip(wl.attrs, xs[:n])), dict(zip(wl.attrs, xs[n:2 * n]))
-                if args.model == 'LSTUR':
-                    lg_ = model.forward_ids(xs[2 * n], xs[2 * n + 1].clone(), cand, click)
-                else:
-                    lg_ = model.forward_ids(cand['title'], click['title']) if args.model == 'NRMS' else model.forward_ids(cand, click)
-                l_ = crit(lg_, target)
+                l_ = loss_of(*xs)
                 l_.backward()
                 return l_
             seg = SegmentedStep(fwd_bwd, flat(batches[0]), opt, warmup=1, overlap=bool(args.seg_overlap))

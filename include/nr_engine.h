@@ -238,6 +238,40 @@ int nr_embed_scatter_sorted(const int64_t* ids_sorted, const int64_t* perm, cons
 int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, float* d_cand, float* d_user,
                      int64_t B, int C, int d, void* stream);
 
+/* ---- the training loop's scorer + loss in one pass (round 6) ------------------------------------------------------
+ * DotProductClickPredictor.forward (src/model/general/click_predictor/dot_product.py:8-19) followed by the training loop's
+ * `loss = criterion(y_pred, y)` with criterion = nn.CrossEntropyLoss() (mean reduction; src/train.py:130,205-206, LSTUR :186-187):
+ *   logits[b,c] = cand[b,c,:] . user[b,:]           (bit-identical to nr_score_dot; logits may be NULL)
+ *   loss_rows[b] = logsumexp_c(logits[b,:]) - logits[b,target[b]]      (target NULL = class 0, what train.py builds with torch.zeros)
+ *   loss[0]     = (1 / B) sum_b loss_rows[b]        (one workgroup, fixed order)
+ *   dl[b,c]     = (softmax_c(logits[b,:])[c] - [c == target[b]]) / B   = d loss / d logits, saved for nr_score_ce_bwd.
+ * cand f32[B,C,d], user f32[B,d] (16-byte aligned), 1 <= C <= 64, d % 4 == 0.  The caller validates target[b] in [0, C). */
+int nr_score_ce_fwd(const float* cand, const float* user, const int64_t* target, float* logits, float* dl, float* loss_rows,
+                    float* loss, int64_t B, int C, int d, void* stream);
+
+/* Backward of the above for a gradient g = gscale[0] arriving at the scalar loss (gscale NULL = 1): d_cand[b,c,:] = g dl[b,c] user[b,:],
+ * d_user[b,:] = g sum_c dl[b,c] cand[b,c,:].  Row (b,c) of d_cand starts at d_cand + (b*C + c)*ldc, row b of d_user at d_user + b*ldu
+ * (floats; multiples of 4, >= d): the candidates' gradient can be written straight into the leading rows of the news encoder's output
+ * gradient, replacing autograd's concatenation. */
+int nr_score_ce_bwd(const float* dl, const float* gscale, const float* cand, const float* user, float* d_cand, int64_t ldc,
+                    float* d_user, int64_t ldu, int64_t B, int C, int d, void* stream);
+
+/* bf16 rows -> f32 rows: dst[r*ldd + c] = src[r*ld + c], r < n, c < d (d, ld, ldd multiples of 4).  The dense input gradient of an encoder
+ * stage (bf16 [n][NR_KP] out of the NT GEMM) written in the f32 layout of the tensor it is the gradient of -- e.g. straight into the history rows
+ * of the news encoder's output gradient (src/model/NRMS/__init__.py:43-48: clicked_news_vector is a slice of the encoder output). */
+int nr_rows_to_f32(const uint16_t* src, int64_t ld, int d, float* dst, int64_t ldd, int64_t n, void* stream);
+
+/* Batched accumulate: for every item, dst[r*dst_ld + c] += src[r*src_ld + c], r < rows, c < cols -- in ONE launch per 48 items.  Replaces
+ * torch.autograd's AccumulateGrad (one element-wise add per parameter after loss.backward(), src/train.py:207,228) for a trainer whose
+ * gradient buffers are persistent; `items` is a HOST array read during the call.  Items of one call must not overlap in dst. */
+typedef struct nr_accum_item {
+  const float* src;
+  float* dst;
+  int64_t src_ld, dst_ld;
+  int32_t rows, cols;
+} nr_accum_item;
+int nr_accum_many(const nr_accum_item* items, int n_items, void* stream);
+
 /* ---- NAML / LSTUR: convolutional text encoder, pooling variants, element encoders ------------------------------
  * "seqpad" layout used below: bf16 [n_seq*(S+1)+1][NR_KP]; token s of sequence q sits in row q*(S+1)+1+s and the rows
  * q*(S+1) are all-zero separators (never written by the kernels: zero-fill once), so a tap shift is a row offset. */

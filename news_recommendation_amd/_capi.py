@@ -59,6 +59,10 @@ SIGNATURES = {
     'nr_score_dot_bwd': ([_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P], c_int),
     'nr_additive_fwd': ([_P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_score_dot': ([_P, _P, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_score_ce_fwd': ([_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P], c_int),
+    'nr_score_ce_bwd': ([_P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P], c_int),
+    'nr_accum_many': ([_P, c_int, _P], c_int),
+    'nr_rows_to_f32': ([_P, c_int64, c_int, _P, c_int64, c_int64, _P], c_int),
     'nr_score_csr': ([_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, _P], c_int),
     'nr_supported_pool_len': ([c_int], c_int),
     'nr_supported_conv_len': ([c_int], c_int),

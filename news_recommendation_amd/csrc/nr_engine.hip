@@ -21,6 +21,7 @@
 #include "k_optim.h"
 #include "k_sort.h"
 #include "k_generic.h"
+#include "k_step.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -826,6 +827,60 @@ int nr_score_dot_bwd(const float* dl, const float* cand, const float* user, floa
   NR_LAUNCH(nr::score_dot_bwd_kernel, grid_for(B * (d / 4), 256, 2048), 256, 0, (hipStream_t)stream, dl, cand, user, d_cand,
             d_user, B, C, d / 4);
   return check_launch("nr_score_dot_bwd");
+}
+
+int nr_score_ce_fwd(const float* cand, const float* user, const int64_t* target, float* logits, float* dl, float* loss_rows, float* loss,
+                    int64_t B, int C, int d, void* stream) {
+  if (!cand || !user || !dl || !loss_rows || !loss || B <= 0 || C <= 0 || C > 64 || d <= 0 || (d & 3))
+    return fail(NR_ERR_BADARG, "nr_score_ce_fwd: bad argument (1 <= C <= 64, d a multiple of 4, B >= 1)");
+  if ((((uintptr_t)cand | (uintptr_t)user) & 15) != 0) return fail(NR_ERR_BADARG, "nr_score_ce_fwd: vectors must be 16-byte aligned");
+  const float inv_B = 1.0f / (float)B;
+  NR_LAUNCH(nr::score_ce_fwd_kernel, (B + 3) / 4, 256, 0, (hipStream_t)stream, cand, user, target, logits, dl, loss_rows, B, C, d / 4, inv_B);
+  NR_LAUNCH(nr::score_ce_mean_kernel, 1, 256, 16, (hipStream_t)stream, (const float*)loss_rows, loss, B, inv_B);
+  return check_launch("nr_score_ce_fwd");
+}
+
+int nr_score_ce_bwd(const float* dl, const float* gscale, const float* cand, const float* user, float* d_cand, int64_t ldc, float* d_user,
+                    int64_t ldu, int64_t B, int C, int d, void* stream) {
+  if (!dl || !cand || !user || !d_cand || !d_user || B < 0 || C <= 0 || d <= 0 || (d & 3) || ldc < d || ldu < d || (ldc & 3) || (ldu & 3))
+    return fail(NR_ERR_BADARG, "nr_score_ce_bwd: bad argument");
+  if ((((uintptr_t)cand | (uintptr_t)user | (uintptr_t)d_cand | (uintptr_t)d_user) & 15) != 0)
+    return fail(NR_ERR_BADARG, "nr_score_ce_bwd: vectors must be 16-byte aligned");
+  if (B == 0) return NR_OK;
+  NR_LAUNCH(nr::score_ce_bwd_kernel, grid_for(B * (d / 4), 256, 2048), 256, 0, (hipStream_t)stream, dl, gscale, cand, user, d_cand, ldc,
+            d_user, ldu, B, C, d / 4);
+  return check_launch("nr_score_ce_bwd");
+}
+
+int nr_rows_to_f32(const uint16_t* src, int64_t ld, int d, float* dst, int64_t ldd, int64_t n, void* stream) {
+  if (!src || !dst || n < 0 || d <= 0 || (d & 3) || ld < d || ldd < d || (ld & 3) || (ldd & 3))
+    return fail(NR_ERR_BADARG, "nr_rows_to_f32: bad argument (d and the row strides must be multiples of 4)");
+  if (((uintptr_t)src & 7) != 0 || ((uintptr_t)dst & 15) != 0) return fail(NR_ERR_BADARG, "nr_rows_to_f32: misaligned buffer");
+  if (n == 0) return NR_OK;
+  NR_LAUNCH(nr::rows_to_f32_kernel, grid_for(n * (d / 4), 256, 8192), 256, 0, (hipStream_t)stream, src, ld, d / 4, dst, ldd, n);
+  return check_launch("nr_rows_to_f32");
+}
+
+int nr_accum_many(const nr_accum_item* items, int n_items, void* stream) {
+  if (n_items < 0 || (n_items > 0 && !items)) return fail(NR_ERR_BADARG, "nr_accum_many: bad argument");
+  static_assert(sizeof(nr_accum_item) == sizeof(nr::AccumItem), "nr_accum_item layout");
+  for (int base = 0; base < n_items; base += nr::ACCUM_MAX_ITEMS) {
+    const int n = n_items - base < nr::ACCUM_MAX_ITEMS ? n_items - base : nr::ACCUM_MAX_ITEMS;
+    nr::AccumBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    int64_t biggest = 0;
+    for (int i = 0; i < n; ++i) {
+      const nr_accum_item& a = items[base + i];
+      if (!a.src || !a.dst || a.rows < 0 || a.cols < 0 || a.src_ld < a.cols || a.dst_ld < a.cols)
+        return fail(NR_ERR_BADARG, "nr_accum_many: bad item (null pointer, negative extent or a row stride below the row length)");
+      batch.it[i] = nr::AccumItem{a.src, a.dst, a.src_ld, a.dst_ld, a.rows, a.cols};
+      const int64_t e = (int64_t)a.rows * a.cols;
+      if (e > biggest) biggest = e;
+    }
+    if (biggest == 0) continue;
+    NR_LAUNCH2(nr::accum_many_kernel, grid_for(biggest, 1024, 64), n, 256, 0, (hipStream_t)stream, batch);
+  }
+  return check_launch("nr_accum_many");
 }
 
 int nr_score_dot(const float* cand, const float* user, float* out, int64_t B, int C, int d, void* stream) {

@@ -7,8 +7,8 @@ impressions/s the engine would starve behind it.  Here the two training files ar
   behaviors_parsed.tsv  -> index arrays: candidates ``[M, 1+K]`` (positive first, data_preprocess.py:63-66), LEFT-padded history
                            ``[M, N]`` (dataset.py:79-83), user id ``[M]``, clicked_news_length ``[M]``
 
-A batch is then two index gathers on the device and feeds ``model.forward_ids`` (the same stacked-id entry point the
-reference-format ``forward(list-of-dicts)`` reduces to).  Same sample semantics as BaseDataset.__getitem__.
+A batch is then one index gather per attribute on the device, already in the order the news encoder consumes (candidates, then history), and
+feeds ``model.forward_stacked`` (what ``forward_ids`` and the reference-format ``forward(list-of-dicts)`` reduce to).  Same sample semantics as BaseDataset.__getitem__.
 """
 from ast import literal_eval
 
@@ -57,20 +57,32 @@ class TrainData:
             yield self.batch(perm[i:i + batch_size])
 
     def batch(self, idx):
+        """The engine's batch layout (model.forward_stacked): per attribute ONE gather of the B*C candidate rows (impression-major) followed by
+        the B*N history rows -- the order the news encoder consumes them in, so that no concatenation follows."""
         di = idx.to(self.device)
         c, h = self.cand[di], self.hist[di]
-        b = {'cand': {a: t[c] for a, t in self.news.items()}, 'click': {a: t[h] for a, t in self.news.items()}}
+        rows = torch.cat([c.reshape(-1), h.reshape(-1)])
+        b = {'ids': {a: t[rows] for a, t in self.news.items()}, 'B': c.shape[0], 'C': c.shape[1]}
         if self.user is not None:
             b['user'] = self.user[di]
         b['length'] = self.length[idx]
         return b
 
 
-def forward_batch(model, b):
-    """Logits [B, 1+K] of a TrainData batch through the model's stacked-id entry point."""
+def split_batch(b):
+    """(cand, click) dicts of [B, C, ...] / [B, N, ...] views of a stacked batch (the layout forward_ids takes)."""
+    B, C = b['B'], b['C']
+    cand = {a: t[:B * C].view(B, C, *t.shape[1:]) for a, t in b['ids'].items()}
+    click = {a: t[B * C:].view(B, -1, *t.shape[1:]) for a, t in b['ids'].items()}
+    return cand, click
+
+
+def forward_batch(model, b, loss=False, target=None):
+    """Logits [B, 1+K] -- or, loss=True, the scalar cross entropy against `target` (None = class 0, train.py:205) -- of a TrainData batch through
+    the model's stacked-id entry point."""
     name = type(model).__name__
     if name == 'NRMS':
-        return model.forward_ids(b['cand']['title'], b['click']['title'])
+        return model.forward_stacked(b['ids']['title'], b['B'], b['C'], loss=loss, target=target)
     if name == 'LSTUR':
-        return model.forward_ids(b['user'], b['length'].clone(), b['cand'], b['click'])
-    return model.forward_ids(b['cand'], b['click'])
+        return model.forward_stacked(b['user'], b['length'].clone(), b['ids'], b['B'], b['C'], loss=loss, target=target)
+    return model.forward_stacked(b['ids'], b['B'], b['C'], loss=loss, target=target)

@@ -58,20 +58,28 @@ class LSTUR(torch.nn.Module):
         click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ATTRS}
         return self.forward_ids(user, clicked_news_length, cand, click)
 
-    def forward_ids(self, user, clicked_news_length, cand, click):
-        dev = self.user_embedding.weight.device
+    def forward_ids(self, user, clicked_news_length, cand, click, loss=False, target=None):
         B, C = cand['category'].shape
         N = click['category'].shape[1]
 
         def flat(k):
             a, b = cand[k], click[k]
             return self.news_encoder.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
-        vec = self.news_encoder.encode(flat('title'), flat('category'), flat('subcategory'))       # one kernel chain for all B*(C+N) news
-        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        return self.forward_stacked(user, clicked_news_length, {k: flat(k) for k in ATTRS}, B, C, loss=loss, target=target)
+
+    def forward_stacked(self, user, clicked_news_length, ids, B, C, loss=False, target=None):
+        """The engine's own batch layout (data_fast.TrainData builds it with one gather per attribute): ids = {attr: int64 [B*C + B*N, ...]} on
+        the device -- the candidates impression-major, then the history.  loss=True: the training loop's scalar `criterion(y_pred, y)`
+        (CrossEntropyLoss, mean; target None = class 0, train.py:186) from the fused scorer + loss kernels instead of the logits."""
+        N = ids['category'].shape[0] // B - C
+        vec = self.news_encoder.encode(ids['title'], ids['category'], ids['subcategory'])       # one kernel chain for all B*(C+N) news
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose consumers write their gradients into one buffer
         candidate_news_vector = cand_rows.view(B, C, -1)
         clicked_news_vector = click_rows.view(B, N, -1)
         user_row = self._user_rows(user, self.training)
         user_vector = self.user_encoder(user_row, clicked_news_length, clicked_news_vector)
+        if loss:
+            return ops.dot_score_ce(candidate_news_vector, user_vector, target)
         return self.click_predictor(candidate_news_vector, user_vector)
 
     def get_news_vector(self, news):

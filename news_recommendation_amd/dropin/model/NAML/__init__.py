@@ -30,7 +30,7 @@ class NAML(torch.nn.Module):
         click = {k: ops.stack_to_device([x[k] for x in clicked_news], dev, ne.table_rows(k), f"{k} id") for k in ne.attrs}
         return self.forward_ids(cand, click)
 
-    def forward_ids(self, cand, click):
+    def forward_ids(self, cand, click, loss=False, target=None):
         """Same on stacked id tensors: dicts of int64 [B, C, ...] / [B, N, ...] (host or device resident)."""
         ne = self.news_encoder
         k0 = ne.attrs[0]
@@ -40,11 +40,21 @@ class NAML(torch.nn.Module):
         def flat(k):
             a, b = cand[k], click[k]
             return ne.to_device(k, torch.cat([a.reshape(B * C, *a.shape[2:]), b.reshape(B * N, *b.shape[2:])], dim=0))
-        vec, vec_b = ne.encode_views({k: flat(k) for k in ne.attrs})
-        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        return self.forward_stacked({k: flat(k) for k in ne.attrs}, B, C, loss=loss, target=target)
+
+    def forward_stacked(self, ids, B, C, loss=False, target=None):
+        """The engine's own batch layout (data_fast.TrainData builds it with one gather per attribute): ids = {attr: int64 [B*C + B*N, ...]} on
+        the device -- the candidates impression-major, then the history.  loss=True: the training loop's scalar `criterion(y_pred, y)`
+        (CrossEntropyLoss, mean; target None = class 0, train.py:205) from the fused scorer + loss kernels instead of the logits."""
+        ne = self.news_encoder
+        N = ids[ne.attrs[0]].shape[0] // B - C
+        vec, vec_b = ne.encode_views(ids)
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose consumers write their gradients into one buffer
         candidate_news_vector = cand_rows.view(B, C, -1)
         clicked_news_vector = click_rows.view(B, N, -1)
         user_vector = self.user_encoder(clicked_news_vector, None if vec_b is None else vec_b[B * C:])
+        if loss:
+            return ops.dot_score_ce(candidate_news_vector, user_vector, target)
         return self.click_predictor(candidate_news_vector, user_vector)
 
     def get_news_vector(self, news):

@@ -30,7 +30,7 @@ class NRMS(torch.nn.Module):
         click = ops.stack_to_device([x["title"] for x in clicked_news], w.device, w.shape[0], "title token id")        # [B, N, L]
         return self.forward_ids(cand, click)
 
-    def forward_ids(self, cand, click):
+    def forward_ids(self, cand, click, loss=False, target=None):
         """Same as forward() on already-stacked id tensors: cand int64 [B, C, L], click int64 [B, N, L]
         (host or device resident)."""
         dev = self.news_encoder.word_embedding.weight.device
@@ -40,11 +40,21 @@ class NRMS(torch.nn.Module):
         ops.check_ids(cand, V, "title token id")
         ops.check_ids(click, V, "title token id")
         ids = torch.cat([cand.reshape(B * C, L), click.reshape(B * N, L)], dim=0).to(dev, non_blocking=True)
+        return self.forward_stacked(ids, B, C, loss=loss, target=target)
+
+    def forward_stacked(self, ids, B, C, loss=False, target=None):
+        """The engine's own batch layout (news_recommendation_amd.data_fast.TrainData builds it with one gather): ids int64 [B*C + B*N, L] on the
+        device -- the candidates' titles impression-major, then the history titles.  loss=False: the click logits [B, C] of forward();
+        loss=True: the training loop's scalar `criterion(y_pred, y)` (CrossEntropyLoss, mean; y = target int64 [B] on the device, None = class 0
+        as train.py:205 builds it) from the fused scorer + loss kernels (ops.dot_score_ce)."""
+        N = ids.shape[0] // B - C
         vec = self.news_encoder.encode_ids(ids)                               # [B*(C+N), D]
-        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose backward is one concatenation
+        cand_rows, click_rows = ops.split_rows(vec, B * C)           # slices whose consumers write their gradients into one buffer
         candidate_news_vector = cand_rows.view(B, C, -1)
         clicked_news_vector = click_rows.view(B, N, -1)
         user_vector = self.user_encoder(clicked_news_vector)
+        if loss:
+            return ops.dot_score_ce(candidate_news_vector, user_vector, target)
         return self.click_predictor(candidate_news_vector, user_vector)
 
     def get_news_vector(self, news):

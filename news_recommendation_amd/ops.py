@@ -502,13 +502,115 @@ _deferred = []
 
 
 def run_deferred():
-    """Run (and forget) the postponed weight-gradient phases of the backward passes since the last call, in their backward order."""
+    """Run (and forget) the postponed weight-gradient phases of the backward passes since the last call, in their backward order; then hand
+    the gradients they (or a backward outside autograd's engine) queued to their buffers (flush_grads)."""
     while _deferred:
         _deferred.pop(0)()
+    flush_grads()
 
 
 def drop_deferred():
     _deferred.clear()
+    _gq.clear()
+
+
+# ---- small weight gradients of a backward pass -> the trainer's persistent gradient buffers, in ONE launch ---------------------------------
+# autograd hands every gradient a backward returns to an AccumulateGrad node: one element-wise add per parameter (21 launches per NAML step,
+# 10 per LSTUR step, each a few microseconds of work behind a launch).  When the trainer owns a persistent buffer for every parameter of a group
+# (inplace_grads), the backward functions queue (buffer, gradient view) pairs here instead and return None; the queue is flushed by one
+# nr_accum_many launch when autograd's engine finishes the pass (Engine.queue_callback), i.e. before loss.backward() returns.
+_gq = []
+_gq_armed = False
+
+
+class _AccumItem(_capi.ctypes.Structure):
+    _fields_ = [('src', _capi.ctypes.c_void_p), ('dst', _capi.ctypes.c_void_p), ('src_ld', _capi.ctypes.c_int64), ('dst_ld', _capi.ctypes.c_int64),
+                ('rows', _capi.ctypes.c_int32), ('cols', _capi.ctypes.c_int32)]
+
+
+def _accum_geometry(t):
+    """(rows, cols, ld) of a 1-D / 2-D float32 view whose rows are contiguous, or None."""
+    if t.dim() == 1:
+        n = t.shape[0]
+        return (1, n, n) if (n <= 1 or t.stride(0) == 1) else (n, 1, t.stride(0))
+    if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1):
+        return (t.shape[0], t.shape[1], max(t.stride(0), t.shape[1]) if t.shape[0] > 1 else t.shape[1])
+    return None
+
+
+def queue_grad(dst, src):
+    """dst += src at the end of the running backward pass (or at the next flush_grads()).  dst: a view of a persistent gradient buffer, src: the
+    gradient (any float32 view of the same shape; 1-D / 2-D views with contiguous rows go in as they are, anything else through a copy)."""
+    if src.dtype != torch.float32:
+        src = src.to(torch.float32)
+    if tuple(dst.shape) != tuple(src.shape):
+        src = src.reshape(dst.shape)
+    if dst.dim() > 2 or _accum_geometry(dst) is None:
+        if not dst.is_contiguous():
+            raise ValueError("queue_grad: the destination must be a contiguous buffer or a 1-D / 2-D view with contiguous rows")
+        dst = dst.view(-1, dst.shape[-1]) if dst.dim() > 1 else dst
+        src = src.reshape(dst.shape)
+    if _accum_geometry(src) is None:
+        src = src.contiguous()
+    _gq.append((dst, src))
+    _arm_flush()
+
+
+def _arm_flush():
+    global _gq_armed
+    if _gq_armed:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_from_engine)
+        _gq_armed = True
+    except RuntimeError:
+        pass                 # not inside a backward pass (a postponed phase run by run_deferred(), a direct call): the caller flushes
+
+
+def _flush_from_engine():
+    global _gq_armed
+    _gq_armed = False
+    flush_grads()
+
+
+def flush_grads():
+    """Issue the queued accumulations now (one launch per 48 items; items that share a destination go into successive launches)."""
+    global _gq_armed
+    if not _gq:
+        return
+    todo = list(_gq)
+    _gq.clear()
+    while todo:
+        seen, now, rest = set(), [], []
+        for d, s_ in todo:
+            key = d.data_ptr()
+            (rest if key in seen else now).append((d, s_))
+            seen.add(key)
+        arr = (_AccumItem * len(now))()
+        for i, (d, s_) in enumerate(now):
+            rd, cd, ldd = _accum_geometry(d)
+            rs, cs, lds = _accum_geometry(s_)
+            if (rd, cd) != (rs, cs):                 # same elements, different 2-D reading (a contiguous vector against a column): one of them is [n] x 1
+                if rd * cd != rs * cs or 1 not in (cd, cs):
+                    raise ValueError("queue_grad: incompatible views")
+                if cd != 1:
+                    rd, cd, ldd = cd, 1, 1
+                if cs != 1:
+                    rs, cs, lds = cs, 1, 1
+            arr[i] = _AccumItem(s_.data_ptr(), d.data_ptr(), lds, ldd, rd, cd)
+        _call('nr_accum_many', _lib().nr_accum_many, _capi.ctypes.cast(arr, _capi.ctypes.c_void_p), len(now), _stream())
+        todo = rest
+
+
+def hand_over_grads(params, vals):
+    """The values a backward returns for ``params``: the gradients themselves for plain autograd; (None, ...) after queueing them for the
+    trainer's persistent buffers when it owns one for every parameter (inplace_grads)."""
+    dst = inplace_grads(params)
+    if dst is None:
+        return tuple(vals)
+    for d, v in zip(dst, vals):
+        queue_grad(d, v)
+    return (None,) * len(params)
 
 
 def inplace_grads(params):
@@ -775,7 +877,11 @@ class _EncoderFn(torch.autograd.Function):
                       _ptr(tdst), table.shape[0], ntok, p_drop, seed, _stream())
                 table_grad_ready(ctx.table_param)
         elif ctx.needs_input_grad[2]:
-            d_x = dX[:, :NR_D].float().view(n_seq, S, NR_D)
+            # f32 in the layout of x; when x is the history part of split_rows(), straight into its half of the shared gradient buffer
+            d_x = grad_dst(xd, (n_seq, S, NR_D)) if xd is not None else None
+            if d_x is None:
+                d_x = torch.empty(n_seq, S, NR_D, dtype=torch.float32, device=dev)
+            _call('nr_rows_to_f32[dx]', lib.nr_rows_to_f32, _ptr(dX), NR_KP, NR_D, _ptr(d_x), NR_D, ntok, _stream())
         # ---- phase 2: the nine weight gradients.  dWa_ext = dpre^T @ [ctx | 1] and dW_ext = dqkv^T @ [X | 1]: split-K ring kernel (csrc/k_gemm.h),
         # partials [P, rows, KP]; column D = bias gradient (ctx[:, D] == X[:, D] == 1).  A trainer with persistent gradient buffers: summed over the
         # partitions and accumulated there in one launch; plain autograd: sums, then slices of the packed geometry that AccumulateGrad adds ------
@@ -796,7 +902,7 @@ class _EncoderFn(torch.autograd.Function):
                 phase2()
             return (None, d_table, d_x) + (None,) * 13
         dWa_parts, dW_parts = weight_grads()
-        d_qv = dq_part.sum(dim=0)[:qdim]
+        d_qv = sum_parts(dq_part)[:qdim]
         dWa_ext = dWa_parts[0] if dWa_parts.shape[0] == 1 else dWa_parts.sum(dim=0)
         dW_ext = dW_parts[0] if dW_parts.shape[0] == 1 else dW_parts.sum(dim=0)
         d_Wa, d_ba = dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D]
@@ -840,19 +946,67 @@ def encode_dense(x, mhsa, additive):
 class _SplitRowsFn(torch.autograd.Function):
     """x[:n], x[n:] for the models' "one encoder pass over candidates + history" layout.  Plain slicing makes autograd build each part's
     gradient as a zero-filled full-size tensor with the slice copied in, and then add the two (5 kernels over 32 MB buffers per NRMS
-    step); the backward here is one concatenation."""
+    step); the backward here is one concatenation -- or none at all: the consumers of the two parts (the scorer for the candidates, the user
+    encoder's first stage for the history) ask grad_dst() where their input gradient should go and write it into the two halves of ONE
+    buffer, which the backward then returns as it is."""
 
     @staticmethod
     def forward(ctx, x, n):
-        return x[:n], x[n:]
+        a, b = x[:n], x[n:]
+        if x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous():
+            ctx.key = (a.data_ptr(), b.data_ptr())
+            slot = {'shape': tuple(x.shape), 'n': n, 'buf': None, 'device': x.device}
+            _grad_dst[ctx.key[0]] = (slot, 0)
+            _grad_dst[ctx.key[1]] = (slot, 1)
+            while len(_grad_dst) > 16:                    # forwards that never ran a backward
+                _grad_dst.pop(next(iter(_grad_dst)))
+        else:
+            ctx.key = None
+        return a, b
 
     @staticmethod
     def backward(ctx, ga, gb):
+        slot = None
+        if ctx.key is not None:
+            e = _grad_dst.pop(ctx.key[0], None)
+            _grad_dst.pop(ctx.key[1], None)
+            slot = e[0] if e is not None else None
+        buf = slot['buf'] if slot is not None else None
+        if buf is not None and ga is not None and gb is not None:
+            n = slot['n']
+            if (ga.data_ptr() == buf.data_ptr() and gb.data_ptr() == buf[n:].data_ptr() and ga.is_contiguous() and gb.is_contiguous()
+                    and ga.dtype == buf.dtype and gb.dtype == buf.dtype and ga.numel() + gb.numel() == buf.numel()):
+                return buf, None                           # both consumers wrote in place
         return torch.cat([ga, gb], dim=0), None
 
 
+_grad_dst = collections.OrderedDict()          # data_ptr of a split_rows() part -> (slot, which part)
+
+
+def grad_dst(x, shape=None):
+    """Where the gradient with respect to ``x`` should be written, if ``x`` is (a view of) a part returned by split_rows(): a float32 view of
+    the shared gradient buffer, shaped like ``x`` (or like ``shape``, same element count); None = allocate your own.  Looked up by address, so a
+    reshaped view of the part finds it too.  Only valid during the backward pass of the step that produced ``x``."""
+    e = _grad_dst.get(x.data_ptr())
+    if e is None or not _GRAD_DST:
+        return None
+    slot, which = e
+    n = slot['n']
+    rows, cols = slot['shape']
+    part_rows = n if which == 0 else rows - n
+    if x.numel() != part_rows * cols or x.dtype != torch.float32 or not x.is_contiguous():
+        return None
+    if slot['buf'] is None:
+        slot['buf'] = torch.empty(rows, cols, dtype=torch.float32, device=slot['device'])
+    part = slot['buf'][:n] if which == 0 else slot['buf'][n:]
+    return part.view(shape if shape is not None else x.shape)
+
+
+_GRAD_DST = os.environ.get('NR_GRAD_DST', '1') == '1'           # A/B knob: 0 = every consumer allocates its own input gradient (one concatenation more)
+
+
 def split_rows(x, n):
-    """(x[:n], x[n:]) with a single-kernel backward."""
+    """(x[:n], x[n:]) with a single-kernel (or no-kernel) backward."""
     return _SplitRowsFn.apply(x, int(n))
 
 
@@ -869,6 +1023,7 @@ class _DotScoreFn(torch.autograd.Function):
         out = torch.empty(B, C, dtype=torch.float32, device=cand.device)
         _call('nr_score_dot', _lib().nr_score_dot, _ptr(c), _ptr(u), _ptr(out), B, C, D, _stream())
         ctx.save_for_backward(c, u)
+        ctx.cand_in = cand if cand.data_ptr() == c.data_ptr() else None           # the caller's tensor: grad_dst() looks it up by address
         return out
 
     @staticmethod
@@ -876,9 +1031,58 @@ class _DotScoreFn(torch.autograd.Function):
         c, u = ctx.saved_tensors
         B, C, D = c.shape
         dl = dl.to(torch.float32).contiguous()
-        dc, du = torch.empty_like(c), torch.empty_like(u)
+        dc = grad_dst(ctx.cand_in) if ctx.cand_in is not None else None
+        if dc is None:
+            dc = torch.empty_like(c)
+        du = torch.empty_like(u)
         _call('nr_score_dot_bwd', _lib().nr_score_dot_bwd, _ptr(dl), _ptr(c), _ptr(u), _ptr(dc), _ptr(du), B, C, D, _stream())
         return dc, du
+
+
+class _DotScoreCEFn(torch.autograd.Function):
+    """mean cross entropy of the dot-product click scores (dot_product.py:8-19 + train.py:205-206) in two launches forward, one backward
+    (nr_score_ce_fwd / nr_score_ce_bwd) instead of scorer + log_softmax + nll_loss and their three backward kernels."""
+
+    @staticmethod
+    def forward(ctx, cand, user, target):
+        B, C, D = cand.shape
+        c, u = _f32c(cand), _f32c(user)
+        dev = cand.device
+        buf = torch.empty(2 * B * C + B + 1, dtype=torch.float32, device=dev)           # logits | dl | loss rows | loss
+        logits, dl, rows, loss = buf[:B * C], buf[B * C:2 * B * C], buf[2 * B * C:2 * B * C + B], buf[2 * B * C + B:]
+        _call('nr_score_ce_fwd', _lib().nr_score_ce_fwd, _ptr(c), _ptr(u), _ptr(target), _ptr(logits), _ptr(dl), _ptr(rows), _ptr(loss),
+              B, C, D, _stream())
+        ctx.save_for_backward(c, u, dl)
+        ctx.cand_in = cand if cand.data_ptr() == c.data_ptr() else None           # the caller's tensor: grad_dst() looks it up by address
+        ctx.logits = logits.view(B, C)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        c, u, dl = ctx.saved_tensors
+        B, C, D = c.shape
+        g = g.to(torch.float32).contiguous()
+        dc = grad_dst(ctx.cand_in) if ctx.cand_in is not None else None
+        if dc is None:
+            dc = torch.empty_like(c)
+        du = torch.empty_like(u)
+        _call('nr_score_ce_bwd', _lib().nr_score_ce_bwd, _ptr(dl), _ptr(g), _ptr(c), _ptr(u), _ptr(dc), D, _ptr(du), D, B, C, D, _stream())
+        return dc, du, None
+
+
+def dot_score_ce(cand, user, target=None):
+    """CrossEntropyLoss()(DotProductClickPredictor()(cand, user), target), mean over the batch; target None = class 0 for every impression (what
+    the training loop builds with torch.zeros, train.py:205).  cand f32 [B, C, D], user f32 [B, D] on the GPU; target int64 [B] on the GPU."""
+    _require_cuda(cand, "candidate_news_vector")
+    B, C, D = cand.shape
+    if D % 4 or not 1 <= C <= 64 or B < 1:
+        raise NotImplementedError("dot_score_ce: feature dim must be a multiple of 4, 1..64 candidates per impression, a non-empty batch")
+    if target is not None:
+        _require_cuda(target, "target")
+        if target.dtype != torch.int64 or tuple(target.shape) != (B,):
+            raise ValueError("dot_score_ce: target must be int64 [B]")
+        target = target.contiguous()
+    return _DotScoreCEFn.apply(cand, user, target)
 
 
 def dot_score(cand, user):

@@ -168,7 +168,7 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
 
     def weight_part():
-        d_qv = dq_part.sum(dim=0)[:qdim]
+        d_qv = ops.sum_parts(dq_part)[:qdim]
         # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
         dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
         return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv
@@ -199,33 +199,48 @@ def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
     _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
     xstore = st.xstore
 
-    def weight_part():
+    def weight_part(dst=None):
         d_Wa, d_ba, d_qv = pool_w()
         # the three tap gradients as ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap
         # shift is a row offset of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three
         both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
         taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
-        d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
         d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
+        if dst is not None:
+            # the trainer's persistent buffers (ops.inplace_grads): tap w of the filter gradient is the strided sub-matrix [:, 0, w, :] of the
+            # [F, 1, 3, D] buffer -- queued as it is, no stacked copy
+            for w in range(3):
+                ops.queue_grad(dst[0][:, 0, w, :], taps[w][:NR_D, :NR_D])
+            for d_, v in zip(dst[1:], (d_conv_b, d_Wa, d_ba, d_qv)):
+                ops.queue_grad(d_, v)
+            return None
+        d_conv_w = torch.stack([t[:NR_D, :NR_D] for t in taps], dim=1).unsqueeze(1)      # [F, 1, 3, D]
         return d_conv_w, d_conv_b, d_Wa, d_ba, d_qv
     return weight_part if later else weight_part()
 
 
 def finish_weight_grads(parts):
-    """parts: [(function -> gradients, the parameter objects they belong to), ...] of one backward call, in its order.  Plain autograd, or no
-    postponement asked for: evaluate now, return the gradients (flat tuple).  A trainer with persistent gradient buffers that asked for the
-    two-phase backward (ops.defer_wgrad): queue ONE postponed phase that evaluates them and accumulates into the parameters' .grad buffers
-    (what AccumulateGrad would do), and hand autograd None for each."""
+    """parts: [(function(dst) -> gradients, the parameter objects they belong to), ...] of one backward call, in its order.  Plain autograd:
+    evaluate now, return the gradients (flat tuple).  A trainer with persistent gradient buffers for all of them (ops.inplace_grads): the
+    functions queue their results for those buffers (ops.queue_grad: ONE accumulate launch at the end of the backward pass instead of one
+    AccumulateGrad add per parameter) and autograd gets None for each -- immediately, or, when the trainer asked for the two-phase backward
+    (ops.defer_wgrad), as ONE postponed phase."""
     params = [q for _, ps in parts for q in ps]
-    dst = ops.inplace_grads(params) if ops.defer_wgrad else None
+    dst = ops.inplace_grads(params)
     if dst is None:
         return tuple(v for fn, _ in parts for v in fn())
+    groups, k = [], 0
+    for fn, ps in parts:
+        groups.append((fn, dst[k:k + len(ps)]))
+        k += len(ps)
 
     def phase2():
-        vals = [v for fn, _ in parts for v in fn()]
-        for gbuf, v in zip(dst, vals):
-            gbuf.add_(v.reshape(gbuf.shape))
-    ops._deferred.append(phase2)
+        for fn, d_ in groups:
+            fn(d_)
+    if ops.defer_wgrad:
+        ops._deferred.append(phase2)
+    else:
+        phase2()
     return (None,) * len(params)
 
 
@@ -247,9 +262,9 @@ def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):
     return d_table
 
 
-def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row):
-    """dst[id] = sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row)."""
-    dst = torch.zeros(num_rows, NR_D, dtype=torch.float32, device=src.device)
+def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row, out=None):
+    """dst[id] += sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row); dst = out (accumulated into) or a fresh zeroed tensor."""
+    dst = torch.zeros(num_rows, NR_D, dtype=torch.float32, device=src.device) if out is None else out
     ids_sorted, perm = ops.sort_ids(ids, num_rows)
     _call('nr_scatter_sorted_f32', _lib().nr_scatter_sorted_f32, _ptr(ids_sorted), _ptr(perm), src.data_ptr() + col0 * 4, ld, _ptr(dst),
           num_rows, ids.numel(), pad_row, _stream())
@@ -296,7 +311,9 @@ class _NamlNewsFn(torch.autograd.Function):
             ctx.meta = (p, seed, Wa_f.shape[0])
             ctx.sorted = sort_tokens_async([title, abstract], table.shape[0]) if ctx.needs_input_grad[4] else None
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
+            ctx.small_params = (cat_table, W_c, b_c, W_s, b_s, Wa_f, ba_f, qv_f)         # the nn.Parameters: ops.hand_over_grads()
         ctx.mark_non_differentiable(out_b)
+        ctx.set_materialize_grads(False)             # the bf16 copy never has a gradient: do not fill 17 MB of zeros for it every step
         return out, out_b
 
     @staticmethod
@@ -307,6 +324,8 @@ class _NamlNewsFn(torch.autograd.Function):
         p, seed, qdim = ctx.meta
         dev = views.device
         T = title.shape[0]
+        if g_out is None:
+            return (None,) * 27
         g_out = g_out.to(torch.float32).contiguous()
         # final attention over the 4 views
         d_Waf, d_baf, d_qvf, dgemm = _pool_bwd(views, Wap, bap, qvp, aw, g_out, T, 4, qdim, 'views', WaT, y_ptr=_ptr(y), y_stride=y.stride(0))
@@ -314,7 +333,9 @@ class _NamlNewsFn(torch.autograd.Function):
         _call('nr_additive_dx[views]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g_out), _ptr(gv), T, 4, 1, _stream())
         # element encoders: reduce per category row, then the tiny table backward
         ncat, dcat = embf.shape
-        dE = torch.stack([_sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1), _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1)])
+        dE = torch.zeros(2, ncat, NR_D, dtype=torch.float32, device=dev)
+        _sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1, out=dE[0])
+        _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1, out=dE[1])
         dW = torch.empty(2, NR_D, dcat, dtype=torch.float32, device=dev)
         db = torch.empty(2, NR_D, dtype=torch.float32, device=dev)
         demb = torch.empty(ncat, dcat, dtype=torch.float32, device=dev)
@@ -329,7 +350,8 @@ class _NamlNewsFn(torch.autograd.Function):
         # the weight gradients of the two text encoders (pooling dWa, conv taps): after the scatter -- under data parallelism while the table flies
         wg = finish_weight_grads([(gt, st_t.params), (ga, st_a.params)])
         ctx.st = None
-        return (None, None, None, None, d_table, demb, *wg, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf, None, None, None, None)
+        small = ops.hand_over_grads(ctx.small_params, (demb, dW[0], db[0], dW[1], db[1], d_Waf, d_baf, d_qvf))
+        return (None, None, None, None, d_table, small[0], *wg, *small[1:], None, None, None, None)
 
 
 def naml_news(title, abstract, cat, sub, table, cat_table, text_t, text_a, elem_c, elem_s, final_att, p_drop, training):
@@ -368,6 +390,8 @@ class _PoolFn(torch.autograd.Function):
               _ptr(aw), n, S, valid, _stream())
         ctx.save_for_backward(x_b, aw, Wap, bap, qvp, None if ops.pool_flat_ok(S, False, n, qdim=Wa.shape[0]) else ops.pack_additive_t(Wa), out)
         ctx.qdim = Wa.shape[0]
+        ctx.x_ref = x.detach()                       # address of the input: ops.grad_dst()
+        ctx.wparams = (Wa, ba, qv)                   # the nn.Parameters: ops.hand_over_grads()
         return out
 
     @staticmethod
@@ -377,9 +401,11 @@ class _PoolFn(torch.autograd.Function):
         n, S = aw.shape
         g = g.to(torch.float32).contiguous()
         d_Wa, d_ba, d_qv, dgemm = _pool_bwd(x_b, Wap, bap, qvp, aw, g, n, S, ctx.qdim, f'user S={S}', WaT, y_ptr=_ptr(y), y_stride=y.stride(0))
-        dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
+        dx = ops.grad_dst(ctx.x_ref, (n, S, NR_D))
+        if dx is None:
+            dx = torch.empty(n, S, NR_D, dtype=torch.float32, device=g.device)
         _call('nr_additive_dx[user]', lib.nr_additive_dx, _ptr(dgemm), NR_KP, _ptr(aw), _ptr(g), _ptr(dx), n, S, 0, _stream())
-        return dx, None, d_Wa, d_ba, d_qv, None
+        return (dx, None, *ops.hand_over_grads(ctx.wparams, (d_Wa, d_ba, d_qv)), None)
 
 
 def pool_rows(x, x_b, additive):
@@ -431,6 +457,7 @@ class _LsturNewsFn(torch.autograd.Function):
             ctx.meta = (p, seed, cat_table.shape[0])
             ctx.sorted = sort_tokens_async([title], table.shape[0]) if ctx.needs_input_grad[3] else None
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
+            ctx.cat_param = cat_table
         return out
 
     @staticmethod
@@ -442,13 +469,15 @@ class _LsturNewsFn(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         T = title.shape[0]
         # category_embedding (padding_idx = 0): two segmented reductions over column blocks of g
-        d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0) + _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0)
+        d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0)
+        _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0, out=d_cat)
         g_title = g[:, 2 * NR_D:].contiguous()
         dx = _workspace('dx_tok', (title.numel(), NR_KP), _BF16_AS_I16, dev)
         gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title', later=True)
         d_table = embed_scatter(ctx.sorted, title.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[3] else None
         wg = finish_weight_grads([(gt, st.params)])
         ctx.st = None
+        (d_cat,) = ops.hand_over_grads((ctx.cat_param,), (d_cat,))
         return (None, None, None, d_table, d_cat, *wg, None, None, None)
 
 

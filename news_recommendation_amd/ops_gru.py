@@ -79,6 +79,31 @@ def _wih_t(Wih_p, Hg, Ip, Kp):
     return ops._packed('gru_wih_t', (Wih_p,), build)
 
 
+# The state history H_all bf16 [T + 1][B][Hp] (48 MB at B = 512, N = 50, Hd = 900) is written by the sweep in every column <= Hd of every row,
+# every call; only the padding columns rely on a zero fill.  The buffer of the last call is therefore reused as it is (no 48 MB fill per step)
+# once its backward has run; a forward that arrives while it is still owed to a backward gets a fresh zero-filled one.
+_hall = {}
+
+
+def _hall_take(T, B, Hp, dev):
+    key = (T, B, Hp, dev)
+    e = _hall.get(key)
+    if e is not None and not e[1]:
+        e[1] = True
+        return e[0]
+    t = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
+    if len(_hall) > 4:
+        _hall.clear()
+    _hall[key] = [t, True]
+    return t
+
+
+def _hall_release(t):
+    for e in _hall.values():
+        if e[0] is t or e[0].data_ptr() == t.data_ptr():
+            e[1] = False
+
+
 class _GruFn(torch.autograd.Function):
     """h_last[b] = GRU state after consuming x[b, 0:len[b]] starting from h0[b] (len >= 1)."""
 
@@ -105,7 +130,7 @@ class _GruFn(torch.autograd.Function):
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
         # hoisted input projection [B*N][3*Hg] f32, hand-written NT kernel (csrc/k_gemm.h): K = Ip (column I of Xb is 1.0, of W_ih the padding 0)
         gi = ops.gemm_nt(Xb, Wih_p, B * N, 3 * Hg, Ip, 'nr_gemm_nt_gru_gi')
-        H_all = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
+        H_all = _hall_take(T, B, Hp, dev) if need_grad else torch.zeros(1, B, Hp, dtype=_BF16_AS_I16, device=dev)
         hf = torch.zeros(2, B, Hp, dtype=torch.float32, device=dev)
         if h0 is not None:
             hf[0][:, :Hd].copy_(h0)
@@ -125,6 +150,8 @@ class _GruFn(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(Xb, H_all, gates, lens_dev, Wih_p, WhhT)
             ctx.meta = (B, N, I, Hd, T, h0 is not None)
+            ctx.x_ref = x.detach()                           # address of the input: ops.grad_dst()
+            ctx.wparams = (W_ih, W_hh, b_ih, b_hh)           # the nn.Parameters: ops.inplace_grads()
         return out
 
     @staticmethod
@@ -153,9 +180,22 @@ class _GruFn(torch.autograd.Function):
         d_x = None
         if ctx.needs_input_grad[0]:
             WihT = _wih_t(Wih_p, Hg, Ip, Kp)
-            d_x = ops.gemm_nt(dgi, WihT, B * N, I, Kp, 'nr_gemm_nt_gru_dx').view(B, N, I)
+            # when x is the history part of split_rows(): straight into its half of the shared gradient buffer
+            d_x = ops.gemm_nt(dgi, WihT, B * N, I, Kp, 'nr_gemm_nt_gru_dx', out=ops.grad_dst(ctx.x_ref, (B * N, I))).view(B, N, I)
         dWi = ops.sum_parts(ops.gemm_tn_parts(dgi, Kp, Xb, Ip, 'nr_gemm_tn_gru_dWih'))                      # [Kp][Ip]; col I = bias gradient
         dWh = ops.sum_parts(ops.gemm_tn_parts(dgh.view(T * B, Kp), Kp, H_all.view((T + 1) * B, Hp), Hp, 'nr_gemm_tn_gru_dWhh', n_tok=T * B))      # [Kp][Hp]; col Hd = bias gradient
+        _hall_release(H_all)                                 # last reader on the stream: the next forward may overwrite it
+        dst = ops.inplace_grads(ctx.wparams) if all(ctx.needs_input_grad[4:8]) else None
+        if dst is not None:
+            # the trainer's persistent buffers: gate q of each gradient is a row block of the padded product -- twelve strided items of the
+            # backward pass's ONE accumulate launch (ops.queue_grad) instead of four concatenations and four AccumulateGrad adds
+            for q in range(3):
+                rows = slice(q * Hg, q * Hg + Hd)
+                ops.queue_grad(dst[0][q * Hd:(q + 1) * Hd], dWi[rows, :I])
+                ops.queue_grad(dst[1][q * Hd:(q + 1) * Hd], dWh[rows, :Hd])
+                ops.queue_grad(dst[2][q * Hd:(q + 1) * Hd], dWi[rows, I])
+                ops.queue_grad(dst[3][q * Hd:(q + 1) * Hd], dWh[rows, Hd])
+            return (d_x, d_h0, None, None, None, None, None, None)
         unpad = lambda m, ncol: torch.cat([m[q * Hg:q * Hg + Hd, :ncol] for q in range(3)], dim=0)
         return (d_x, d_h0, None, None, unpad(dWi, I), unpad(dWh, Hd), unpad(dWi, I + 1)[:, I].contiguous(), unpad(dWh, Hd + 1)[:, Hd].contiguous())
 

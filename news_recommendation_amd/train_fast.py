@@ -97,7 +97,6 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
     n_total = data.n_total
     if rank == 0:
         log(f"Load training dataset with size {n_total}.")
-    criterion = torch.nn.CrossEntropyLoss()
     # Adam with the reference's hyper-parameters (train.py:127-128) on the engine's flat buffers: fused update kernel, gradient exchange
     # overlapped with the backward, LSTUR's user table as a row-sparse table; state_dict() keeps torch.optim.Adam's format
     optimizer = EngineAdam(model, lr=config.learning_rate, row_sparse=('user_embedding.weight',) if model_name == 'LSTUR' else ())
@@ -122,7 +121,6 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
     if max_steps is not None:
         n_iter = min(n_iter, max_steps)
     it = data.batches(per_rank_batch)
-    target = torch.zeros(per_rank_batch, dtype=torch.long, device=device)
     # train.py:225,241-244 appends loss.item() every step (a device->host sync per step); here the running sum and the last 256 losses
     # stay on the device and are read only on the steps that print
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
@@ -138,7 +136,7 @@ def train(model_name, config, workdir='.', max_steps=None, log=print):
     window = []                           # (iteration, optimiser step index, batch) since the last look
 
     def train_step(b):
-        loss = criterion(forward_batch(model, b), target)
+        loss = forward_batch(model, b, loss=True)           # scorer + CrossEntropyLoss against class 0 (train.py:205-206) as one kernel pair
         loss.backward()                   # table all-reduce starts inside; gradients accumulate into the optimiser's flat buffer
         optimizer.step()                  # remaining exchange + fused Adam (clears the gradients: no zero_grad pass)
         return loss.detach()

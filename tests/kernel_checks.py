@@ -622,6 +622,91 @@ def check_score_bwd(be, B=33, C=3):
     np.testing.assert_allclose(be.np(du), np.einsum('bc,bcd->bd', dl, cand), rtol=1e-5, atol=1e-5)
 
 
+def check_score_ce(be, B=33, C=3, with_target=False, with_scale=False, ld_extra=0):
+    """nr_score_ce_fwd / nr_score_ce_bwd against DotProductClickPredictor + CrossEntropyLoss in float64 (dot_product.py:8-19, train.py:205-206):
+    logits bit-identical to nr_score_dot, the mean loss, the logit gradient, and the vector gradients written with row strides."""
+    import ctypes
+    rng = np.random.default_rng(41)
+    cand = rng.normal(size=(B, C, NR_D)).astype(np.float32) * 0.2
+    user = rng.normal(size=(B, NR_D)).astype(np.float32) * 0.2
+    target = rng.integers(0, C, size=B).astype(np.int64) if with_target else np.zeros(B, dtype=np.int64)
+    dc_, du_ = be.dev(cand), be.dev(user)
+    t_ = be.dev(target) if with_target else None
+    ref_logits_dev = be.poison((B, C), np.float32)
+    ck(be, be.lib.nr_score_dot(be.ptr(dc_), be.ptr(du_), be.ptr(ref_logits_dev), B, C, NR_D, be.stream))
+    logits = be.poison((B, C), np.float32); dl = be.poison((B, C), np.float32)
+    rows = be.poison((B,), np.float32); loss = be.poison((1,), np.float32)
+    ck(be, be.lib.nr_score_ce_fwd(be.ptr(dc_), be.ptr(du_), be.ptr(t_) if with_target else None, be.ptr(logits), be.ptr(dl), be.ptr(rows),
+                                  be.ptr(loss), B, C, NR_D, be.stream))
+    be.sync()
+    assert np.array_equal(be.np(logits), be.np(ref_logits_dev))                     # bit exact
+    lg = onp.dot_score(cand.astype(np.float64), user.astype(np.float64))
+    m = lg.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(lg - m).sum(axis=1)) + m[:, 0]
+    ref_rows = lse - lg[np.arange(B), target]
+    sm = np.exp(lg - lse[:, None])
+    ref_dl = sm.copy(); ref_dl[np.arange(B), target] -= 1.0; ref_dl /= B
+    np.testing.assert_allclose(be.np(rows), ref_rows, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(be.np(loss)[0], ref_rows.mean(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(be.np(dl), ref_dl, rtol=2e-4, atol=2e-7)
+    # backward, into strided destinations
+    ldc, ldu = NR_D + ld_extra, NR_D + 2 * ld_extra
+    g = np.array([0.37], dtype=np.float32) if with_scale else None
+    dcand = be.poison((B * C, ldc), np.float32); duser = be.poison((B, ldu), np.float32)
+    ck(be, be.lib.nr_score_ce_bwd(be.ptr(dl), be.ptr(be.dev(g)) if with_scale else None, be.ptr(dc_), be.ptr(du_), be.ptr(dcand), ldc,
+                                  be.ptr(duser), ldu, B, C, NR_D, be.stream))
+    be.sync()
+    gs = 0.37 if with_scale else 1.0
+    dlv = be.np(dl).astype(np.float64) * np.float64(np.float32(gs))
+    np.testing.assert_allclose(be.np(dcand)[:, :NR_D].reshape(B, C, NR_D), dlv[:, :, None] * user[:, None, :], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(be.np(duser)[:, :NR_D], np.einsum('bc,bcd->bd', dlv, cand), rtol=1e-5, atol=1e-8)
+    # bad arguments: C beyond one wave, misaligned d
+    assert be.lib.nr_score_ce_fwd(be.ptr(dc_), be.ptr(du_), None, None, be.ptr(dl), be.ptr(rows), be.ptr(loss), B, 65, NR_D, be.stream) == -2
+    assert be.lib.nr_score_ce_fwd(be.ptr(dc_), be.ptr(du_), None, None, be.ptr(dl), be.ptr(rows), be.ptr(loss), B, C, NR_D + 2, be.stream) == -2
+
+
+def check_rows_to_f32(be, n=37):
+    rng = np.random.default_rng(44)
+    src = bf16_round(rng.normal(size=(n, NR_KP)).astype(np.float32))
+    dst = be.poison((n, NR_D + 8), np.float32)
+    before = be.np(dst).copy()
+    ck(be, be.lib.nr_rows_to_f32(be.ptr(be.dev(f32_to_bf16(src))), NR_KP, NR_D, be.ptr(dst), NR_D + 8, n, be.stream))
+    be.sync()
+    got = be.np(dst)
+    assert np.array_equal(got[:, :NR_D], src[:, :NR_D])
+    assert np.array_equal(got[:, NR_D:].view(np.uint32), before[:, NR_D:].view(np.uint32))          # columns beyond d untouched
+
+
+def check_accum_many(be, n_items=5):
+    """nr_accum_many: dst[r, c] += src[r, c] over strided sub-matrices, all items in one launch; more items than one launch holds."""
+    import ctypes
+    rng = np.random.default_rng(43)
+
+    class Item(ctypes.Structure):
+        _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('src_ld', ctypes.c_int64), ('dst_ld', ctypes.c_int64),
+                    ('rows', ctypes.c_int32), ('cols', ctypes.c_int32)]
+    items = (Item * n_items)()
+    keep = []
+    for i in range(n_items):
+        rows, cols = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        if i == 0:
+            rows, cols = 300, 301
+        if i == 1:
+            rows, cols = 1, 1
+        sld, dld = cols + int(rng.integers(0, 9)), cols + int(rng.integers(0, 5))
+        src = rng.normal(size=(rows, sld)).astype(np.float32); dst = rng.normal(size=(rows, dld)).astype(np.float32)
+        hs, hd = be.dev(src), be.dev(dst)
+        items[i] = Item(be.ptr(hs), be.ptr(hd), sld, dld, rows, cols)
+        keep.append((src, dst, hs, hd, rows, cols))
+    ck(be, be.lib.nr_accum_many(ctypes.cast(items, ctypes.c_void_p), n_items, be.stream))
+    be.sync()
+    for src, dst, hs, hd, rows, cols in keep:
+        ref = dst.copy(); ref[:, :cols] += src[:, :cols]
+        assert np.array_equal(be.np(hd), ref)              # one fp32 add per element: bit exact; columns beyond `cols` untouched
+    items[0].src_ld = 3
+    assert be.lib.nr_accum_many(ctypes.cast(items, ctypes.c_void_p), n_items, be.stream) == -2
+
+
 def check_mhsa_x_save(be, S=20, n_seq=7, V=300, p_drop=0.2, seed=99):
     """nr_mhsa_fwd_ex's x_save output == nr_gather_bf16 of the same ids / dropout stream (bit exact), ctx unchanged."""
     params = make_params(20, V)

@@ -64,7 +64,9 @@ def test_parsed_files_feed_the_engine_readers(tmp_path):
     assert len(data) > 0 and data.news['title'].shape[1] == 20 and data.news['abstract'].shape[1] == 50
     assert int(data.news['title'].max()) <= sizes[1] and int(data.news['category'].max()) <= sizes[0]
     b = data.batch(torch.arange(min(4, len(data))))
-    assert b['cand']['title'].shape[1:] == (3, 20) and b['click']['title'].shape[1:] == (50, 20)
+    from news_recommendation_amd.data_fast import split_batch
+    cand, click = split_batch(b)
+    assert b['ids']['title'].shape == (b['B'] * 53, 20) and cand['title'].shape[1:] == (3, 20) and click['title'].shape[1:] == (50, 20)
     plan = evaluate_fast.build_plan(os.path.join(root, 'data/val'), cfg.dataset_attributes['news'], 50,
                                     user2int_path=os.path.join(root, 'data/train/user2int.tsv'))
     assert len(plan.imp_user_row) == 80 and plan.cand_ptr[-1] == len(plan.cand_idx)

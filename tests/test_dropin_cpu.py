@@ -225,7 +225,10 @@ def test_pool_flat_dispatch_by_shape(monkeypatch):
     monkeypatch.setattr(ops, '_POOL_FLAT_MIN_TOK', 98304)
     q = dict(qdim=200)
     assert ops.pool_flat_ok(20, False, 27136, **q) and ops.pool_flat_ok(50, True, 28160, **q) and ops.pool_flat_ok(20, True, 28160, **q)
-    assert not ops.pool_flat_ok(4, False, 28160, **q)            # the four views of a NAML news item: 13 sequences in 48 tokens
+    monkeypatch.setattr(ops, '_POOL_FLAT_SHORT', True)
+    assert ops.pool_flat_ok(4, False, 28160, **q) and not ops.pool_flat_ok(3, False, 40000, **q)     # the four views of a NAML news item: 13 sequences in 48 tokens (second slot tile, round 6)
+    monkeypatch.setattr(ops, '_POOL_FLAT_SHORT', False)
+    assert not ops.pool_flat_ok(4, False, 28160, **q)            # NR_POOL_FLAT_VIEWS=0: the sequence-shaped kernel at the view level
     assert ops.pool_flat_ok(7, False, 20000, **q) and not ops.pool_flat_ok(15, True, 20000, **q) and ops.pool_flat_ok(16, True, 20000, **q)
     assert not ops.pool_flat_ok(50, False, 512, **q)             # 512 click histories: the sequence-shaped kernel is faster
     assert ops.pool_flat_ok(50, False, **q)                      # shape-only question (operands packed before the batch is known)

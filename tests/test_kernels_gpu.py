@@ -62,6 +62,12 @@ def test_wgrad_unpack_small_qdim(be): kc.check_wgrad_unpack(be, nc_w=1, nc_a=1, 
 def test_gather_bf16(be): kc.check_gather_bf16(be, n_tokens=100003, V=5000)
 def test_scatter_add(be): kc.check_scatter_add(be, n_tokens=200001, V=3000)
 def test_score_bwd(be): kc.check_score_bwd(be, B=513)
+def test_score_ce(be): kc.check_score_ce(be, B=513, C=3)
+def test_score_ce_target_scale_strided(be): kc.check_score_ce(be, B=130, C=5, with_target=True, with_scale=True, ld_extra=600)
+def test_score_ce_64(be): kc.check_score_ce(be, B=7, C=64, with_target=True)
+def test_rows_to_f32(be): kc.check_rows_to_f32(be, n=25601)
+def test_accum_many(be): kc.check_accum_many(be, n_items=21)
+def test_accum_many_two_launches(be): kc.check_accum_many(be, n_items=53)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be, n_tokens=200001, V=3000)
 def test_dropout_under_step_counter(be): kc.check_dropout_under_step_counter(be)
 def test_scatter_sorted_nodrop(be): kc.check_scatter_sorted(be, n_tokens=54321, V=70976, p_drop=0.0)

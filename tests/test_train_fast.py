@@ -23,7 +23,7 @@ os.chdir(workdir)
 import config as ref_config
 import dataset as ref_dataset                                   # the reference's dataset.py (read-only)
 from news_recommendation_amd import default_config
-from news_recommendation_amd.data_fast import TrainData
+from news_recommendation_amd.data_fast import TrainData, split_batch
 rc = getattr(ref_config, model_name + 'Config'); dc = getattr(default_config, model_name + 'Config')
 for k in dir(dc):
     if not k.startswith('_'):
@@ -33,6 +33,7 @@ td = TrainData('data/train/behaviors_parsed.tsv', 'data/train/news_parsed.tsv', 
 assert len(ds) == len(td)
 idx = torch.tensor([0, 3, len(ds) - 1, 7])
 b = td.batch(idx)
+b['cand'], b['click'] = split_batch(b)          # [B, C, ...] / [B, N, ...] views of the stacked layout
 for j, i in enumerate(idx.tolist()):
     it = ds[i]
     for c in range(len(it['candidate_news'])):

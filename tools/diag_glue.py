@@ -12,7 +12,7 @@ opt = wl.make_optimizer(model)
 crit = torch.nn.CrossEntropyLoss(); target = torch.zeros(512, dtype=torch.long, device=dev)
 batches = wl.batches(0, 2, 512, dev)
 def step(i):
-    loss = crit(wl.forward(model, batches[i % 2]), target); loss.backward(); opt.step()
+    loss = wl.loss(model, batches[i % 2], crit, target); loss.backward(); opt.step()
 for i in range(5): step(i)
 torch.cuda.synchronize()
 NS = 4
