@@ -333,6 +333,12 @@ int64_t nr_additive_bwd_flat_grid(int64_t n_tok);
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
                          float p_drop, int64_t n_seq, int S, int qdim, void* stream);
+/* Same with the sequence gradients as a column block of wider rows: row r of g_out starts at g_out + r*g_stride (floats; a multiple of 4, >= D,
+ * g_out 16-byte aligned).  LSTUR's news vector is [category row | subcategory row | title vector] (src/model/LSTUR/news_encoder.py:73-76): the
+ * title encoder's backward reads its third of the [n, 3F] gradient in place instead of from a contiguous copy. */
+int nr_additive_bwd_flat_gs(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
+                            int64_t g_stride, const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx,
+                            uint16_t* dy_pad, float p_drop, int64_t n_seq, int S, int qdim, void* stream);
 /* Profiling aid (tools/pool3_phases.py): with NR_POOL_DEBUG set, the debug instantiation of the flat kernel writes cycle-counter stamps of the
  * first 8 iterations of waves 0-1 of workgroups 0-3 to buf (device memory, 4 * 2 * 8 * 8 uint64, owned by the caller until it passes NULL
  * again, which switches the stamps off). */

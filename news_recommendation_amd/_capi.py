@@ -52,6 +52,7 @@ SIGNATURES = {
     'nr_debug_gru_stamps': ([_P], c_int),
     'nr_debug_gru_stamps_bwd': ([_P], c_int),
     'nr_additive_bwd_flat': ([_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_float, c_int64, c_int, c_int, _P], c_int),
+    'nr_additive_bwd_flat_gs': ([_P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_float, c_int64, c_int, c_int, _P], c_int),
     'nr_additive_bwd_ex': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_gather_bf16': ([_P, _P, c_int64, _P, _P, c_int64, c_float, c_uint64, _P], c_int),
     'nr_embed_scatter_add': ([_P, _P, c_int, _P, c_int64, c_int64, c_float, c_uint64, _P], c_int),

@@ -63,7 +63,8 @@ struct Pool3Params {
   const float* bap;      // [QP]
   const float* qvp;      // [QP]
   const float* attn_w;   // [n_tok]  forward attention weights
-  const float* g_out;    // [n_seq][D]
+  const float* g_out;    // [n_seq][D], row r at g_out + r * g_row_bytes / 4 (a column block of wider rows: LSTUR's [category | subcategory | title] gradient)
+  uint32_t g_row_bytes;  // >= D * 4, a multiple of 16
   const float* tot;      // [n_seq]  g_out[seq] . y[seq]
   u16* dpre;             // [n_tok][QP] bf16
   float* dq_part;        // [gridDim.x][QP]
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
     const int rowl = l >> 2;                   // + 16 t: the lane's row in the row-piece layout
     // every global access of the group: a buffer resource on the group's rows (rows past the end: loads give 0, stores vanish) + 32-bit offsets
     const BufRsrc r_aw = make_buf(p.attn_w + tok0, (uint32_t)(nrows * 4));
-    const BufRsrc r_g = make_buf(p.g_out, (uint32_t)(p.n_seq * (D * 4))), r_tot = make_buf(p.tot, (uint32_t)(p.n_seq * 4));
+    const BufRsrc r_g = make_buf(p.g_out, (uint32_t)((p.n_seq - 1) * p.g_row_bytes + D * 4)), r_tot = make_buf(p.tot, (uint32_t)(p.n_seq * 4));
     const BufRsrc r_dpre = make_buf(p.dpre + tok0 * QP, (uint32_t)(nrows * QP * 2));
     // dw[tok] = g_out[seq(tok)] . x[tok] on the matrix core: the group's rows belong to at most 8 sequences (S >= 7; 16 for S >= 3: a second tile), "slots" sq0 .. sq0 + 7.  A tile:
     // row li = (slot li >> 1, part li & 1) of g_out split into two bf16 numbers (g = hi + lo to 2^-17: the products with the bf16 rows are exact,
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
       f32x4 accg[MT], accg2[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) { accg[m] = f32x4{0.f, 0.f, 0.f, 0.f}; accg2[m] = accg[m]; }
-      uint32_t go = (sq0 + (uint32_t)(li >> 1)) * (uint32_t)(D * 4) + (uint32_t)(g * 32);      // (slots past the last sequence: outside the buffer, zeros)
+      uint32_t go = (sq0 + (uint32_t)(li >> 1)) * p.g_row_bytes + (uint32_t)(g * 32);      // (slots past the last sequence: outside the buffer, zeros)
       NR_OPAQUE(go);
       auto gstep = [&](auto ks_tag) {
         constexpr int ks = decltype(ks_tag)::value;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
           for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32_bf16(fr, xr[ks][m], acc[m]);
         };
         slots(go, accg);
-        if (two) slots(go + 8u * (uint32_t)(D * 4), accg2);
+        if (two) slots(go + 8u * p.g_row_bytes, accg2);
       };
       if (!(dbg & 2)) {
         gstep(IntTag<0>{}); gstep(IntTag<1>{}); gstep(IntTag<2>{}); gstep(IntTag<3>{}); gstep(IntTag<4>{});
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(Pool3Geom::THREADS) void pool3_bwd_kernel(Pool3Para
           const bool mine = (int)(seq_of(m * 16 + li) - sq0) == g;
           bd[m] = u16x4{mine ? ah : (u16)0, mine ? ah : (u16)0, mine ? al : (u16)0, 0};
         }
-        uint32_t gq = (sq0 + (uint32_t)g) * (uint32_t)(D * 4) + (uint32_t)(li * 4);
+        uint32_t gq = (sq0 + (uint32_t)g) * p.g_row_bytes + (uint32_t)(li * 4);
         NR_OPAQUE(gq);
         auto gload = [&](int dt) -> float { return dt * 16 + li < D ? buf_load4f(r_g, gq + (uint32_t)(dt * 64)) : 0.0f; };
         float gn = gload(0), gn2 = gload(1);      // two tiles ahead: the wait for a value then never covers the stores and row requests of the tile before

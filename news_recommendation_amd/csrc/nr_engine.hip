@@ -878,7 +878,7 @@ int nr_accum_many(const nr_accum_item* items, int n_items, void* stream) {
       if (e > biggest) biggest = e;
     }
     if (biggest == 0) continue;
-    NR_LAUNCH2(nr::accum_many_kernel, grid_for(biggest, 1024, 64), n, 256, 0, (hipStream_t)stream, batch);
+    NR_LAUNCH2(nr::accum_many_kernel, grid_for(biggest, 1024, 256), n, 256, 0, (hipStream_t)stream, batch);
   }
   return check_launch("nr_accum_many");
 }
@@ -1005,20 +1005,27 @@ int64_t nr_additive_bwd_flat_grid(int64_t n_tok) {
 int nr_additive_bwd_flat(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
                          const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx, uint16_t* dy_pad,
                          float p_drop, int64_t n_seq, int S, int qdim, void* stream) {
+  return nr_additive_bwd_flat_gs(ctx, Wap, bap, qvp, attn_w, g_out, NR_D, y, y_stride, tot, dpre, dq_part, dctx, dy_pad, p_drop, n_seq, S, qdim, stream);
+}
+
+int nr_additive_bwd_flat_gs(const uint16_t* ctx, const uint16_t* Wap, const float* bap, const float* qvp, const float* attn_w, const float* g_out,
+                            int64_t g_stride, const float* y, int64_t y_stride, float* tot, uint16_t* dpre, float* dq_part, uint16_t* dctx,
+                            uint16_t* dy_pad, float p_drop, int64_t n_seq, int S, int qdim, void* stream) {
   if (!ctx || !Wap || !bap || !qvp || !attn_w || !g_out || !y || !tot || !dpre || !dq_part || n_seq < 0 || (dctx && dy_pad) ||
-      y_stride < NR_D || (y_stride & 3))
+      y_stride < NR_D || (y_stride & 3) || g_stride < NR_D || (g_stride & 3) || ((uintptr_t)g_out & 15) != 0)
     return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: bad argument");
   if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: dropout probability out of range");
   if (qdim < 1 || qdim > NR_QP) return fail(NR_ERR_BADARG, "nr_additive_bwd_flat: query_vector_dim out of range");
   if (qdim > nr::Pool3Geom::WROWS)
     return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: the flat kernel keeps 200 rows of Wa in LDS (query_vector_dim <= 200); use nr_additive_bwd_ex / _act");
   // 48 consecutive tokens belong to 1 + ceil(47 / S) sequences: the kernel has 8 slots for them (16 below S = 7), 4 in the activation-gradient form
-  if (S < 4 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (int64_t)(NR_D * 4) >= (1LL << 31))
-    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 4 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq < 2^31 / 1200");
+  if (S < 4 || (dy_pad && S < 16) || n_seq * (int64_t)S >= (1LL << 31) || n_seq * (g_stride * 4) >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_additive_bwd_flat: sequence length must be >= 4 (>= 16 with dy_pad), n_seq * S < 2^31 and n_seq * g_stride < 2^29");
   if (n_seq == 0) return NR_OK;
-  NR_LAUNCH(nr::rowdot_kernel, grid_for(n_seq, 4, 4096), 256, 0, (hipStream_t)stream, g_out, (int64_t)NR_D, y, y_stride, n_seq, NR_D, tot);
+  NR_LAUNCH(nr::rowdot_kernel, grid_for(n_seq, 4, 4096), 256, 0, (hipStream_t)stream, g_out, g_stride, y, y_stride, n_seq, NR_D, tot);
   nr::Pool3Params p;
-  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.tot = tot; p.dpre = dpre; p.dq_part = dq_part;
+  p.ctx = ctx; p.Wap = Wap; p.bap = bap; p.qvp = qvp; p.attn_w = attn_w; p.g_out = g_out; p.g_row_bytes = (uint32_t)(g_stride * 4);
+  p.tot = tot; p.dpre = dpre; p.dq_part = dq_part;
   p.dctx = dctx; p.dy_pad = dy_pad; p.act_scale = 1.0f / (1.0f - p_drop); p.n_seq = n_seq; p.n_tok = n_seq * S; p.S = (uint32_t)S;
   p.s_magic = (uint32_t)((1ULL << 32) / (uint32_t)S) + 1u;
   const int64_t grid = nr_additive_bwd_flat_grid(p.n_tok);

@@ -476,10 +476,10 @@ def pool_fwd_flat_ok(S, n_seq, *, qdim):
     return _POOL_FWD_FLAT and 16 <= S <= 64 and qdim <= NR_POOL_FLAT_QMAX and n_seq * S >= _POOL_FLAT_MIN_TOK
 
 
-def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag=''):
+def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag='', g_stride=NR_D):
     """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
     y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused
-    activation gradient goes there instead of dgemm."""
+    activation gradient goes there instead of dgemm.  g_stride: row stride of g in floats (a column block of wider rows is read in place)."""
     lib = _lib()
     dev = ctx_b.device
     ntok = n_seq * S
@@ -488,8 +488,8 @@ def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, 
     dq_part = _workspace(f'dqp[{ws_tag}]' if ws_tag else 'dqp', (nwg, NR_QP), torch.float32, dev)
     tot = _workspace('pool_tot', (n_seq,), torch.float32, dev)
     dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev) if (want_dctx and dy is None) else None
-    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), y_ptr, y_stride,
-          _ptr(tot), _ptr(dpre), _ptr(dq_part), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, qdim, _stream())
+    _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat_gs, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), g_stride, y_ptr,
+          y_stride, _ptr(tot), _ptr(dpre), _ptr(dq_part), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, qdim, _stream())
     return dpre, dq_part, dgemm
 
 

@@ -138,7 +138,7 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     return st
 
 
-def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0, y_ptr=None, y_stride=NR_D, later=False):
+def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_drop=0.0, y_ptr=None, y_stride=NR_D, later=False, g_stride=NR_D):
     """Backward of one additive-attention pooling level up to the GEMM part of its input gradient.
     Returns (d_Wa, d_ba, d_qv, dgemm bf16 [n_seq*S][KP]); the caller adds the direct term aw (x) g.
     With ``dy`` (seqpad buffer of a conv text encoder whose activations ctx_b are) the gradient goes on through the relu / dropout stage
@@ -152,8 +152,11 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     flat = ops.pool_flat_ok(S, dy is not None, n_seq, qdim=qdim) and y_ptr is not None
     wt = tag if later else ''
     if flat:
-        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop, ws_tag=wt)
+        dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop, ws_tag=wt,
+                                                 g_stride=g_stride)
     else:
+        if g_stride != NR_D:
+            raise ValueError("_pool_bwd: only the flat kernel reads a strided sequence gradient")
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace(f'dpre[{wt}]' if wt else 'dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
         dq_part = _workspace(f'dqp[{wt}]' if wt else 'dqp', (nwg, NR_QP), torch.float32, dev)
@@ -177,6 +180,14 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     return (*weight_part(), dgemm)
 
 
+_G_STRIDED = os.environ.get('NR_POOL_G_STRIDED', '1') == '1'       # A/B knob: 0 = LSTUR's title third of the gradient through a contiguous copy
+
+
+def text_bwd_strided_ok(st):
+    """Whether text_bwd reads the pooled-vector gradient in place from wider rows (g_stride > D): the flat pooling backward does (csrc/k_pool3.h)."""
+    return _G_STRIDED and ops.pool_flat_ok(st.S, True, st.n_seq, qdim=st.qdim) and st.y_ptr is not None
+
+
 def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
     """Backward of text_fwd for pooled-vector gradients g (f32 device pointer/tensor rows of stride g_stride).
     Writes the token gradient (bf16 [n_seq*S][KP]) into dx_out and returns (d_conv_w, d_conv_b, d_Wa, d_ba, d_qv) -- or, with later=True,
@@ -186,15 +197,15 @@ def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
     lib = _lib()
     n_seq, S = st.n_seq, st.S
     dev = st.act.device
-    if g_stride != NR_D:
-        raise ValueError("text_bwd: the pooled-vector gradient must be contiguous [n_seq, D]")
+    if g_stride != NR_D and not text_bwd_strided_ok(st):
+        raise ValueError("text_bwd: the pooled-vector gradient must be contiguous [n_seq, D] on this path (text_bwd_strided_ok)")
     rp, nc, ra = _seqpad_alloc(n_seq, S)
     dy = _workspace(f'dy{S}', (ra, NR_KP), _BF16_AS_I16, dev, zero=True)              # separator / tail rows stay zero
     # pooling backward and the relu / dropout gradient of the conv stage in one call: dy = (dpre @ Wa + aw (x) g) * [act != 0] / (1 - p)
     if getattr(st, 'y_version', None) is not None and st.y._version != st.y_version:
         raise RuntimeError("text_bwd: the pooled vectors were modified in place after the forward; the pooling backward needs them unchanged")
     pool_w, _ = _pool_bwd(st.act, st.Wap, st.bap, st.qvp, st.aw, g, n_seq, S, st.qdim, tag, st.WaT, dy=dy, p_drop=p,
-                          y_ptr=st.y_ptr, y_stride=st.y_stride, later=True)
+                          y_ptr=st.y_ptr, y_stride=st.y_stride, later=True, g_stride=g_stride)
     # the data gradient as ONE GEMM over virtual 3-tap rows of dy (csrc/k_gemm.h, NT3 form)
     _call(f'nr_conv3_dgrad[{tag}]', lib.nr_conv3_dgrad_gemm, _ptr(dy), _ptr(st.Wd2), dx_out, n_seq, S, _stream())
     xstore = st.xstore
@@ -471,9 +482,11 @@ class _LsturNewsFn(torch.autograd.Function):
         # category_embedding (padding_idx = 0): two segmented reductions over column blocks of g
         d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0)
         _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0, out=d_cat)
-        g_title = g[:, 2 * NR_D:].contiguous()
+        # the title encoder's third of the [T, 3F] gradient: read in place by the flat pooling backward (no 32 MB contiguous copy per step)
+        strided = text_bwd_strided_ok(st)
+        g_title = g[:, 2 * NR_D:] if strided else g[:, 2 * NR_D:].contiguous()
         dx = _workspace('dx_tok', (title.numel(), NR_KP), _BF16_AS_I16, dev)
-        gt = text_bwd(st, g_title, NR_D, p, dx.data_ptr(), 'title', later=True)
+        gt = text_bwd(st, g_title, 3 * NR_D if strided else NR_D, p, dx.data_ptr(), 'title', later=True)
         d_table = embed_scatter(ctx.sorted, title.numel(), dx, ctx.table_param, p, seed) if ctx.needs_input_grad[3] else None
         wg = finish_weight_grads([(gt, st.params)])
         ctx.st = None

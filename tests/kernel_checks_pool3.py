@@ -57,7 +57,7 @@ def _reference(params, ctx_u, go, S, n_seq, V_):
     return W, w, dpre_ref, dq_ref
 
 
-def check_flat(be, S=20, n_seq=6, valid=None, seed=15, y_stride=NR_D, with_dctx=True):
+def check_flat(be, S=20, n_seq=6, valid=None, seed=15, y_stride=NR_D, with_dctx=True, g_stride=NR_D):
     """dpre, dq and the fused dctx = dpre @ Wa of nr_additive_bwd_flat: sequences that straddle the 48-row groups of the waves, padded tails
     (valid < S: exact zeros there), a strided y, and -- with_dctx=False -- the form that stops at dpre / dq."""
     params, ctx_u, hctx, (Wap, bap, qvp), out, aw, go = _setup(be, S, n_seq, valid, seed, y_stride=y_stride)
@@ -68,8 +68,10 @@ def check_flat(be, S=20, n_seq=6, valid=None, seed=15, y_stride=NR_D, with_dctx=
     dqp = be.poison((nwg, NR_QP), np.float32)
     tot = be.poison((n_seq,), np.float32)
     dctx = be.poison((n_seq * S, NR_KP), np.uint16) if with_dctx else None
-    ck(be, be.lib.nr_additive_bwd_flat(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(be.dev(go)), be.ptr(out), y_stride,
-                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), be.ptr(dctx) if with_dctx else None, None, 0.0, n_seq, S, 200, be.stream))
+    hgo, g_off = _wide_rows(be, go, g_stride)
+    ck(be, be.lib.nr_additive_bwd_flat_gs(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo) + g_off, g_stride, be.ptr(out),
+                                          y_stride, be.ptr(tot), be.ptr(dpre), be.ptr(dqp), be.ptr(dctx) if with_dctx else None, None, 0.0, n_seq, S,
+                                          200, be.stream))
     be.sync()
     W, w, dpre_ref, dq_ref = _reference(params, ctx_u, go, S, n_seq, V_)
     # the per-sequence scalar: g . y == sum_s w[s] (g . x[s])
@@ -91,18 +93,28 @@ def check_flat(be, S=20, n_seq=6, valid=None, seed=15, y_stride=NR_D, with_dctx=
         close_bf16(dc.reshape(-1, NR_KP)[:, :NR_D], dref, f'flat pooling bwd fused dctx S={S}', rel=2.0 ** -7, floor=1e-3)
 
 
-def check_flat_act(be, S=20, n_seq=7, p_drop=0.2, seed=22):
+def _wide_rows(be, go, g_stride):
+    """The sequence gradients as the LAST NR_D columns of rows of g_stride floats (everything else NaN: the kernel must not read it);
+    returns (device handle, byte offset of row 0's block).  g_stride == NR_D: the plain contiguous matrix."""
+    if g_stride == NR_D:
+        return be.dev(go), 0
+    wide = np.full((go.shape[0], g_stride), np.nan, dtype=np.float32)
+    wide[:, g_stride - NR_D:] = go
+    return be.dev(wide), (g_stride - NR_D) * 4
+
+
+def check_flat_act(be, S=20, n_seq=7, p_drop=0.2, seed=22, g_stride=NR_D):
     """The fused activation gradient (dy_pad) of nr_additive_bwd_flat against the float64 formula and, where the sequence-shaped kernels
     exist, against nr_additive_bwd_act (same dpre / dy_pad up to bf16 rounding of slightly different fp32 sums)."""
     params, ctx_u, hctx, (Wap, bap, qvp), out, aw, go = _setup(be, S, n_seq, None, seed, relu=True)
-    hgo = be.dev(go)
+    hgo, g_off = _wide_rows(be, go, g_stride)
     nwg = be.lib.nr_additive_bwd_flat_grid(n_seq * S)
     dpre = be.poison((n_seq * S, NR_QP), np.uint16)
     dqp = be.poison((nwg, NR_QP), np.float32)
     tot = be.poison((n_seq,), np.float32)
     dy = be.empty((seqpad_rows(n_seq, S), NR_KP), np.uint16)
-    ck(be, be.lib.nr_additive_bwd_flat(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo), be.ptr(out), NR_D,
-                                       be.ptr(tot), be.ptr(dpre), be.ptr(dqp), None, be.ptr(dy), p_drop, n_seq, S, 200, be.stream))
+    ck(be, be.lib.nr_additive_bwd_flat_gs(be.ptr(hctx), be.ptr(Wap), be.ptr(bap), be.ptr(qvp), be.ptr(aw), be.ptr(hgo) + g_off, g_stride, be.ptr(out), NR_D,
+                                          be.ptr(tot), be.ptr(dpre), be.ptr(dqp), None, be.ptr(dy), p_drop, n_seq, S, 200, be.stream))
     be.sync()
     W, w, dpre_ref, dq_ref = _reference(params, ctx_u, go, S, n_seq, S)
     got = bf16_to_f32(be.np(dpre))

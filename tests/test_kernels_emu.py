@@ -158,6 +158,7 @@ def test_pool_flat_s7(be): k3.check_flat(be, S=7, n_seq=30, seed=3)             
 def test_pool_flat_s4_views(be): k3.check_flat(be, S=4, n_seq=83, seed=6); k3.check_flat(be, S=5, n_seq=40, seed=7); k3.check_flat(be, S=6, n_seq=31, seed=8)     # 13 sequences per group (NAML's 4 views): the second slot tile
 def test_pool_flat_valid_and_strided_y(be): k3.check_flat(be, S=20, n_seq=7, valid=13, y_stride=3 * 300)
 def test_pool_flat_any_length_dpre_only(be): k3.check_flat(be, S=33, n_seq=4, with_dctx=False, seed=5)     # a length no forward kernel is instantiated for
+def test_pool_flat_strided_g(be): k3.check_flat(be, S=20, n_seq=7, g_stride=900, seed=11); k3.check_flat_act(be, S=20, n_seq=9, g_stride=900, seed=12); k3.check_flat(be, S=4, n_seq=83, g_stride=304, seed=13)
 def test_pool_flat_act_s20(be): k3.check_flat_act(be, S=20, n_seq=7)
 def test_pool_flat_act_s50(be): k3.check_flat_act(be, S=50, n_seq=3); k3.check_flat_act(be, S=16, n_seq=10, seed=8)      # 16: four sequences in 48 tokens
 def test_pool_flat_persistent_loop(be): k3.check_flat(be, S=20, n_seq=130, seed=9); k3.check_flat_act(be, S=50, n_seq=60, seed=4)    # > 24 groups: several iterations per wave

@@ -191,6 +191,7 @@ def test_pool_flat_s4_views(be): k3.check_flat(be, S=4, n_seq=28160, seed=6); k3
 def test_pool_flat_valid_strided_any_length(be):
     k3.check_flat(be, S=20, n_seq=1027, valid=13, y_stride=3 * 300); k3.check_flat(be, S=50, n_seq=131, valid=37)
     k3.check_flat(be, S=33, n_seq=517, with_dctx=False, seed=5)
+def test_pool_flat_strided_g(be): k3.check_flat(be, S=20, n_seq=1027, g_stride=900, seed=11); k3.check_flat_act(be, S=20, n_seq=2051, g_stride=900, seed=12); k3.check_flat(be, S=4, n_seq=4001, g_stride=304, seed=13)
 def test_pool_flat_act(be): k3.check_flat_act(be, S=20, n_seq=1027); k3.check_flat_act(be, S=50, n_seq=2051); k3.check_flat_act(be, S=16, n_seq=333, seed=8)
 def test_pool_flat_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3)
 def test_pool_flat_act_at_bench_scale(be): k3.check_flat_scale(be, S=20, n_seq=27136, act=True); k3.check_flat_scale(be, S=50, n_seq=27136 // 2 + 3, act=True)

@@ -103,9 +103,12 @@ if name.startswith('pool_flat'):     # flat pooling backward (csrc/k_pool3.h): p
     dc_ = torch.empty(Tn * S, NR_KP, dtype=torch.int16, device=dev)
     dy_ = torch.zeros(Tn * (S + 1) + 1, NR_KP, dtype=torch.int16, device=dev)
     act_ = 'act' in name
-    fns[name] = lambda: ck(lib.nr_additive_bwd_flat(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), y_.data_ptr(), NR_D,
-                                                    tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
-                                                    0.2 if act_ else 0.0, Tn, S, 200, st()))
+    gs_ = NR_D
+    if 'gs' in name:                    # the sequence gradients as the last third of [Tn, 900] rows (LSTUR's news-vector gradient): nr_additive_bwd_flat_gs
+        wide_ = torch.zeros(Tn, 3 * NR_D, device=dev); wide_[:, 2 * NR_D:] = go_; go_ = wide_[:, 2 * NR_D:]; gs_ = 3 * NR_D
+    fns[name] = lambda: ck(lib.nr_additive_bwd_flat_gs(cx.data_ptr(), Wap.data_ptr(), bap.data_ptr(), qvp.data_ptr(), aw_.data_ptr(), go_.data_ptr(), gs_, y_.data_ptr(), NR_D,
+                                                       tot_.data_ptr(), dp_.data_ptr(), dq_.data_ptr(), None if act_ else dc_.data_ptr(), dy_.data_ptr() if act_ else None,
+                                                       0.2 if act_ else 0.0, Tn, S, 200, st()))
 if name.startswith('cgemm'):          # the convolution as a persistent ring GEMM (csrc/k_convgemm.h): cgemm_dgrad50 / cgemm_dgrad20; NR_CONVGEMM_DEBUG switches phases off, NR_CONV_GEMM_PERSIST=0: the one-tile-per-workgroup kernel
     S = 50 if '50' in name else 20
     Tn = B * 55
