@@ -132,6 +132,8 @@ class Workload:
             C, N = cand.shape[1], hist.shape[1]
             b['ids'] = {k: torch.cat([b['cand'][k].reshape(B * C, *b['cand'][k].shape[2:]), b['click'][k].reshape(B * N, *b['click'][k].shape[2:])])
                         for k in self.attrs}
+            from news_recommendation_amd.data_fast import pack_text_streams
+            b['ids'] = pack_text_streams(b['ids'])           # title and abstract tokens back to back, as TrainData.batch lays them out
             b['B'], b['C'] = B, C
             out.append(b)
         return out

@@ -62,11 +62,44 @@ class TrainData:
         di = idx.to(self.device)
         c, h = self.cand[di], self.hist[di]
         rows = torch.cat([c.reshape(-1), h.reshape(-1)])
-        b = {'ids': {a: t[rows] for a, t in self.news.items()}, 'B': c.shape[0], 'C': c.shape[1]}
+        b = {'ids': gather_rows(self.news, rows), 'B': c.shape[0], 'C': c.shape[1]}
         if self.user is not None:
             b['user'] = self.user[di]
         b['length'] = self.length[idx]
         return b
+
+
+def gather_rows(tables, rows):
+    """{attr: table[rows]} with the TEXT attributes gathered into ONE allocation, back to back in the order of `tables` (title tokens, then
+    abstract tokens): the embedding backward sorts all token ids of a step as one stream (ops_conv.sort_tokens_async), and finds it there without
+    a concatenation."""
+    text = [a for a in tables if a in TEXT_ATTRS and tables[a].dim() == 2]
+    out = {}
+    if len(text) > 1:
+        n = rows.shape[0]
+        buf = torch.empty(sum(n * tables[a].shape[1] for a in text), dtype=tables[text[0]].dtype, device=rows.device)
+        lo = 0
+        for a in text:
+            w = tables[a].shape[1]
+            out[a] = torch.index_select(tables[a], 0, rows, out=buf[lo:lo + n * w].view(n, w))
+            lo += n * w
+    for a, t in tables.items():
+        if a not in out:
+            out[a] = t[rows]
+    return {a: out[a] for a in tables}
+
+
+def pack_text_streams(ids):
+    """The same layout for id tensors that already exist: the text attributes of `ids` copied into one allocation, back to back."""
+    text = [a for a in ids if a in TEXT_ATTRS and ids[a].dim() == 2]
+    if len(text) < 2:
+        return ids
+    buf = torch.cat([ids[a].reshape(-1) for a in text])
+    out, lo = dict(ids), 0
+    for a in text:
+        out[a] = buf[lo:lo + ids[a].numel()].view(ids[a].shape)
+        lo += ids[a].numel()
+    return out
 
 
 def split_batch(b):

@@ -712,6 +712,37 @@ def sorted_ids_ready(pack):
 _WS_ZERO_SHAPES = 4
 
 
+# ---- buffers that live from a forward to its backward and rely on an initial fill of the regions no kernel writes -------------------------------
+# (the GRU's state history: padding columns; a text encoder's seqpad token store: the row before the first sequence and the tail rows).  The buffer
+# of the previous step is handed out again -- no fill -- once its backward has released it; a forward that arrives while it is still owed to a
+# backward (two forwards in flight, a forward whose backward never runs) gets a fresh, initialised one, which then becomes the pooled one.
+_step_pool = {}
+
+
+def step_buffer(key, shape, dtype, device, init):
+    """init(t): fills a fresh tensor's never-written regions.  Returns a tensor of `shape` whose kernel-written regions hold stale data."""
+    k = (key, tuple(int(x) for x in shape), dtype, str(device))
+    e = _step_pool.get(k)
+    if e is not None and not e[1]:
+        e[1] = True
+        return e[0]
+    t = torch.empty(k[1], dtype=dtype, device=device)
+    init(t)
+    if len(_step_pool) > 16:
+        _step_pool.clear()
+    _step_pool[k] = [t, True]
+    return t
+
+
+def step_buffer_release(t):
+    """The backward's last reader of `t` has been enqueued: the next forward on this stream may overwrite it."""
+    if t is None:
+        return
+    for e in _step_pool.values():
+        if e[0] is t or (e[0].data_ptr() == t.data_ptr() and e[0].numel() == t.numel()):
+            e[1] = False
+
+
 def _workspace(key, shape, dtype, device, zero=False):
     """Reusable scratch buffers that live only inside one backward call (all users are ordered on the current stream).
     Plain buffers: ONE flat allocation per (key, dtype, device), grown to the largest request and sliced -- a cache keyed on the shape

@@ -105,9 +105,12 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
     st.xstore = None
     if need_grad:
         rp, nc, ra = _seqpad_alloc(n_seq, S)
-        st.xstore = torch.empty(ra + 2, NR_KP, dtype=_BF16_AS_I16, device=dev)       # row 0 = the "-1" row of the tap shift
-        st.xstore[0].zero_()
-        st.xstore[rp + 1:].zero_()
+        # row 0 = the "-1" row of the tap shift; it and the tail rows past the last sequence are never written by the kernel: zeroed when the
+        # buffer is created, and the previous step's buffer is reused once its backward has read it (ops.step_buffer: no fills per step)
+        def init(t):
+            t[0].zero_()
+            t[rp + 1:].zero_()
+        st.xstore = ops.step_buffer(f'xstore[{tag}]', (ra + 2, NR_KP), _BF16_AS_I16, dev, init)
         xs_ptr = st.xstore.data_ptr() + NR_KP * 2
     tab = table.detach()
     assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
@@ -215,6 +218,7 @@ def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
         # the three tap gradients as ONE hand-written 3-tap GEMM (csrc/k_gemm.h): out[f][w * KP + d] = sum_rows dY[row][f] X[row + w][d] -- the tap
         # shift is a row offset of the seqpad store, so the virtual operand row is [x[row], x[row + 1], x[row + 2]] and dY is fetched once for all three
         both = ops.sum_parts(ops.gemm_tn_parts(dy, NR_KP, xstore, NR_KP, f'nr_gemm_tn_dWconv[{tag}]', taps=3, n_tok=ra))
+        ops.step_buffer_release(xstore)              # last reader: the next forward may overwrite the token store
         taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
         d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
         if dst is not None:
@@ -256,8 +260,16 @@ def finish_weight_grads(parts):
 
 
 def sort_tokens_async(ids_list, num_rows):
-    """Concatenate the token streams and sort them on the side stream while the forward kernels run (ops.sort_ids_async)."""
-    return ops.sort_ids_async(torch.cat([i.reshape(-1) for i in ids_list]), num_rows)
+    """The token streams as one, sorted on the side stream while the forward kernels run (ops.sort_ids_async).  Streams that already lie back to
+    back in one allocation (data_fast.pack_text_streams: the engine's own batches) are taken as they are; anything else is concatenated."""
+    flat = [i.reshape(-1) for i in ids_list]
+    one = flat[0]
+    if len(flat) > 1:
+        adjacent = all(a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                       and b.storage_offset() == a.storage_offset() + a.numel() for a, b in zip(flat, flat[1:]))
+        one = (torch.as_strided(flat[0], (sum(f.numel() for f in flat),), (1,), flat[0].storage_offset()) if adjacent
+               else torch.cat(flat))
+    return ops.sort_ids_async(one, num_rows)
 
 
 def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):

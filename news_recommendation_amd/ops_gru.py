@@ -80,28 +80,7 @@ def _wih_t(Wih_p, Hg, Ip, Kp):
 
 
 # The state history H_all bf16 [T + 1][B][Hp] (48 MB at B = 512, N = 50, Hd = 900) is written by the sweep in every column <= Hd of every row,
-# every call; only the padding columns rely on a zero fill.  The buffer of the last call is therefore reused as it is (no 48 MB fill per step)
-# once its backward has run; a forward that arrives while it is still owed to a backward gets a fresh zero-filled one.
-_hall = {}
-
-
-def _hall_take(T, B, Hp, dev):
-    key = (T, B, Hp, dev)
-    e = _hall.get(key)
-    if e is not None and not e[1]:
-        e[1] = True
-        return e[0]
-    t = torch.zeros(T + 1, B, Hp, dtype=_BF16_AS_I16, device=dev)
-    if len(_hall) > 4:
-        _hall.clear()
-    _hall[key] = [t, True]
-    return t
-
-
-def _hall_release(t):
-    for e in _hall.values():
-        if e[0] is t or e[0].data_ptr() == t.data_ptr():
-            e[1] = False
+# every call; only the padding columns rely on a zero fill: ops.step_buffer hands the previous step's buffer out again (no 48 MB fill per step).
 
 
 class _GruFn(torch.autograd.Function):
@@ -130,7 +109,8 @@ class _GruFn(torch.autograd.Function):
         Xb = rows_to_bf16(xf, I, Ip)                                                         # [B*N][Ip], col I = 1.0
         # hoisted input projection [B*N][3*Hg] f32, hand-written NT kernel (csrc/k_gemm.h): K = Ip (column I of Xb is 1.0, of W_ih the padding 0)
         gi = ops.gemm_nt(Xb, Wih_p, B * N, 3 * Hg, Ip, 'nr_gemm_nt_gru_gi')
-        H_all = _hall_take(T, B, Hp, dev) if need_grad else torch.zeros(1, B, Hp, dtype=_BF16_AS_I16, device=dev)
+        H_all = (ops.step_buffer('gru_H_all', (T + 1, B, Hp), _BF16_AS_I16, dev, lambda t: t.zero_()) if need_grad
+                 else torch.zeros(1, B, Hp, dtype=_BF16_AS_I16, device=dev))
         hf = torch.zeros(2, B, Hp, dtype=torch.float32, device=dev)
         if h0 is not None:
             hf[0][:, :Hd].copy_(h0)
@@ -184,7 +164,7 @@ class _GruFn(torch.autograd.Function):
             d_x = ops.gemm_nt(dgi, WihT, B * N, I, Kp, 'nr_gemm_nt_gru_dx', out=ops.grad_dst(ctx.x_ref, (B * N, I))).view(B, N, I)
         dWi = ops.sum_parts(ops.gemm_tn_parts(dgi, Kp, Xb, Ip, 'nr_gemm_tn_gru_dWih'))                      # [Kp][Ip]; col I = bias gradient
         dWh = ops.sum_parts(ops.gemm_tn_parts(dgh.view(T * B, Kp), Kp, H_all.view((T + 1) * B, Hp), Hp, 'nr_gemm_tn_gru_dWhh', n_tok=T * B))      # [Kp][Hp]; col Hd = bias gradient
-        _hall_release(H_all)                                 # last reader on the stream: the next forward may overwrite it
+        ops.step_buffer_release(H_all)                       # last reader on the stream: the next forward may overwrite it
         dst = ops.inplace_grads(ctx.wparams) if all(ctx.needs_input_grad[4:8]) else None
         if dst is not None:
             # the trainer's persistent buffers: gate q of each gradient is a row block of the padded product -- twelve strided items of the
