@@ -858,7 +858,7 @@ def gather_point(lib, table, ids, device):
 def kernel_source_hash():
     h = hashlib.sha256()
     for f in ('k_mhsa_fwd2.h', 'k_mhsa_fwd.h', 'k_additive_fwd.h', 'k_bwd.h', 'k_attn_bwd2.h', 'k_proj.h', 'k_gemm.h', 'k_pool2.h', 'k_pool3.h', 'k_misc.h', 'k_conv.h', 'k_gru.h',
-              'k_gru_persist.h', 'k_xcd.h', 'k_pool4.h', 'k_convgemm.h', 'k_optim.h', 'k_eval.h', 'nr_common.h', 'nr_prims.h'):
+              'k_gru_persist.h', 'k_xcd.h', 'k_pool4.h', 'k_convgemm.h', 'k_optim.h', 'k_eval.h', 'k_step.h', 'nr_common.h', 'nr_prims.h'):
         with open(os.path.join(ROOT, 'news_recommendation_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

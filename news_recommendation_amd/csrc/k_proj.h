@@ -133,7 +133,8 @@ __global__ __launch_bounds__(ProjGeom::NWAVE * 64, NR_PROJ_OCC) void qkv_proj_ke
   const int dbg = DBG ? p.debug : 0;
   p.dc = drop_resolve(p.dc);
   NR_SMEM_DECL(smem);
-  const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
+  int l = lane_id(), h = l >> 5, li = l & 31;                   // (re-derived after the gather phase, see below)
+  const int w = wave_id();
   const int64_t tile_tok0 = ((int64_t)blockIdx.x * Gm::NWAVE + w) * Gm::TOKW;
   unsigned char* const stage = smem + 2 * Gm::CH_BYTES + w * Gm::STAGE_BYTES;      // wave-private
 
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(ProjGeom::NWAVE * 64, NR_PROJ_OCC) void qkv_proj_ke
     }
   }
   __syncthreads();
+  // The lane coordinates of the product phase are taken from the hardware lane counter: as values derived from the work-item id they were live
+  // across the gather phase's register peak, where the allocator (128 registers for four waves per SIMD) spilled two of them -- 12 bytes of
+  // scratch per lane.  Without the spill: 473 -> 467 us per launch on one box, step unchanged within noise (profiles/r06_ab_qkv_scratch.txt;
+  // the ~35 us dispatch gap a rocprofv3 trace shows in front of this kernel is there with and without scratch: an artefact of the tracer)
+  l = lane_id_fresh(); h = l >> 5; li = l & 31;
 
   // write-out geometry of a column group (fixed per lane): 16-byte piece idx = l + 64 i of [3 heads][32 tokens x 40 B].  A wave's 32 tokens
   // start at an even position of their title (32 k mod 20 is even) and title fragments hold an even number of tokens, so every fragment

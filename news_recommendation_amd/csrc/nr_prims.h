@@ -81,6 +81,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// the same number from the hardware lane counter (all lanes active): a fresh definition that does not depend on the work-item id register, for
+// a late phase of a kernel whose early phase would otherwise keep lane-derived values alive (or spill them) across its register peak
+__device__ __forceinline__ int lane_id_fresh() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // wave index inside the workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes, but the compiler only knows that after
 // readfirstlane; everything derived from it (tile / sequence / pair indices, base pointers, loop bounds, branches) then runs on the
 // scalar unit instead of costing vector instructions in VALU-bound kernels.

@@ -984,9 +984,9 @@ class _SplitRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         a, b = x[:n], x[n:]
-        if x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous():
+        if x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and any(ctx.needs_input_grad):
             ctx.key = (a.data_ptr(), b.data_ptr())
-            slot = {'shape': tuple(x.shape), 'n': n, 'buf': None, 'device': x.device}
+            slot = {'shape': tuple(x.shape), 'n': n, 'buf': None, 'device': x.device, 'taken': [False, False]}
             _grad_dst[ctx.key[0]] = (slot, 0)
             _grad_dst[ctx.key[1]] = (slot, 1)
             while len(_grad_dst) > 16:                    # forwards that never ran a backward
@@ -1025,8 +1025,9 @@ def grad_dst(x, shape=None):
     n = slot['n']
     rows, cols = slot['shape']
     part_rows = n if which == 0 else rows - n
-    if x.numel() != part_rows * cols or x.dtype != torch.float32 or not x.is_contiguous():
+    if x.numel() != part_rows * cols or x.dtype != torch.float32 or not x.is_contiguous() or slot['taken'][which]:
         return None
+    slot['taken'][which] = True                # each half is handed out once: a second asker (an unrelated tensor at a recycled address) allocates its own
     if slot['buf'] is None:
         slot['buf'] = torch.empty(rows, cols, dtype=torch.float32, device=slot['device'])
     part = slot['buf'][:n] if which == 0 else slot['buf'][n:]

@@ -160,6 +160,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__forceinline__ int lane_id_fresh() { return (int)(threadIdx.x & 63); }
 __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
 __forceinline__ float bf2f(u16 h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
