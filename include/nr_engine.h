@@ -261,14 +261,18 @@ int nr_score_ce_bwd(const float* dl, const float* gscale, const float* cand, con
  * of the news encoder's output gradient (src/model/NRMS/__init__.py:43-48: clicked_news_vector is a slice of the encoder output). */
 int nr_rows_to_f32(const uint16_t* src, int64_t ld, int d, float* dst, int64_t ldd, int64_t n, void* stream);
 
-/* Batched accumulate: for every item, dst[r*dst_ld + c] += src[r*src_ld + c], r < rows, c < cols -- in ONE launch per 48 items.  Replaces
- * torch.autograd's AccumulateGrad (one element-wise add per parameter after loss.backward(), src/train.py:207,228) for a trainer whose
- * gradient buffers are persistent; `items` is a HOST array read during the call.  Items of one call must not overlap in dst. */
+/* Batched accumulate: for every item, dst[r*dst_ld + c] += sum_{p < parts} src[p*part_stride + r*src_ld + c], r < rows, c < cols -- in ONE launch
+ * per 48 items.  Replaces torch.autograd's AccumulateGrad (one element-wise add per parameter after loss.backward(), src/train.py:207,228) for
+ * a trainer whose gradient buffers are persistent; parts > 1 folds the fixed-order sum over a persistent kernel's per-workgroup partial rows
+ * (the query-vector gradient of additive.py:20) into the same launch.  `items` is a HOST array read during the call.  Items of one call must not
+ * overlap in dst.  parts >= 1; reserved = 0. */
 typedef struct nr_accum_item {
   const float* src;
   float* dst;
   int64_t src_ld, dst_ld;
   int32_t rows, cols;
+  int32_t parts, reserved;
+  int64_t part_stride;
 } nr_accum_item;
 int nr_accum_many(const nr_accum_item* items, int n_items, void* stream);
 

@@ -536,6 +536,40 @@ __global__ __launch_bounds__(256) void pack_gru_kernel(const float* __restrict__
   }
 }
 
+// The tile-order case (tiled != 0: W_hh and its transpose, re-packed after every optimiser step) by OUTPUT piece: one lane produces one 16-byte
+// piece of the tile-order image -- eight consecutive columns of one row -- and consecutive lanes take consecutive pieces, i.e. the 16 rows of a
+// tile: stores are contiguous, and the reads of the transpose (element (k, c) = W[c][k]) touch 64 contiguous bytes per column across the 16 lanes
+// of a row group.  The element-per-lane form above walks the transpose column-fastest: every read of a wave in a different row of W (46 us per
+// LSTUR step for the two 2,736 x 928 images).
+__global__ __launch_bounds__(256) void pack_gru_tiled_kernel(const float* __restrict__ W, int Hd, int K, int Hg, int Kpad, u16* __restrict__ dst,
+                                                             u16* __restrict__ dstT, int Trows, int Kp) {
+  const int n1 = 3 * Hg * Kpad / 8;                       // pieces of dst  [3 Hg][Kpad]
+  const int n2 = dstT ? Trows * Kp / 8 : 0;               // pieces of dstT [Trows][Kp]
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
+    const bool tr = i >= n1;
+    const int pi = tr ? i - n1 : i;
+    const int ncol = tr ? Kp : Kpad;
+    const int blk = pi >> 6, lane = pi & 63;              // 64 pieces per 16 x 32 block
+    const int kb = ncol >> 5;
+    const int r = (blk / kb) * 16 + (lane & 15);          // row of the image
+    const int c0 = (blk % kb) * 32 + (lane >> 4) * 8;     // its first column
+    u16x8 o;
+    if (!tr) {                                            // dst[row][k] = W[q Hd + j][k], row = q Hg + j
+      const int q = r / Hg, j = r - q * Hg;
+      const float* src = W + ((size_t)q * Hd + j) * K;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf((j < Hd && c0 + e < K) ? src[c0 + e] : 0.0f);
+    } else {                                              // dstT[k][c] = W[q Hd + j][k], c = q Hg + j
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e, q = c / Hg, j = c - q * Hg;
+        o[e] = f2bf((q < 3 && j < Hd && r < K) ? W[((size_t)q * Hd + j) * K + r] : 0.0f);
+      }
+    }
+    *(u16x8*)((tr ? dstT : dst) + (size_t)pi * 8) = o;
+  }
+}
+
 // f32 rows [n][d] (row stride lds_) -> bf16 rows [n][dp]: cols < d converted, col d = 1.0 (when d < dp), rest 0.
 __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, int64_t lds_, int d, u16* __restrict__ dst, int dp,
                                                            int64_t n) {
@@ -544,6 +578,25 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restri
     const int64_t r = i / dp;
     const int c = (int)(i - r * dp);
     dst[i] = c < d ? f2bf(src[r * lds_ + c]) : (u16)(c == d ? 0x3F80 : 0);
+  }
+}
+
+// the same, four columns per lane (d, dp, the row stride and both base addresses multiples of 4 elements: every case of the training steps).  The
+// element-per-lane form above spends a 64-bit division per element: 52 us for LSTUR's [25,600][900] history block (139 MB moved), this one is
+// bound by the bytes.
+__global__ __launch_bounds__(256) void rows_to_bf16_v4_kernel(const float* __restrict__ src, int64_t lds_, int d, u16* __restrict__ dst, int dp,
+                                                              int64_t n) {
+  const int q = dp >> 2;
+  const int64_t total = n * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    u16x4 o = u16x4{0, 0, 0, 0};
+    if (c < d) {
+      const f32x4 v = *(const f32x4*)(src + r * lds_ + c);
+      o = pack4(v);
+    } else if (c == d) o[0] = 0x3F80;
+    *(u16x4*)(dst + r * (int64_t)dp + c) = o;
   }
 }
 

@@ -98,25 +98,68 @@ __global__ __launch_bounds__(256) void rows_to_f32_kernel(const u16* __restrict_
 }
 
 // ---- batched strided accumulate ---------------------------------------------------------------------------------
-// item i: dst[r * dst_ld + c] += src[r * src_ld + c] for r < rows, c < cols.  blockIdx.y = item, blockIdx.x strides its elements.
+// item i: dst[r * dst_ld + c] += sum_{p < parts} src[p * part_stride + r * src_ld + c] for r < rows, c < cols (parts = 1: a plain add; parts > 1:
+// the per-workgroup partial sums of a persistent kernel -- the query-vector gradient of a pooling level, one row per workgroup -- summed in a fixed
+// order on the way).  blockIdx.y = item, blockIdx.x strides its elements.
 struct AccumItem {
   const float* src;
   float* dst;
   int64_t src_ld, dst_ld;
   int32_t rows, cols;
+  int32_t parts, pad_;
+  int64_t part_stride;
 };
-constexpr int ACCUM_MAX_ITEMS = 48;
+constexpr int ACCUM_MAX_ITEMS = 48;      // 48 x 56 B of kernel arguments
 struct AccumBatch {
   AccumItem it[ACCUM_MAX_ITEMS];
 };
 
+constexpr int ACCUM_PG = 16;               // part groups of an item with parts > 1 (fixed: the order of the additions is part of the result)
+
 __global__ __launch_bounds__(256) void accum_many_kernel(AccumBatch batch) {
+  NR_SMEM_DECL(smem);
   const AccumItem it = batch.it[blockIdx.y];
   const int64_t n = (int64_t)it.rows * it.cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / it.cols;
-    const int c = (int)(i - r * it.cols);
-    it.dst[r * it.dst_ld + c] += it.src[r * it.src_ld + c];
+  if (it.parts <= 1) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / it.cols;
+      const int c = (int)(i - r * it.cols);
+      it.dst[r * it.dst_ld + c] += it.src[r * it.src_ld + c];
+    }
+    return;
+  }
+  // parts > 1 (uniform per workgroup): 16 elements x 16 part groups per pass -- lane (e, pg) sums the parts [pg * per, (pg + 1) * per) of element e in
+  // part order, the 16 group sums are added in group order.  A single lane walking 256 partial rows one batch of loads after the other took ~50 us.
+  float* red = (float*)smem;                 // [ACCUM_PG][16]
+  const int e = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int per = (it.parts + ACCUM_PG - 1) / ACCUM_PG;
+  const int q0 = pg * per, q1 = (q0 + per < it.parts) ? q0 + per : it.parts;
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
+    const int64_t i = base + e;
+    float v = 0.0f;
+    int64_t r = 0;
+    int c = 0;
+    if (i < n) {
+      r = i / it.cols;
+      c = (int)(i - r * it.cols);
+      const float* sp = it.src + r * it.src_ld + c;
+      int q = q0;
+      for (; q + 4 <= q1; q += 4) {
+        const float a0 = sp[(int64_t)q * it.part_stride], a1 = sp[(int64_t)(q + 1) * it.part_stride];
+        const float a2 = sp[(int64_t)(q + 2) * it.part_stride], a3 = sp[(int64_t)(q + 3) * it.part_stride];
+        v += a0; v += a1; v += a2; v += a3;
+      }
+      for (; q < q1; ++q) v += sp[(int64_t)q * it.part_stride];
+    }
+    red[pg * 16 + e] = v;
+    __syncthreads();
+    if (pg == 0 && i < n) {
+      float t = 0.0f;
+#pragma unroll
+      for (int g = 0; g < ACCUM_PG; ++g) t += red[g * 16 + e];
+      it.dst[r * it.dst_ld + c] += t;
+    }
+    __syncthreads();
   }
 }
 

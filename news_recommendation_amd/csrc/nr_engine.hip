@@ -512,6 +512,11 @@ int nr_gemm_tn_parts(int M, int N, int64_t n_tok) {
   int P = (256 + tiles - 1) / tiles;            // one workgroup per CU
   P = (P + 7) / 8 * 8;
   while (P > 8 && n_tok / P < 512) P -= 8;      // short token lists (the user encoder's 25,600 rows): at least 16 chunks per partition --
+  if (tiles > 32) {                             // more output tiles than 8 partitions fill the device with evenly (the GRU's 2,736 x 928 weight gradients: 44 tiles)
+    const char* e = getenv("NR_TN_P_MANY_TILES");        // A/B knob
+    const int want = e ? atoi(e) : 8;
+    if (want >= 8 && !(want & 7) && n_tok / want >= 512) P = want;
+  }
   return P;                                     // every partition costs a full M x N block of fp32 partials
 
 }
@@ -871,14 +876,14 @@ int nr_accum_many(const nr_accum_item* items, int n_items, void* stream) {
     int64_t biggest = 0;
     for (int i = 0; i < n; ++i) {
       const nr_accum_item& a = items[base + i];
-      if (!a.src || !a.dst || a.rows < 0 || a.cols < 0 || a.src_ld < a.cols || a.dst_ld < a.cols)
-        return fail(NR_ERR_BADARG, "nr_accum_many: bad item (null pointer, negative extent or a row stride below the row length)");
-      batch.it[i] = nr::AccumItem{a.src, a.dst, a.src_ld, a.dst_ld, a.rows, a.cols};
-      const int64_t e = (int64_t)a.rows * a.cols;
+      if (!a.src || !a.dst || a.rows < 0 || a.cols < 0 || a.src_ld < a.cols || a.dst_ld < a.cols || a.parts < 1 || (a.parts > 1 && a.part_stride < 1))
+        return fail(NR_ERR_BADARG, "nr_accum_many: bad item (null pointer, negative extent, a row stride below the row length, parts < 1)");
+      batch.it[i] = nr::AccumItem{a.src, a.dst, a.src_ld, a.dst_ld, a.rows, a.cols, a.parts, 0, a.part_stride};
+      const int64_t e = (int64_t)a.rows * a.cols * (a.parts > 1 ? 64 : 1);      // (an item with parts covers 16 elements per workgroup pass, not 1024)
       if (e > biggest) biggest = e;
     }
     if (biggest == 0) continue;
-    NR_LAUNCH2(nr::accum_many_kernel, grid_for(biggest, 1024, 256), n, 256, 0, (hipStream_t)stream, batch);
+    NR_LAUNCH2(nr::accum_many_kernel, grid_for(biggest, 1024, 256), n, 256, nr::ACCUM_PG * 16 * 4, (hipStream_t)stream, batch);
   }
   return check_launch("nr_accum_many");
 }
@@ -1107,14 +1112,20 @@ int nr_gru_dims(int Hd, int* Hg, int* Hp, int* Kp) {
 int nr_pack_gru(const float* W, int Hd, int K, int Kpad, uint16_t* dst, uint16_t* dstT, int tiled, void* stream) {
   if (!W || !dst || Hd <= 0 || K <= 0 || Kpad < K || (Kpad & 31)) return fail(NR_ERR_BADARG, "nr_pack_gru: bad argument");
   const int Hg = ceil_to(Hd, 16), Kp = ceil_to(3 * Hg, 32);
-  NR_LAUNCH(nr::pack_gru_kernel, 1024, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp, tiled);
+  if (tiled && !(Hg & 15))          // (3 Hg rows and Kpad / Kp columns are whole 16 x 32 blocks: the image is a sequence of 16-byte pieces)
+    NR_LAUNCH(nr::pack_gru_tiled_kernel, 2048, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp);
+  else
+    NR_LAUNCH(nr::pack_gru_kernel, 1024, 256, 0, (hipStream_t)stream, W, Hd, K, Hg, Kpad, dst, dstT, Kpad, Kp, tiled);
   return check_launch("nr_pack_gru");
 }
 
 int nr_rows_to_bf16(const float* src, int64_t ld, int d, uint16_t* dst, int dp, int64_t n, void* stream) {
   if (!src || !dst || d <= 0 || dp < d || ld < d || n < 0) return fail(NR_ERR_BADARG, "nr_rows_to_bf16: bad argument");
   if (n == 0) return NR_OK;
-  NR_LAUNCH(nr::rows_to_bf16_kernel, grid_for(n * dp, 256, 8192), 256, 0, (hipStream_t)stream, src, ld, d, dst, dp, n);
+  if (!(d & 3) && !(dp & 3) && !(ld & 3) && (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 7) == 0))
+    NR_LAUNCH(nr::rows_to_bf16_v4_kernel, grid_for(n * (dp / 4), 256, 8192), 256, 0, (hipStream_t)stream, src, ld, d, dst, dp, n);
+  else
+    NR_LAUNCH(nr::rows_to_bf16_kernel, grid_for(n * dp, 256, 8192), 256, 0, (hipStream_t)stream, src, ld, d, dst, dp, n);
   return check_launch("nr_rows_to_bf16");
 }
 

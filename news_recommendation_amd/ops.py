@@ -476,7 +476,8 @@ def pool_fwd_flat_ok(S, n_seq, *, qdim):
     return _POOL_FWD_FLAT and 16 <= S <= 64 and qdim <= NR_POOL_FLAT_QMAX and n_seq * S >= _POOL_FLAT_MIN_TOK
 
 
-def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag='', g_stride=NR_D):
+def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, want_dctx=True, dy=None, p_drop=0.0, ws_tag='', g_stride=NR_D,
+                  dq_ring=False):
     """nr_additive_bwd_flat on workspaces: returns (dpre bf16 [n_seq*S][QP], dq_part f32 [grid][QP], dgemm bf16 [n_seq*S][KP] or None).
     y_ptr / y_stride: the pooled vectors of the forward (f32 rows).  dy: seqpad gradient buffer of a conv text encoder -> the fused
     activation gradient goes there instead of dgemm.  g_stride: row stride of g in floats (a column block of wider rows is read in place)."""
@@ -485,7 +486,9 @@ def pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, 
     ntok = n_seq * S
     nwg = lib.nr_additive_bwd_flat_grid(ntok)
     dpre = _workspace(f'dpre[{ws_tag}]' if ws_tag else 'dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-    dq_part = _workspace(f'dqp[{ws_tag}]' if ws_tag else 'dqp', (nwg, NR_QP), torch.float32, dev)
+    dq_part = dq_slot(nwg, dev) if dq_ring else None          # (its sum may wait for the end of the backward pass: PartSum)
+    if dq_part is None:
+        dq_part = _workspace(f'dqp[{ws_tag}]' if ws_tag else 'dqp', (nwg, NR_QP), torch.float32, dev)
     tot = _workspace('pool_tot', (n_seq,), torch.float32, dev)
     dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev) if (want_dctx and dy is None) else None
     _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_flat_gs, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), g_stride, y_ptr,
@@ -510,8 +513,10 @@ def run_deferred():
 
 
 def drop_deferred():
+    global _dq_outstanding
     _deferred.clear()
     _gq.clear()
+    _dq_outstanding = 0
 
 
 # ---- small weight gradients of a backward pass -> the trainer's persistent gradient buffers, in ONE launch ---------------------------------
@@ -525,7 +530,48 @@ _gq_armed = False
 
 class _AccumItem(_capi.ctypes.Structure):
     _fields_ = [('src', _capi.ctypes.c_void_p), ('dst', _capi.ctypes.c_void_p), ('src_ld', _capi.ctypes.c_int64), ('dst_ld', _capi.ctypes.c_int64),
-                ('rows', _capi.ctypes.c_int32), ('cols', _capi.ctypes.c_int32)]
+                ('rows', _capi.ctypes.c_int32), ('cols', _capi.ctypes.c_int32), ('parts', _capi.ctypes.c_int32), ('reserved', _capi.ctypes.c_int32),
+                ('part_stride', _capi.ctypes.c_int64)]
+
+
+class PartSum:
+    """parts[:, :cols].sum(0) of a persistent kernel's per-workgroup partial rows (f32 [P, ld]: the query-vector gradient of a pooling level),
+    not evaluated yet: queue_grad() folds the sum into the backward pass's one accumulate launch; materialize() runs it now (nr_sum_parts)."""
+
+    def __init__(self, parts, cols):
+        self.parts, self.cols = parts, int(cols)
+        self.shape = (self.cols,)
+
+    def materialize(self):
+        return sum_parts(self.parts)[:self.cols]
+
+
+# per-workgroup partial rows that wait for the end of the backward pass must not be overwritten by the next pooling level's: a ring of small
+# scratch buffers, one per PartSum outstanding (a backward pass holds at most a handful: title, abstract, views, user)
+_DQ_SLOTS = 12
+_dq_next = 0
+_dq_outstanding = 0
+
+
+def dq_slot(nwg, device):
+    """f32 [nwg, NR_QP] scratch for a pooling level's query-vector partials, or None when the ring is exhausted (the caller then uses its shared
+    workspace and sums at once)."""
+    global _dq_next, _dq_outstanding
+    if _dq_outstanding >= _DQ_SLOTS or not _PART_SUM:
+        return None
+    _dq_outstanding += 1
+    k = _dq_next
+    _dq_next = (k + 1) % _DQ_SLOTS
+    t = _workspace(f'dqp#{k}', (nwg, NR_QP), torch.float32, device)
+    t._nr_dq_ring = True
+    return t
+
+
+def is_dq_slot(t):
+    return getattr(t, '_nr_dq_ring', False)
+
+
+_PART_SUM = os.environ.get('NR_PART_SUM', '1') == '1'      # A/B knob: 0 = every query-vector gradient through its own nr_sum_parts launch
 
 
 def _accum_geometry(t):
@@ -541,6 +587,13 @@ def _accum_geometry(t):
 def queue_grad(dst, src):
     """dst += src at the end of the running backward pass (or at the next flush_grads()).  dst: a view of a persistent gradient buffer, src: the
     gradient (any float32 view of the same shape; 1-D / 2-D views with contiguous rows go in as they are, anything else through a copy)."""
+    if isinstance(src, PartSum):
+        if dst.dim() != 1 or dst.shape[0] != src.cols or not dst.is_contiguous() or src.parts.stride(1) != 1:
+            src = src.materialize()
+        else:
+            _gq.append((dst, src))
+            _arm_flush()
+            return
     if src.dtype != torch.float32:
         src = src.to(torch.float32)
     if tuple(dst.shape) != tuple(src.shape):
@@ -575,7 +628,8 @@ def _flush_from_engine():
 
 def flush_grads():
     """Issue the queued accumulations now (one launch per 48 items; items that share a destination go into successive launches)."""
-    global _gq_armed
+    global _gq_armed, _dq_outstanding
+    _dq_outstanding = 0                        # (the ring's rows are read by the launches below, in stream order before anything can refill them)
     if not _gq:
         return
     todo = list(_gq)
@@ -588,6 +642,9 @@ def flush_grads():
             seen.add(key)
         arr = (_AccumItem * len(now))()
         for i, (d, s_) in enumerate(now):
+            if isinstance(s_, PartSum):
+                arr[i] = _AccumItem(s_.parts.data_ptr(), d.data_ptr(), s_.cols, s_.cols, 1, s_.cols, s_.parts.shape[0], 0, s_.parts.stride(0))
+                continue
             rd, cd, ldd = _accum_geometry(d)
             rs, cs, lds = _accum_geometry(s_)
             if (rd, cd) != (rs, cs):                 # same elements, different 2-D reading (a contiguous vector against a column): one of them is [n] x 1
@@ -597,7 +654,7 @@ def flush_grads():
                     rd, cd, ldd = cd, 1, 1
                 if cs != 1:
                     rs, cs, lds = cs, 1, 1
-            arr[i] = _AccumItem(s_.data_ptr(), d.data_ptr(), lds, ldd, rd, cd)
+            arr[i] = _AccumItem(s_.data_ptr(), d.data_ptr(), lds, ldd, rd, cd, 1, 0, 0)
         _call('nr_accum_many', _lib().nr_accum_many, _capi.ctypes.cast(arr, _capi.ctypes.c_void_p), len(now), _stream())
         todo = rest
 
@@ -607,7 +664,7 @@ def hand_over_grads(params, vals):
     trainer's persistent buffers when it owns one for every parameter (inplace_grads)."""
     dst = inplace_grads(params)
     if dst is None:
-        return tuple(vals)
+        return tuple(v.materialize() if isinstance(v, PartSum) else v for v in vals)
     for d, v in zip(dst, vals):
         queue_grad(d, v)
     return (None,) * len(params)

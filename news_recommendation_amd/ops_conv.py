@@ -156,13 +156,15 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
     wt = tag if later else ''
     if flat:
         dpre, dq_part, dgemm = ops.pool_bwd_flat(ctx_b, Wap, bap, qvp, aw, g, y_ptr, y_stride, n_seq, S, qdim, tag, dy=dy, p_drop=p_drop, ws_tag=wt,
-                                                 g_stride=g_stride)
+                                                 g_stride=g_stride, dq_ring=True)
     else:
         if g_stride != NR_D:
             raise ValueError("_pool_bwd: only the flat kernel reads a strided sequence gradient")
         nwg = lib.nr_additive_bwd_grid(n_seq, S)
         dpre = _workspace(f'dpre[{wt}]' if wt else 'dpre', (ntok, NR_QP), _BF16_AS_I16, dev)
-        dq_part = _workspace(f'dqp[{wt}]' if wt else 'dqp', (nwg, NR_QP), torch.float32, dev)
+        dq_part = ops.dq_slot(nwg, dev)
+        if dq_part is None:
+            dq_part = _workspace(f'dqp[{wt}]' if wt else 'dqp', (nwg, NR_QP), torch.float32, dev)
         dgemm = _workspace(f'dctx[{tag}]', (ntok, NR_KP), _BF16_AS_I16, dev)        # = dpre @ Wa, produced inside the kernel
     if flat:
         pass
@@ -173,8 +175,12 @@ def _pool_bwd(ctx_b, Wap, bap, qvp, aw, g, n_seq, S, qdim, tag, WaT, dy=None, p_
         _call(f'nr_additive_bwd[{tag}]', lib.nr_additive_bwd_act, _ptr(ctx_b), _ptr(Wap), _ptr(bap), _ptr(qvp), _ptr(aw), _ptr(g), _ptr(dpre),
               _ptr(dq_part), _ptr(WaT), _ptr(dgemm), _ptr(dy), p_drop, n_seq, S, _stream())
 
+    ring = ops.is_dq_slot(dq_part)
+
     def weight_part():
-        d_qv = ops.sum_parts(dq_part)[:qdim]
+        # the per-workgroup partial rows of the query-vector gradient: summed by the backward pass's one accumulate launch when the trainer owns
+        # the gradient buffers (ops.PartSum -> nr_accum_many), by nr_sum_parts otherwise (ops.hand_over_grads / the callers' materialize())
+        d_qv = ops.PartSum(dq_part, qdim) if ring else ops.sum_parts(dq_part)[:qdim]
         # split-K ring kernel (csrc/k_gemm.h), one 256 x 320 tile per token partition, partials summed in fixed order
         dWa_ext = ops.sum_parts(ops.gemm_tn_parts(dpre, NR_QP, ctx_b, NR_KP, f'nr_gemm_tn_dWa[{tag}]'))
         return dWa_ext[:qdim, :NR_D], dWa_ext[:qdim, NR_D], d_qv
@@ -221,6 +227,8 @@ def text_bwd(st, g, g_stride, p, dx_out, tag, later=False):
         ops.step_buffer_release(xstore)              # last reader: the next forward may overwrite the token store
         taps = [both[:, w * NR_KP:(w + 1) * NR_KP] for w in range(3)]
         d_conv_b = taps[1][:NR_D, NR_D]                                                  # X column D is 1.0 on token rows
+        if dst is None and isinstance(d_qv, ops.PartSum):
+            d_qv = d_qv.materialize()
         if dst is not None:
             # the trainer's persistent buffers (ops.inplace_grads): tap w of the filter gradient is the strided sub-matrix [:, 0, w, :] of the
             # [F, 1, 3, D] buffer -- queued as it is, no stacked copy
@@ -285,10 +293,11 @@ def embed_scatter(sorted_pack, n_tokens, dx, table, p, seed):
     return d_table
 
 
-def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row, out=None):
-    """dst[id] += sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row); dst = out (accumulated into) or a fresh zeroed tensor."""
+def _sorted_rows_scatter(ids, src, col0, ld, num_rows, pad_row, out=None, sorted_pack=None):
+    """dst[id] += sum of the f32 rows src[i, col0:col0+D] with ids[i] == id (ids > pad_row); dst = out (accumulated into) or a fresh zeroed tensor.
+    sorted_pack: the ids already sorted on the side stream at forward time (ops.sort_ids_async) -- else they are sorted here, on this stream."""
     dst = torch.zeros(num_rows, NR_D, dtype=torch.float32, device=src.device) if out is None else out
-    ids_sorted, perm = ops.sort_ids(ids, num_rows)
+    ids_sorted, perm = ops.sorted_ids_ready(sorted_pack) if sorted_pack is not None else ops.sort_ids(ids, num_rows)
     _call('nr_scatter_sorted_f32', _lib().nr_scatter_sorted_f32, _ptr(ids_sorted), _ptr(perm), src.data_ptr() + col0 * 4, ld, _ptr(dst),
           num_rows, ids.numel(), pad_row, _stream())
     return dst
@@ -333,6 +342,8 @@ class _NamlNewsFn(torch.autograd.Function):
             ctx.st = (st_t, st_a)
             ctx.meta = (p, seed, Wa_f.shape[0])
             ctx.sorted = sort_tokens_async([title, abstract], table.shape[0]) if ctx.needs_input_grad[4] else None
+            # the category / subcategory ids of the element encoders' backward: sorted on the side stream too, off the backward's critical path
+            ctx.sorted_elem = (ops.sort_ids_async(cat, ncat), ops.sort_ids_async(sub, ncat))
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
             ctx.small_params = (cat_table, W_c, b_c, W_s, b_s, Wa_f, ba_f, qv_f)         # the nn.Parameters: ops.hand_over_grads()
         ctx.mark_non_differentiable(out_b)
@@ -357,8 +368,8 @@ class _NamlNewsFn(torch.autograd.Function):
         # element encoders: reduce per category row, then the tiny table backward
         ncat, dcat = embf.shape
         dE = torch.zeros(2, ncat, NR_D, dtype=torch.float32, device=dev)
-        _sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1, out=dE[0])
-        _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1, out=dE[1])
+        _sorted_rows_scatter(cat, gv[2], 0, NR_D, ncat, -1, out=dE[0], sorted_pack=ctx.sorted_elem[0])
+        _sorted_rows_scatter(sub, gv[3], 0, NR_D, ncat, -1, out=dE[1], sorted_pack=ctx.sorted_elem[1])
         dW = torch.empty(2, NR_D, dcat, dtype=torch.float32, device=dev)
         db = torch.empty(2, NR_D, dtype=torch.float32, device=dev)
         demb = torch.empty(ncat, dcat, dtype=torch.float32, device=dev)
@@ -479,6 +490,7 @@ class _LsturNewsFn(torch.autograd.Function):
             ctx.st = st
             ctx.meta = (p, seed, cat_table.shape[0])
             ctx.sorted = sort_tokens_async([title], table.shape[0]) if ctx.needs_input_grad[3] else None
+            ctx.sorted_elem = (ops.sort_ids_async(cat, cat_table.shape[0]), ops.sort_ids_async(sub, cat_table.shape[0]))     # side stream, as the tokens
             ctx.table_param = table                  # the caller's tensor object (the nn.Parameter): ops.grad_target()
             ctx.cat_param = cat_table
         return out
@@ -492,8 +504,8 @@ class _LsturNewsFn(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         T = title.shape[0]
         # category_embedding (padding_idx = 0): two segmented reductions over column blocks of g
-        d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0)
-        _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0, out=d_cat)
+        d_cat = _sorted_rows_scatter(cat, g, 0, 3 * NR_D, ncat, 0, sorted_pack=ctx.sorted_elem[0])
+        _sorted_rows_scatter(sub, g, NR_D, 3 * NR_D, ncat, 0, out=d_cat, sorted_pack=ctx.sorted_elem[1])
         # the title encoder's third of the [T, 3F] gradient: read in place by the flat pooling backward (no 32 MB contiguous copy per step)
         strided = text_bwd_strided_ok(st)
         g_title = g[:, 2 * NR_D:] if strided else g[:, 2 * NR_D:].contiguous()

@@ -373,8 +373,9 @@ class EngineAdam:
             return
         for st in self.sparse:
             if st.pending:
-                ids = torch.cat([i for i, _ in st.pending])
-                rows = torch.cat([r for _, r in st.pending])
+                # (one (ids, rows) pair per backward is the rule: no concatenation kernels then)
+                ids = st.pending[0][0] if len(st.pending) == 1 else torch.cat([i for i, _ in st.pending])
+                rows = st.pending[0][1] if len(st.pending) == 1 else torch.cat([r for _, r in st.pending])
                 st.pending.clear()
                 self._row_step(st, ids, rows, 1.0)
 

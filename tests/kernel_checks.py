@@ -677,6 +677,23 @@ def check_rows_to_f32(be, n=37):
     assert np.array_equal(got[:, NR_D:].view(np.uint32), before[:, NR_D:].view(np.uint32))          # columns beyond d untouched
 
 
+def check_rows_to_bf16(be, n=37):
+    """nr_rows_to_bf16: f32 rows (strided) -> bf16 rows [n][dp], column d = 1.0, the rest 0 -- the four-columns-per-lane form (everything a
+    multiple of 4) and the element form (odd width / stride), both bit-exact against round-to-nearest-even."""
+    rng = np.random.default_rng(45)
+    for d, dp, ld in ((900, 928, 900), (300, 320, 904), (450, 480, 451), (7, 9, 11), (300, 300, 300)):
+        src = rng.normal(size=(n, ld)).astype(np.float32)
+        src[0, :4] = [np.float32(1.0) + np.float32(2.0 ** -8), -0.0, 3.0e38, 1e-40]          # a tie, signed zero, near overflow, a denormal
+        dst = be.poison((n, dp), np.uint16)
+        ck(be, be.lib.nr_rows_to_bf16(be.ptr(be.dev(src)), ld, d, be.ptr(dst), dp, n, be.stream))
+        be.sync()
+        want = np.zeros((n, dp), dtype=np.uint16)
+        want[:, :d] = f32_to_bf16(src[:, :d])
+        if d < dp:
+            want[:, d] = 0x3F80
+        assert np.array_equal(be.np(dst), want), (d, dp, ld)
+
+
 def check_accum_many(be, n_items=5):
     """nr_accum_many: dst[r, c] += src[r, c] over strided sub-matrices, all items in one launch; more items than one launch holds."""
     import ctypes
@@ -684,7 +701,8 @@ def check_accum_many(be, n_items=5):
 
     class Item(ctypes.Structure):
         _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('src_ld', ctypes.c_int64), ('dst_ld', ctypes.c_int64),
-                    ('rows', ctypes.c_int32), ('cols', ctypes.c_int32)]
+                    ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('parts', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                    ('part_stride', ctypes.c_int64)]
     items = (Item * n_items)()
     keep = []
     for i in range(n_items):
@@ -693,16 +711,32 @@ def check_accum_many(be, n_items=5):
             rows, cols = 300, 301
         if i == 1:
             rows, cols = 1, 1
+        parts = 1
+        if i == 2:
+            rows, cols, parts = 1, 200, 256                # the query-vector gradient of a pooling level: one partial row per workgroup
+        if i == 3:
+            parts = 7
         sld, dld = cols + int(rng.integers(0, 9)), cols + int(rng.integers(0, 5))
-        src = rng.normal(size=(rows, sld)).astype(np.float32); dst = rng.normal(size=(rows, dld)).astype(np.float32)
+        src = rng.normal(size=(parts, rows, sld)).astype(np.float32); dst = rng.normal(size=(rows, dld)).astype(np.float32)
         hs, hd = be.dev(src), be.dev(dst)
-        items[i] = Item(be.ptr(hs), be.ptr(hd), sld, dld, rows, cols)
+        items[i] = Item(be.ptr(hs), be.ptr(hd), sld, dld, rows, cols, parts, 0, rows * sld)
         keep.append((src, dst, hs, hd, rows, cols))
     ck(be, be.lib.nr_accum_many(ctypes.cast(items, ctypes.c_void_p), n_items, be.stream))
     be.sync()
     for src, dst, hs, hd, rows, cols in keep:
-        ref = dst.copy(); ref[:, :cols] += src[:, :cols]
-        assert np.array_equal(be.np(hd), ref)              # one fp32 add per element: bit exact; columns beyond `cols` untouched
+        tot = np.zeros((rows, cols), dtype=np.float32)
+        P = src.shape[0]
+        if P == 1:
+            tot += src[0, :, :cols]
+        else:                                               # the kernel's order: 16 groups of ceil(P / 16) consecutive parts, each summed in part order; then the groups in order
+            per = (P + 15) // 16
+            for g_ in range(16):
+                sub = np.zeros((rows, cols), dtype=np.float32)
+                for q in range(g_ * per, min(P, (g_ + 1) * per)):
+                    sub += src[q, :, :cols]
+                tot += sub
+        ref = dst.copy(); ref[:, :cols] += tot
+        assert np.array_equal(be.np(hd), ref)              # fp32 adds in a fixed order: bit exact; columns beyond `cols` untouched
     items[0].src_ld = 3
     assert be.lib.nr_accum_many(ctypes.cast(items, ctypes.c_void_p), n_items, be.stream) == -2
 

@@ -72,6 +72,7 @@ def test_score_bwd(be): kc.check_score_bwd(be)
 def test_score_ce(be): kc.check_score_ce(be)
 def test_score_ce_target_scale_strided(be): kc.check_score_ce(be, B=9, C=5, with_target=True, with_scale=True, ld_extra=4)
 def test_rows_to_f32(be): kc.check_rows_to_f32(be)
+def test_rows_to_bf16(be): kc.check_rows_to_bf16(be)
 def test_accum_many(be): kc.check_accum_many(be)
 def test_accum_many_two_launches(be): kc.check_accum_many(be, n_items=53)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be)

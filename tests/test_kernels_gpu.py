@@ -66,6 +66,7 @@ def test_score_ce(be): kc.check_score_ce(be, B=513, C=3)
 def test_score_ce_target_scale_strided(be): kc.check_score_ce(be, B=130, C=5, with_target=True, with_scale=True, ld_extra=600)
 def test_score_ce_64(be): kc.check_score_ce(be, B=7, C=64, with_target=True)
 def test_rows_to_f32(be): kc.check_rows_to_f32(be, n=25601)
+def test_rows_to_bf16(be): kc.check_rows_to_bf16(be, n=2561)
 def test_accum_many(be): kc.check_accum_many(be, n_items=21)
 def test_accum_many_two_launches(be): kc.check_accum_many(be, n_items=53)
 def test_scatter_sorted(be): kc.check_scatter_sorted(be, n_tokens=200001, V=3000)
