@@ -149,8 +149,12 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
                     uint16_t* x_save, int64_t n_seq, int S, float p_drop, uint64_t seed, void* stream);
 /* Input gradient of the three projections as a hand-written GEMM (autograd of multihead_self.py:53-55 w.r.t. its input, triggered at
  * src/train.py:231): dX bf16[n_tok][NR_KP] = dqkv bf16[n_tok][NR_LDG] @ [Wq; Wk; Wv] (rows = the NR_LDG columns of dqkv, padding rows zero;
- * columns >= D of dX come out as exact zeros).  WdX: the weights packed by nr_pack_qkv_dx, bf16[60][10][64][8]: block (k-step ks, column
- * tile nt) = the 64 lanes' v_mfma_f32_32x32x16_bf16 fragments, lane l: Wall[16 ks + 8 (l >> 5) + j][32 nt + (l & 31)], j = 0..7. */
+ * columns >= D of dX come out as exact zeros).  WdX: the weights packed by nr_pack_qkv_dx / nr_pack_encoder OF THE SAME PROCESS, 307,200 bf16,
+ * opaque to the caller.  Default form: bf16[60][10][64][8], block (k-step ks, column tile nt) = the 64 lanes' v_mfma_f32_32x32x16_bf16
+ * fragments, lane l: Wall[16 ks + 8 (l >> 5) + j][32 nt + (l & 31)], j = 0..7, read by dx_gemm_ring_kernel (csrc/k_proj.h: one workgroup per
+ * 256-token tile).  NR_DX_STREAM=1 (read once per process; A/B, a tie on MI355X): row-major [NR_KP n][NR_LDG k], WdX[n][which NR_KP + f] =
+ * W_which[f][n], read by the persistent stream kernel (conv_gemm_kernel<., PLAIN>, csrc/k_convgemm.h: one workgroup per CU walks the tiles,
+ * the copy ring never drains). */
 int nr_pack_qkv_dx(const float* Wq, const float* Wk, const float* Wv, uint16_t* WdX, void* stream);
 int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t n_tok, void* stream);
 /* Weight (and bias) gradients of a linear layer as a hand-written split-K "TN" GEMM (autograd of multihead_self.py:53-55 / additive.py:35

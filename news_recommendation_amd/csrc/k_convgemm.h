@@ -56,10 +56,17 @@ struct ConvGemmParams {
 struct CgYes { static constexpr bool v = true; };
 struct CgNo { static constexpr bool v = false; };
 
-template <bool DBG = false>
+// PLAIN: the same stream over an ordinary [n_rows][3 KP] row-major operand (row stride 3 KP instead of the overlapping KP of the seqpad rows, no
+// separator rows, virtual row = output row): the input gradient of the title encoder's projections, dX = dqkv [Wq; Wk; Wv] (nr_dx_gemm, k_proj.h:
+// A[n][which KP + f] = W_which[f][n]).  Chunks in straight column order.
+// PAIRS (conv form only): chunk order (tap 0, block 2 j), (tap 0, block 2 j + 1), (tap 1, 2 j), (tap 1, 2 j + 1), (tap 2, 2 j), (tap 2, 2 j + 1): the
+// two 64-byte halves of a 128-byte line of the rows are requested by consecutive chunks, the taps' re-reads stay two chunks apart (A/B:
+// NR_CONVGEMM_PAIRS).
+template <bool DBG = false, bool PLAIN = false, bool PAIRS = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   using Gm = ConvGemmGeom;
   constexpr int TM = Gm::TM, TN = Gm::TN, CP = Gm::CP, NCH = Gm::NCH;
+  constexpr int LDR = PLAIN ? 3 * KP : KP;                         // row stride of the token-row operand
   NR_SMEM_DECL(smem);
   const int l = lane_id(), w = wave_id(), h = l >> 5, li = l & 31;
   const int wr = w >> 2, wc = w & 3;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
     auto rowoff = [&](int blk) -> uint32_t {
       int r = (blk - Gm::ABLK) * 16 + (l >> 2);
       r = r < lim ? r : lim - 1;
-      return (uint32_t)((r * KP + sl * 8) * 2);
+      return (uint32_t)((r * LDR + sl * 8) * 2);
     };
     voff[2] = a2 ? (uint32_t)((((w + 16) * 16 + (l >> 2)) * (3 * KP) + sl * 8) * 2) : rowoff(w + 16);
     voff[3] = rowoff(w + 24);
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   auto tile_lim = [&](int tord) -> int { const int64_t left = p.n_rows - tile_rows(tord); return left < Gm::BN ? (int)left : Gm::BN; };
   // the fetch stream: running pointers at (tile, chunk) = (ft, fc); tap-inner order: + KP columns twice, then back and + 32
   const u16* fa = p.A;
-  const u16* fr = p.R + tile_rows(0) * KP;
+  const u16* fr = p.R + tile_rows(0) * LDR;
   int ft = 0, fc = 0, ftap = 0;
   uint32_t fdst = 0;                                               // byte offset of the ring slot being filled
   set_row_offsets(tile_lim(0));
@@ -109,14 +116,22 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   };
   auto advance = [&]() __attribute__((always_inline)) {            // the fetch stream moves on by one chunk
     fdst = fdst + Gm::BUF < (uint32_t)Gm::RING ? fdst + Gm::BUF : 0u;
-    const int d = ftap == 2 ? 32 - 2 * KP : KP;
-    ftap = ftap == 2 ? 0 : ftap + 1;
+    int d;
+    if (PLAIN) {
+      d = 32;                                                      // straight order: the other half of a 128-byte line is the next chunk's
+    } else if (PAIRS) {
+      d = (ftap & 1) == 0 ? 32 : (ftap == 5 ? 32 - 2 * KP : KP - 32);
+      ftap = ftap == 5 ? 0 : ftap + 1;
+    } else {
+      d = ftap == 2 ? 32 - 2 * KP : KP;
+      ftap = ftap == 2 ? 0 : ftap + 1;
+    }
     fa += d; fr += d;
     if (++fc == NCH) {
       fc = 0; ++ft;
       fa = p.A;
       if (ft < n_my) {
-        fr = p.R + tile_rows(ft) * KP;
+        fr = p.R + tile_rows(ft) * LDR;
         const int lim = tile_lim(ft);
         if (lim < Gm::BN) set_row_offsets(lim);                    // (only the last tile of the problem, i.e. the last of this stream)
       }
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
     unsigned char* stg = smem + slot * Gm::BUF + w * (32 * SROW);
     auto token_of = [&](int tl, int jt, uint32_t& tok) -> bool {   // token row of local row tl of the wave's tile jt; false: separator / past the end
       const int64_t vr = n0 + (wc * TN + jt) * 32 + tl;            // virtual row = seqpad row vr + 1
+      if (PLAIN) { tok = (uint32_t)vr; return vr < p.n_rows; }
       const uint32_t sp = (uint32_t)(vr + 1);
       uint32_t sq = mulhi_u32(sp, p.s1_magic);                     // floor(sp / (S + 1)) or one more
       sq -= (sq * p.S1 > sp) ? 1u : 0u;

@@ -475,9 +475,20 @@ __global__ __launch_bounds__(AttnFwdGeom::WPB * 64, 4) void attn_fwd_kernel(Attn
 constexpr int DXK = 3 * KP;                 // 960 contraction columns
 // packed operand of dx_gemm_ring_kernel: WdX bf16 [60 k-steps][10 n-tiles][64 lanes][8]: lane l of block (ks, nt) holds
 // Wall[k = 16 ks + 8 (l >> 5) + j][n = 32 nt + (l & 31)], j = 0..7, Wall[which * KP + f][n] = W_which[f][n] (zero for f, n >= D)
+// rowmajor != 0 (the process runs dX in the persistent stream kernel, conv_gemm_kernel<., PLAIN> of k_convgemm.h; same 307,200 elements): WdX bf16
+// [KP n][960 k] row-major, WdX[n][which KP + f] = W_which[f][n]
 __device__ __forceinline__ void pack_qkv_dx_body(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                                 u16* __restrict__ WdX, int bid, int nb) {
+                                                 u16* __restrict__ WdX, int bid, int nb, int rowmajor) {
   const int total = DXK * KP;
+  if (rowmajor) {
+    for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+      const int n = i / DXK, k = i - n * DXK;
+      const int which = k / KP, f = k - which * KP;
+      const float* W = which == 0 ? Wq : (which == 1 ? Wk : Wv);
+      WdX[i] = f2bf((f < D && n < D) ? W[f * D + n] : 0.0f);
+    }
+    return;
+  }
   for (int i = bid * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
     const int k = i / KP, n = i - k * KP;
     const int which = k / KP, f = k - which * KP;
@@ -488,8 +499,8 @@ __device__ __forceinline__ void pack_qkv_dx_body(const float* __restrict__ Wq, c
   }
 }
 __global__ __launch_bounds__(256) void pack_qkv_dx_kernel(const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                                          u16* __restrict__ WdX) {
-  pack_qkv_dx_body(Wq, Wk, Wv, WdX, blockIdx.x, gridDim.x);
+                                                          u16* __restrict__ WdX, int rowmajor) {
+  pack_qkv_dx_body(Wq, Wk, Wv, WdX, blockIdx.x, gridDim.x, rowmajor);
 }
 
 // Every operand packing of ONE encoder (projection operands of the inference / training forward and of the input-gradient GEMM, the pooling
@@ -500,7 +511,8 @@ struct PackEncoderParams {
   int qdim;
   u16* Wp; float* bp;          // pack_qkv (register-resident forward, S = 50 encoder)
   u16* Wp32; float* bp32;      // pack_qkv32 (qkv_proj_kernel)
-  u16* WdX;                    // pack_qkv_dx (dx_gemm_ring_kernel)
+  u16* WdX;                    // pack_qkv_dx (dx_gemm_ring_kernel, or row-major for the persistent stream kernel)
+  int dx_rowmajor;
   u16* Wap; float* bap; float* qvp;     // pack_additive
   u16* WaT;                    // pack_additive_t
 };
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256) void pack_encoder_kernel(PackEncoderParams p) 
   switch (blockIdx.y) {
     case 0: if (p.Wp) pack_qkv_body(p.Wq, p.bq, p.Wk, p.bk, p.Wv, p.bv, p.Wp, p.bp, bid, nb); break;
     case 1: if (p.Wp32) pack_qkv32_body(p.Wq, p.bq, p.Wk, p.bk, p.Wv, p.bv, p.Wp32, p.bp32, bid, nb); break;
-    case 2: if (p.WdX) pack_qkv_dx_body(p.Wq, p.Wk, p.Wv, p.WdX, bid, nb); break;
+    case 2: if (p.WdX) pack_qkv_dx_body(p.Wq, p.Wk, p.Wv, p.WdX, bid, nb, p.dx_rowmajor); break;
     case 3: if (p.Wap) pack_additive_body(p.Wa, p.ba, p.qv, p.qdim, p.Wap, p.bap, p.qvp, bid, nb); break;
     default: if (p.WaT) pack_additive_t_body(p.Wa, p.qdim, p.WaT, bid, nb); break;
   }

@@ -115,6 +115,14 @@ static bool conv_gemm_persist_ok(int64_t n_seq, int S) {
   static const int on = [] { const char* e = getenv("NR_CONV_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   return on != 0 && n_seq * S * (int64_t)(NR_KP * 2) < (1LL << 31) && n_seq * (S + 1) < (1LL << 31);
 }
+// Form of nr_dx_gemm AND of its packed operand (nr_pack_qkv_dx / nr_pack_encoder write what the kernel of this process reads): 0 (default) the
+// one-tile-per-workgroup ring of k_proj.h over a fragment-ordered operand, NR_DX_STREAM=1 the persistent stream kernel of k_convgemm.h over a
+// row-major operand -- a TIE on MI355X (365 - 369 vs 367 - 371 us per NRMS step, profiles/r06_ab_dx_stream.txt; with the conv form's tap-inner
+// chunk order it LOST, 389 - 393 us: the two 64-byte halves of a 128-byte line were requested three chunks apart).  Read once.
+static int dx_stream_form() {
+  static const int on = [] { const char* e = getenv("NR_DX_STREAM"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
+  return on;
+}
 static int launch_conv_gemm(nr::ConvGemmParams& p, int64_t n_seq, int S, void* stream, const char* who) {
   using G = nr::ConvGemmGeom;
   p.n_rows = n_seq * (S + 1) - 1; p.n_tok = n_seq * S;
@@ -125,6 +133,14 @@ static int launch_conv_gemm(nr::ConvGemmParams& p, int64_t n_seq, int S, void* s
   if (p.debug) {
     if (allow_smem(nr::conv_gemm_kernel<true>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
     NR_LAUNCH((nr::conv_gemm_kernel<true>), p.n_tiles < cus ? p.n_tiles : cus, 512, G::SMEM, (hipStream_t)stream, p);
+    return check_launch(who);
+  }
+  // chunk order of a tile (k_convgemm.h): pairs of column blocks under each tap (default) or tap-inner (NR_CONVGEMM_PAIRS=0); read once.
+  // NAML step, one box: titles 316 / 318 vs 325 / 322 us, abstracts 748 / 763 vs 764 / 760 us (profiles/r06_ab_convgemm_pairs.txt)
+  static const int pairs = [] { const char* e = getenv("NR_CONVGEMM_PAIRS"); return e ? atoi(e) : 1; }();
+  if (pairs) {
+    if (allow_smem(nr::conv_gemm_kernel<false, false, true>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
+    NR_LAUNCH((nr::conv_gemm_kernel<false, false, true>), p.n_tiles < cus ? p.n_tiles : cus, 512, G::SMEM, (hipStream_t)stream, p);
     return check_launch(who);
   }
   if (allow_smem(nr::conv_gemm_kernel<false>, G::SMEM)) return fail(NR_ERR_LAUNCH, who, ": cannot reserve LDS");
@@ -414,7 +430,7 @@ int nr_pack_encoder(const float* Wq, const float* bq, const float* Wk, const flo
   if (!Wq || !bq || !Wk || !bk || !Wv || !bv || !Wa || !ba || !qv) return fail(NR_ERR_BADARG, "nr_pack_encoder: null parameter");
   if ((Wp && !bp) || (Wp32 && !bp32) || (Wap && (!bap || !qvp))) return fail(NR_ERR_BADARG, "nr_pack_encoder: an operand without its bias / query vector");
   if (qdim <= 0 || qdim > NR_QP) return fail(NR_ERR_UNSUPPORTED, "nr_pack_encoder: query_vector_dim must be in [1,208]");
-  nr::PackEncoderParams p{Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, qdim, Wp, bp, Wp32, bp32, WdX, Wap, bap, qvp, WaT};
+  nr::PackEncoderParams p{Wq, bq, Wk, bk, Wv, bv, Wa, ba, qv, qdim, Wp, bp, Wp32, bp32, WdX, dx_stream_form(), Wap, bap, qvp, WaT};
   NR_LAUNCH2(nr::pack_encoder_kernel, 128, 5, 256, 0, (hipStream_t)stream, p);
   return check_launch("nr_pack_encoder");
 }
@@ -446,7 +462,7 @@ int nr_qkv_proj_fwd(const int64_t* ids, const float* table, int64_t num_rows, co
 
 int nr_pack_qkv_dx(const float* Wq, const float* Wk, const float* Wv, uint16_t* WdX, void* stream) {
   if (!Wq || !Wk || !Wv || !WdX) return fail(NR_ERR_BADARG, "nr_pack_qkv_dx: null pointer");
-  NR_LAUNCH(nr::pack_qkv_dx_kernel, 256, 256, 0, (hipStream_t)stream, Wq, Wk, Wv, WdX);
+  NR_LAUNCH(nr::pack_qkv_dx_kernel, 256, 256, 0, (hipStream_t)stream, Wq, Wk, Wv, WdX, dx_stream_form());
   return check_launch("nr_pack_qkv_dx");
 }
 
@@ -454,6 +470,21 @@ int nr_dx_gemm(const uint16_t* dqkv, const uint16_t* WdX, uint16_t* dX, int64_t 
   if (!dqkv || !WdX || !dX || n_tok < 0) return fail(NR_ERR_BADARG, "nr_dx_gemm: bad argument");
   if ((((uintptr_t)dqkv | (uintptr_t)WdX | (uintptr_t)dX) & 15) != 0) return fail(NR_ERR_BADARG, "nr_dx_gemm: buffers must be 16-byte aligned");
   if (n_tok == 0) return NR_OK;
+  if (dx_stream_form()) {
+    // the persistent stream kernel (k_convgemm.h, PLAIN): 32-bit output offsets -> launches of at most 2^31 / 640 output rows
+    using G = nr::ConvGemmGeom;
+    const int64_t seg = ((1LL << 31) / (NR_KP * 2) / G::BN - 1) * G::BN;
+    const int cus = nr::device_cus();
+    if (allow_smem(nr::conv_gemm_kernel<false, true>, G::SMEM)) return fail(NR_ERR_LAUNCH, "nr_dx_gemm: cannot reserve LDS");
+    for (int64_t t0 = 0; t0 < n_tok; t0 += seg) {
+      nr::ConvGemmParams q{};
+      q.A = WdX; q.R = dqkv + t0 * (3 * NR_KP); q.C = dX + t0 * NR_KP;
+      q.n_rows = q.n_tok = n_tok - t0 < seg ? n_tok - t0 : seg;
+      q.n_tiles = (int)((q.n_rows + G::BN - 1) / G::BN);
+      NR_LAUNCH((nr::conv_gemm_kernel<false, true>), q.n_tiles < cus ? q.n_tiles : cus, 512, G::SMEM, (hipStream_t)stream, q);
+    }
+    return check_launch("nr_dx_gemm");
+  }
   nr::DxParams p;
   p.dqkv = dqkv; p.WdX = WdX; p.dX = dX; p.n_tok = n_tok;
   using R = nr::DxRingGeom;

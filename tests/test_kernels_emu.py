@@ -102,6 +102,14 @@ def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=3, val
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
 def test_conv_dgrad_gemm_form(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=14); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=3)       # 293 / 152 virtual rows: two tiles, the second partial
+def test_conv_dgrad_gemm_tap_inner_order():
+    """NR_CONVGEMM_PAIRS=0 (read once per process: a child): the tap-inner chunk order of the persistent conv data-gradient GEMM."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('from tests.backends import EmuBackend; from tests import kernel_checks_conv as kcc; be = EmuBackend(); '
+            'kcc.check_conv_dgrad_gemm(be, S=20, n_seq=50); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=3); print("tap-inner ok")')
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, NR_CONVGEMM_PAIRS='0'), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'tap-inner ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 def test_conv_dgrad_gemm_persistent_stream(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=50)       # 1,049 virtual rows = 5 tiles over the emulator's 3 "CUs": two tiles per workgroup, the ring runs across the tile boundary
 def test_conv_act_bwd(be): kcc.check_conv_act_bwd(be)
 def test_additive_bwd_act_fused_s20(be): kcc.check_additive_bwd_act(be, S=20, n_seq=7); kcc.check_additive_bwd_act(be, S=20, n_seq=17)

@@ -70,6 +70,18 @@ def test_dx_gemm(be):
     kp.check_dx_gemm(be, n_tok=20000 + 77, seed=32)
 
 
+def test_dx_gemm_stream_form():
+    """NR_DX_STREAM=1: nr_dx_gemm in the persistent stream kernel (csrc/k_convgemm.h, PLAIN) over its row-major operand (the switch is read
+    once per process: a child process); 513 tiles = two or three per workgroup, the ring runs across tile boundaries."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('from tests.backends import GpuBackend; from tests import kernel_checks_proj as kp; be = GpuBackend(); '
+            'kp.check_dx_gemm(be, n_tok=300); kp.check_dx_gemm(be, n_tok=20077, seed=32); kp.check_dx_gemm(be, n_tok=2 * 256 * 256 + 77, seed=34); '
+            'kp.check_pack_encoder(be); print("stream ok")')
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, NR_DX_STREAM='1'), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'stream ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_tn_gemm(be):
     from tests import kernel_checks_proj as kp
     kp.check_tn_gemm(be, n_tok=300, M=960, P=8)
