@@ -310,6 +310,14 @@ int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int
  * contraction of length 3 * NR_KP): Wd2 bf16 [NR_KP][3 * NR_KP] row-major from nr_pack_conv_dgrad (Wd2[d][t * NR_KP + f] = W[f][2 - t][d]).
  * Same result as nr_conv3_dgrad up to the order of the fp32 additions; columns >= D of dx come out as exact zeros. */
 int nr_pack_conv_dgrad(const float* W, int F, int D, uint16_t* Wd2, void* stream);
+/* The TRAINING forward of the text encoders (same reference lines and outputs as nr_conv3_fwd_v with x_save: NAML news_encoder.py:23-32, LSTUR
+ * news_encoder.py:58-67) as a gather pass + the persistent ring GEMM of csrc/k_convgemm.h (EPI): x_save (required: bf16 seqpad
+ * [n_seq*(S+1)+1][NR_KP], the operand of the weight-gradient GEMMs) is written first and is the GEMM's token-row operand; act = dropout2(relu(y + b)),
+ * column D = 1.0.  Wf2 bf16 [NR_KP][3 * NR_KP] row-major from nr_pack_conv_fwd2 (Wf2[f][t * NR_KP + d] = W[f][t][d]); bc: nr_pack_conv's f32[NR_KP].
+ * Same dropout counters as nr_conv3_fwd_v: same masks, x_save bit-identical, act equal up to the summation order of the taps. */
+int nr_pack_conv_fwd2(const float* W, int F, int D, uint16_t* Wf2, void* stream);
+int nr_conv3_fwd_gemm(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wf2, const float* bc, uint16_t* act,
+                      uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream);
 int nr_conv3_dgrad_gemm(const uint16_t* dy_pad, const uint16_t* Wd2, uint16_t* dx, int64_t n_seq, int S, void* stream);
 /* Gradient through dropout+relu: dy_pad[row(q,s)] = (dact_gemm[t] + attn_w[t] * g_out[q]) * [act[t] != 0] / (1 - p_drop);
  * dact_gemm bf16 [n_seq*S][ldc] = dpre @ Wa (plain GEMM by the caller), g_out f32 rows of stride g_stride. */

@@ -101,6 +101,8 @@ SIGNATURES = {
     'nr_row_adam_step': ([_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, c_double, c_double, c_double,
                           c_float, c_int, _P], c_int),
     'nr_pack_conv_dgrad': ([_P, c_int, c_int, _P, _P], c_int),
+    'nr_pack_conv_fwd2': ([_P, c_int, c_int, _P, _P], c_int),
+    'nr_conv3_fwd_gemm': ([_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, c_int64, _P], c_int),
     'nr_conv3_dgrad_gemm': ([_P, _P, _P, c_int64, c_int, _P], c_int),
     'nr_gemm_nt': ([_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P], c_int),
     'nr_gemm_tn_parts': ([c_int, c_int, c_int64], c_int),

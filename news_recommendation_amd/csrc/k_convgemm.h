@@ -21,8 +21,12 @@
 //     that epilogue (its code is the compiler's, which may move the destination registers of a read it believes complete).
 // Stores enter the same in-order memory counter as the copies; they are always YOUNGER than the copies a counted wait is for, so the waits stay
 // correct (at worst they also wait for a few stores of the previous tile).
-// A forward form of the same kernel (gather pass + GEMM with the bias / relu / dropout epilogue) was built and measured in round 6: 1.29 ms against
-// the LDS-tile kernel's 1.13 ms for the abstracts (the gather pass alone is 0.23 ms, the epilogue's registers spill inside the loop): not shipped.
+// A forward form of the same kernel (gather pass + GEMM with the bias / relu / dropout epilogue) was built and measured twice in round 6.  First
+// version (bias fragments in registers): 1.29 ms against the LDS-tile kernel's 1.13 ms for the abstracts (the gather pass alone is 0.23 ms, the
+// epilogue's registers spilled inside the loop), removed.  Second version (EPI below + conv_gather_kernel: bias from LDS, no spill on the per-chunk
+// path): 1.47 against 1.20 ms, titles 0.65 against 0.57 ms (profiles/r06_ab_conv_fwd_gemm.txt) -- one counter hash per output quad (~35 VALU
+// instructions) by all eight waves at once behind the tile's last barrier is ~0.45 ms that nothing overlaps.  Kept behind NR_CONV_FWD_GEMM=1
+// (parity-tested: tests/kernel_checks_conv.py gemm=True), NOT the default.
 #pragma once
 #include "nr_common.h"
 
@@ -38,7 +42,8 @@ struct ConvGemmGeom {
   static constexpr int CP = 5;                                     // copies per wave and chunk (36 blocks over 8 waves; waves 4..7 repeat one)
   static constexpr int NCH = 3 * KP / 32;                          // 30 chunks per tile, TAP-INNER: chunk c = tap c % 3, columns 32 (c / 3)
   static constexpr int SMEM = RING;
-  static_assert(SMEM <= 163840 && BM == 2 * TM * 32 && BN == 4 * TN * 32, "LDS; wave grid");
+  static constexpr int SMEM_EPI = RING + KP * 4;                   // + the bias row of the forward epilogue
+  static_assert(SMEM_EPI <= 163840 && BM == 2 * TM * 32 && BN == 4 * TN * 32, "LDS; wave grid");
 };
 
 struct ConvGemmParams {
@@ -51,6 +56,10 @@ struct ConvGemmParams {
   uint32_t S1;           // S + 1
   uint32_t s1_magic;     // floor(2^32 / (S + 1)) + 1
   int debug;             // profiling only (NR_CONVGEMM_DEBUG): 1 no copies of A, 2 no copies of the token rows, 4 no MFMAs, 8 no stores, 16 A is chunk-major
+  // EPI (the FORWARD convolution over the masked token rows, nr_conv3_fwd_gemm): C = dropout2(relu(y + bias)), column D = 1.0, columns > D zero
+  const float* bias;     // f32 [KP] (zero padded)
+  int64_t tok_offset;    // added to the token index in the dropout counters (as in conv3_kernel)
+  DropCfg dc;
 };
 
 struct CgYes { static constexpr bool v = true; };
@@ -62,7 +71,10 @@ struct CgNo { static constexpr bool v = false; };
 // PAIRS (conv form only): chunk order (tap 0, block 2 j), (tap 0, block 2 j + 1), (tap 1, 2 j), (tap 1, 2 j + 1), (tap 2, 2 j), (tap 2, 2 j + 1): the
 // two 64-byte halves of a 128-byte line of the rows are requested by consecutive chunks, the taps' re-reads stay two chunks apart (A/B:
 // NR_CONVGEMM_PAIRS).
-template <bool DBG = false, bool PLAIN = false, bool PAIRS = false>
+// EPI: the epilogue of the forward convolution (NAML news_encoder.py:27-32, LSTUR news_encoder.py:62-67) on the way through the staging rows:
+// + bias (f32, from 1,280 bytes of LDS behind the ring: nothing stays in registers across the stream), relu, the counter-based dropout of
+// conv3_kernel's output stage (site 2, quad = (tok_offset + token) D4 + column / 4: the same masks), column D = 1.0, columns > D zero.
+template <bool DBG = false, bool PLAIN = false, bool PAIRS = false, bool EPI = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   using Gm = ConvGemmGeom;
   constexpr int TM = Gm::TM, TN = Gm::TN, CP = Gm::CP, NCH = Gm::NCH;
@@ -76,6 +88,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   const int T = n_my * NCH;                                        // chunks of this workgroup's stream
   const int dbg = DBG ? p.debug : 0;       // the production instantiation folds every switch away
   const uint32_t smem32 = lds_addr32(smem);
+  float* const bias_s = (float*)(smem + Gm::RING);
+  if (EPI) {
+    p.dc = drop_resolve(p.dc);
+    if (threadIdx.x < KP) bias_s[threadIdx.x] = p.bias[threadIdx.x];         // (published by the stream's barriers long before the first tile leaves)
+  }
 
   // ---- copies.  Block b of a chunk buffer = rows 16 b .. + 15 of A (b < 20) / of the tile's token rows (b - 20); the lane's piece inside a block:
   // row l >> 2, physical 16-byte slot l & 3 <- logical k-slot (l & 3) ^ ((row >> 2) & 3) (16 b does not move the swizzle).  Wave w copies blocks
@@ -211,10 +228,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
     };
 #pragma unroll
     for (int jt = 0; jt < TN; ++jt) {
+      uint32_t tokq = 0;                                             // EPI: the token this lane's accumulator quads belong to
+      if (EPI) token_of(li, jt, tokq);
       auto put = [&](int a, int pos) __attribute__((always_inline)) {       // channel tile a of the wave -> bytes 64 pos .. + 63 of the staging rows
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 y = f32x4{acc[a][jt][4 * q], acc[a][jt][4 * q + 1], acc[a][jt][4 * q + 2], acc[a][jt][4 * q + 3]};
+          if (EPI) {
+            const int col = (wr * TM + a) * 32 + q * 8 + h * 4;     // 4 consecutive filters of token tokq
+            y = y + *(const f32x4*)(bias_s + col);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+            if (col < D) {
+              if (p.dc.enabled) y = y * drop_mul4(p.dc, 2u, (uint64_t)(p.tok_offset + (int64_t)tokq) * D4 + (uint32_t)(col >> 2));
+            } else {
+              y = col == D ? f32x4{1.0f, 0.0f, 0.0f, 0.0f} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+          }
           *(u16x4*)(stg + li * SROW + pos * 64 + q * 16 + h * 8) = pack4(y);
         }
       };
@@ -297,6 +327,58 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(ConvGemmParams p) {
   NR_WAIT_LGKMCNT(0);
   NR_BARRIER_RAW();                                                // everybody has read the last chunk: its slot is the staging area
   store_tile(n_my - 1, rb);
+}
+
+// ---- the input stage of the forward convolution as its own pass (the GEMM form's R operand IS the x_save buffer the weight-gradient GEMMs read):
+// x_save seqpad rows [n_seq (S + 1) + 1][KP] = bf16(F.dropout(table[ids])) (NAML news_encoder.py:23-25 / LSTUR :58-60), column D = 1.0 in token
+// rows, zero separators; positions s >= valid are zero vectors.  Same counters, same arithmetic, same bits as conv3_kernel's staging phase.
+struct ConvGatherParams {
+  const int64_t* ids;
+  const float* table;
+  int64_t num_rows;
+  u16* x_save;
+  int64_t n_seq;
+  int S, valid;
+  int64_t tok_offset;
+  DropCfg dc;
+};
+__global__ __launch_bounds__(256) void conv_gather_kernel(ConvGatherParams p) {
+  p.dc = drop_resolve(p.dc);
+  constexpr int QR = KP / 4;                                       // 80 quads per row
+  const int64_t rows_total = p.n_seq * (p.S + 1) + 1;
+  const int64_t total = rows_total * QR;
+  const uint32_t S1 = (uint32_t)(p.S + 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gr = i / QR;
+    const int c = (int)(i - gr * QR);
+    const int64_t seq = gr / S1;
+    const int s = (int)(gr - seq * S1) - 1;
+    u16x4 o = u16x4{0, 0, 0, 0};
+    if (s >= 0 && seq < p.n_seq) {
+      if (c < D4) {
+        if (p.valid <= 0 || s < p.valid) {
+          const int64_t tok = seq * p.S + s;
+          int64_t id = p.ids[tok];
+          id = id < 0 ? 0 : (id >= p.num_rows ? p.num_rows - 1 : id);
+          f32x4 x = *(const f32x4*)(p.table + ((size_t)id * D4 + c) * 4);
+          if (p.dc.enabled) x = x * drop_mul4(p.dc, 1u, (uint64_t)(p.tok_offset + tok) * D4 + c);
+          o = pack4(x);
+        }
+      } else if (c == D4) {
+        o[0] = 0x3F80;
+      }
+    }
+    *(u16x4*)(p.x_save + gr * KP + c * 4) = o;
+  }
+}
+
+// A operand of the forward GEMM form: Wf2[f][tap * KP + d] = W[f][tap][d] (Conv2d weight f32 [F][1][3][D]), bf16 row-major [KP][3 * KP], zero padded
+__global__ __launch_bounds__(256) void pack_conv_fwd2_kernel(const float* __restrict__ W, int F_, int D_, u16* __restrict__ Wf2) {
+  const int total = KP * 3 * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int f = i / (3 * KP), rem = i - f * 3 * KP, tap = rem / KP, d = rem - tap * KP;
+    Wf2[i] = f2bf((f < F_ && d < D_) ? W[((size_t)f * 3 + tap) * D_ + d] : 0.0f);
+  }
 }
 
 }  // namespace nr

@@ -987,6 +987,39 @@ int nr_conv3_fwd_v(const int64_t* ids, const float* table, int64_t num_rows, con
   return launch_conv(p, S, stream, "nr_conv3_fwd");
 }
 
+int nr_pack_conv_fwd2(const float* W, int F, int D, uint16_t* Wf2, void* stream) {
+  if (!W || !Wf2 || F <= 0 || F > NR_D || D <= 0 || D > NR_D) return fail(NR_ERR_BADARG, "nr_pack_conv_fwd2: bad argument");
+  NR_LAUNCH(nr::pack_conv_fwd2_kernel, 300, 256, 0, (hipStream_t)stream, W, F, D, Wf2);
+  return check_launch("nr_pack_conv_fwd2");
+}
+
+// The training forward of the text encoders as gather pass + persistent ring GEMM (csrc/k_convgemm.h, EPI): same outputs as nr_conv3_fwd_v with
+// x_save (which is the GEMM's token-row operand here, hence required).
+int nr_conv3_fwd_gemm(const int64_t* ids, const float* table, int64_t num_rows, const uint16_t* Wf2, const float* bc, uint16_t* act,
+                      uint16_t* x_save, int64_t n_seq, int S, int valid, float p_drop, uint64_t seed, int64_t tok_offset, void* stream) {
+  if (!ids || !table || num_rows <= 0 || !Wf2 || !bc || !act || !x_save || n_seq < 0 || tok_offset < 0 || S < 1 || valid < 1 || valid > S)
+    return fail(NR_ERR_BADARG, "nr_conv3_fwd_gemm: bad argument");
+  if (p_drop < 0.0f || p_drop >= 1.0f) return fail(NR_ERR_BADARG, "nr_conv3_fwd_gemm: dropout probability out of range");
+  if ((((uintptr_t)Wf2 | (uintptr_t)act | (uintptr_t)x_save | (uintptr_t)table) & 15) != 0) return fail(NR_ERR_BADARG, "nr_conv3_fwd_gemm: buffers must be 16-byte aligned");
+  if (n_seq == 0) return NR_OK;
+  if (n_seq * S * (int64_t)(NR_KP * 2) >= (1LL << 31) || n_seq * (S + 1) >= (1LL << 31))
+    return fail(NR_ERR_UNSUPPORTED, "nr_conv3_fwd_gemm: more than 2 GiB of output rows (use nr_conv3_fwd_v)");
+  using G = nr::ConvGemmGeom;
+  nr::ConvGatherParams g;
+  g.ids = ids; g.table = table; g.num_rows = num_rows; g.x_save = x_save; g.n_seq = n_seq; g.S = S; g.valid = valid; g.tok_offset = tok_offset;
+  g.dc = make_drop(p_drop, seed);
+  NR_LAUNCH(nr::conv_gather_kernel, grid_for((n_seq * (S + 1) + 1) * (NR_KP / 4), 256, 16384), 256, 0, (hipStream_t)stream, g);
+  nr::ConvGemmParams q{};
+  q.A = Wf2; q.R = x_save; q.C = act; q.bias = bc; q.tok_offset = tok_offset; q.dc = g.dc;
+  q.n_rows = n_seq * (S + 1) - 1; q.n_tok = n_seq * S;
+  q.n_tiles = (int)((q.n_rows + G::BN - 1) / G::BN);
+  q.S1 = (uint32_t)(S + 1); q.s1_magic = (uint32_t)((1ULL << 32) / (uint32_t)(S + 1)) + 1u;
+  const int cus = nr::device_cus();
+  if (allow_smem(nr::conv_gemm_kernel<false, false, true, true>, G::SMEM_EPI)) return fail(NR_ERR_LAUNCH, "nr_conv3_fwd_gemm: cannot reserve LDS");
+  NR_LAUNCH((nr::conv_gemm_kernel<false, false, true, true>), q.n_tiles < cus ? q.n_tiles : cus, 512, G::SMEM_EPI, (hipStream_t)stream, q);
+  return check_launch("nr_conv3_fwd_gemm");
+}
+
 int nr_conv3_dgrad(const uint16_t* dy_pad, const uint16_t* Wd, uint16_t* dx, int64_t n_seq, int S, void* stream) {
   if (!dy_pad || !Wd || !dx || n_seq < 0) return fail(NR_ERR_BADARG, "nr_conv3_dgrad: bad argument");
   if (n_seq == 0) return NR_OK;

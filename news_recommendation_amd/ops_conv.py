@@ -62,6 +62,23 @@ def pack_conv_dgrad(W):
     return ops._packed('conv_dgrad', (W,), build)[0]
 
 
+def pack_conv_fwd2(W):
+    """Conv2d weight -> the A operand of the training forward in GEMM form (nr_conv3_fwd_gemm): bf16 [KP][3 KP] row-major, cached per state."""
+    def build():
+        Wf2 = torch.empty(NR_KP, 3 * NR_KP, dtype=_BF16_AS_I16, device=W.device)
+        _call('nr_pack_conv_fwd2', _lib().nr_pack_conv_fwd2, _ptr(_f32c(W)), W.shape[0], W.shape[3], _ptr(Wf2), _stream())
+        return (Wf2,)
+    return ops._packed('conv_fwd2', (W,), build)[0]
+
+
+def conv_fwd_gemm_ok(n_seq, S):
+    """The training forward as gather pass + persistent ring GEMM (csrc/k_convgemm.h): NR_CONV_FWD_GEMM (default below), output rows within 2 GiB."""
+    return _CONV_FWD_GEMM and n_seq * S * NR_KP * 2 < 2 ** 31
+
+
+_CONV_FWD_GEMM = os.environ.get('NR_CONV_FWD_GEMM', '0') != '0'
+
+
 def _seqpad_alloc(n_seq, S):
     """(seqpad rows, chunk count, allocated rows = chunk count x chunk rows)."""
     rp = n_seq * (S + 1) + 1
@@ -114,8 +131,12 @@ def text_fwd(ids, table, conv_w, conv_b, Wa, ba, qv, p, seed, tok_offset, need_g
         xs_ptr = st.xstore.data_ptr() + NR_KP * 2
     tab = table.detach()
     assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[1] == NR_D
-    _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd_v, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
-          n_seq, S, valid, p, seed, tok_offset, _stream())
+    if need_grad and conv_fwd_gemm_ok(n_seq, S):
+        _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd_gemm, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(pack_conv_fwd2(conv_w)), _ptr(bc), _ptr(st.act),
+              xs_ptr, n_seq, S, valid, p, seed, tok_offset, _stream())
+    else:
+        _call(f'nr_conv3_fwd[{tag}]', lib.nr_conv3_fwd_v, _ptr(ids), _ptr(tab), tab.shape[0], _ptr(Wc), _ptr(bc), _ptr(st.act), xs_ptr,
+              n_seq, S, valid, p, seed, tok_offset, _stream())
     st.aw = torch.empty(n_seq, S, dtype=torch.float32, device=dev)
     # the pooled vectors in f32 are an operand of the backward (csrc/k_pool3.h): a private buffer when the caller only wants the bf16 copy;
     # a caller-owned `out` is the autograd function's own output, referenced through y_keep (detached: no reference cycle)

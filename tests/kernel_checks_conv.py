@@ -61,7 +61,15 @@ def to_seqpad(x_tok, n_seq, S):
     return out
 
 
-def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0):
+def _fwd_gemm_operand(be, W):
+    Wf2 = be.poison((NR_KP, 3 * NR_KP), np.uint16)
+    ck(be, be.lib.nr_pack_conv_fwd2(be.ptr(be.dev(W)), W.shape[0], W.shape[3], be.ptr(Wf2), be.stream))
+    return Wf2
+
+
+def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0, gemm=False):
+    """gemm=True: the training forward as gather pass + persistent ring GEMM (nr_conv3_fwd_gemm, csrc/k_convgemm.h EPI) against the same oracle,
+    and its x_save bit for bit against the LDS-tile kernel's contract."""
     W, b = conv_params(2)
     rng = np.random.default_rng(3)
     table = rng.normal(0, 0.5, size=(V, NR_D)).astype(np.float32)
@@ -71,8 +79,13 @@ def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0
     Wc, _, bc = pack_conv(be, W, b, False)
     act = be.poison((n_seq * S, NR_KP), np.uint16)
     xs = be.poison((seqpad_rows(n_seq, S), NR_KP), np.uint16)      # the kernel writes the separator rows too
-    ck(be, be.lib.nr_conv3_fwd(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
-                               n_seq, S, p_drop, seed, tok_offset, be.stream))
+    if gemm:
+        Wf2 = _fwd_gemm_operand(be, W)
+        ck(be, be.lib.nr_conv3_fwd_gemm(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wf2), be.ptr(bc),
+                                        be.ptr(act), be.ptr(xs), n_seq, S, S, p_drop, seed, tok_offset, be.stream))
+    else:
+        ck(be, be.lib.nr_conv3_fwd(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
+                                   n_seq, S, p_drop, seed, tok_offset, be.stream))
     be.sync()
     x = table[ids].astype(np.float64)
     m2, scale = None, 1.0
@@ -103,7 +116,7 @@ def check_conv_fwd(be, S=20, n_seq=6, V=300, p_drop=0.0, seed=4321, tok_offset=0
     return err.max() / np.abs(ref).max()
 
 
-def check_conv_fwd_valid(be, S=20, n_seq=6, V=300, valid=13):
+def check_conv_fwd_valid(be, S=20, n_seq=6, V=300, valid=13, gemm=False):
     """nr_conv3_fwd_v: texts of `valid` tokens zero-padded to S (padding ids are NOT zero here, to prove they are ignored): the first
     `valid` outputs of every sequence equal the convolution of the truncated text (Conv2d zero padding right after its last token)."""
     W, b = conv_params(2)
@@ -113,8 +126,15 @@ def check_conv_fwd_valid(be, S=20, n_seq=6, V=300, valid=13):
     Wc, _, bc = pack_conv(be, W, b, False)
     act = be.poison((n_seq * S, NR_KP), np.uint16)
     xs = be.poison((seqpad_rows(n_seq, S), NR_KP), np.uint16)
-    ck(be, be.lib.nr_conv3_fwd_v(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
-                                 n_seq, S, valid, 0.0, 0, 0, be.stream))
+    if gemm:
+        Wf2 = _fwd_gemm_operand(be, W)
+        ck(be, be.lib.nr_conv3_fwd_gemm(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wf2), be.ptr(bc),
+                                        be.ptr(act), be.ptr(xs), n_seq, S, valid, 0.0, 0, 0, be.stream))
+        assert be.lib.nr_conv3_fwd_gemm(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wf2), be.ptr(bc),
+                                        be.ptr(act), None, n_seq, S, valid, 0.0, 0, 0, be.stream) != 0 and b'nr_conv3_fwd_gemm' in be.lib.nr_last_error()
+    else:
+        ck(be, be.lib.nr_conv3_fwd_v(be.ptr(be.dev(ids.astype(np.int64))), be.ptr(be.dev(table)), V, be.ptr(Wc), be.ptr(bc), be.ptr(act), be.ptr(xs),
+                                     n_seq, S, valid, 0.0, 0, 0, be.stream))
     be.sync()
     xq = bf16_round(table[ids[:, :valid]]).astype(np.float64)
     ref = np.maximum(conv_ref(xq, bf16_round(W).astype(np.float64), b.astype(np.float64)), 0.0)

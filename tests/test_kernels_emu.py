@@ -99,6 +99,10 @@ def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=5, p_drop=
 def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=3, p_drop=0.2)
 def test_conv_fwd_valid_s20(be): kcc.check_conv_fwd_valid(be, S=20, n_seq=6, valid=13)
 def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=3, valid=33)
+def test_conv_fwd_gemm_s20(be): kcc.check_conv_fwd(be, S=20, n_seq=14, gemm=True)                      # the training forward as gather pass + persistent ring GEMM (csrc/k_convgemm.h, EPI): two tiles
+def test_conv_fwd_gemm_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=50, p_drop=0.2, tok_offset=140, gemm=True)      # 5 tiles over 3 "CUs": the stream crosses a tile boundary
+def test_conv_fwd_gemm_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=3, p_drop=0.2, gemm=True)
+def test_conv_fwd_gemm_valid(be): kcc.check_conv_fwd_valid(be, S=20, n_seq=6, valid=13, gemm=True); kcc.check_conv_fwd_valid(be, S=50, n_seq=3, valid=33, gemm=True)
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=5)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=3)
 def test_conv_dgrad_gemm_form(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=14); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=3)       # 293 / 152 virtual rows: two tiles, the second partial

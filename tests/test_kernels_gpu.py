@@ -92,6 +92,14 @@ def test_conv_fwd_s20_dropout(be): kcc.check_conv_fwd(be, S=20, n_seq=515, V=500
 def test_conv_fwd_s50(be): kcc.check_conv_fwd(be, S=50, n_seq=203, V=5000, p_drop=0.2)
 def test_conv_fwd_valid_s20(be): kcc.check_conv_fwd_valid(be, S=20, n_seq=515, valid=13)
 def test_conv_fwd_valid_s50(be): kcc.check_conv_fwd_valid(be, S=50, n_seq=131, valid=33)
+def test_conv_fwd_gemm(be):
+    """The training forward as gather pass + persistent ring GEMM (nr_conv3_fwd_gemm, csrc/k_convgemm.h EPI); 3,300 titles = 271 tiles: the stream
+    crosses a tile boundary on some CUs."""
+    kcc.check_conv_fwd(be, S=20, n_seq=1027, V=5000, gemm=True)
+    kcc.check_conv_fwd(be, S=20, n_seq=3300, V=5000, p_drop=0.2, tok_offset=140, gemm=True)
+    kcc.check_conv_fwd(be, S=50, n_seq=203, V=5000, p_drop=0.2, gemm=True)
+    kcc.check_conv_fwd_valid(be, S=20, n_seq=515, valid=13, gemm=True)
+    kcc.check_conv_fwd_valid(be, S=50, n_seq=131, valid=33, gemm=True)
 def test_conv_dgrad_s20(be): kcc.check_conv_dgrad(be, S=20, n_seq=515)
 def test_conv_dgrad_s50(be): kcc.check_conv_dgrad(be, S=50, n_seq=131)
 def test_conv_dgrad_gemm_form(be): kcc.check_conv_dgrad_gemm(be, S=20, n_seq=2051); kcc.check_conv_dgrad_gemm(be, S=50, n_seq=1031)
